@@ -1,0 +1,125 @@
+"""ctypes binding of ``libdynode_hip.so`` (the C-ABI declared in include/dynode_hip.h).
+
+This is the only door from Python into the HIP kernels.  There is no CPU fallback: if the
+shared library is missing, or a shape is not compiled in, the call raises.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+from dataclasses import dataclass
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libdynode_hip.so")
+
+DYN_TSIT5, DYN_DOPRI5 = 0, 1
+DYN_F32, DYN_F64 = 0, 1
+STATUS_OK, STATUS_MAX_STEPS, STATUS_NONFINITE = 0, 1, 2
+
+ERR_NAMES = {
+    -1: "DYN_ERR_NULL", -2: "DYN_ERR_MODEL", -3: "DYN_ERR_SIZE", -4: "DYN_ERR_OPTS",
+    -5: "DYN_ERR_TOL", -6: "DYN_ERR_JUMP", -7: "DYN_ERR_UNSUPPORTED", -8: "DYN_ERR_LAUNCH",
+}
+
+# every symbol include/dynode_hip.h declares (checked by tests/test_abi.py)
+EXPORTED_SYMBOLS = (
+    "dyn_abi_version", "dyn_state_dim", "dyn_param_dim", "dyn_n_compartments",
+    "dyn_compartment_offsets", "dyn_is_supported", "dyn_trajectories_per_wave",
+    "dyn_last_error", "dyn_solve_batch",
+)
+
+
+class ModelDescC(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in (
+        "n_age", "n_strain", "has_e", "has_wane", "has_c", "n_wane", "normalize", "seasonal")]
+
+
+class SolverOptsC(ctypes.Structure):
+    _fields_ = [
+        ("method", ctypes.c_int32),
+        ("dtype", ctypes.c_int32),
+        ("rtol", ctypes.c_double),
+        ("atol", ctypes.c_double),
+        ("max_steps", ctypes.c_int64),
+        ("constant_dt", ctypes.c_double),
+        ("jump_ts", ctypes.POINTER(ctypes.c_double)),
+        ("n_jump", ctypes.c_int32),
+    ]
+
+
+@dataclass(frozen=True)
+class ModelDesc:
+    """Python view of ``dyn_model_desc``: one member of the compartmental RHS family."""
+
+    n_age: int = 1
+    n_strain: int = 1
+    has_e: bool = False
+    has_wane: bool = False
+    has_c: bool = False
+    n_wane: int = 1
+    normalize: bool = True
+    seasonal: bool = False
+
+    def c(self) -> ModelDescC:
+        return ModelDescC(self.n_age, self.n_strain, int(self.has_e), int(self.has_wane),
+                          int(self.has_c), self.n_wane, int(self.normalize), int(self.seasonal))
+
+    # pure-Python mirrors of dyn_state_dim & co (host logic must not need the .so)
+    @property
+    def compartment_names(self) -> tuple:
+        return ("s",) + (("e",) if self.has_e else ()) + ("i", "r") + (("c",) if self.has_c else ())
+
+    @property
+    def compartment_sizes(self) -> tuple:
+        A, AS = self.n_age, self.n_age * self.n_strain
+        return (A,) + ((AS,) if self.has_e else ()) + (AS, AS * self.n_wane) + (
+            (AS,) if self.has_c else ())
+
+    @property
+    def state_dim(self) -> int:
+        return sum(self.compartment_sizes)
+
+    @property
+    def param_dim(self) -> int:
+        return self.n_strain * (2 + int(self.has_e) + int(self.has_wane)) + (
+            3 if self.seasonal else 0)
+
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+    """Load libdynode_hip.so; raise loudly if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipLibraryMissing(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; "
+                "g.build()'` or `make -C dynode_amd/csrc`. dynode_amd has no CPU fallback."
+            )
+        L = ctypes.CDLL(LIB_PATH)
+        pm, po = ctypes.POINTER(ModelDescC), ctypes.POINTER(SolverOptsC)
+        L.dyn_abi_version.restype = ctypes.c_int32
+        for name in ("dyn_state_dim", "dyn_param_dim", "dyn_n_compartments",
+                     "dyn_trajectories_per_wave"):
+            getattr(L, name).argtypes = [pm]
+            getattr(L, name).restype = ctypes.c_int32
+        L.dyn_compartment_offsets.argtypes = [pm, ctypes.c_void_p]
+        L.dyn_compartment_offsets.restype = ctypes.c_int32
+        L.dyn_is_supported.argtypes = [pm, po]
+        L.dyn_is_supported.restype = ctypes.c_int32
+        L.dyn_last_error.restype = ctypes.c_char_p
+        L.dyn_solve_batch.restype = ctypes.c_int
+        L.dyn_solve_batch.argtypes = [
+            pm, po, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,
+            ctypes.c_int64, ctypes.c_double, ctypes.c_double, ctypes.c_void_p, ctypes.c_int32,
+            ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+            ctypes.c_void_p,
+        ]
+        _lib = L
+    return _lib

@@ -1,0 +1,225 @@
+// dynode_hip.hip -- C-ABI of libdynode_hip.so (see include/dynode_hip.h): argument
+// validation, shape dispatch and kernel enqueue.  No allocation, no synchronisation,
+// no global mutable state (the last-error text is thread-local).
+#include "../../include/dynode_hip.h"
+#include "solve_kernel.hpp"
+
+#include <stdio.h>
+#include <string.h>
+
+namespace dyn {
+
+#define X(T, METHOD, G, S, E, WN, C, W) \
+    extern template hipError_t launch<T, METHOD, G, S, E, WN, C, W>(const KArgs<T> &, hipStream_t);
+#include "instances.def"
+#undef X
+
+template <typename T>
+struct DType;
+template <>
+struct DType<float> {
+    static constexpr int id = DYN_F32;
+};
+template <>
+struct DType<double> {
+    static constexpr int id = DYN_F64;
+};
+
+struct Entry {
+    int dtype, method, G, S, E, WN, C, W;
+    void *fn; // hipError_t (*)(const KArgs<T>&, hipStream_t)
+};
+
+static const Entry kEntries[] = {
+#define X(T, METHOD, G, S, E, WN, C, W)                       \
+    {DType<T>::id, METHOD, G, S, E, WN, C, W,                 \
+     (void *)(hipError_t(*)(const KArgs<T> &, hipStream_t)) & \
+         launch<T, METHOD, G, S, E, WN, C, W>},
+#include "instances.def"
+#undef X
+};
+static constexpr int kNumEntries = sizeof(kEntries) / sizeof(kEntries[0]);
+
+static int group_width(int A) {
+    int g = 1;
+    while (g < A) g <<= 1;
+    return g;
+}
+
+static const Entry *find_entry(const dyn_model_desc *m, int dtype, int method) {
+    const int G = group_width(m->n_age);
+    for (int i = 0; i < kNumEntries; ++i) {
+        const Entry &e = kEntries[i];
+        if (e.dtype == dtype && e.method == method && e.G == G && e.S == m->n_strain &&
+            e.E == (m->has_e != 0) && e.WN == (m->has_wane != 0) && e.C == (m->has_c != 0) &&
+            e.W == m->n_wane)
+            return &e;
+    }
+    return nullptr;
+}
+
+static thread_local char tl_error[256] = "";
+
+static int check_model(const dyn_model_desc *m) {
+    if (!m) return DYN_ERR_NULL;
+    if (m->n_age < 1 || m->n_age > 64 || m->n_strain < 1 || m->n_wane < 1) return DYN_ERR_MODEL;
+    if (m->n_wane > 1 && !m->has_wane) return DYN_ERR_MODEL;
+    return 0;
+}
+
+template <typename T>
+static int enqueue(const Entry *e, const dyn_model_desc *m, const dyn_solver_opts *o,
+                   const void *y0, int32_t y0_is_batched, const void *params, const void *contact,
+                   int64_t B, double t0, double t1, const void *save_ts, int32_t n_save,
+                   const uint8_t *save_mask, void *ys_out, int32_t *status, int32_t *n_accept,
+                   int32_t *n_reject, hipStream_t stream) {
+    KArgs<T> ka;
+    ka.y0 = (const T *)y0;
+    ka.params = (const T *)params;
+    ka.contact = (const T *)contact;
+    ka.save_ts = (const T *)save_ts;
+    ka.out = (T *)ys_out;
+    ka.status = status;
+    ka.n_acc = n_accept;
+    ka.n_rej = n_reject;
+    ka.B = B;
+    ka.max_steps = o->max_steps;
+    ka.t0 = (T)t0;
+    ka.t1 = (T)t1;
+    ka.rtol = (T)o->rtol;
+    ka.atol = (T)o->atol;
+    ka.constant_dt = o->constant_dt > 0.0 ? (T)o->constant_dt : (T)0;
+    ka.y0_batched = y0_is_batched ? 1 : 0;
+    ka.n_save = n_save;
+    ka.A = m->n_age;
+    ka.P = dyn_param_dim(m);
+    ka.normalize = m->normalize ? 1 : 0;
+    ka.seasonal = m->seasonal ? 1 : 0;
+
+    // saved-row layout: saved compartments concatenated in state order
+    int32_t off[8];
+    const int ncomp = dyn_compartment_offsets(m, off);
+    // compartment slots of the kernel: 0 s, 1 e, 2 i, 3 r, 4 c
+    int slot_of[5], n = 0;
+    slot_of[n++] = 0;
+    if (m->has_e) slot_of[n++] = 1;
+    slot_of[n++] = 2;
+    slot_of[n++] = 3;
+    if (m->has_c) slot_of[n++] = 4;
+    for (int s = 0; s < 5; ++s) ka.save_off[s] = -1;
+    int pos = 0;
+    bool aligned = true;
+    const int per16 = 16 / (int)sizeof(T);
+    for (int c = 0; c < ncomp; ++c) {
+        if (save_mask && !save_mask[c]) continue;
+        ka.save_off[slot_of[c]] = pos;
+        if (pos % per16) aligned = false;
+        pos += off[c + 1] - off[c];
+    }
+    ka.d_saved = pos;
+    ka.vec_ok = (aligned && pos % per16 == 0 && ((uintptr_t)ys_out % 16) == 0) ? 1 : 0;
+    if (pos == 0 || n_save == 0) {
+        // nothing to write: still run (status / step counts are outputs too)
+        ka.d_saved = pos;
+    }
+    typedef hipError_t (*fn_t)(const KArgs<T> &, hipStream_t);
+    const hipError_t err = ((fn_t)e->fn)(ka, stream);
+    if (err != hipSuccess) {
+        snprintf(tl_error, sizeof(tl_error), "kernel launch failed: %s", hipGetErrorString(err));
+        return DYN_ERR_LAUNCH;
+    }
+    return 0;
+}
+
+} // namespace dyn
+
+extern "C" {
+
+int32_t dyn_abi_version(void) { return DYN_ABI_VERSION; }
+
+int32_t dyn_n_compartments(const dyn_model_desc *m) {
+    return 3 + (m->has_e ? 1 : 0) + (m->has_c ? 1 : 0);
+}
+
+int32_t dyn_compartment_offsets(const dyn_model_desc *m, int32_t *off) {
+    const int A = m->n_age, AS = m->n_age * m->n_strain;
+    int n = 0, pos = 0;
+    off[n++] = pos;
+    pos += A;
+    if (m->has_e) {
+        off[n++] = pos;
+        pos += AS;
+    }
+    off[n++] = pos;
+    pos += AS;
+    off[n++] = pos;
+    pos += AS * m->n_wane;
+    if (m->has_c) {
+        off[n++] = pos;
+        pos += AS;
+    }
+    off[n] = pos;
+    return n;
+}
+
+int32_t dyn_state_dim(const dyn_model_desc *m) {
+    return m->n_age *
+           (1 + m->n_strain * ((m->has_e ? 1 : 0) + 1 + m->n_wane + (m->has_c ? 1 : 0)));
+}
+
+int32_t dyn_param_dim(const dyn_model_desc *m) {
+    return m->n_strain * (2 + (m->has_e ? 1 : 0) + (m->has_wane ? 1 : 0)) + (m->seasonal ? 3 : 0);
+}
+
+int32_t dyn_trajectories_per_wave(const dyn_model_desc *m) {
+    if (dyn::check_model(m)) return 0;
+    return 64 / dyn::group_width(m->n_age);
+}
+
+int32_t dyn_is_supported(const dyn_model_desc *m, const dyn_solver_opts *o) {
+    if (dyn::check_model(m) || !o) return 0;
+    return dyn::find_entry(m, o->dtype, o->method) ? 1 : 0;
+}
+
+const char *dyn_last_error(void) { return dyn::tl_error; }
+
+int dyn_solve_batch(const dyn_model_desc *m, const dyn_solver_opts *o, const void *y0,
+                    int32_t y0_is_batched, const void *params, const void *contact, int64_t B,
+                    double t0, double t1, const void *save_ts, int32_t n_save,
+                    const uint8_t *save_mask, void *ys_out, int32_t *status, int32_t *n_accept,
+                    int32_t *n_reject, void *stream) {
+    dyn::tl_error[0] = 0;
+    int rc = dyn::check_model(m);
+    if (rc) return rc;
+    if (!o || !y0 || !params || !contact || !status || !n_accept || !n_reject) return DYN_ERR_NULL;
+    if (B < 0 || n_save < 0 || (n_save > 0 && (!save_ts || !ys_out))) return DYN_ERR_SIZE;
+    if ((o->method != DYN_TSIT5 && o->method != DYN_DOPRI5) ||
+        (o->dtype != DYN_F32 && o->dtype != DYN_F64))
+        return DYN_ERR_OPTS;
+    if (!(o->constant_dt > 0.0) && (!(o->rtol > 0.0) || !(o->atol > 0.0))) return DYN_ERR_TOL;
+    if (o->max_steps < 1 || !(t1 >= t0)) return DYN_ERR_TOL;
+    if (o->n_jump < 0 || (o->n_jump > 0 && !o->jump_ts)) return DYN_ERR_JUMP;
+    if (o->n_jump > 0) {
+        snprintf(dyn::tl_error, sizeof(dyn::tl_error),
+                 "discontinuity_points are not supported by the HIP path yet");
+        return DYN_ERR_UNSUPPORTED;
+    }
+    const dyn::Entry *e = dyn::find_entry(m, o->dtype, o->method);
+    if (!e) {
+        snprintf(dyn::tl_error, sizeof(dyn::tl_error),
+                 "no kernel compiled for A=%d S=%d e=%d wane=%d c=%d W=%d dtype=%d method=%d",
+                 m->n_age, m->n_strain, m->has_e, m->has_wane, m->has_c, m->n_wane, o->dtype,
+                 o->method);
+        return DYN_ERR_UNSUPPORTED;
+    }
+    if (B == 0) return 0;
+    if (o->dtype == DYN_F64)
+        return dyn::enqueue<double>(e, m, o, y0, y0_is_batched, params, contact, B, t0, t1,
+                                    save_ts, n_save, save_mask, ys_out, status, n_accept, n_reject,
+                                    (hipStream_t)stream);
+    return dyn::enqueue<float>(e, m, o, y0, y0_is_batched, params, contact, B, t0, t1, save_ts,
+                               n_save, save_mask, ys_out, status, n_accept, n_reject,
+                               (hipStream_t)stream);
+}
+
+} // extern "C"

@@ -1,0 +1,577 @@
+// solve_kernel.hpp -- fused adaptive RK5(4) + compartmental RHS kernel for gfx950 (MI355X).
+//
+// Replaces, for B independent parameter samples, the whole of
+//   diffrax.diffeqsolve(ODETerm(ode), Tsit5()|Dopri5(), t0, t1, dt0=None, y0, args,
+//                       ClipStepSizeController(PIDController(rtol, atol)), SaveAt(ts), max_steps)
+// as called by dynode.simulation.simulate (reference src/dynode/simulation/odes.py:107-144)
+// with the RHS family of the reference's examples/*.py.
+//
+// Mapping (CDNA4, 64-lane wavefronts): a trajectory is owned by a group of G lanes
+// (G = power of two >= n_age); lane `a` of the group holds EVERY compartment value of age
+// bin `a` in VGPRs (NV = 1 + S*(E + 1 + W + C) values), together with all 7 RK stages.
+// A wavefront therefore integrates 64/G trajectories with all lanes busy.  The only
+// cross-lane traffic is (1) the age-contact contraction sum_b C[a][b] x_b -- an all-gather
+// inside the lane group by xor-exchange against a pre-permuted contact row held in VGPRs --
+// and (2) the RMS error norm (xor-butterfly).  No LDS allocation, no barriers, no atomics;
+// HBM traffic is the compulsory I/O only: P + D floats in, n_save*D_saved floats out.
+// The whole [t0,t1] solve (all steps, accept/reject, dense output) runs inside ONE launch.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dyn {
+
+enum { ST_OK = 0, ST_MAX_STEPS = 1, ST_NONFINITE = 2 };
+
+template <typename T>
+struct KArgs {
+    const T *y0;
+    const T *params;
+    const T *contact;
+    const T *save_ts;
+    T *out;
+    int32_t *status;
+    int32_t *n_acc;
+    int32_t *n_rej;
+    int64_t B;
+    int64_t max_steps;
+    T t0, t1, rtol, atol, constant_dt;
+    int32_t y0_batched, n_save, A, P, normalize, seasonal, d_saved, vec_ok;
+    int32_t save_off[5]; // offset of s,e,i,r,c inside a saved row; -1 = not saved
+};
+
+// ---------------------------------------------------------------- math per precision
+template <typename T>
+struct Mth;
+template <>
+struct Mth<float> {
+    static __device__ __forceinline__ float abs(float x) { return fabsf(x); }
+    static __device__ __forceinline__ float max(float a, float b) { return fmaxf(a, b); }
+    static __device__ __forceinline__ float min(float a, float b) { return fminf(a, b); }
+    static __device__ __forceinline__ float sqrt(float x) { return sqrtf(x); }
+    static __device__ __forceinline__ float sin(float x) { return sinf(x); }
+    // 1-ulp hardware reciprocal: used only for the error-norm scaling
+    static __device__ __forceinline__ float rcp_fast(float x) { return __builtin_amdgcn_rcpf(x); }
+    // x^e through v_log_f32 / v_exp_f32: only ever sets the next step size
+    static __device__ __forceinline__ float pow_fast(float x, float e) {
+        return __builtin_amdgcn_exp2f(e * __builtin_amdgcn_logf(x));
+    }
+    static __device__ __forceinline__ float inf() { return __builtin_huge_valf(); }
+    static constexpr float clip_tol = 1e-6f; // diffrax _clip_to_end tolerance, float32
+};
+template <>
+struct Mth<double> {
+    static __device__ __forceinline__ double abs(double x) { return fabs(x); }
+    static __device__ __forceinline__ double max(double a, double b) { return fmax(a, b); }
+    static __device__ __forceinline__ double min(double a, double b) { return fmin(a, b); }
+    static __device__ __forceinline__ double sqrt(double x) { return ::sqrt(x); }
+    static __device__ __forceinline__ double sin(double x) { return ::sin(x); }
+    static __device__ __forceinline__ double rcp_fast(double x) { return 1.0 / x; }
+    static __device__ __forceinline__ double pow_fast(double x, double e) { return ::pow(x, e); }
+    static __device__ __forceinline__ double inf() { return __builtin_huge_val(); }
+    static constexpr double clip_tol = 1e-10;
+};
+
+// ---------------------------------------------------------------- tableaux
+// Constants identical to oracle/dynode_oracle.c (checked against the RK order conditions
+// in tests/test_tableau.py).
+template <int METHOD>
+struct Tab;
+template <>
+struct Tab<0> { // Tsit5
+    static constexpr double c[7] = {0.0, 0.161, 0.327, 0.9, 0.9800255409045097, 1.0, 1.0};
+    static constexpr double a[7][7] = {
+        {0},
+        {0.161},
+        {-0.008480655492356989, 0.335480655492357},
+        {2.8971530571054935, -6.359448489975075, 4.3622954328695815},
+        {5.325864828439257, -11.748883564062828, 7.4955393428898365, -0.09249506636175525},
+        {5.86145544294642, -12.92096931784711, 8.159367898576159, -0.071584973281401,
+         -0.028269050394068383},
+        {0.09646076681806523, 0.01, 0.4798896504144996, 1.379008574103742, -3.290069515436081,
+         2.324710524099774}};
+    static constexpr double berr[7] = {0.00178001105222577714, 0.0008164344596567469,
+                                       -0.007880878010261995,  0.1447110071732629,
+                                       -0.5823571654525552,    0.45808210592918697,
+                                       -0.015151515151515152};
+};
+template <>
+struct Tab<1> { // Dopri5
+    static constexpr double c[7] = {0.0, 1.0 / 5, 3.0 / 10, 4.0 / 5, 8.0 / 9, 1.0, 1.0};
+    static constexpr double a[7][7] = {
+        {0},
+        {1.0 / 5},
+        {3.0 / 40, 9.0 / 40},
+        {44.0 / 45, -56.0 / 15, 32.0 / 9},
+        {19372.0 / 6561, -25360.0 / 2187, 64448.0 / 6561, -212.0 / 729},
+        {9017.0 / 3168, -355.0 / 33, 46732.0 / 5247, 49.0 / 176, -5103.0 / 18656},
+        {35.0 / 384, 0.0, 500.0 / 1113, 125.0 / 192, -2187.0 / 6784, 11.0 / 84}};
+    static constexpr double berr[7] = {35.0 / 384 - 5179.0 / 57600,
+                                       0.0,
+                                       500.0 / 1113 - 7571.0 / 16695,
+                                       125.0 / 192 - 393.0 / 640,
+                                       -2187.0 / 6784 + 92097.0 / 339200,
+                                       11.0 / 84 - 187.0 / 2100,
+                                       -1.0 / 40};
+    static constexpr double cmid[7] = {6025192743.0 / 30085553152.0 / 2,
+                                       0.0,
+                                       51252292925.0 / 65400821598.0 / 2,
+                                       -2691868925.0 / 45128329728.0 / 2,
+                                       187940372067.0 / 1594534317056.0 / 2,
+                                       -1776094331.0 / 19743644256.0 / 2,
+                                       11237099.0 / 235043384.0 / 2};
+};
+
+// ---------------------------------------------------------------- cross-lane helpers
+// Lane `a` of a group reads the value held by lane `a ^ K` of the same group.
+template <int K, typename T>
+__device__ __forceinline__ T xchg_xor(T v) {
+    return __shfl_xor(v, K, 64);
+}
+
+template <int G, typename T>
+__device__ __forceinline__ T group_sum(T v) {
+    if constexpr (G >= 2) v += xchg_xor<1>(v);
+    if constexpr (G >= 4) v += xchg_xor<2>(v);
+    if constexpr (G >= 8) v += xchg_xor<4>(v);
+    if constexpr (G >= 16) v += xchg_xor<8>(v);
+    if constexpr (G >= 32) v += xchg_xor<16>(v);
+    if constexpr (G >= 64) v += xchg_xor<32>(v);
+    return v;
+}
+
+// store CNT contiguous values; 16-byte vector stores when the host proved alignment
+template <typename T, int CNT>
+__device__ __forceinline__ void store_run(T *p, const T (&v)[CNT], bool vec_ok) {
+    constexpr int PER = 16 / sizeof(T);
+    if constexpr (CNT % PER == 0) {
+        if (vec_ok) {
+            typedef T vec_t __attribute__((ext_vector_type(PER)));
+#pragma unroll
+            for (int q = 0; q < CNT / PER; ++q) {
+                vec_t pk;
+#pragma unroll
+                for (int z = 0; z < PER; ++z) pk[z] = v[q * PER + z];
+                *reinterpret_cast<vec_t *>(p + q * PER) = pk;
+            }
+            return;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < CNT; ++q) p[q] = v[q];
+}
+
+// ---------------------------------------------------------------- the kernel
+template <typename T, int METHOD, int G, int S, bool HAS_E, bool HAS_WANE, bool HAS_C, int W>
+struct Solver {
+    static constexpr int NE = HAS_E ? S : 0;
+    static constexpr int NC = HAS_C ? S : 0;
+    static constexpr int NV = 1 + NE + S + S * W + NC;
+    static constexpr int IE = 1, II = 1 + NE, IR = II + S, IC = IR + S * W;
+    static constexpr int TPW = 64 / G;
+    using M = Mth<T>;
+    using TB = Tab<METHOD>;
+
+    // per-lane model data
+    T beta[S], gamma[S], sigma[S], omega[S];
+    T Cx[G]; // Cx[k] = contact[a][a ^ k] (0 outside the matrix)
+    T amp, phase, w_season;
+    bool pad, normalize, seasonal;
+
+    // f(t, y) for this lane's age bin; reference RHS: see include/dynode_hip.h
+    __device__ __forceinline__ void rhs(T t, const T (&y)[NV], T (&dy)[NV]) const {
+        T se = 0, si = 0, sr = 0;
+#pragma unroll
+        for (int l = 0; l < S; ++l) {
+            if constexpr (HAS_E) se += y[IE + l];
+            si += y[II + l];
+#pragma unroll
+            for (int w = 0; w < W; ++w) sr += y[IR + l * W + w];
+        }
+        const T N = ((y[0] + se) + si) + sr;
+        T invN = T(1);
+        if (normalize) invN = pad ? T(0) : T(1) / N;
+        T season = T(1);
+        if (seasonal) season = T(1) + amp * M::sin(w_season * t + phase);
+        T acc[S];
+#pragma unroll
+        for (int l = 0; l < S; ++l) {
+            const T x = y[II + l] * invN;
+            acc[l] = Cx[0] * x;
+            // all-gather of x over the lane group, fused with the contact row
+            if constexpr (G > 1) gather<1>(x, acc[l]);
+        }
+        T out_s = 0, back_s = 0;
+#pragma unroll
+        for (int l = 0; l < S; ++l) {
+            const T foi = (beta[l] * season) * acc[l];
+            const T flux = foi * y[0];
+            const T g_i = gamma[l] * y[II + l];
+            out_s += flux;
+            if constexpr (HAS_E) {
+                const T s_e = sigma[l] * y[IE + l];
+                dy[IE + l] = flux - s_e;
+                dy[II + l] = s_e - g_i;
+            } else {
+                dy[II + l] = flux - g_i;
+            }
+            if constexpr (HAS_WANE) {
+                const T wrate = T(W) * omega[l];
+                T inflow = g_i;
+#pragma unroll
+                for (int w = 0; w < W; ++w) {
+                    const T o = wrate * y[IR + l * W + w];
+                    dy[IR + l * W + w] = inflow - o;
+                    inflow = o;
+                }
+                back_s += inflow;
+            } else {
+                dy[IR + l * W] = g_i;
+#pragma unroll
+                for (int w = 1; w < W; ++w) dy[IR + l * W + w] = T(0);
+            }
+            if constexpr (HAS_C) dy[IC + l] = flux;
+        }
+        dy[0] = back_s - out_s;
+    }
+
+    template <int K>
+    __device__ __forceinline__ void gather(T x, T &acc) const {
+        acc += Cx[K] * xchg_xor<K>(x);
+        if constexpr (K + 1 < G) gather<K + 1>(x, acc);
+    }
+
+    // dense output at theta in [0,1] for the accepted step (y -> y1), k = stage derivatives
+    struct Dense {
+        T b[7]; // Tsit5: b_i(theta); Dopri5: theta powers folded below
+        T theta;
+    };
+    __device__ __forceinline__ static void dense_prepare(T th, Dense &d) {
+        d.theta = th;
+        if constexpr (METHOD == 0) {
+            const T t2 = th * th;
+            d.b[0] = T(-1.0530884977290216) * th * (th - T(1.3299890189751412)) *
+                     (t2 - T(1.4364028541716351) * th + T(0.7139816917074209));
+            d.b[1] = T(0.1017) * t2 * (t2 - T(2.1966568338249754) * th + T(1.2949852507374631));
+            d.b[2] = T(2.490627285651252793) * t2 *
+                     (t2 - T(2.38535645472061657) * th + T(1.57803468208092486));
+            d.b[3] = T(-16.54810288924490272) * (th - T(1.21712927295533244)) *
+                     (th - T(0.61620406037800089)) * t2;
+            d.b[4] = T(47.37952196281928122) * (th - T(1.203071208372362603)) *
+                     (th - T(0.658047292653547382)) * t2;
+            d.b[5] = T(-34.87065786149660974) * (th - T(1.2)) * (th - T(0.666666666666666667)) * t2;
+            d.b[6] = T(2.5) * (th - T(1.0)) * (th - T(0.6)) * t2;
+        }
+    }
+    __device__ __forceinline__ static T dense_eval(const Dense &d, T dt, T y0v, T y1v, T k0, T k1,
+                                                   T k2, T k3, T k4, T k5, T k6) {
+        if constexpr (METHOD == 0) {
+            T a = d.b[0] * k0;
+            a += d.b[1] * k1;
+            a += d.b[2] * k2;
+            a += d.b[3] * k3;
+            a += d.b[4] * k4;
+            a += d.b[5] * k5;
+            a += d.b[6] * k6;
+            return y0v + dt * a;
+        } else {
+            // quartic through y0, y1, ymid, f0, f1 (Shampine midpoint weights)
+            T mid = T(TB::cmid[0]) * k0;
+            mid += T(TB::cmid[2]) * k2;
+            mid += T(TB::cmid[3]) * k3;
+            mid += T(TB::cmid[4]) * k4;
+            mid += T(TB::cmid[5]) * k5;
+            mid += T(TB::cmid[6]) * k6;
+            const T ymid = y0v + dt * mid;
+            const T f0 = dt * k0, f1 = dt * k6;
+            const T ca = T(2) * (f1 - f0) - T(8) * (y1v + y0v) + T(16) * ymid;
+            const T cb = T(5) * f0 - T(3) * f1 + T(18) * y0v + T(14) * y1v - T(32) * ymid;
+            const T cc = f1 - T(4) * f0 - T(11) * y0v - T(5) * y1v + T(16) * ymid;
+            const T th = d.theta;
+            return (((ca * th + cb) * th + cc) * th + f0) * th + y0v;
+        }
+    }
+
+    // interpolate + store one compartment block [FIRST, FIRST+CNT) of this lane
+    template <int FIRST, int CNT>
+    __device__ __forceinline__ static void save_block(const Dense &d, T dt, const T (&y)[NV],
+                                                      const T (&y1)[NV], const T (&k)[7][NV],
+                                                      T *dst, bool vec_ok) {
+        T v[CNT];
+#pragma unroll
+        for (int q = 0; q < CNT; ++q) {
+            const int j = FIRST + q;
+            v[q] = dense_eval(d, dt, y[j], y1[j], k[0][j], k[1][j], k[2][j], k[3][j], k[4][j],
+                              k[5][j], k[6][j]);
+        }
+        store_run<T, CNT>(dst, v, vec_ok);
+    }
+
+    __device__ __forceinline__ static void run(const KArgs<T> &ka) {
+        const int lane = threadIdx.x & 63;
+        const int a = lane % G;
+        const int grp = lane / G;
+        int64_t traj = (int64_t)blockIdx.x * TPW + grp;
+        const bool valid_traj = traj < ka.B;
+        if (!valid_traj) traj = ka.B - 1; // duplicate a real trajectory, never store
+        const int A = ka.A;
+        Solver L;
+        L.pad = a >= A;
+        L.normalize = ka.normalize != 0;
+        L.seasonal = ka.seasonal != 0;
+        const int aa = L.pad ? 0 : a;
+        const bool writer = valid_traj && !L.pad;
+
+        // ---- flat-state offsets (compartment-major layout)
+        const int offE = A, offI = A + A * NE, offR = offI + A * S, offC = offR + A * S * W;
+        const int D = offC + A * NC;
+
+        // ---- per-trajectory parameters (broadcast loads inside the lane group)
+        {
+            const T *p = ka.params + traj * ka.P;
+#pragma unroll
+            for (int l = 0; l < S; ++l) {
+                L.beta[l] = p[l];
+                L.gamma[l] = p[S + l];
+                L.sigma[l] = HAS_E ? p[2 * S + l] : T(0);
+                L.omega[l] = HAS_WANE ? p[(2 + (HAS_E ? 1 : 0)) * S + l] : T(0);
+            }
+            L.amp = T(0);
+            L.phase = T(0);
+            L.w_season = T(0);
+            if (L.seasonal) {
+                const T *sp = p + (2 + (HAS_E ? 1 : 0) + (HAS_WANE ? 1 : 0)) * S;
+                L.amp = sp[0];
+                L.phase = sp[1];
+                L.w_season = T(6.283185307179586476925286766559) / sp[2];
+            }
+        }
+        // ---- contact row, pre-permuted to the xor-exchange order
+#pragma unroll
+        for (int k = 0; k < G; ++k) {
+            const int b = a ^ k;
+            L.Cx[k] = (!L.pad && b < A) ? ka.contact[aa * A + b] : T(0);
+        }
+
+        // ---- initial state
+        T y[NV], yt[NV], k[7][NV];
+        {
+            const T *y0 = ka.y0 + (ka.y0_batched ? traj * D : 0);
+            y[0] = L.pad ? T(0) : y0[aa];
+#pragma unroll
+            for (int l = 0; l < S; ++l) {
+                if constexpr (HAS_E) y[IE + l] = L.pad ? T(0) : y0[offE + aa * S + l];
+                y[II + l] = L.pad ? T(0) : y0[offI + aa * S + l];
+#pragma unroll
+                for (int w = 0; w < W; ++w)
+                    y[IR + l * W + w] = L.pad ? T(0) : y0[offR + (aa * S + l) * W + w];
+                if constexpr (HAS_C) y[IC + l] = L.pad ? T(0) : y0[offC + aa * S + l];
+            }
+        }
+
+        const T rtol = ka.rtol, atol = ka.atol, t_end = ka.t1;
+        const T Dn = T(D);
+        const bool constant = ka.constant_dt > T(0);
+        T tprev = ka.t0, tnext;
+        L.rhs(tprev, y, k[0]);
+
+        if (constant) {
+            tnext = tprev + ka.constant_dt;
+        } else {
+            // Hairer-Norsett-Wanner II.4 starting step (diffrax _select_initial_step)
+            T s0 = 0, s1 = 0;
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const T sc = atol + M::abs(y[v]) * rtol;
+                const T q0 = y[v] / sc, q1 = k[0][v] / sc;
+                s0 += q0 * q0;
+                s1 += q1 * q1;
+            }
+            const T d0 = M::sqrt(group_sum<G>(s0) / Dn), d1 = M::sqrt(group_sum<G>(s1) / Dn);
+            const bool small = (d0 < T(1e-5)) || (d1 < T(1e-5));
+            const T h0 = small ? T(1e-6) : T(0.01) * (d0 / d1);
+#pragma unroll
+            for (int v = 0; v < NV; ++v) yt[v] = y[v] + h0 * k[0][v];
+            L.rhs(tprev + h0, yt, k[1]);
+            T s2 = 0;
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const T sc = atol + M::abs(y[v]) * rtol;
+                const T q2 = (k[1][v] - k[0][v]) / sc;
+                s2 += q2 * q2;
+            }
+            const T d2 = M::sqrt(group_sum<G>(s2) / Dn) / h0;
+            const T max_d = M::max(d1, d2);
+            const T h1 = (max_d <= T(1e-15)) ? M::max(T(1e-6), h0 * T(1e-3))
+                                              : M::pow_fast(T(0.01) / max_d, T(0.2));
+            tnext = tprev + M::min(T(100) * h0, h1);
+        }
+        tnext = M::min(tnext, t_end);
+
+        int save_idx = 0;
+        const int n_save = ka.n_save;
+        T ts_next = n_save > 0 ? ka.save_ts[0] : M::inf();
+        int64_t steps = 0;
+        int32_t n_acc = 0, n_rej = 0, st = ST_OK;
+        bool done = !(tprev < t_end);
+        T *const out_traj = ka.out + traj * (int64_t)n_save * ka.d_saved;
+        const bool vec_ok = ka.vec_ok != 0;
+
+        while (__any(!done)) {
+            const T dt = tnext - tprev;
+            // ---- stages 2..7 (k[] hold f; k[0] is FSAL)
+#pragma unroll
+            for (int sg = 1; sg < 7; ++sg) {
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    T acc = T(TB::a[sg][0]) * k[0][v];
+#pragma unroll
+                    for (int q = 1; q < sg; ++q)
+                        if (TB::a[sg][q] != 0.0) acc += T(TB::a[sg][q]) * k[q][v];
+                    yt[v] = y[v] + dt * acc;
+                }
+                L.rhs(tprev + T(TB::c[sg]) * dt, yt, k[sg]);
+            }
+            // after stage 7, yt == y1 (a[6][:] == b) and k[6] == f(tnext, y1)
+
+            // ---- embedded error, RMS norm over the whole state, I-controller
+            bool keep = true, finite = true;
+            T factor = T(1);
+            if (!constant) {
+                T ss = 0;
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    T e = T(TB::berr[0]) * k[0][v];
+#pragma unroll
+                    for (int q = 1; q < 7; ++q)
+                        if (TB::berr[q] != 0.0) e += T(TB::berr[q]) * k[q][v];
+                    const T ym = M::max(M::abs(y[v]), M::abs(yt[v]));
+                    const T r = (dt * e) * M::rcp_fast(atol + ym * rtol);
+                    ss += r * r;
+                }
+                const T err = M::sqrt(group_sum<G>(ss) / Dn);
+                keep = err < T(1);
+                finite = (err == err) && (err < M::inf());
+                // factor = clip(safety * err^(-1/order), keep ? 1 : factormin, factormax)
+                T f = (err == T(0)) ? T(0.9) : T(0.9) * M::pow_fast(err, T(-0.2));
+                f = M::max(f, keep ? T(1) : T(0.2));
+                factor = M::min(f, T(10));
+            } else {
+                T chk = 0;
+#pragma unroll
+                for (int v = 0; v < NV; ++v) chk += yt[v] - yt[v];
+                chk = group_sum<G>(chk);
+                finite = (chk == T(0));
+            }
+            const bool act = !done;
+            steps += act ? 1 : 0;
+            if (act && !finite) {
+                st = ST_NONFINITE;
+                done = true;
+            }
+            const bool accept = act && finite && keep;
+
+            // ---- SaveAt(ts): dense output at every save time in (tprev, tnext]
+            bool pending = accept && (save_idx < n_save) && (ts_next <= tnext);
+            while (__any(pending)) {
+                if (pending) {
+                    Dense dn;
+                    dense_prepare((ts_next - tprev) / dt, dn);
+                    if (writer) {
+                        T *row = out_traj + (int64_t)save_idx * ka.d_saved;
+                        if (ka.save_off[0] >= 0)
+                            save_block<0, 1>(dn, dt, y, yt, k, row + ka.save_off[0] + a, false);
+                        if constexpr (HAS_E)
+                            if (ka.save_off[1] >= 0)
+                                save_block<IE, S>(dn, dt, y, yt, k, row + ka.save_off[1] + a * S,
+                                                  vec_ok);
+                        if (ka.save_off[2] >= 0)
+                            save_block<II, S>(dn, dt, y, yt, k, row + ka.save_off[2] + a * S,
+                                              vec_ok);
+                        if (ka.save_off[3] >= 0)
+                            save_block<IR, S * W>(dn, dt, y, yt, k,
+                                                  row + ka.save_off[3] + a * S * W, vec_ok);
+                        if constexpr (HAS_C)
+                            if (ka.save_off[4] >= 0)
+                                save_block<IC, S>(dn, dt, y, yt, k, row + ka.save_off[4] + a * S,
+                                                  vec_ok);
+                    }
+                    ++save_idx;
+                    ts_next = save_idx < n_save ? ka.save_ts[save_idx] : M::inf();
+                }
+                pending = accept && (save_idx < n_save) && (ts_next <= tnext);
+            }
+
+            // ---- commit / reject
+            if (accept) {
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    y[v] = yt[v];
+                    k[0][v] = k[6][v];
+                }
+                ++n_acc;
+            } else if (act && finite) {
+                ++n_rej;
+            }
+            // ---- next interval: prev_dt * factor, then diffeqsolve's clip-to-end
+            const T next_t0 = accept ? tnext : tprev;
+            T next_t1 = next_t0 + (constant ? ka.constant_dt : dt * factor);
+            const T tp = M::min(next_t0, t_end);
+            if (next_t1 > t_end - M::clip_tol)
+                next_t1 = accept ? t_end : tp + T(0.5) * (t_end - tp);
+            if (!done) {
+                tprev = tp;
+                tnext = next_t1;
+                if (!(tprev < t_end)) {
+                    done = true;
+                } else if (steps >= ka.max_steps) {
+                    st = ST_MAX_STEPS;
+                    done = true;
+                }
+            }
+        }
+
+        // rows never reached (failed solves): +inf, like diffrax's unfilled SaveAt buffer
+        if (writer) {
+            for (; save_idx < n_save; ++save_idx) {
+                T *row = out_traj + (int64_t)save_idx * ka.d_saved;
+                const T v = M::inf();
+                if (ka.save_off[0] >= 0) row[ka.save_off[0] + a] = v;
+                if constexpr (HAS_E)
+                    if (ka.save_off[1] >= 0)
+                        for (int q = 0; q < S; ++q) row[ka.save_off[1] + a * S + q] = v;
+                if (ka.save_off[2] >= 0)
+                    for (int q = 0; q < S; ++q) row[ka.save_off[2] + a * S + q] = v;
+                if (ka.save_off[3] >= 0)
+                    for (int q = 0; q < S * W; ++q) row[ka.save_off[3] + a * S * W + q] = v;
+                if constexpr (HAS_C)
+                    if (ka.save_off[4] >= 0)
+                        for (int q = 0; q < S; ++q) row[ka.save_off[4] + a * S + q] = v;
+            }
+            if (a == 0) {
+                ka.status[traj] = st;
+                ka.n_acc[traj] = n_acc;
+                ka.n_rej[traj] = n_rej;
+            }
+        }
+    }
+};
+
+template <typename T, int METHOD, int G, int S, bool HAS_E, bool HAS_WANE, bool HAS_C, int W>
+__global__ void __launch_bounds__(64)
+solve_kernel(const KArgs<T> ka) {
+    Solver<T, METHOD, G, S, HAS_E, HAS_WANE, HAS_C, W>::run(ka);
+}
+
+// host-side launcher, one explicit instantiation per compiled shape (instances.def)
+template <typename T, int METHOD, int G, int S, bool HAS_E, bool HAS_WANE, bool HAS_C, int W>
+hipError_t launch(const KArgs<T> &ka, hipStream_t stream) {
+    constexpr int TPW = 64 / G;
+    const int64_t blocks = (ka.B + TPW - 1) / TPW;
+    if (blocks <= 0) return hipSuccess;
+    hipLaunchKernelGGL((solve_kernel<T, METHOD, G, S, HAS_E, HAS_WANE, HAS_C, W>),
+                       dim3((unsigned)blocks), dim3(64), 0, stream, ka);
+    return hipGetLastError();
+}
+
+} // namespace dyn

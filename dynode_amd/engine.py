@@ -1,0 +1,125 @@
+"""Batched-solve driver: torch tensors in HBM -> ``dyn_solve_batch`` -> torch tensors in HBM.
+
+PyTorch is plumbing here (device memory, streams); the arithmetic is the HIP kernel in
+csrc/solve_kernel.hpp reached through the C-ABI.  There is no CPU path: without a GPU or
+without ``libdynode_hip.so`` every call raises.
+"""
+
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _abi
+from ._abi import ModelDesc
+
+_METHODS = {"tsit5": _abi.DYN_TSIT5, "dopri5": _abi.DYN_DOPRI5}
+_DTYPES = {torch.float32: _abi.DYN_F32, torch.float64: _abi.DYN_F64}
+
+
+class SolveError(RuntimeError):
+    """An argument error reported by the C-ABI (negative DYN_ERR_* code)."""
+
+    def __init__(self, code: int, detail: str = ""):
+        self.code = code
+        name = _abi.ERR_NAMES.get(code, str(code))
+        super().__init__(f"dyn_solve_batch failed: {name}" + (f" ({detail})" if detail else ""))
+
+
+@dataclass
+class BatchResult:
+    """Outputs of one batched solve, all resident on the device."""
+
+    ys: torch.Tensor        # [B, n_save, D_saved]
+    status: torch.Tensor    # [B] int32: 0 ok, 1 max_steps, 2 non-finite
+    n_accept: torch.Tensor  # [B] int32
+    n_reject: torch.Tensor  # [B] int32
+    saved: tuple            # names of the saved compartments, in row order
+    sizes: tuple            # flat size of each saved compartment
+
+
+def require_gpu() -> torch.device:
+    if not torch.cuda.is_available():
+        raise RuntimeError(
+            "dynode_amd needs an AMD GPU (gfx950): torch.cuda.is_available() is False and "
+            "there is no CPU fallback."
+        )
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def _dev(x, dtype, device) -> torch.Tensor:
+    if isinstance(x, torch.Tensor):
+        return x.to(device=device, dtype=dtype).contiguous()
+    return torch.as_tensor(np.ascontiguousarray(x), dtype=dtype, device=device).contiguous()
+
+
+def save_mask_bytes(model: ModelDesc, save_mask: Optional[Sequence[bool]]):
+    names = model.compartment_names
+    if save_mask is None:
+        return None, names, model.compartment_sizes
+    mask = [bool(v) for v in save_mask]
+    if len(mask) != len(names):
+        raise ValueError(f"save_mask needs {len(names)} entries ({names}), got {len(mask)}")
+    saved = tuple(n for n, m in zip(names, mask) if m)
+    sizes = tuple(s for s, m in zip(model.compartment_sizes, mask) if m)
+    return (ctypes.c_uint8 * len(mask))(*[int(v) for v in mask]), saved, sizes
+
+
+def solve_batch(model: ModelDesc, y0, params, contact, t1: float, save_ts, *, t0: float = 0.0,
+                method: str = "tsit5", dtype: torch.dtype = torch.float32, rtol: float = 1e-5,
+                atol: float = 1e-6, max_steps: int = 10**6, constant_dt: float = 0.0,
+                jump_ts: Sequence[float] = (), save_mask: Optional[Sequence[bool]] = None,
+                out: Optional[torch.Tensor] = None, stats_out: Optional[tuple] = None,
+                stream: Optional[torch.cuda.Stream] = None) -> BatchResult:
+    """Integrate B parameter samples of ``model`` over [t0, t1] on the current GPU.
+
+    Replaces the per-sample ``diffeqsolve`` call of dynode.simulation.simulate
+    (/root/reference/src/dynode/simulation/odes.py:133-144).  Asynchronous: work is enqueued
+    on ``stream`` (default: torch's current stream); nothing is synchronised here.
+    """
+    device = require_gpu()
+    L = _abi.lib()
+    D, P, A = model.state_dim, model.param_dim, model.n_age
+    params_t = _dev(params, dtype, device).reshape(-1, P)
+    B = params_t.shape[0]
+    y0_t = _dev(y0, dtype, device)
+    batched = y0_t.dim() == 2
+    if tuple(y0_t.shape) != ((B, D) if batched else (D,)):
+        raise ValueError(f"y0 has shape {tuple(y0_t.shape)}, expected {(D,)} or {(B, D)}")
+    contact_t = _dev(contact, dtype, device)
+    if contact_t.numel() != A * A:
+        raise ValueError(f"contact matrix must have {A}x{A} entries")
+    ts_t = _dev(save_ts, dtype, device).reshape(-1)
+    n_save = ts_t.shape[0]
+    mask_c, saved, sizes = save_mask_bytes(model, save_mask)
+    d_saved = int(sum(sizes))
+    if out is None:
+        out = torch.empty((B, n_save, d_saved), dtype=dtype, device=device)
+    elif tuple(out.shape) != (B, n_save, d_saved) or out.dtype != dtype or not out.is_contiguous():
+        raise ValueError("`out` must be a contiguous [B, n_save, D_saved] tensor of `dtype`")
+    if stats_out is None:
+        stats = torch.empty((3, B), dtype=torch.int32, device=device)
+        status, n_acc, n_rej = stats[0], stats[1], stats[2]
+    else:
+        status, n_acc, n_rej = stats_out
+    jt = np.ascontiguousarray(jump_ts, dtype=np.float64)
+    opts = _abi.SolverOptsC(
+        _METHODS[method], _DTYPES[dtype], float(rtol), float(atol), int(max_steps),
+        float(constant_dt),
+        jt.ctypes.data_as(ctypes.POINTER(ctypes.c_double)) if jt.size else None, int(jt.size))
+    s = stream if stream is not None else torch.cuda.current_stream(device)
+    rc = L.dyn_solve_batch(
+        ctypes.byref(model.c()), ctypes.byref(opts), y0_t.data_ptr(), int(batched),
+        params_t.data_ptr(), contact_t.data_ptr(), B, float(t0), float(t1), ts_t.data_ptr(),
+        n_save, mask_c, out.data_ptr(), status.data_ptr(), n_acc.data_ptr(), n_rej.data_ptr(),
+        ctypes.c_void_p(s.cuda_stream))
+    if rc != 0:
+        raise SolveError(rc, L.dyn_last_error().decode())
+    # keep inputs alive until the stream has consumed them
+    for t in (y0_t, params_t, contact_t, ts_t):
+        t.record_stream(s)
+    return BatchResult(out, status, n_acc, n_rej, saved, sizes)
