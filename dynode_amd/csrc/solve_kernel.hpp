@@ -123,10 +123,45 @@ struct Tab<1> { // Dopri5
 };
 
 // ---------------------------------------------------------------- cross-lane helpers
-// Lane `a` of a group reads the value held by lane `a ^ K` of the same group.
+// xchg_xor<K>(v): lane l receives the value held by lane l ^ K.  Built from DPP row
+// permutations (VALU operand modifiers: no LDS pipe, no lgkmcnt wait) composed as
+//   K in 1..3  : quad_perm            K in 4..7  : row_half_mirror (l -> l^7) then quad_perm
+//   K in 8..15 : row_mirror (l -> l^15) then the K^15 case
+//   K in 16..31: ds_swizzle xor 16 first;   K >= 32: ds_bpermute xor 32 first.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(
+        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xF, 0xF, true);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ float swz_xor16(float v) {
+    return __builtin_bit_cast(float,
+                              __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));
+}
+__device__ __forceinline__ double swz_xor16(double v) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_ds_swizzle((int)b, 0x401F);
+    const int hi = __builtin_amdgcn_ds_swizzle((int)(b >> 32), 0x401F);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+
 template <int K, typename T>
 __device__ __forceinline__ T xchg_xor(T v) {
-    return __shfl_xor(v, K, 64);
+    static_assert(K >= 0 && K < 64, "lane xor out of range");
+    if constexpr (K == 0) return v;
+    else if constexpr (K == 1) return dpp_mov<0xB1>(v); // quad_perm [1,0,3,2]
+    else if constexpr (K == 2) return dpp_mov<0x4E>(v); // quad_perm [2,3,0,1]
+    else if constexpr (K == 3) return dpp_mov<0x1B>(v); // quad_perm [3,2,1,0]
+    else if constexpr (K < 8) return xchg_xor<(K ^ 7)>(dpp_mov<0x141>(v));   // row_half_mirror
+    else if constexpr (K < 16) return xchg_xor<(K ^ 15)>(dpp_mov<0x140>(v)); // row_mirror
+    else if constexpr (K < 32) return xchg_xor<(K ^ 16)>(swz_xor16(v));
+    else return xchg_xor<(K ^ 32)>(__shfl_xor(v, 32, 64));
 }
 
 template <int G, typename T>
@@ -453,7 +488,8 @@ struct Solver {
                 keep = err < T(1);
                 finite = (err == err) && (err < M::inf());
                 // factor = clip(safety * err^(-1/order), keep ? 1 : factormin, factormax)
-                T f = (err == T(0)) ? T(0.9) : T(0.9) * M::pow_fast(err, T(-0.2));
+                // err == 0 -> +inf -> clipped to factormax
+                T f = T(0.9) * M::pow_fast(err, T(-0.2));
                 f = M::max(f, keep ? T(1) : T(0.2));
                 factor = M::min(f, T(10));
             } else {

@@ -106,6 +106,8 @@ def solve_batch(model: ModelDesc, y0, params, contact, t1: float, save_ts, *, t0
         status, n_acc, n_rej = stats[0], stats[1], stats[2]
     else:
         status, n_acc, n_rej = stats_out
+    if B == 0:  # empty batch: nothing to enqueue (zero-size tensors have null data pointers)
+        return BatchResult(out, status, n_acc, n_rej, saved, sizes)
     jt = np.ascontiguousarray(jump_ts, dtype=np.float64)
     opts = _abi.SolverOptsC(
         _METHODS[method], _DTYPES[dtype], float(rtol), float(atol), int(max_steps),

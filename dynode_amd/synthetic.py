@@ -1,0 +1,135 @@
+"""Synthetic epidemic ensembles for the BASELINE.json configs (recipes: SURVEY.md 8d).
+
+Pure numpy, deterministic per seed; used by bench.py, the smoke test and the parity tests.
+Every generator returns a :class:`Workload` whose arrays are float64 on the host; callers
+cast to the solve dtype.  Literal constants cite the reference example they come from.
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+
+from ._abi import ModelDesc
+
+
+@dataclass
+class Workload:
+    name: str
+    model: ModelDesc
+    y0: np.ndarray        # [D] or [B, D]
+    params: np.ndarray    # [B, P]
+    contact: np.ndarray   # [A, A]
+    t1: float
+    save_ts: np.ndarray   # [n_save]
+    population: float     # scale of the state, for norm-wise error reporting
+
+    @property
+    def B(self) -> int:
+        return self.params.shape[0]
+
+    @property
+    def n_save(self) -> int:
+        return self.save_ts.shape[0]
+
+    def bytes_per_trajectory(self, itemsize: int = 4, d_saved: int | None = None) -> int:
+        """Algorithmic HBM bytes per trajectory: w * (P + [y0 if batched] + n_save * D_saved)."""
+        d = self.model.state_dim if d_saved is None else d_saved
+        y0 = self.model.state_dim if self.y0.ndim == 2 else 0
+        return itemsize * (self.model.param_dim + y0 + self.n_save * d)
+
+
+def save_grid(t1: float, step: int = 1) -> np.ndarray:
+    """linspace(0, T, T//step + 1) -- reference odes.py:177-180 (not arange)."""
+    if step <= 0:
+        step = 1
+    return np.linspace(0.0, t1, int(t1 // step) + 1)
+
+
+def contact_matrix(rng: np.random.Generator, A: int) -> np.ndarray:
+    """Symmetric positive matrix normalised by its spectral radius (sir_age_stratified.py:81-85)."""
+    M = rng.uniform(0.05, 1.0, (A, A))
+    C = 0.5 * (M + M.T) + 2.0 * np.eye(A)
+    return C / np.max(np.real(np.linalg.eigvals(C)))
+
+
+def _trunc_normal(rng, loc, scale, low, high, size):
+    out = rng.normal(loc, scale, size)
+    bad = (out < low) | (out > high)
+    while bad.any():
+        out[bad] = rng.normal(loc, scale, int(bad.sum()))
+        bad = (out < low) | (out > high)
+    return out
+
+
+def sir_literal() -> Workload:
+    """cfg 1(i): examples/sir.py literal -- 1 bin, y0=(0.9,0.1,0), r0=2, T_inf=7 (sir.py:34,43,90-91)."""
+    model = ModelDesc(n_age=1)
+    return Workload("sir_literal", model, np.array([0.9, 0.1, 0.0]),
+                    np.array([[2.0 / 7.0, 1.0 / 7.0]]), np.array([[1.0]]), 150.0,
+                    save_grid(150.0), 1.0)
+
+
+def sir_two_age_literal(t1: float = 100.0, r0: float = 2.0, infectious_period: float = 7.0) -> Workload:
+    """cfg 1(ii): the 2-age model of examples/sir_age_stratified.py:46-66,70,81-85,118-119."""
+    model = ModelDesc(n_age=2)
+    demo = np.array([0.75, 0.25])
+    y0 = np.concatenate([1000 * 0.99 * demo, 1000 * 0.01 * demo, np.zeros(2)])
+    C = np.array([[0.7, 0.3], [0.3, 0.7]])
+    C = C / np.max(np.real(np.linalg.eigvals(C)))
+    params = np.array([[r0 / infectious_period, 1.0 / infectious_period]])
+    return Workload("sir_two_age_literal", model, y0, params, C, t1, save_grid(t1), 1000.0)
+
+
+def sir_age_stratified(B: int = 4096, seed: int = 0, A: int = 8, t1: float = 365.0) -> Workload:
+    """cfg 2: A-age SIR, priors of examples/sir_infer_parameters.py:50-56, shared y0 and C."""
+    rng = np.random.default_rng(seed)
+    w = rng.dirichlet(5.0 * np.ones(A))
+    C = contact_matrix(rng, A)
+    r0 = 1.5 + rng.beta(0.5, 0.5, B)
+    t_inf = _trunc_normal(rng, 8.0, 2.0, 2.0, 15.0, B)
+    params = np.stack([r0 / t_inf, 1.0 / t_inf], axis=1)
+    y0 = np.concatenate([0.99 * 1000 * w, 0.01 * 1000 * w, np.zeros(A)])
+    return Workload("sir_age_stratified", ModelDesc(n_age=A), y0, params, C, t1, save_grid(t1),
+                    1000.0)
+
+
+def seirs_multi_strain(B: int = 16384, seed: int = 1, A: int = 8, S: int = 4, W: int = 1,
+                       seasonal: bool = False, t1: float = 365.0) -> Workload:
+    """cfg 3 (and cfg 5 with seasonal=True): A-age x S-strain SEIRS + cumulative incidence.
+
+    RHS/initializer pattern: examples/seirs_multi_strain_age_stratified.py:146-172,213-243;
+    parameter ranges bracket the literals at :46-49; seasonal literals from
+    examples/seirs_seasonal_forcing.py:61-63.  W > 1 is the build-defined Erlang waning chain.
+    """
+    rng = np.random.default_rng(seed)
+    w = rng.dirichlet(5.0 * np.ones(A))
+    C = contact_matrix(rng, A)
+    r0 = rng.uniform(1.8, 2.8, (B, S))
+    t_inf = rng.uniform(5.0, 9.0, (B, S))
+    t_lat = rng.uniform(2.0, 4.0, (B, S))
+    t_wane = rng.uniform(50.0, 90.0, (B, S))
+    cols = [r0 / t_inf, 1.0 / t_inf, 1.0 / t_lat, 1.0 / t_wane]
+    if seasonal:
+        cols += [rng.uniform(0.0, 0.4, (B, 1)), rng.uniform(0.0, 2 * np.pi, (B, 1)),
+                 np.full((B, 1), 365.0)]
+    params = np.concatenate(cols, axis=1)
+    model = ModelDesc(n_age=A, n_strain=S, has_e=True, has_wane=True, has_c=True, n_wane=W,
+                      seasonal=seasonal)
+    D = model.state_dim
+    y0 = np.zeros((B, D))
+    y0[:, :A] = 1000 * 0.99 * w
+    dom = r0 / r0.sum(axis=1, keepdims=True)
+    off_i = A + A * S
+    y0[:, off_i:off_i + A * S] = (1000 * 0.01 * w[None, :, None] * dom[:, None, :]).reshape(B, -1)
+    name = "seirs_seasonal_forcing_multi_strain" if seasonal else "seirs_multi_strain_age_stratified"
+    return Workload(name, model, y0, params, C, t1, save_grid(t1), 1000.0)
+
+
+WORKLOADS = {
+    "cfg2": lambda B=4096, seed=0: sir_age_stratified(B, seed),
+    "cfg3": lambda B=16384, seed=1: seirs_multi_strain(B, seed),
+    "cfg3w8": lambda B=16384, seed=1: seirs_multi_strain(B, seed, W=8),
+    "cfg5": lambda B=8192, seed=5: seirs_multi_strain(B, seed, seasonal=True),
+}

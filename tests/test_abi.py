@@ -1,0 +1,107 @@
+"""The C-ABI library loads and exports every symbol include/dynode_hip.h declares.
+
+CPU-only: no compute call is made (argument validation happens before any HIP call, so the
+error paths are safe to exercise without a GPU).
+"""
+
+import ctypes
+import os
+import re
+
+import pytest
+
+import helpers as H
+from dynode_amd import ModelDesc, _abi
+
+
+def _declared_symbols():
+    text = open(os.path.join(H.ROOT, "include", "dynode_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return set(re.findall(r"\b(dyn_[a-z_0-9]+)\s*\(", text))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _abi.lib()
+    declared = _declared_symbols()
+    assert declared == set(_abi.EXPORTED_SYMBOLS)
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert lib.dyn_abi_version() == 1
+
+
+def test_no_torch_types_in_the_header():
+    text = open(os.path.join(H.ROOT, "include", "dynode_hip.h")).read()
+    assert "torch" not in text and "at::" not in text and "#include <hip" not in text
+
+
+@pytest.mark.parametrize("m", [
+    ModelDesc(n_age=1), ModelDesc(n_age=8), ModelDesc(n_age=1, has_e=True, has_wane=True, seasonal=True),
+    ModelDesc(n_age=2, n_strain=3, has_e=True, has_wane=True, has_c=True),
+    ModelDesc(n_age=8, n_strain=4, has_e=True, has_wane=True, has_c=True, n_wane=8),
+])
+def test_dimension_queries_agree_with_python_mirror_and_oracle(m):
+    lib = _abi.lib()
+    c = m.c()
+    assert lib.dyn_state_dim(ctypes.byref(c)) == m.state_dim == H.O.state_dim(H.omodel(m))
+    assert lib.dyn_param_dim(ctypes.byref(c)) == m.param_dim == H.O.param_dim(H.omodel(m))
+    n = lib.dyn_n_compartments(ctypes.byref(c))
+    assert n == len(m.compartment_names)
+    off = (ctypes.c_int32 * 8)()
+    assert lib.dyn_compartment_offsets(ctypes.byref(c), off) == n
+    sizes = tuple(off[i + 1] - off[i] for i in range(n))
+    assert sizes == m.compartment_sizes
+    assert list(off[:n + 1]) == list(H.O.compartment_offsets(H.omodel(m)))
+
+
+def test_trajectories_per_wave():
+    lib = _abi.lib()
+    for A, want in ((1, 64), (2, 32), (3, 16), (8, 8), (9, 4), (33, 1), (64, 1)):
+        assert lib.dyn_trajectories_per_wave(ctypes.byref(ModelDesc(n_age=A).c())) == want
+    assert lib.dyn_trajectories_per_wave(ctypes.byref(ModelDesc(n_age=65).c())) == 0
+
+
+def _opts(**kw):
+    d = dict(method=0, dtype=0, rtol=1e-5, atol=1e-6, max_steps=10**6, constant_dt=0.0, jump_ts=None, n_jump=0)
+    d.update(kw)
+    return _abi.SolverOptsC(**d)
+
+
+def test_supported_shapes_cover_the_baseline_configs():
+    lib = _abi.lib()
+    for m in (ModelDesc(n_age=1), ModelDesc(n_age=2), ModelDesc(n_age=8),
+              ModelDesc(n_age=1, has_e=True, has_wane=True),
+              ModelDesc(n_age=2, n_strain=3, has_e=True, has_wane=True, has_c=True),
+              ModelDesc(n_age=8, n_strain=4, has_e=True, has_wane=True, has_c=True)):
+        assert lib.dyn_is_supported(ctypes.byref(m.c()), ctypes.byref(_opts())) == 1, m
+    assert lib.dyn_is_supported(ctypes.byref(ModelDesc(n_age=8, n_strain=7).c()), ctypes.byref(_opts())) == 0
+
+
+def test_argument_errors_are_codes_not_crashes():
+    lib = _abi.lib()
+    m, o = ModelDesc(n_age=8).c(), _opts()
+    one = ctypes.c_void_p(16)  # never dereferenced: validation fails first
+
+    def call(model=m, opts=o, y0=one, B=4, t1=10.0, n_save=2, save_ts=one, out=one):
+        return lib.dyn_solve_batch(ctypes.byref(model), ctypes.byref(opts), y0, 0, one, one, B, 0.0, t1, save_ts,
+                                   n_save, None, out, one, one, one, None)
+
+    assert call(y0=None) == -1                                   # DYN_ERR_NULL
+    assert call(model=ModelDesc(n_age=0).c()) == -2              # DYN_ERR_MODEL
+    assert call(model=ModelDesc(n_age=2, n_wane=3).c()) == -2    # W > 1 needs waning
+    assert call(B=-1) == -3                                      # DYN_ERR_SIZE
+    assert call(save_ts=None) == -3
+    assert call(opts=_opts(method=5)) == -4                      # DYN_ERR_OPTS
+    assert call(opts=_opts(rtol=0.0)) == -5                      # DYN_ERR_TOL (params.py: PositiveFloat)
+    assert call(opts=_opts(max_steps=0)) == -5
+    assert call(t1=-1.0) == -5
+    assert call(opts=_opts(n_jump=2)) == -6                      # DYN_ERR_JUMP
+    assert call(model=ModelDesc(n_age=8, n_strain=7).c()) == -7  # DYN_ERR_UNSUPPORTED
+    assert b"no kernel compiled" in lib.dyn_last_error()
+    assert call(B=0) == 0                                        # empty batch: nothing enqueued
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    monkeypatch.setattr(_abi, "_lib", None)
+    monkeypatch.setattr(_abi, "LIB_PATH", "/nonexistent/libdynode_hip.so")
+    with pytest.raises(_abi.HipLibraryMissing):
+        _abi.lib()

@@ -1,0 +1,252 @@
+"""Parity tests proper: the HIP path, called through the C-ABI, against the CPU oracle.
+
+Bars (north_star: trajectories within rtol=1e-5 of the CPU path):
+  fp64 : |hip - oracle| / scale < 1e-11 and IDENTICAL accepted/rejected step counts -- the
+         two implementations run the same algorithm; only summation order / FMA contraction differ.
+  fp32 : |hip - oracle| / scale < 1e-5 (norm-wise, scale = population), the reference's dtype.
+At BASELINE.json's full sizes the oracle is too slow, so size-independent properties are used:
+mass conservation, exact first row, batch-position invariance, bitwise determinism.
+"""
+
+import numpy as np
+import pytest
+import torch
+from scipy.optimize import root_scalar
+
+import helpers as H
+from dynode_amd import ModelDesc, synthetic
+from dynode_amd.engine import SolveError, solve_batch
+
+pytestmark = pytest.mark.gpu
+O = H.O
+F32, F64 = torch.float32, torch.float64
+NP = {F32: np.float32, F64: np.float64}
+
+
+def hip(m, y0, p, C, t1, ts, **kw):
+    r = solve_batch(m, y0, np.atleast_2d(p), C, float(t1), ts, **kw)
+    torch.cuda.synchronize()
+    return r.ys.cpu().numpy(), r.status.cpu().numpy(), r.n_accept.cpu().numpy(), r.n_reject.cpu().numpy()
+
+
+def random_workload(m, B, seed, t1=200.0):
+    """Generic random ensemble for any member of the RHS family."""
+    rng = np.random.default_rng(seed)
+    A, S, W = m.n_age, m.n_strain, m.n_wane
+    C = synthetic.contact_matrix(rng, A) if A > 1 else np.array([[1.0]])
+    C = C * rng.uniform(0.8, 1.2, (A, A))  # asymmetric on purpose
+    r0 = rng.uniform(1.5, 3.0, (B, S)); ti = rng.uniform(4, 9, (B, S))
+    cols = [r0 / ti, 1 / ti]
+    if m.has_e:
+        cols.append(1 / rng.uniform(2, 4, (B, S)))
+    if m.has_wane:
+        cols.append(1 / rng.uniform(40, 90, (B, S)))
+    if m.seasonal:
+        cols += [rng.uniform(0, 0.4, (B, 1)), rng.uniform(0, 2 * np.pi, (B, 1)), np.full((B, 1), 365.0)]
+    params = np.concatenate(cols, 1)
+    w = rng.dirichlet(5 * np.ones(A))
+    y0 = np.zeros((B, m.state_dim))
+    y0[:, :A] = 990 * w
+    off_i = A + (A * S if m.has_e else 0)
+    y0[:, off_i:off_i + A * S] = (10 * w[None, :, None] * rng.dirichlet(np.ones(S), B)[:, None, :]).reshape(B, -1)
+    return y0, params, C, t1, synthetic.save_grid(t1)
+
+
+SHAPES = [
+    ModelDesc(n_age=1), ModelDesc(n_age=2), ModelDesc(n_age=3), ModelDesc(n_age=6), ModelDesc(n_age=8),
+    ModelDesc(n_age=13),
+    ModelDesc(n_age=1, has_e=True, has_wane=True), ModelDesc(n_age=1, has_e=True, has_wane=True, seasonal=True),
+    ModelDesc(n_age=2, has_e=True, has_wane=True), ModelDesc(n_age=7, has_e=True, has_wane=True),
+    ModelDesc(n_age=2, n_strain=3, has_e=True, has_wane=True, has_c=True),
+    ModelDesc(n_age=2, n_strain=4, has_e=True, has_wane=True, has_c=True),
+    ModelDesc(n_age=8, n_strain=4, has_e=True, has_wane=True, has_c=True),
+    ModelDesc(n_age=8, n_strain=4, has_e=True, has_wane=True, has_c=True, seasonal=True),
+    ModelDesc(n_age=5, n_strain=4, has_e=True, has_wane=True, has_c=True),
+]
+
+
+def _supported(m, dtype, method):
+    import ctypes
+    from dynode_amd import _abi
+    o = _abi.SolverOptsC(method={"tsit5": 0, "dopri5": 1}[method], dtype=0 if dtype == F32 else 1, rtol=1e-5,
+                         atol=1e-6, max_steps=10**6, constant_dt=0.0, jump_ts=None, n_jump=0)
+    return bool(_abi.lib().dyn_is_supported(ctypes.byref(m.c()), ctypes.byref(o)))
+
+
+@pytest.mark.parametrize("method", ["tsit5", "dopri5"])
+@pytest.mark.parametrize("dtype", [F64, F32])
+@pytest.mark.parametrize("m", SHAPES, ids=lambda m: f"A{m.n_age}S{m.n_strain}e{int(m.has_e)}w{int(m.has_wane)}c{int(m.has_c)}s{int(m.seasonal)}")
+def test_hip_matches_oracle(m, dtype, method):
+    if not _supported(m, dtype, method):
+        pytest.skip("shape not compiled for this dtype/method")
+    B = 67  # ragged: not a multiple of any trajectories-per-wave
+    y0, p, C, t1, ts = random_workload(m, B, seed=42 + m.state_dim)
+    got, st, na, nr = hip(m, y0, p, C, t1, ts, dtype=dtype, method=method)
+    want, st_o, na_o, nr_o = O.solve(H.omodel(m), y0, p, C, t1, ts, dtype=NP[dtype], method=method, n_threads=8)
+    assert st.max() == 0 and st_o.max() == 0
+    err = np.abs(got - want).max() / 1000.0
+    if dtype == F64:
+        assert err < 1e-11, err
+        assert np.array_equal(na, na_o) and np.array_equal(nr, nr_o)
+    else:
+        assert err < 1e-5, err
+        # fp32 error estimates carry ~1e-3 relative rounding noise (cancellation in sum berr*k), so
+        # accept/reject decisions with err within that band of 1 flip between implementations
+        d = np.abs(na.astype(int) + nr - na_o - nr_o)
+        assert d.max() <= 8 and np.median(d) <= 2
+
+
+GT = np.load(H.GOLDEN + "/ground_truth.npz")
+
+
+@pytest.mark.parametrize("name", [str(n) for n in GT["names"]])
+def test_hip_vs_scipy_ground_truth(name):
+    f = [int(v) for v in GT[f"{name}/model"]]
+    m = ModelDesc(f[0], f[1], bool(f[2]), bool(f[3]), bool(f[4]), f[5], bool(f[6]), bool(f[7]))
+    if not _supported(m, F32, "tsit5"):
+        pytest.skip("shape not compiled")
+    y0, p, C, t1, ts, want = (GT[f"{name}/{k}"] for k in ("y0", "params", "contact", "t1", "ts", "ys"))
+    scale = np.abs(want).max()
+    got, st, _, _ = hip(m, y0, p, C, float(t1), ts, dtype=F32)
+    assert st[0] == 0 and np.abs(got[0] - want).max() / scale < 2e-4   # solver-tolerance level (defaults)
+    if _supported(m, F64, "tsit5"):
+        got, st, _, _ = hip(m, y0, p, C, float(t1), ts, dtype=F64, rtol=1e-10, atol=1e-10 * scale)
+        assert st[0] == 0 and np.abs(got[0] - want).max() / scale < 2e-8
+
+
+# ------------------------------------------------------------------ BASELINE sizes, property checks
+@pytest.mark.parametrize("wl", [synthetic.sir_age_stratified(4096, seed=0), synthetic.seirs_multi_strain(16384, seed=1),
+                                synthetic.seirs_multi_strain(8192, seed=5, seasonal=True)], ids=lambda w: w.name)
+def test_full_size_properties(wl):
+    m = wl.model
+    r = solve_batch(m, wl.y0, wl.params, wl.contact, wl.t1, wl.save_ts, dtype=F32)
+    r2 = solve_batch(m, wl.y0, wl.params, wl.contact, wl.t1, wl.save_ts, dtype=F32)
+    torch.cuda.synchronize()
+    assert int(r.status.max()) == 0
+    ys = r.ys
+    assert ys.shape == (wl.B, 366, m.state_dim) and bool(torch.isfinite(ys).all())
+    assert torch.equal(ys, r2.ys)                                         # bitwise deterministic
+    y0 = torch.as_tensor(np.broadcast_to(wl.y0, (wl.B, m.state_dim)).astype(np.float32), device="cuda")
+    assert torch.equal(ys[:, 0, :], y0)                                   # test_odes.py:63-74
+    n_pop = m.state_dim - (m.n_age * m.n_strain if m.has_c else 0)        # c is book-keeping, not population
+    total = ys[:, :, :n_pop].double().sum(-1)
+    assert float((total - 1000.0).abs().max()) < 5e-3                     # mass conservation (fp32, N=1000)
+    assert float(ys.min()) > -1e-3
+    if m.has_c:
+        c = ys[:, :, n_pop:]
+        assert float((c[:, 1:] - c[:, :-1]).min()) > -1e-3                # cumulative incidence never decreases
+    # batch-position invariance: a trajectory's bits do not depend on its lane group or wave
+    perm = torch.randperm(wl.B, generator=torch.Generator().manual_seed(0)).numpy()
+    y0p = wl.y0[perm] if wl.y0.ndim == 2 else wl.y0
+    rp = solve_batch(m, y0p, wl.params[perm], wl.contact, wl.t1, wl.save_ts, dtype=F32)
+    assert torch.equal(rp.ys, ys[torch.as_tensor(perm, device="cuda")])
+    # spot-check 64 trajectories against the oracle
+    idx = np.arange(0, wl.B, wl.B // 64)[:64]
+    y0s = wl.y0[idx] if wl.y0.ndim == 2 else wl.y0
+    want, _, _, _ = O.solve(H.omodel(m), y0s, wl.params[idx], wl.contact, wl.t1, wl.save_ts, dtype=np.float32, n_threads=8)
+    assert np.abs(ys[torch.as_tensor(idx, device="cuda")].cpu().numpy() - want).max() / 1000.0 < 1e-5
+
+
+# ------------------------------------------------------------------ edge cases of the boundary
+SIR1 = ModelDesc(n_age=1)
+UNNORM = ModelDesc(n_age=1, normalize=False)
+
+
+@pytest.mark.parametrize("B", [1, 2, 63, 64, 65, 129])
+def test_ragged_batches(B):
+    m = ModelDesc(n_age=2)
+    y0, p, C, t1, ts = random_workload(m, B, seed=B, t1=60.0)
+    got, st, _, _ = hip(m, y0, p, C, t1, ts, dtype=F64)
+    want, _, _, _ = O.solve(H.omodel(m), y0, p, C, t1, ts, dtype=np.float64)
+    assert got.shape == (B, 61, 6) and st.max() == 0
+    assert np.abs(got - want).max() / 1000 < 1e-11
+
+
+def test_empty_batch_and_single_save_point():
+    r = solve_batch(SIR1, [0.9, 0.1, 0.0], np.zeros((0, 2)), [[1.0]], 10.0, synthetic.save_grid(10))
+    assert r.ys.shape == (0, 11, 3)
+    got, st, _, _ = hip(SIR1, [0.9, 0.1, 0.0], [2 / 7, 1 / 7], [[1.0]], 10.0, np.array([0.0]))
+    assert got.shape == (1, 1, 3) and np.array_equal(got[0, 0], np.float32([0.9, 0.1, 0.0]))
+
+
+@pytest.mark.parametrize("days", [50, 100, 200, 300.0])
+def test_expected_shapes_and_first_row(days):
+    """reference tests/test_simulation/test_odes.py:45-74."""
+    got, st, _, _ = hip(UNNORM, [99.0, 1.0, 0.0], [2 / 7, 1 / 7], [[1.0]], days, synthetic.save_grid(days))
+    assert got.shape == (1, int(days) + 1, 3) and st[0] == 0
+    assert np.array_equal(got[0, 0], np.float32([99.0, 1.0, 0.0]))
+
+
+@pytest.mark.parametrize("save_step", [1, 2, 3, 7])
+def test_save_step(save_step):
+    """reference tests/test_simulation/test_odes.py:77-92."""
+    ts = synthetic.save_grid(100, save_step)
+    got, _, _, _ = hip(UNNORM, [99.0, 1.0, 0.0], [2 / 7, 1 / 7], [[1.0]], 100, ts, dtype=F64)
+    want, _, _, _ = O.solve(H.omodel(UNNORM), [99.0, 1.0, 0.0], [[2 / 7, 1 / 7]], [[1.0]], 100, ts, dtype=np.float64)
+    assert got.shape == (1, int(100 / save_step) + 1, 3)
+    assert np.abs(got - want).max() < 1e-10
+
+
+@pytest.mark.parametrize("mask", [(1, 0, 0), (0, 1, 0), (0, 0, 1), (1, 1, 0), (1, 0, 1), (0, 1, 1), (1, 1, 1)])
+def test_sub_save_indices(mask):
+    """reference tests/test_simulation/test_odes.py:95-120 (SubSaveAt)."""
+    m = ModelDesc(n_age=8)
+    y0, p, C, t1, ts = random_workload(m, 9, seed=5, t1=100.0)
+    full, _, _, _ = hip(m, y0, p, C, t1, ts)
+    sub, _, _, _ = hip(m, y0, p, C, t1, ts, save_mask=mask)
+    cols = np.concatenate([np.arange(8) + 8 * j for j in range(3) if mask[j]])
+    assert sub.shape == (9, 101, cols.size)
+    np.testing.assert_array_equal(sub, full[:, :, cols])
+
+
+def test_sub_save_multi_strain_only_cumulative():
+    m = ModelDesc(n_age=8, n_strain=4, has_e=True, has_wane=True, has_c=True)
+    y0, p, C, t1, ts = random_workload(m, 20, seed=9, t1=120.0)
+    full, _, _, _ = hip(m, y0, p, C, t1, ts)
+    sub, _, _, _ = hip(m, y0, p, C, t1, ts, save_mask=(0, 0, 0, 0, 1))
+    np.testing.assert_array_equal(sub, full[:, :, -32:])
+
+
+def test_max_steps_status_and_inf_rows():
+    got, st, na, nr = hip(SIR1, [0.99, 0.01, 0.0], [2 / 7, 1 / 7], [[1.0]], 300, synthetic.save_grid(300), max_steps=5)
+    want, st_o, na_o, nr_o = O.solve(H.omodel(SIR1), [0.99, 0.01, 0.0], [[2 / 7, 1 / 7]], [[1.0]], 300,
+                                     synthetic.save_grid(300), max_steps=5)
+    assert st[0] == 1 == st_o[0] and na[0] + nr[0] == 5
+    assert np.isinf(got[0, -1]).all() and np.array_equal(np.isinf(got), np.isinf(want))
+
+
+def test_nonfinite_parameters_are_flagged():
+    p = np.array([[2 / 7, 1 / 7], [np.nan, 1 / 7], [2 / 7, 1 / 7]])
+    got, st, _, _ = hip(SIR1, [0.99, 0.01, 0.0], p, [[1.0]], 50, synthetic.save_grid(50))
+    assert list(st) == [0, 2, 0]
+    assert np.isfinite(got[[0, 2]]).all() and np.array_equal(got[0], got[2])
+
+
+def test_constant_step_size():
+    got, st, na, nr = hip(SIR1, [0.99, 0.01, 0.0], [2 / 7, 1 / 7], [[1.0]], 100, synthetic.save_grid(100),
+                          constant_dt=0.5, dtype=F64)
+    want, _, na_o, _ = O.solve(H.omodel(SIR1), [0.99, 0.01, 0.0], [[2 / 7, 1 / 7]], [[1.0]], 100,
+                               synthetic.save_grid(100), constant_dt=0.5, dtype=np.float64)
+    assert st[0] == 0 and nr[0] == 0 and na[0] == 200 == na_o[0]
+    assert np.abs(got - want).max() < 1e-12
+
+
+def test_zero_infection_state_reaches_t1():
+    """reference tests/test_sir_dynamics/test_sir.py:75 (i0 = 0): zero error must grow the step."""
+    got, st, na, _ = hip(SIR1, [0.8, 0.0, 0.2], [2 / 7, 1 / 7], [[1.0]], 120, synthetic.save_grid(120))
+    assert st[0] == 0 and na[0] < 50 and np.all(got[0] == np.float32([0.8, 0.0, 0.2]))
+
+
+@pytest.mark.parametrize("s0,i0", [(0.99, 0.01), (0.95, 0.05), (0.90, 0.10), (0.80, 0.20)])
+def test_final_size_on_gpu(s0, i0):
+    """reference tests/test_sir_dynamics/test_sir.py:18-65."""
+    got, _, _, _ = hip(SIR1, [s0, i0, 0.0], [2 / 7, 1 / 7], [[1.0]], 300, synthetic.save_grid(300))
+    s_inf = root_scalar(lambda x: x - s0 * np.exp(-2.0 * (1 - x)), bracket=[0.0, s0], method="bisect", xtol=1e-8).root
+    assert got[0, -1, 2] == pytest.approx(1 - s_inf, abs=2e-2)
+
+
+def test_unsupported_shape_and_jumps_fail_loudly():
+    with pytest.raises(SolveError, match="UNSUPPORTED"):
+        solve_batch(ModelDesc(n_age=8, n_strain=7), np.zeros(8 * 15), np.zeros((1, 14)), np.eye(8), 10.0, [0.0, 10.0])
+    with pytest.raises(SolveError, match="UNSUPPORTED"):
+        solve_batch(SIR1, [0.9, 0.1, 0], [[0.3, 0.1]], [[1.0]], 10.0, [0.0, 10.0], jump_ts=[5.0])
