@@ -11,7 +11,8 @@ import os
 from dataclasses import dataclass
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libdynode_hip.so")
+# DYNODE_HIP_LIB overrides the library path (diagnostic builds only)
+LIB_PATH = os.environ.get("DYNODE_HIP_LIB") or os.path.join(_HERE, "lib", "libdynode_hip.so")
 
 DYN_TSIT5, DYN_DOPRI5 = 0, 1
 DYN_F32, DYN_F64 = 0, 1

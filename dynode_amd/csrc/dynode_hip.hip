@@ -199,6 +199,12 @@ int dyn_solve_batch(const dyn_model_desc *m, const dyn_solver_opts *o, const voi
     if (!(o->constant_dt > 0.0) && (!(o->rtol > 0.0) || !(o->atol > 0.0))) return DYN_ERR_TOL;
     if (o->max_steps < 1 || !(t1 >= t0)) return DYN_ERR_TOL;
     if (o->n_jump < 0 || (o->n_jump > 0 && !o->jump_ts)) return DYN_ERR_JUMP;
+    if ((size_t)n_save * (o->dtype == DYN_F64 ? 8 : 4) > DYN_MAX_SAVE_BYTES) {
+        snprintf(dyn::tl_error, sizeof(dyn::tl_error),
+                 "save grid of %d points exceeds the %d-byte LDS table: split the solve in time",
+                 n_save, DYN_MAX_SAVE_BYTES);
+        return DYN_ERR_UNSUPPORTED;
+    }
     if (o->n_jump > 0) {
         snprintf(dyn::tl_error, sizeof(dyn::tl_error),
                  "discontinuity_points are not supported by the HIP path yet");

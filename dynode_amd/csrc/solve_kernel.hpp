@@ -52,6 +52,11 @@ struct Mth<float> {
     static __device__ __forceinline__ float sin(float x) { return sinf(x); }
     // 1-ulp hardware reciprocal: used only for the error-norm scaling
     static __device__ __forceinline__ float rcp_fast(float x) { return __builtin_amdgcn_rcpf(x); }
+    // 1/x to ~1 ulp: v_rcp_f32 + one Newton step (3 VALU ops instead of the 10-op IEEE sequence)
+    static __device__ __forceinline__ float recip(float x) {
+        const float r = __builtin_amdgcn_rcpf(x);
+        return __builtin_fmaf(__builtin_fmaf(-x, r, 1.0f), r, r);
+    }
     // x^e through v_log_f32 / v_exp_f32: only ever sets the next step size
     static __device__ __forceinline__ float pow_fast(float x, float e) {
         return __builtin_amdgcn_exp2f(e * __builtin_amdgcn_logf(x));
@@ -67,6 +72,7 @@ struct Mth<double> {
     static __device__ __forceinline__ double sqrt(double x) { return ::sqrt(x); }
     static __device__ __forceinline__ double sin(double x) { return ::sin(x); }
     static __device__ __forceinline__ double rcp_fast(double x) { return 1.0 / x; }
+    static __device__ __forceinline__ double recip(double x) { return 1.0 / x; }
     static __device__ __forceinline__ double pow_fast(double x, double e) { return ::pow(x, e); }
     static __device__ __forceinline__ double inf() { return __builtin_huge_val(); }
     static constexpr double clip_tol = 1e-10;
@@ -164,6 +170,48 @@ __device__ __forceinline__ T xchg_xor(T v) {
     else return xchg_xor<(K ^ 32)>(__shfl_xor(v, 32, 64));
 }
 
+// acc_a += sum_j c_j * xa[lane ^ j], acc_b likewise for xb, j = 0..3: the quad_perm rides on
+// the FMA itself (v_fmac_f32_dpp, ~the cost of a plain FMA; a separate v_mov_dpp costs 2x).
+// The two plain FMAs in front give the >= 2 wait states a DPP read needs after a VALU write
+// of its source (hipcc pads nothing inside an asm statement).  EXEC must be all ones.
+__device__ __forceinline__ void fma_quad_pair(float &acc_a, float &acc_b, float xa, float xb,
+                                              float c0, float c1, float c2, float c3) {
+    asm("v_fmac_f32_e32 %0, %2, %4\n\t"
+        "v_fmac_f32_e32 %1, %3, %4\n\t"
+        "v_fmac_f32_dpp %0, %2, %5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %1, %3, %5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %0, %2, %6 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %1, %3, %6 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %0, %2, %7 quad_perm:[3,2,1,0] row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %1, %3, %7 quad_perm:[3,2,1,0] row_mask:0xf bank_mask:0xf"
+        : "+v"(acc_a), "+v"(acc_b)
+        : "v"(xa), "v"(xb), "v"(c0), "v"(c1), "v"(c2), "v"(c3));
+}
+__device__ __forceinline__ void fma_quad_one(float &acc, float x, float c0, float c1, float c2,
+                                             float c3) {
+    asm("v_fmac_f32_e32 %0, %1, %2\n\t"
+        "s_nop 0\n\t"
+        "v_fmac_f32_dpp %0, %1, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %0, %1, %4 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %0, %1, %5 quad_perm:[3,2,1,0] row_mask:0xf bank_mask:0xf"
+        : "+v"(acc)
+        : "v"(x), "v"(c0), "v"(c1), "v"(c2), "v"(c3));
+}
+// generic (double / fallback) versions of the same contraction
+template <typename T>
+__device__ __forceinline__ void fma_quad_one(T &acc, T x, T c0, T c1, T c2, T c3) {
+    acc += c0 * x;
+    acc += c1 * xchg_xor<1>(x);
+    acc += c2 * xchg_xor<2>(x);
+    acc += c3 * xchg_xor<3>(x);
+}
+template <typename T>
+__device__ __forceinline__ void fma_quad_pair(T &acc_a, T &acc_b, T xa, T xb, T c0, T c1, T c2,
+                                              T c3) {
+    fma_quad_one<T>(acc_a, xa, c0, c1, c2, c3);
+    fma_quad_one<T>(acc_b, xb, c0, c1, c2, c3);
+}
+
 template <int G, typename T>
 __device__ __forceinline__ T group_sum(T v) {
     if constexpr (G >= 2) v += xchg_xor<1>(v);
@@ -225,16 +273,25 @@ struct Solver {
         }
         const T N = ((y[0] + se) + si) + sr;
         T invN = T(1);
-        if (normalize) invN = pad ? T(0) : T(1) / N;
+        if (normalize) invN = pad ? T(0) : M::recip(N);
         T season = T(1);
         if (seasonal) season = T(1) + amp * M::sin(w_season * t + phase);
-        T acc[S];
+        T x[S], acc[S];
 #pragma unroll
         for (int l = 0; l < S; ++l) {
-            const T x = y[II + l] * invN;
-            acc[l] = Cx[0] * x;
-            // all-gather of x over the lane group, fused with the contact row
-            if constexpr (G > 1) gather<1>(x, acc[l]);
+            x[l] = y[II + l] * invN;
+            acc[l] = T(0);
+        }
+        // all-gather of x over the lane group, fused with the pre-permuted contact row:
+        // acc_l = sum_k Cx[k] * x_l[lane ^ k]
+        if constexpr (G < 4) {
+#pragma unroll
+            for (int l = 0; l < S; ++l) {
+                acc[l] = Cx[0] * x[l];
+                if constexpr (G == 2) acc[l] += Cx[1] * xchg_xor<1>(x[l]);
+            }
+        } else {
+            gather_base<0>(x, acc); // bases: x, then x^7, x^15, x^8, ... (see gather_base)
         }
         T out_s = 0, back_s = 0;
 #pragma unroll
@@ -270,10 +327,24 @@ struct Solver {
         dy[0] = back_s - out_s;
     }
 
-    template <int K>
-    __device__ __forceinline__ void gather(T x, T &acc) const {
-        acc += Cx[K] * xchg_xor<K>(x);
-        if constexpr (K + 1 < G) gather<K + 1>(x, acc);
+    // Base b of the all-gather covers the four lane offsets {o, o^1, o^2, o^3} with
+    // o = 0 (x itself), 7 (row_half_mirror), 15 (row_mirror), 8 (= 15 then 7), and for wider
+    // groups the same four bases of the xor-16 / xor-32 images.
+    template <int BASE>
+    __device__ __forceinline__ void gather_base(const T (&x)[S], T (&acc)[S]) const {
+        constexpr int o = (BASE & 3) == 0 ? 0 : (BASE & 3) == 1 ? 7 : (BASE & 3) == 2 ? 15 : 8;
+        constexpr int hi = (BASE >> 2) * 16; // 0, 16, 32, 48
+        constexpr int off = o ^ hi;
+        T xb[S];
+#pragma unroll
+        for (int l = 0; l < S; ++l) xb[l] = xchg_xor<off>(x[l]);
+#pragma unroll
+        for (int l = 0; l + 1 < S; l += 2)
+            fma_quad_pair(acc[l], acc[l + 1], xb[l], xb[l + 1], Cx[off], Cx[off ^ 1], Cx[off ^ 2],
+                          Cx[off ^ 3]);
+        if constexpr (S % 2 == 1)
+            fma_quad_one(acc[S - 1], xb[S - 1], Cx[off], Cx[off ^ 1], Cx[off ^ 2], Cx[off ^ 3]);
+        if constexpr ((BASE + 1) * 4 < G) gather_base<BASE + 1>(x, acc);
     }
 
     // dense output at theta in [0,1] for the accepted step (y -> y1), k = stage derivatives
@@ -336,10 +407,18 @@ struct Solver {
 #pragma unroll
         for (int q = 0; q < CNT; ++q) {
             const int j = FIRST + q;
+#ifdef DYN_DIAG_NOMATH
+            v[q] = y[j] + d.theta;
+#else
             v[q] = dense_eval(d, dt, y[j], y1[j], k[0][j], k[1][j], k[2][j], k[3][j], k[4][j],
                               k[5][j], k[6][j]);
+#endif
         }
+#ifdef DYN_DIAG_NOSTORE
+        if (v[0] == T(-12345.678)) store_run<T, CNT>(dst, v, vec_ok);
+#else
         store_run<T, CNT>(dst, v, vec_ok);
+#endif
     }
 
     __device__ __forceinline__ static void run(const KArgs<T> &ka) {
@@ -445,14 +524,30 @@ struct Solver {
 
         int save_idx = 0;
         const int n_save = ka.n_save;
-        T ts_next = n_save > 0 ? ka.save_ts[0] : M::inf();
+        // The save grid lives in LDS: a global load inside the save loop would share the
+        // in-order vmcnt counter with the output stores, and waiting for it would drain every
+        // store of the previous round (measured: the dominant stall of the save path).
+        // LDS reads count on lgkmcnt, so stores stay fire-and-forget.
+        extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
+        T *const ts_tab = reinterpret_cast<T *>(dyn_smem); // LDS address space: ds_read only
+        for (int j = lane; j < n_save; j += 64) ts_tab[j] = ka.save_ts[j];
+        __syncthreads();
+        // next two save times kept in registers (the read of ts[idx+2] overlaps a whole round)
+        T ts_next = n_save > 0 ? ts_tab[0] : M::inf();
+        T ts_next2 = n_save > 1 ? ts_tab[1] : M::inf();
         int64_t steps = 0;
         int32_t n_acc = 0, n_rej = 0, st = ST_OK;
         bool done = !(tprev < t_end);
         T *const out_traj = ka.out + traj * (int64_t)n_save * ka.d_saved;
         const bool vec_ok = ka.vec_ok != 0;
 
+#ifdef DYN_DIAG_ROUNDS
+        int diag_iters = 0, diag_rounds = 0;
+#endif
         while (__any(!done)) {
+#ifdef DYN_DIAG_ROUNDS
+            ++diag_iters;
+#endif
             const T dt = tnext - tprev;
             // ---- stages 2..7 (k[] hold f; k[0] is FSAL)
 #pragma unroll
@@ -509,10 +604,14 @@ struct Solver {
 
             // ---- SaveAt(ts): dense output at every save time in (tprev, tnext]
             bool pending = accept && (save_idx < n_save) && (ts_next <= tnext);
+            const T inv_dt = M::recip(dt);
             while (__any(pending)) {
+#ifdef DYN_DIAG_ROUNDS
+                ++diag_rounds;
+#endif
                 if (pending) {
                     Dense dn;
-                    dense_prepare((ts_next - tprev) / dt, dn);
+                    dense_prepare((ts_next - tprev) * inv_dt, dn);
                     if (writer) {
                         T *row = out_traj + (int64_t)save_idx * ka.d_saved;
                         if (ka.save_off[0] >= 0)
@@ -533,7 +632,8 @@ struct Solver {
                                                   vec_ok);
                     }
                     ++save_idx;
-                    ts_next = save_idx < n_save ? ka.save_ts[save_idx] : M::inf();
+                    ts_next = ts_next2;
+                    ts_next2 = save_idx + 1 < n_save ? ts_tab[save_idx + 1] : M::inf();
                 }
                 pending = accept && (save_idx < n_save) && (ts_next <= tnext);
             }
@@ -586,6 +686,10 @@ struct Solver {
             }
             if (a == 0) {
                 ka.status[traj] = st;
+#ifdef DYN_DIAG_ROUNDS
+                n_acc = diag_iters;
+                n_rej = diag_rounds;
+#endif
                 ka.n_acc[traj] = n_acc;
                 ka.n_rej[traj] = n_rej;
             }
@@ -605,8 +709,9 @@ hipError_t launch(const KArgs<T> &ka, hipStream_t stream) {
     constexpr int TPW = 64 / G;
     const int64_t blocks = (ka.B + TPW - 1) / TPW;
     if (blocks <= 0) return hipSuccess;
+    const size_t lds = (size_t)ka.n_save * sizeof(T); // save grid staged in LDS
     hipLaunchKernelGGL((solve_kernel<T, METHOD, G, S, HAS_E, HAS_WANE, HAS_C, W>),
-                       dim3((unsigned)blocks), dim3(64), 0, stream, ka);
+                       dim3((unsigned)blocks), dim3(64), lds, stream, ka);
     return hipGetLastError();
 }
 

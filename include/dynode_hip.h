@@ -34,6 +34,8 @@ extern "C" {
 #endif
 
 #define DYN_ABI_VERSION 1
+/* the save grid is staged in LDS: n_save * sizeof(real) must not exceed this */
+#define DYN_MAX_SAVE_BYTES 49152
 
 /*
  * One member of the compartmental RHS family (the examples of the reference).

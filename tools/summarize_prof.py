@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Condense a tools/profile.sh run into profiles/<tag>_rocprof_summary.md (+ traffic.json entry).
+
+FETCH_SIZE / WRITE_SIZE are in KiB.  Per MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE reads
+exactly half of a wide coalesced streaming read, so reads are doubled; WRITE_SIZE is exact for
+16-byte-per-lane streaming stores (this kernel's store shape).
+"""
+import csv, glob, json, os, sys, collections
+
+out_dir, tag = sys.argv[1], sys.argv[2]
+extra = sys.argv[3:]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KERNEL = "solve_kernel"
+
+stats = None
+for f in glob.glob(os.path.join(out_dir, "trace", "**", "*kernel_stats.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        if KERNEL in r["Name"]:
+            stats = r
+counters = collections.defaultdict(list)
+meta = {}
+for f in glob.glob(os.path.join(out_dir, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        if KERNEL in r["Kernel_Name"]:
+            counters[r["Counter_Name"]].append(float(r["Counter_Value"]))
+            meta = {k: r[k] for k in ("Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "Scratch_Size")}
+mean = {k: sum(v) / len(v) for k, v in counters.items()}
+
+workload, batch = "cfg3", None
+for i, a in enumerate(extra):
+    if a == "--workload": workload = extra[i + 1]
+    if a == "--batch": batch = int(extra[i + 1])
+defaults = {"cfg2": 4096, "cfg3": 16384, "cfg3w8": 16384, "cfg5": 8192}
+batch = batch or defaults[workload]
+
+lines = [f"# rocprofv3 summary `{tag}` -- bench.py --workload {workload} (B={batch} per GPU)", ""]
+if stats:
+    lines += ["## kernel-trace --stats (20 timed + 3 warm-up launches)", "",
+              "| kernel | calls | avg ns | min ns | max ns | % of GPU time |", "|---|---|---|---|---|---|",
+              f"| `{stats['Name'][:90]}` | {stats['Calls']} | {float(stats['AverageNs']):.0f} | {stats['MinNs']} | {stats['MaxNs']} | {stats['Percentage']} |", ""]
+if meta:
+    lines += ["## dispatch", "", "| " + " | ".join(meta) + " |", "|" + "---|" * len(meta), "| " + " | ".join(meta.values()) + " |", ""]
+if mean:
+    lines += ["## PMC (mean per launch, separate passes)", "", "| counter | value |", "|---|---|"]
+    for k in sorted(mean):
+        lines.append(f"| {k} | {mean[k]:.6g} |")
+    lines.append("")
+hbm = None
+if "FETCH_SIZE" in mean and "WRITE_SIZE" in mean:
+    rd = mean["FETCH_SIZE"] * 1024 * 2      # gfx950 correction: x2 for wide coalesced reads
+    wr = mean["WRITE_SIZE"] * 1024
+    hbm = rd + wr
+    lines += ["## HBM traffic per launch", "",
+              f"- reads  = FETCH_SIZE x 1024 x 2 (gfx950 half-count correction) = {rd/1e6:.2f} MB",
+              f"- writes = WRITE_SIZE x 1024 = {wr/1e6:.2f} MB",
+              f"- total  = {hbm/1e6:.2f} MB", ""]
+if "SQ_WAVE_CYCLES" in mean and "SQ_WAVES" in mean:
+    wc = mean["SQ_WAVE_CYCLES"]
+    lines += ["## derived", ""]
+    for k in ("SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_SCA"):
+        if k in mean:
+            lines.append(f"- {k} / SQ_WAVE_CYCLES = {mean[k]/wc:.3f}")
+    lines.append(f"- VALU instructions per wave = {mean.get('SQ_INSTS_VALU',0)/mean['SQ_WAVES']:.0f}; SALU per wave = {mean.get('SQ_INSTS_SALU',0)/mean['SQ_WAVES']:.0f}; LDS per wave = {mean.get('SQ_INSTS_LDS',0)/mean['SQ_WAVES']:.0f}")
+    if "GRBM_GUI_ACTIVE" in mean and stats:
+        lines.append(f"- effective clock ~ GRBM_GUI_ACTIVE / 8 / kernel time = {mean['GRBM_GUI_ACTIVE']/8/float(stats['AverageNs']):.2f} GHz (profiled pass)")
+    lines.append("")
+os.makedirs(os.path.join(root, "profiles"), exist_ok=True)
+open(os.path.join(root, "profiles", f"{tag}_rocprof_summary.md"), "w").write("\n".join(lines))
+if hbm:
+    tp = os.path.join(root, "profiles", "traffic.json")
+    rec = json.load(open(tp)) if os.path.exists(tp) else {}
+    rec[f"{workload}:{batch}"] = {"hbm_bytes_per_launch": hbm, "read_bytes": rd, "write_bytes": wr, "source": f"profiles/{tag}_rocprof_summary.md"}
+    json.dump(rec, open(tp, "w"), indent=1, sort_keys=True)
+print("\n".join(lines))
