@@ -1,0 +1,319 @@
+"""Declarative ODE right-hand sides: the plugin surface for ``simulate``'s ``ode`` argument.
+
+In the reference ``ode`` is an arbitrary JAX callable ``(t, state, params) -> grads``
+(src/dynode/typing/typing.py:18-21) that diffrax traces.  A Python callable cannot run inside a
+HIP kernel, so here ``ode`` is a :class:`CompartmentalODE` descriptor naming one member of the
+compartmental family the fused kernel implements (include/dynode_hip.h).  The descriptors below
+cover every RHS the reference ships, with the same names, the same
+parameter dataclasses and the same state-tuple order, so user code written against the
+reference examples runs unchanged.  Anything outside the family is rejected loudly.
+
+A descriptor is still callable -- ``ode(t, state, p)`` evaluates the derivative with NumPy for
+inspection and for the property tests -- but ``simulate`` never uses that path.
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass, fields
+from types import SimpleNamespace
+from typing import Any, Optional, Tuple
+
+import numpy as np
+import torch
+
+from ._abi import ModelDesc
+
+
+def _np(x) -> np.ndarray:
+    if isinstance(x, torch.Tensor):
+        return x.detach().cpu().numpy().astype(np.float64)
+    return np.asarray(x, dtype=np.float64)
+
+
+@dataclass
+class AbstractODEParams:
+    """Base of the parameter containers handed to an ODE (reference odes.py:25-32).
+
+    Fields are arrays (numpy / torch / python scalars).  A leading batch axis on any field makes
+    the solve batched: one trajectory per row.
+    """
+
+
+@dataclass
+class SIR_ODEParams(AbstractODEParams):
+    """examples/sir.py:70-74 and sir_age_stratified.py:103-107 (contact_matrix optional)."""
+
+    beta: Any
+    gamma: Any
+    contact_matrix: Any = None
+
+
+@dataclass
+class SEIRS_ODEParams(AbstractODEParams):
+    """examples/seirs.py:80-85."""
+
+    beta: Any
+    gamma: Any
+    sigma: Any
+    omega: Any
+
+
+@dataclass
+class SeasonalityParams:
+    """examples/seirs_seasonal_forcing.py:22-26."""
+
+    forcing_amp: Any
+    forcing_phase: Any
+    forcing_period: Any
+
+
+@dataclass
+class SEIRS_Seasonal_ODEParams(AbstractODEParams):
+    """examples/seirs_seasonal_forcing.py:30-36."""
+
+    beta: Any
+    gamma: Any
+    sigma: Any
+    omega: Any
+    seasonality_params: SeasonalityParams
+
+
+@dataclass
+class SEIRS_MultiStrain_ODEParams(AbstractODEParams):
+    """examples/seirs_multi_strain_age_stratified.py:177-184 (+ optional seasonality, cfg 5)."""
+
+    beta: Any            # [S] or [B, S]
+    gamma: Any
+    sigma: Any
+    omega: Any
+    contact_matrix: Any  # [A, A]
+    idx: Optional[SimpleNamespace] = None
+    seasonality_params: Optional[SeasonalityParams] = None
+
+
+@dataclass
+class Packed:
+    """Everything ``dyn_solve_batch`` needs, host side, float64."""
+
+    model: ModelDesc
+    y0: np.ndarray          # [D] or [B, D]
+    params: np.ndarray      # [B, P]
+    contact: np.ndarray     # [A, A]
+    batch: Optional[int]    # None = unbatched call
+    shapes: Tuple[tuple, ...]  # per-compartment shapes without time/batch axes
+
+
+class CompartmentalODE:
+    """One member of the kernel's RHS family, exposed under the reference example's name."""
+
+    def __init__(self, name: str, params_type: type, compartments: Tuple[str, ...], *,
+                 multi_strain: bool = False, has_e: bool = False, has_wane: bool = False,
+                 has_c: bool = False, seasonal: Optional[bool] = False, normalize: bool = True,
+                 contact_ndim: int = 1, n_wane: int = 1, doc: str = ""):
+        self.__name__ = name
+        self.__doc__ = doc
+        self.params_type = params_type
+        self.compartments = compartments
+        self.multi_strain = multi_strain
+        self.has_e, self.has_wane, self.has_c = has_e, has_wane, has_c
+        self.seasonal = seasonal  # None = decided by the params object (multi-strain, cfg 5)
+        self.normalize = normalize
+        self.contact_ndim = contact_ndim
+        self.n_wane = n_wane
+
+    def __repr__(self) -> str:
+        return f"<CompartmentalODE {self.__name__}>"
+
+    # ------------------------------------------------------------------ packing
+    def _param_matrix(self, p) -> Tuple[np.ndarray, Optional[int], bool]:
+        cols, batch = [], None
+        names = ["beta", "gamma"] + (["sigma"] if self.has_e else []) + (["omega"] if self.has_wane else [])
+        strain_rank = 1 if self.multi_strain else 0
+        arrays = []
+        for n in names:
+            a = _np(getattr(p, n))
+            if not self.multi_strain and a.ndim == 1 and a.size == 1 and strain_rank == 0:
+                a = a.reshape(())  # the examples pass shape-(1,) or scalar for single-strain models
+            if a.ndim == strain_rank + 1:
+                batch = a.shape[0] if batch is None else batch
+                if a.shape[0] != batch:
+                    raise ValueError(f"inconsistent batch sizes in ode parameters ({n})")
+            elif a.ndim != strain_rank:
+                raise ValueError(f"parameter {n} has shape {a.shape}; expected rank {strain_rank} "
+                                 f"(or {strain_rank + 1} with a leading batch axis)")
+            arrays.append(a)
+        S = arrays[0].shape[-1] if self.multi_strain else 1
+        seas = getattr(p, "seasonality_params", None)
+        seasonal = bool(self.seasonal) if self.seasonal is not None else seas is not None
+        seas_arrays = []
+        if seasonal:
+            for n in ("forcing_amp", "forcing_phase", "forcing_period"):
+                a = _np(getattr(seas, n))
+                a = a.reshape(()) if a.size == 1 and a.ndim <= 1 else a
+                if a.ndim == 1:
+                    batch = a.shape[0] if batch is None else batch
+                    if a.shape[0] != batch:
+                        raise ValueError(f"inconsistent batch sizes in seasonality parameters ({n})")
+                elif a.ndim != 0:
+                    raise ValueError(f"seasonality parameter {n} must be a scalar or [B]")
+                seas_arrays.append(a)
+        B = batch or 1
+        for a in arrays:
+            a2 = a.reshape(-1, S) if a.ndim == strain_rank + 1 else np.broadcast_to(a.reshape(1, S), (B, S))
+            cols.append(np.broadcast_to(a2, (B, S)))
+        for a in seas_arrays:
+            cols.append(np.broadcast_to(a.reshape(-1, 1), (B, 1)))
+        return np.ascontiguousarray(np.concatenate(cols, axis=1)), batch, seasonal
+
+    def _contact(self, p, A: int, contact_shape: tuple) -> np.ndarray:
+        C = getattr(p, "contact_matrix", None)
+        if C is None:
+            if A != 1:
+                raise ValueError(f"{self.__name__}: a contact_matrix is required for {A} bins")
+            return np.ones((1, 1))
+        C = _np(C)
+        if self.contact_ndim == 2:
+            # sir_age_risk_stratified.py:113-115,164-166: foi_kl = sum_ij C4[i,j,k,l] x_ij
+            # -> flattened foi_q = sum_p M[q,p] x_p with M = C4.reshape(AR, AR).T
+            if C.shape != contact_shape + contact_shape:
+                raise ValueError(f"contact tensor has shape {C.shape}, expected {contact_shape + contact_shape}")
+            return np.ascontiguousarray(C.reshape(A, A).T)
+        if C.shape != (A, A):
+            raise ValueError(f"contact_matrix has shape {C.shape}, expected {(A, A)}")
+        return np.ascontiguousarray(C)
+
+    def pack(self, initial_state, p) -> Packed:
+        """Flatten (initial_state, params) into the kernel's layout."""
+        if len(initial_state) != len(self.compartments):
+            raise ValueError(f"{self.__name__} expects compartments {self.compartments}, got "
+                             f"{len(initial_state)} arrays")
+        params, pbatch, seasonal = self._param_matrix(p)
+        arrs = [_np(a) for a in initial_state]
+        s = arrs[0]
+        sbatch = None
+        if s.ndim == self.contact_ndim + 1:
+            sbatch = s.shape[0]
+        elif s.ndim != self.contact_ndim:
+            raise ValueError(f"compartment s has shape {s.shape}; expected rank {self.contact_ndim}")
+        contact_shape = s.shape[1:] if sbatch is not None else s.shape
+        A = int(np.prod(contact_shape))
+        S = params.shape[1] // (2 + int(self.has_e) + int(self.has_wane)) if self.multi_strain else 1
+        if self.multi_strain:
+            S = (params.shape[1] - (3 if seasonal else 0)) // (2 + int(self.has_e) + int(self.has_wane))
+        batch = pbatch if pbatch is not None else sbatch
+        if pbatch is not None and sbatch is not None and pbatch != sbatch:
+            raise ValueError(f"batch of parameters ({pbatch}) and of initial_state ({sbatch}) differ")
+        flat, shapes = [], []
+        for name, a in zip(self.compartments, arrs):
+            tail = () if name == "s" else (((S,) if self.multi_strain else ()) + ((self.n_wane,) if (name == "r" and self.n_wane > 1) else ()))
+            want = contact_shape + tail
+            if a.shape == want:
+                flat.append(a.reshape(-1))
+            elif sbatch is not None and a.shape == (sbatch,) + want:
+                flat.append(a.reshape(sbatch, -1))
+            elif sbatch is None and a.ndim == len(want) + 1 and a.shape[1:] == want:
+                sbatch = a.shape[0]
+                flat.append(a.reshape(sbatch, -1))
+            else:
+                raise ValueError(f"compartment {name} has shape {a.shape}; expected {want} "
+                                 f"(optionally with a leading batch axis)")
+            shapes.append(want)
+        if sbatch is not None:
+            if batch is not None and batch != sbatch:
+                raise ValueError("batch of parameters and of initial_state differ")
+            batch = sbatch
+            y0 = np.concatenate([f if f.ndim == 2 else np.broadcast_to(f, (sbatch, f.size)) for f in flat], axis=1)
+            if params.shape[0] == 1 and sbatch > 1:
+                params = np.ascontiguousarray(np.broadcast_to(params, (sbatch, params.shape[1])))
+        else:
+            y0 = np.concatenate(flat)
+        model = ModelDesc(n_age=A, n_strain=S, has_e=self.has_e, has_wane=self.has_wane, has_c=self.has_c,
+                          n_wane=self.n_wane, normalize=self.normalize, seasonal=seasonal)
+        assert y0.shape[-1] == model.state_dim and params.shape[1] == model.param_dim
+        return Packed(model, np.ascontiguousarray(y0), params, self._contact(p, A, contact_shape), batch,
+                      tuple(shapes))
+
+    # ------------------------------------------------------------------ host evaluation
+    def __call__(self, t, state, p):
+        """f(t, state, p) with NumPy, unbatched -- for inspection/tests, never used by simulate."""
+        pk = self.pack(state, p)
+        if pk.batch is not None:
+            raise ValueError("the host evaluation of an ODE descriptor is unbatched")
+        m, y, q, C = pk.model, pk.y0, pk.params[0], pk.contact
+        A, S, W = m.n_age, m.n_strain, m.n_wane
+        pos = 0
+        s = y[pos:pos + A]; pos += A
+        e = None
+        if m.has_e:
+            e = y[pos:pos + A * S].reshape(A, S); pos += A * S
+        i = y[pos:pos + A * S].reshape(A, S); pos += A * S
+        r = y[pos:pos + A * S * W].reshape(A, S, W); pos += A * S * W
+        beta, gamma = q[:S], q[S:2 * S]
+        k = 2
+        sigma = q[k * S:(k + 1) * S] if m.has_e else None
+        k += int(m.has_e)
+        omega = q[k * S:(k + 1) * S] if m.has_wane else None
+        k += int(m.has_wane)
+        if m.seasonal:
+            amp, phase, period = q[k * S:k * S + 3]
+            beta = beta * (1.0 + amp * np.sin(2 * np.pi * t / period + phase))
+        N = s + i.sum(1) + r.sum((1, 2)) + (e.sum(1) if e is not None else 0.0)
+        x = i / N[:, None] if m.normalize else i
+        flux = (beta[None, :] * (C @ x)) * s[:, None]
+        g_i = gamma[None, :] * i
+        ds = -flux.sum(1)
+        out = []
+        if e is not None:
+            s_e = sigma[None, :] * e
+            de, di = flux - s_e, s_e - g_i
+        else:
+            de, di = None, flux - g_i
+        dr = np.zeros_like(r)
+        if m.has_wane:
+            rate = W * omega[None, :, None] * r
+            dr[:, :, 0] = g_i - rate[:, :, 0]
+            dr[:, :, 1:] = rate[:, :, :-1] - rate[:, :, 1:]
+            ds = ds + rate[:, :, -1].sum(1)
+        else:
+            dr[:, :, 0] = g_i
+        parts = [ds] + ([de] if de is not None else []) + [di, dr] + ([flux] if m.has_c else [])
+        for arr, shape in zip(parts, pk.shapes):
+            out.append(np.asarray(arr).reshape(shape))
+        return tuple(out)
+
+
+# ---------------------------------------------------------------------- the shipped RHS family
+sir_ode = CompartmentalODE(
+    "sir_ode", SIR_ODEParams, ("s", "i", "r"),
+    doc="SIR with optional age stratification: examples/sir.py:78-84, sir_age_stratified.py:127-142.")
+
+sir_ode_unnormalised = CompartmentalODE(
+    "sir_ode", SIR_ODEParams, ("s", "i", "r"), normalize=False,
+    doc="beta*s*i without the /N: the reference's tests/test_simulation/test_odes.py:17-28.")
+
+sir_age_risk_ode = CompartmentalODE(
+    "sir_ode", SIR_ODEParams, ("s", "i", "r"), contact_ndim=2,
+    doc="Age x risk SIR with a 4-D contact tensor: examples/sir_age_risk_stratified.py:157-173.")
+
+seirs_ode = CompartmentalODE(
+    "seirs_ode", SEIRS_ODEParams, ("s", "e", "i", "r"), has_e=True, has_wane=True,
+    doc="SEIRS: examples/seirs.py:88-95.")
+
+seirs_ode_seasonal = CompartmentalODE(
+    "seirs_ode_seasonal", SEIRS_Seasonal_ODEParams, ("s", "e", "i", "r"), has_e=True, has_wane=True,
+    seasonal=True, doc="SEIRS with sinusoidal beta: examples/seirs_seasonal_forcing.py:40-55.")
+
+seirs_multi_strain_ode = CompartmentalODE(
+    "seirs_multi_strain_ode", SEIRS_MultiStrain_ODEParams, ("s", "e", "i", "r", "c"),
+    multi_strain=True, has_e=True, has_wane=True, has_c=True, seasonal=None,
+    doc="Age x strain SEIRS + cumulative incidence: examples/seirs_multi_strain_age_stratified.py:213-243; "
+        "seasonal when p.seasonality_params is set (BASELINE cfg 5).")
+
+
+def check_param_fields(p) -> None:
+    """Reject parameter containers with non-array leaves early (clear error instead of a bad pack)."""
+    for f in fields(p):
+        v = getattr(p, f.name)
+        if f.name in ("idx",) or v is None or isinstance(v, SeasonalityParams):
+            continue
+        np.asarray(_np(v))

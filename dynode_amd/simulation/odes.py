@@ -1,0 +1,153 @@
+"""``simulate``: DynODE's ODE-solve entry point on the MI355X engine.
+
+Mirror of /root/reference/src/dynode/simulation/odes.py:35-198 -- same signature, argument
+meaning, output structure and error behaviour -- with ``diffrax.diffeqsolve`` replaced by the
+fused HIP kernel behind ``dyn_solve_batch`` (include/dynode_hip.h).  One extension: any
+parameter / initial-state array may carry a leading batch axis, in which case B trajectories
+are integrated in one launch and every ``ys`` entry gains a leading batch axis.
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+
+from .. import _abi
+from ..config import SolverParams
+from ..engine import solve_batch
+from ..rhs import AbstractODEParams, CompartmentalODE  # noqa: F401
+from ..typing import CompartmentState, is_array
+
+_X64 = False
+
+
+def enable_x64(flag: bool = True) -> None:
+    """Like ``jax.config.update("jax_enable_x64", ...)``: solve in float64.  Off by default --
+    the reference never enables x64, so its effective dtype is float32."""
+    global _X64
+    _X64 = bool(flag)
+
+
+class SolverError(RuntimeError):
+    """The solve did not reach t1 (max_steps exhausted or non-finite state); the reference raises
+    from diffeqsolve in the same situations (params.py:51-55)."""
+
+
+@dataclass
+class SaveAt:
+    """What ``build_saveat`` returns: the save grid and the per-compartment mask (SubSaveAt)."""
+
+    ts: np.ndarray
+    mask: Optional[Tuple[bool, ...]] = None
+
+
+@dataclass
+class Solution:
+    """Result of ``simulate`` (the fields of diffrax.Solution the reference's callers use).
+
+    ``ys`` is a tuple with one array per compartment, leading time axis, i.e.
+    ``ys[c].shape == (n_save, *compartment_shape)`` -- or ``(B, n_save, *compartment_shape)`` for a
+    batched call; compartments excluded by ``sub_save_indices`` come back as ``(n_save, 0)``.
+    Arrays are torch tensors resident on the GPU (views of one [B, n_save, D_saved] buffer).
+    """
+
+    ts: torch.Tensor
+    ys: Tuple[torch.Tensor, ...]
+    stats: dict = field(default_factory=dict)
+    result: torch.Tensor = None      # per-trajectory status (0 ok, 1 max_steps, 2 non-finite)
+    t0: float = 0.0
+    t1: float = 0.0
+
+
+def build_saveat(start: float, stop, step: int = 1,
+                 sub_save_indices: Optional[Tuple[int, ...]] = None, n_compartments: Optional[int] = None) -> SaveAt:
+    """Save grid ``linspace(start, stop, int(stop // step) + 1)`` (odes.py:177-180; ``step <= 0``
+    means 1) and the compartments to keep (odes.py:182-193)."""
+    if step <= 0:
+        step = 1
+    ts = np.linspace(start, stop, int(stop // step) + 1)
+    mask = None
+    if sub_save_indices is not None:
+        n = n_compartments if n_compartments is not None else (max(sub_save_indices) + 1 if len(sub_save_indices) else 0)
+        bad = [i for i in sub_save_indices if not (-n <= i < n)]
+        if bad:
+            # the reference swallows the IndexError with a print (odes.py:194-197)
+            print(f"An index passed to sub_save_indices was out of range for initial_state values. Exception: {bad}")
+        else:
+            keep = {i % n for i in sub_save_indices}
+            mask = tuple(i in keep for i in range(n))
+    return SaveAt(ts, mask)
+
+
+def simulate(ode, duration_days, initial_state: CompartmentState, ode_parameters, solver_parameters: SolverParams,
+             sub_save_indices: Optional[Tuple[int, ...]] = None, save_step: int = 1, *, dtype=None,
+             throw: bool = True) -> Solution:
+    """Solve ``ode`` for ``duration_days`` days from ``initial_state`` (reference odes.py:35-145).
+
+    Parameters follow the reference one for one.  ``ode`` is a :class:`CompartmentalODE` descriptor
+    (see ``dynode_amd.rhs``); ``ode_parameters`` must be an instance of exactly ``ode.params_type``.
+
+    Raises
+    ------
+    TypeError        ``initial_state`` holds something that is not an array (odes.py:93-98)
+    AssertionError   wrong parameter type, or non-numeric ``duration_days`` (odes.py:100-112)
+    SolverError      max_steps exhausted / non-finite state (only when ``throw``)
+    """
+    if any(not is_array(c) for c in initial_state):
+        raise TypeError("Please pass numpy / torch arrays (not lists or scalars) as initial_state to ODEs")
+    if not isinstance(ode, CompartmentalODE):
+        raise TypeError(
+            "ode must be a dynode_amd.rhs.CompartmentalODE descriptor: arbitrary Python callables cannot run "
+            "inside the HIP kernel (see dynode_amd/rhs.py for the supported RHS family)")
+    expected = ode.params_type
+    assert type(ode_parameters) is expected, (
+        f"passed {type(ode_parameters)} ode parameters, but your ODE model expects {expected}")
+    assert isinstance(duration_days, (int, float)) and not isinstance(duration_days, bool), (
+        "tf must be of type int or float")
+
+    packed = ode.pack(initial_state, ode_parameters)
+    saveat = build_saveat(0.0, duration_days, save_step, sub_save_indices, len(initial_state))
+    if dtype is None:
+        dtype = torch.float64 if _X64 else torch.float32
+    sp = solver_parameters
+    res = solve_batch(
+        packed.model, packed.y0, packed.params, packed.contact, float(duration_days), saveat.ts, t0=0.0,
+        method=sp.solver_method.method, dtype=dtype, rtol=sp.ode_solver_rel_tolerance,
+        atol=sp.ode_solver_abs_tolerance, max_steps=sp.max_steps,
+        constant_dt=sp.constant_step_size if sp.constant_step_size > 0.0 else 0.0,
+        jump_ts=sp.discontinuity_points, save_mask=saveat.mask)
+
+    if throw:
+        bad = int((res.status != _abi.STATUS_OK).sum())
+        if bad:
+            first = int(torch.nonzero(res.status != _abi.STATUS_OK)[0])
+            code = int(res.status[first])
+            why = "max_steps reached" if code == _abi.STATUS_MAX_STEPS else "non-finite state"
+            raise SolverError(f"{bad} of {res.status.numel()} trajectories failed ({why} at index {first}); "
+                              f"raise SolverParams.max_steps or pass throw=False to inspect Solution.result")
+
+    batched = packed.batch is not None
+    n_save = res.ys.shape[1]
+    ys, pos = [], 0
+    keep = saveat.mask if saveat.mask is not None else (True,) * len(initial_state)
+    for shape, saved in zip(packed.shapes, keep):
+        if not saved:
+            empty = (res.ys.shape[0], n_save, 0) if batched else (n_save, 0)
+            ys.append(torch.empty(empty, dtype=res.ys.dtype, device=res.ys.device))
+            continue
+        size = int(np.prod(shape))
+        block = res.ys[:, :, pos:pos + size].reshape((res.ys.shape[0], n_save) + tuple(shape))
+        ys.append(block if batched else block[0])
+        pos += size
+    unb = (lambda t: t) if batched else (lambda t: t[0])
+    stats = {
+        "num_steps": unb(res.n_accept + res.n_reject),
+        "num_accepted_steps": unb(res.n_accept),
+        "num_rejected_steps": unb(res.n_reject),
+        "max_steps": sp.max_steps,
+    }
+    ts = torch.as_tensor(saveat.ts, dtype=res.ys.dtype, device=res.ys.device)
+    return Solution(ts=ts, ys=tuple(ys), stats=stats, result=unb(res.status), t0=0.0, t1=float(duration_days))

@@ -1,0 +1,271 @@
+"""Host logic of the drop-in surface, CPU only (no compute calls).
+
+Mirrors the reference's own tests where they pin the boundary: tests/test_config/*,
+tests/test_infer/test_sample.py, tests/test_simulation/test_odes.py (error behaviour),
+tests/test_age_risk_groups/test_age_risk_groups.py (contact tensor literals).
+"""
+
+import numpy as np
+import pytest
+import torch
+from pydantic import ValidationError
+
+import helpers as H
+from dynode_amd import (Bin, Compartment, DeterministicParameter, Dimension, Dopri5, Params, SimulationConfig,
+                        SolverParams, Strain, TransmissionParams, Tsit5, rhs, simulate)
+from dynode_amd.config import AgeBin
+from dynode_amd.infer import distributions as dist
+from dynode_amd.infer import handlers, resolve_deterministic, sample_distributions, sample_then_resolve
+from dynode_amd.simulation import build_saveat
+from examples import seirs as ex_seirs
+from examples import seirs_multi_strain_age_stratified as ex_ms
+from examples import sir as ex_sir
+from examples import sir_age_risk_stratified as ex_risk
+from examples import sir_age_stratified as ex_age
+
+O = H.O
+
+
+# ------------------------------------------------------------------ config / idx
+def test_idx_namespace_is_recursive_ints():
+    """reference tests/test_config/test_simulation_config.py:42-48, test_compartment.py:21-22."""
+    cfg = ex_ms.get_config()
+    idx = cfg.idx
+    assert (idx.s, idx.e, idx.i, idx.r, idx.c) == (0, 1, 2, 3, 4)
+    assert idx.e.age == 0 and idx.e.strain == 1          # axis numbers WITHOUT the time axis
+    assert idx.e.age.old == 1 and idx.e.strain.C == 2
+    assert isinstance(idx.c, int) and cfg.get_compartment("e").shape == (2, 3)
+    with pytest.raises(AssertionError):
+        cfg.get_compartment("nope")
+
+
+def test_config_validators():
+    d = Dimension(name="age", bins=[Bin(name="a"), Bin(name="b")])
+    with pytest.raises(ValidationError):
+        Bin(name="1bad")
+    with pytest.raises(ValidationError):
+        Bin(name="has space")
+    with pytest.raises(ValidationError):
+        Dimension(name="age", bins=[])
+    with pytest.raises(ValidationError):
+        Dimension(name="age", bins=[Bin(name="a"), Bin(name="a")])
+    with pytest.raises(ValidationError):
+        Dimension(name="age", bins=[AgeBin(0, 4), AgeBin(6, 9)])      # gap
+    assert Dimension(name="age", bins=[AgeBin(0, 4), AgeBin(5, 9)]).idx.a5_9 == 1
+    with pytest.raises(ValidationError):
+        Compartment(name="s", dimensions=[d, d])
+    cfg = ex_sir.get_config()
+    with pytest.raises(ValidationError):
+        SimulationConfig(compartments=cfg.compartments + [cfg.compartments[0]], initializer=cfg.initializer,
+                         parameters=cfg.parameters)
+    with pytest.raises(ValidationError):
+        TransmissionParams(strains=[], strain_interactions={})
+    with pytest.raises(ValidationError):
+        TransmissionParams(strains=[Strain(strain_name="a", r0=2.0, infectious_period=7.0)],
+                           strain_interactions={"b": {"b": 1.0}})
+
+
+def test_solver_params_defaults_and_validation():
+    """reference src/dynode/config/params.py:24-67, tests/test_config/test_params.py:133-161."""
+    sp = SolverParams()
+    assert sp.solver_method == Tsit5() and sp.ode_solver_rel_tolerance == 1e-5
+    assert sp.ode_solver_abs_tolerance == 1e-6 and sp.max_steps == 10**6
+    assert sp.constant_step_size == 0 and sp.discontinuity_points == []
+    assert SolverParams(solver_method=Dopri5()).solver_method.method == "dopri5"
+    for bad in (dict(ode_solver_rel_tolerance=0.0), dict(ode_solver_abs_tolerance=-1e-6), dict(max_steps=0),
+                dict(constant_step_size=-1.0)):
+        with pytest.raises(ValidationError):
+            SolverParams(**bad)
+
+
+# ------------------------------------------------------------------ save grid
+def test_build_saveat_grid_and_mask():
+    """reference odes.py:177-198: linspace(0, T, T//step + 1); step <= 0 -> 1."""
+    assert build_saveat(0.0, 100).ts.shape == (101,)
+    g = build_saveat(0.0, 100, 3).ts
+    assert g.shape == (34,) and g[-1] == 100.0 and g[1] == pytest.approx(100 / 33)
+    assert build_saveat(0.0, 300.0, 0).ts.shape == (301,)
+    assert build_saveat(0.0, 100, 1, (0, 2), 3).mask == (True, False, True)
+    assert build_saveat(0.0, 100, 1, None, 3).mask is None
+    assert build_saveat(0.0, 100, 1, (0, 7), 3).mask is None   # out-of-range index: printed, all saved
+
+
+# ------------------------------------------------------------------ RHS descriptors
+def _flat(parts):
+    return np.concatenate([np.asarray(p, float).ravel() for p in parts])
+
+
+@pytest.mark.parametrize("case", ["sir", "sir_age", "seirs", "seasonal", "multi", "risk"])
+def test_descriptor_host_evaluation_matches_oracle_rhs(case):
+    rng = np.random.default_rng(1)
+    if case == "sir":
+        ode, st = rhs.sir_ode, tuple(rng.uniform(0.1, 1, (3, 1)))
+        p = rhs.SIR_ODEParams(beta=np.array(0.3), gamma=np.array(0.1))
+    elif case == "sir_age":
+        ode, st = rhs.sir_ode, tuple(rng.uniform(1, 9, (3, 4)))
+        p = rhs.SIR_ODEParams(beta=0.3, gamma=0.1, contact_matrix=rng.uniform(0.1, 1, (4, 4)))
+    elif case == "seirs":
+        ode, st = rhs.seirs_ode, tuple(rng.uniform(0.1, 1, (4, 1)))
+        p = rhs.SEIRS_ODEParams(beta=0.3, gamma=0.1, sigma=0.3, omega=0.02)
+    elif case == "seasonal":
+        ode, st = rhs.seirs_ode_seasonal, tuple(rng.uniform(0.1, 1, (4, 1)))
+        p = rhs.SEIRS_Seasonal_ODEParams(beta=0.3, gamma=0.1, sigma=0.3, omega=0.02,
+                                         seasonality_params=rhs.SeasonalityParams(0.2, 0.4, 365.0))
+    elif case == "multi":
+        ode = rhs.seirs_multi_strain_ode
+        st = (rng.uniform(1, 9, 2),) + tuple(rng.uniform(0.1, 3, (4, 2, 3)))
+        p = rhs.SEIRS_MultiStrain_ODEParams(beta=rng.uniform(.2, .4, 3), gamma=rng.uniform(.1, .2, 3),
+                                            sigma=rng.uniform(.2, .5, 3), omega=rng.uniform(.01, .03, 3),
+                                            contact_matrix=rng.uniform(0.1, 1, (2, 2)))
+    else:
+        ode, st = rhs.sir_age_risk_ode, tuple(rng.uniform(1, 9, (3, 3, 2)))
+        p = rhs.SIR_ODEParams(beta=0.3, gamma=0.1, contact_matrix=ex_risk.contact_tensor(rng.uniform(.1, 1, (3, 3)),
+                                                                                          rng.uniform(.1, 1, (2, 2))))
+    pk = ode.pack(st, p)
+    got = _flat(ode(11.0, st, p))
+    want = O.rhs(H.omodel(pk.model), 11.0, pk.y0, pk.params[0], pk.contact)
+    np.testing.assert_allclose(got, want, rtol=1e-13)
+    assert [g.shape for g in ode(11.0, st, p)] == [np.asarray(s).shape for s in st]
+
+
+def test_age_risk_contact_tensor_literals():
+    """reference tests/test_age_risk_groups/test_age_risk_groups.py: einsum("ij,kl->ikjl") known answers."""
+    np.testing.assert_allclose(ex_risk.contact_tensor([[2.0]], [[3.0]]), np.full((1, 1, 1, 1), 6.0), atol=1e-6)
+    age = np.array([[1.0, 0.5, 0.2], [0.5, 1.0, 0.3], [0.2, 0.3, 1.0]])
+    t = ex_risk.contact_tensor(age, [[1.0]])
+    assert t.shape == (3, 1, 3, 1) and np.allclose(t[:, 0, :, 0], age, atol=1e-6)
+    risk = np.array([[1.0, 0.4], [0.4, 1.0]])
+    t = ex_risk.contact_tensor(age, risk)
+    assert t.shape == (3, 2, 3, 2)
+    for i in range(3):
+        for k in range(2):
+            np.testing.assert_allclose(t[i, k], np.outer(age[i], risk[k]), atol=1e-6)
+    state = ex_risk.get_config().initializer.get_initial_state()
+    assert state[0].shape == (3, 2) and np.isclose(sum(s.sum() for s in state), 1000.0)
+
+
+def test_pack_batches_and_rejects_bad_shapes():
+    st = ex_ms.get_config().initializer.get_initial_state(ex_ms.get_config())
+    p = ex_ms.get_odeparams(ex_ms.get_config())
+    pk = rhs.seirs_multi_strain_ode.pack(st, p)
+    assert pk.batch is None and pk.y0.shape == (26,) and pk.params.shape == (1, 12)
+    p.beta = np.tile(p.beta, (7, 1))
+    pk = rhs.seirs_multi_strain_ode.pack(st, p)
+    assert pk.batch == 7 and pk.params.shape == (7, 12) and pk.y0.shape == (26,)
+    pk = rhs.seirs_multi_strain_ode.pack(tuple(np.tile(a, (7,) + (1,) * a.ndim) for a in st), p)
+    assert pk.y0.shape == (7, 26)
+    with pytest.raises(ValueError):
+        rhs.seirs_multi_strain_ode.pack(tuple(np.tile(a, (5,) + (1,) * a.ndim) for a in st), p)   # 5 vs 7
+    with pytest.raises(ValueError):
+        rhs.seirs_multi_strain_ode.pack(st[:4], p)
+    with pytest.raises(ValueError):
+        rhs.sir_ode.pack((np.ones(3), np.ones(3), np.ones(3)), rhs.SIR_ODEParams(beta=.3, gamma=.1))  # no contact
+
+
+def test_get_odeparams_formulas():
+    """A6: beta = r0/T_inf, gamma = 1/T_inf, sigma = 1/latent, omega = 1/waning (examples get_odeparams)."""
+    p = ex_sir.get_odeparams(ex_sir.get_config(r_0=3.0, infectious_period=6.0))
+    assert float(p.beta) == 0.5 and float(p.gamma) == pytest.approx(1 / 6)
+    q = ex_seirs.get_seirs_odeparams(ex_seirs.get_config())
+    assert (float(q.sigma), float(q.omega)) == (pytest.approx(1 / 3), pytest.approx(1 / 60))
+    m = ex_ms.get_odeparams(ex_ms.get_config())
+    np.testing.assert_allclose(m.beta, [2 / 7, 2.5 / 6, 1.8 / 8])
+    np.testing.assert_allclose(m.omega, [1 / 60, 1 / 80, 1 / 50])
+    y0 = ex_ms.get_config().initializer.get_initial_state(ex_ms.get_config())
+    np.testing.assert_allclose(y0[2].sum(1), [7.5, 2.5])                      # i0 split over strains by r0
+    np.testing.assert_allclose(y0[2][0] / y0[2][0].sum(), np.array([2.0, 2.5, 1.8]) / 6.3)
+    a = ex_age.get_config().initializer.get_initial_state()
+    np.testing.assert_allclose(a[0], [742.5, 247.5])
+    np.testing.assert_allclose(ex_age.get_config().parameters.transmission_params.contact_matrix, [[.7, .3], [.3, .7]])
+
+
+# ------------------------------------------------------------------ simulate(): error behaviour
+def test_simulate_validation_errors_match_reference():
+    """reference odes.py:93-112: TypeError for non-array state, AssertionError for param type / duration."""
+    cfg = ex_sir.get_config()
+    y0, p, sp = cfg.initializer.get_initial_state(), ex_sir.get_odeparams(cfg), cfg.parameters.solver_params
+    with pytest.raises(TypeError):
+        simulate(rhs.sir_ode, 10, ([0.9], [0.1], [0.0]), p, sp)
+    with pytest.raises(AssertionError):
+        simulate(rhs.sir_ode, 10, y0, rhs.SEIRS_ODEParams(beta=1, gamma=1, sigma=1, omega=1), sp)
+
+    class Sub(rhs.SIR_ODEParams):  # exact `is`, not isinstance (odes.py:103)
+        pass
+    with pytest.raises(AssertionError):
+        simulate(rhs.sir_ode, 10, y0, Sub(beta=1, gamma=1), sp)
+    with pytest.raises(AssertionError):
+        simulate(rhs.sir_ode, "10", y0, p, sp)
+    with pytest.raises(TypeError):
+        simulate(lambda t, y, a: y, 10, y0, p, sp)          # arbitrary callables are rejected loudly
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="CPU-only behaviour")
+def test_simulate_without_gpu_fails_loudly_no_cpu_fallback():
+    cfg = ex_sir.get_config()
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        simulate(rhs.sir_ode, 10, cfg.initializer.get_initial_state(), ex_sir.get_odeparams(cfg),
+                 cfg.parameters.solver_params)
+
+
+# ------------------------------------------------------------------ sample / resolve (site names)
+def test_sample_site_naming_rules():
+    """reference tests/test_infer/test_sample.py:17-151: a, b_1, c_0, d_nested_dict; prefixes."""
+    params = {"a": dist.Normal(), "b": [0, dist.Normal(), 2], "c": [dist.Normal()], "d": {"nested_dict": dist.Normal()},
+              "e": 5.0}
+    with handlers.seed(1), handlers.trace() as tr:
+        out = sample_distributions(params)
+    assert list(tr.sites) == ["a", "b_1", "c_0", "d_nested_dict"]
+    assert out["e"] == 5.0 and out["b"][0] == 0 and isinstance(out["b"][1], torch.Tensor)
+    with handlers.seed(1), handlers.trace() as tr:
+        sample_distributions(params, _prefix="fit_")
+    assert list(tr.sites) == ["fit_a", "fit_b_1", "fit_c_0", "fit_d_nested_dict"]
+    with pytest.raises(RuntimeError):
+        sample_distributions({"a": dist.Normal()})            # no randomness supplied
+    assert float(sample_distributions({"a": dist.Normal()}, rng_key=3)["a"]) == float(
+        sample_distributions({"a": dist.Normal()}, rng_key=3)["a"])
+
+
+def test_resolve_deterministic_including_slices():
+    params = {"x": 3.0, "y": DeterministicParameter("x"), "x_lst": [0.0, 1.5, 2.0],
+              "y_lst": [0.0, DeterministicParameter("x_lst", index=1), 2.0],
+              "z": DeterministicParameter("x_lst", index=slice(0, 2)),
+              "w": DeterministicParameter("x", transform=lambda v: 2 * v)}
+    with handlers.trace() as tr:
+        out = resolve_deterministic(params, root_params=params)
+    assert out["y"] == 3.0 and out["y_lst"] == [0.0, 1.5, 2.0] and out["z"] == [0.0, 1.5] and out["w"] == 6.0
+    assert list(tr.sites) == ["y", "y_lst_1", "z", "w"]
+    with pytest.raises(Exception, match="Was unable to find"):
+        resolve_deterministic({"y": DeterministicParameter("missing")}, root_params={})
+
+
+def test_sample_then_resolve_copies_and_names_strain_sites():
+    """A15: posterior keys strains_0_r0 / strains_0_infectious_period (sir_infer_parameters.py:47-58)."""
+    tp = TransmissionParams(
+        strains=[Strain(strain_name="swo9",
+                        r0=dist.TransformedDistribution(dist.Beta(0.5, 0.5), dist.transforms.AffineTransform(1.5, 1)),
+                        infectious_period=dist.TruncatedNormal(loc=8, scale=2, low=2, high=15))],
+        strain_interactions={"swo9": {"swo9": 1.0}}, contact_matrix=np.eye(2))
+    with handlers.seed(0, batch=256), handlers.trace() as tr:
+        out = sample_then_resolve(tp)
+    assert list(tr.sites) == ["strains_0_r0", "strains_0_infectious_period"]
+    r0, ti = out.strains[0].r0, out.strains[0].infectious_period
+    assert r0.shape == (256,) and float(r0.min()) >= 1.5 and float(r0.max()) <= 2.5
+    assert float(ti.min()) >= 2 and float(ti.max()) <= 15
+    assert isinstance(tp.strains[0].r0, dist.Distribution)          # the original is untouched
+    with handlers.substitute({"strains_0_r0": 2.0}), handlers.seed(0):
+        fixed = sample_then_resolve(tp)
+    assert float(fixed.strains[0].r0) == 2.0
+
+
+def test_distribution_log_probs_against_scipy():
+    from scipy import stats
+    x = np.array([1.6, 2.0, 2.4])
+    d = dist.TransformedDistribution(dist.Beta(0.5, 0.5), dist.transforms.AffineTransform(1.5, 1))
+    np.testing.assert_allclose(d.log_prob(x), stats.beta(0.5, 0.5, loc=1.5).logpdf(x), rtol=1e-10)
+    t = dist.TruncatedNormal(8, 2, low=2, high=15)
+    np.testing.assert_allclose(t.log_prob([3.0, 8.0, 14.0]), stats.truncnorm(-3, 3.5, loc=8, scale=2).logpdf([3, 8, 14]),
+                               rtol=1e-10)
+    assert float(t.log_prob(1.0)) == -np.inf
+    np.testing.assert_allclose(dist.Poisson([2.0, 30.0]).log_prob([3.0, 25.0]), stats.poisson([2.0, 30.0]).logpmf([3, 25]),
+                               rtol=1e-10)
+    assert float(t.median) == pytest.approx(stats.truncnorm(-3, 3.5, loc=8, scale=2).median(), rel=1e-9)
