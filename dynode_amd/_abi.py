@@ -27,7 +27,7 @@ ERR_NAMES = {
 EXPORTED_SYMBOLS = (
     "dyn_abi_version", "dyn_state_dim", "dyn_param_dim", "dyn_n_compartments",
     "dyn_compartment_offsets", "dyn_is_supported", "dyn_trajectories_per_wave",
-    "dyn_last_error", "dyn_solve_batch",
+    "dyn_last_error", "dyn_solve_batch", "dyn_solve_batch_jvp", "dyn_is_supported_jvp",
 )
 
 
@@ -119,6 +119,16 @@ def lib() -> ctypes.CDLL:
         L.dyn_solve_batch.argtypes = [
             pm, po, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,
             ctypes.c_int64, ctypes.c_double, ctypes.c_double, ctypes.c_void_p, ctypes.c_int32,
+            ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+            ctypes.c_void_p,
+        ]
+        L.dyn_is_supported_jvp.argtypes = [pm, po, ctypes.c_int32]
+        L.dyn_is_supported_jvp.restype = ctypes.c_int32
+        L.dyn_solve_batch_jvp.restype = ctypes.c_int
+        L.dyn_solve_batch_jvp.argtypes = [
+            pm, po, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,
+            ctypes.c_int64, ctypes.c_double, ctypes.c_double, ctypes.c_void_p, ctypes.c_int32,
+            ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32,
             ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
             ctypes.c_void_p,
         ]

@@ -9,8 +9,8 @@
 
 namespace dyn {
 
-#define X(T, METHOD, G, S, E, WN, C, W) \
-    extern template hipError_t launch<T, METHOD, G, S, E, WN, C, W>(const KArgs<T> &, hipStream_t);
+#define X(T, METHOD, G, S, E, WN, C, W, ND) \
+    extern template hipError_t launch<T, METHOD, G, S, E, WN, C, W, ND>(const KArgs<T> &, hipStream_t);
 #include "instances.def"
 #undef X
 
@@ -26,15 +26,15 @@ struct DType<double> {
 };
 
 struct Entry {
-    int dtype, method, G, S, E, WN, C, W;
+    int dtype, method, G, S, E, WN, C, W, ND;
     void *fn; // hipError_t (*)(const KArgs<T>&, hipStream_t)
 };
 
 static const Entry kEntries[] = {
-#define X(T, METHOD, G, S, E, WN, C, W)                       \
-    {DType<T>::id, METHOD, G, S, E, WN, C, W,                 \
+#define X(T, METHOD, G, S, E, WN, C, W, ND)                   \
+    {DType<T>::id, METHOD, G, S, E, WN, C, W, ND,             \
      (void *)(hipError_t(*)(const KArgs<T> &, hipStream_t)) & \
-         launch<T, METHOD, G, S, E, WN, C, W>},
+         launch<T, METHOD, G, S, E, WN, C, W, ND>},
 #include "instances.def"
 #undef X
 };
@@ -46,13 +46,13 @@ static int group_width(int A) {
     return g;
 }
 
-static const Entry *find_entry(const dyn_model_desc *m, int dtype, int method) {
+static const Entry *find_entry(const dyn_model_desc *m, int dtype, int method, int nd = 0) {
     const int G = group_width(m->n_age);
     for (int i = 0; i < kNumEntries; ++i) {
         const Entry &e = kEntries[i];
         if (e.dtype == dtype && e.method == method && e.G == G && e.S == m->n_strain &&
             e.E == (m->has_e != 0) && e.WN == (m->has_wane != 0) && e.C == (m->has_c != 0) &&
-            e.W == m->n_wane)
+            e.W == m->n_wane && e.ND == nd)
             return &e;
     }
     return nullptr;
@@ -72,8 +72,13 @@ static int enqueue(const Entry *e, const dyn_model_desc *m, const dyn_solver_opt
                    const void *y0, int32_t y0_is_batched, const void *params, const void *contact,
                    int64_t B, double t0, double t1, const void *save_ts, int32_t n_save,
                    const uint8_t *save_mask, void *ys_out, int32_t *status, int32_t *n_accept,
-                   int32_t *n_reject, hipStream_t stream) {
+                   int32_t *n_reject, hipStream_t stream, const void *dparams = nullptr,
+                   const void *dy0 = nullptr, int32_t dy0_is_batched = 0, void *dys_out = nullptr) {
     KArgs<T> ka;
+    ka.dparams = (const T *)dparams;
+    ka.dy0 = (const T *)dy0;
+    ka.dout = (T *)dys_out;
+    ka.dy0_batched = dy0_is_batched ? 1 : 0;
     ka.y0 = (const T *)y0;
     ka.params = (const T *)params;
     ka.contact = (const T *)contact;
@@ -117,7 +122,8 @@ static int enqueue(const Entry *e, const dyn_model_desc *m, const dyn_solver_opt
         pos += off[c + 1] - off[c];
     }
     ka.d_saved = pos;
-    ka.vec_ok = (aligned && pos % per16 == 0 && ((uintptr_t)ys_out % 16) == 0) ? 1 : 0;
+    ka.vec_ok = (aligned && pos % per16 == 0 && ((uintptr_t)ys_out % 16) == 0 &&
+                 ((uintptr_t)dys_out % 16) == 0) ? 1 : 0;
     if (pos == 0 || n_save == 0) {
         // nothing to write: still run (status / step counts are outputs too)
         ka.d_saved = pos;
@@ -183,16 +189,18 @@ int32_t dyn_is_supported(const dyn_model_desc *m, const dyn_solver_opts *o) {
 
 const char *dyn_last_error(void) { return dyn::tl_error; }
 
-int dyn_solve_batch(const dyn_model_desc *m, const dyn_solver_opts *o, const void *y0,
-                    int32_t y0_is_batched, const void *params, const void *contact, int64_t B,
-                    double t0, double t1, const void *save_ts, int32_t n_save,
-                    const uint8_t *save_mask, void *ys_out, int32_t *status, int32_t *n_accept,
-                    int32_t *n_reject, void *stream) {
+static int solve_impl(const dyn_model_desc *m, const dyn_solver_opts *o, const void *y0,
+                      int32_t y0_is_batched, const void *params, const void *contact, int64_t B,
+                      double t0, double t1, const void *save_ts, int32_t n_save,
+                      const uint8_t *save_mask, void *ys_out, int32_t *status, int32_t *n_accept,
+                      int32_t *n_reject, void *stream, int32_t n_dir, const void *dparams,
+                      const void *dy0, int32_t dy0_is_batched, void *dys_out) {
     dyn::tl_error[0] = 0;
     int rc = dyn::check_model(m);
     if (rc) return rc;
     if (!o || !y0 || !params || !contact || !status || !n_accept || !n_reject) return DYN_ERR_NULL;
     if (B < 0 || n_save < 0 || (n_save > 0 && (!save_ts || !ys_out))) return DYN_ERR_SIZE;
+    if (n_dir < 0 || (n_dir > 0 && (!dparams || (n_save > 0 && !dys_out)))) return DYN_ERR_NULL;
     if ((o->method != DYN_TSIT5 && o->method != DYN_DOPRI5) ||
         (o->dtype != DYN_F32 && o->dtype != DYN_F64))
         return DYN_ERR_OPTS;
@@ -210,22 +218,50 @@ int dyn_solve_batch(const dyn_model_desc *m, const dyn_solver_opts *o, const voi
                  "discontinuity_points are not supported by the HIP path yet");
         return DYN_ERR_UNSUPPORTED;
     }
-    const dyn::Entry *e = dyn::find_entry(m, o->dtype, o->method);
+    const dyn::Entry *e = dyn::find_entry(m, o->dtype, o->method, n_dir);
     if (!e) {
         snprintf(dyn::tl_error, sizeof(dyn::tl_error),
-                 "no kernel compiled for A=%d S=%d e=%d wane=%d c=%d W=%d dtype=%d method=%d",
+                 "no kernel compiled for A=%d S=%d e=%d wane=%d c=%d W=%d dtype=%d method=%d "
+                 "tangent directions=%d",
                  m->n_age, m->n_strain, m->has_e, m->has_wane, m->has_c, m->n_wane, o->dtype,
-                 o->method);
+                 o->method, n_dir);
         return DYN_ERR_UNSUPPORTED;
     }
     if (B == 0) return 0;
     if (o->dtype == DYN_F64)
         return dyn::enqueue<double>(e, m, o, y0, y0_is_batched, params, contact, B, t0, t1,
                                     save_ts, n_save, save_mask, ys_out, status, n_accept, n_reject,
-                                    (hipStream_t)stream);
+                                    (hipStream_t)stream, dparams, dy0, dy0_is_batched, dys_out);
     return dyn::enqueue<float>(e, m, o, y0, y0_is_batched, params, contact, B, t0, t1, save_ts,
                                n_save, save_mask, ys_out, status, n_accept, n_reject,
-                               (hipStream_t)stream);
+                               (hipStream_t)stream, dparams, dy0, dy0_is_batched, dys_out);
+}
+
+int dyn_solve_batch(const dyn_model_desc *m, const dyn_solver_opts *o, const void *y0,
+                    int32_t y0_is_batched, const void *params, const void *contact, int64_t B,
+                    double t0, double t1, const void *save_ts, int32_t n_save,
+                    const uint8_t *save_mask, void *ys_out, int32_t *status, int32_t *n_accept,
+                    int32_t *n_reject, void *stream) {
+    return solve_impl(m, o, y0, y0_is_batched, params, contact, B, t0, t1, save_ts, n_save,
+                      save_mask, ys_out, status, n_accept, n_reject, stream, 0, nullptr, nullptr, 0,
+                      nullptr);
+}
+
+int dyn_solve_batch_jvp(const dyn_model_desc *m, const dyn_solver_opts *o, const void *y0,
+                        int32_t y0_is_batched, const void *params, const void *contact, int64_t B,
+                        double t0, double t1, const void *save_ts, int32_t n_save,
+                        const uint8_t *save_mask, int32_t n_dir, const void *dparams,
+                        const void *dy0, int32_t dy0_is_batched, void *ys_out, void *dys_out,
+                        int32_t *status, int32_t *n_accept, int32_t *n_reject, void *stream) {
+    if (n_dir < 1) return DYN_ERR_SIZE;
+    return solve_impl(m, o, y0, y0_is_batched, params, contact, B, t0, t1, save_ts, n_save,
+                      save_mask, ys_out, status, n_accept, n_reject, stream, n_dir, dparams, dy0,
+                      dy0_is_batched, dys_out);
+}
+
+int32_t dyn_is_supported_jvp(const dyn_model_desc *m, const dyn_solver_opts *o, int32_t n_dir) {
+    if (dyn::check_model(m) || !o) return 0;
+    return dyn::find_entry(m, o->dtype, o->method, n_dir) ? 1 : 0;
 }
 
 } // extern "C"

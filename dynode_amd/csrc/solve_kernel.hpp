@@ -38,6 +38,11 @@ struct KArgs {
     T t0, t1, rtol, atol, constant_dt;
     int32_t y0_batched, n_save, A, P, normalize, seasonal, d_saved, vec_ok;
     int32_t save_off[5]; // offset of s,e,i,r,c inside a saved row; -1 = not saved
+    // forward-mode tangents (dyn_solve_batch_jvp); unused when the kernel's ND == 0
+    const T *dparams; // [B][ND][P] seed directions of the parameter vector
+    const T *dy0;     // [ND][D] or [B][ND][D] seeds of the initial state, or nullptr (= 0)
+    T *dout;          // [B][n_save][ND][D_saved]
+    int32_t dy0_batched;
 };
 
 // ---------------------------------------------------------------- math per precision
@@ -50,6 +55,7 @@ struct Mth<float> {
     static __device__ __forceinline__ float min(float a, float b) { return fminf(a, b); }
     static __device__ __forceinline__ float sqrt(float x) { return sqrtf(x); }
     static __device__ __forceinline__ float sin(float x) { return sinf(x); }
+    static __device__ __forceinline__ float cos(float x) { return cosf(x); }
     // 1-ulp hardware reciprocal: used only for the error-norm scaling
     static __device__ __forceinline__ float rcp_fast(float x) { return __builtin_amdgcn_rcpf(x); }
     // 1/x to ~1 ulp: v_rcp_f32 + one Newton step (3 VALU ops instead of the 10-op IEEE sequence)
@@ -71,6 +77,7 @@ struct Mth<double> {
     static __device__ __forceinline__ double min(double a, double b) { return fmin(a, b); }
     static __device__ __forceinline__ double sqrt(double x) { return ::sqrt(x); }
     static __device__ __forceinline__ double sin(double x) { return ::sin(x); }
+    static __device__ __forceinline__ double cos(double x) { return ::cos(x); }
     static __device__ __forceinline__ double rcp_fast(double x) { return 1.0 / x; }
     static __device__ __forceinline__ double recip(double x) { return 1.0 / x; }
     static __device__ __forceinline__ double pow_fast(double x, double e) { return ::pow(x, e); }
@@ -245,13 +252,21 @@ __device__ __forceinline__ void store_run(T *p, const T (&v)[CNT], bool vec_ok) 
 }
 
 // ---------------------------------------------------------------- the kernel
-template <typename T, int METHOD, int G, int S, bool HAS_E, bool HAS_WANE, bool HAS_C, int W>
+// ND > 0 adds forward-mode tangents: NC = 1 + ND "planes" of every state array, plane 0 the
+// primal.  RK stages, FSAL and the dense output are linear in (y, k), so they are applied
+// plane by plane; only the RHS is non-linear and carries an explicit JVP.  Step sizes and the
+// accept/reject decision come from the primal alone (what jax.grad through diffrax does: the
+// controller is under stop_gradient), so the tangents are the exact derivative of the computed
+// trajectory ("discretise-then-optimise"), see dyn_solve_batch_jvp in include/dynode_hip.h.
+template <typename T, int METHOD, int G, int S, bool HAS_E, bool HAS_WANE, bool HAS_C, int W, int ND>
 struct Solver {
     static constexpr int NE = HAS_E ? S : 0;
-    static constexpr int NC = HAS_C ? S : 0;
-    static constexpr int NV = 1 + NE + S + S * W + NC;
+    static constexpr int NCU = HAS_C ? S : 0;
+    static constexpr int NV = 1 + NE + S + S * W + NCU;
     static constexpr int IE = 1, II = 1 + NE, IR = II + S, IC = IR + S * W;
     static constexpr int TPW = 64 / G;
+    static constexpr int NC = 1 + ND;          // planes
+    static constexpr int NDA = ND > 0 ? ND : 1; // array extent for tangent-only data
     using M = Mth<T>;
     using TB = Tab<METHOD>;
 
@@ -259,31 +274,16 @@ struct Solver {
     T beta[S], gamma[S], sigma[S], omega[S];
     T Cx[G]; // Cx[k] = contact[a][a ^ k] (0 outside the matrix)
     T amp, phase, w_season;
+    // parameter seeds per direction
+    T dbeta[NDA][S], dgamma[NDA][S], dsigma[NDA][S], domega[NDA][S];
+    T damp[NDA], dphase[NDA], dw_season[NDA];
     bool pad, normalize, seasonal;
 
-    // f(t, y) for this lane's age bin; reference RHS: see include/dynode_hip.h
-    __device__ __forceinline__ void rhs(T t, const T (&y)[NV], T (&dy)[NV]) const {
-        T se = 0, si = 0, sr = 0;
+    // acc_l = sum_k Cx[k] * x_l[lane ^ k]: all-gather over the lane group fused with the
+    // pre-permuted contact row
+    __device__ __forceinline__ void contract(const T (&x)[S], T (&acc)[S]) const {
 #pragma unroll
-        for (int l = 0; l < S; ++l) {
-            if constexpr (HAS_E) se += y[IE + l];
-            si += y[II + l];
-#pragma unroll
-            for (int w = 0; w < W; ++w) sr += y[IR + l * W + w];
-        }
-        const T N = ((y[0] + se) + si) + sr;
-        T invN = T(1);
-        if (normalize) invN = pad ? T(0) : M::recip(N);
-        T season = T(1);
-        if (seasonal) season = T(1) + amp * M::sin(w_season * t + phase);
-        T x[S], acc[S];
-#pragma unroll
-        for (int l = 0; l < S; ++l) {
-            x[l] = y[II + l] * invN;
-            acc[l] = T(0);
-        }
-        // all-gather of x over the lane group, fused with the pre-permuted contact row:
-        // acc_l = sum_k Cx[k] * x_l[lane ^ k]
+        for (int l = 0; l < S; ++l) acc[l] = T(0);
         if constexpr (G < 4) {
 #pragma unroll
             for (int l = 0; l < S; ++l) {
@@ -291,40 +291,128 @@ struct Solver {
                 if constexpr (G == 2) acc[l] += Cx[1] * xchg_xor<1>(x[l]);
             }
         } else {
-            gather_base<0>(x, acc); // bases: x, then x^7, x^15, x^8, ... (see gather_base)
+            gather_base<0>(x, acc);
         }
+    }
+
+    // f(t, y) for this lane's age bin (plane 0) and its JVP (planes 1..ND);
+    // reference RHS: see include/dynode_hip.h
+    __device__ __forceinline__ void rhs(T t, const T (&y)[NC][NV], T (&dy)[NC][NV]) const {
+        const T(&y0)[NV] = y[0];
+        T se = 0, si = 0, sr = 0;
+#pragma unroll
+        for (int l = 0; l < S; ++l) {
+            if constexpr (HAS_E) se += y0[IE + l];
+            si += y0[II + l];
+#pragma unroll
+            for (int w = 0; w < W; ++w) sr += y0[IR + l * W + w];
+        }
+        const T N = ((y0[0] + se) + si) + sr;
+        T invN = T(1);
+        if (normalize) invN = pad ? T(0) : M::recip(N);
+        T season = T(1), sin_arg = T(0), cos_arg = T(0);
+        if (seasonal) {
+            const T arg = w_season * t + phase;
+            sin_arg = M::sin(arg);
+            if constexpr (ND > 0) cos_arg = M::cos(arg);
+            season = T(1) + amp * sin_arg;
+        }
+        T x[S], acc[S], foi[S];
+#pragma unroll
+        for (int l = 0; l < S; ++l) x[l] = y0[II + l] * invN;
+        contract(x, acc);
         T out_s = 0, back_s = 0;
 #pragma unroll
         for (int l = 0; l < S; ++l) {
-            const T foi = (beta[l] * season) * acc[l];
-            const T flux = foi * y[0];
-            const T g_i = gamma[l] * y[II + l];
+            foi[l] = (beta[l] * season) * acc[l];
+            const T flux = foi[l] * y0[0];
+            const T g_i = gamma[l] * y0[II + l];
             out_s += flux;
             if constexpr (HAS_E) {
-                const T s_e = sigma[l] * y[IE + l];
-                dy[IE + l] = flux - s_e;
-                dy[II + l] = s_e - g_i;
+                const T s_e = sigma[l] * y0[IE + l];
+                dy[0][IE + l] = flux - s_e;
+                dy[0][II + l] = s_e - g_i;
             } else {
-                dy[II + l] = flux - g_i;
+                dy[0][II + l] = flux - g_i;
             }
             if constexpr (HAS_WANE) {
                 const T wrate = T(W) * omega[l];
                 T inflow = g_i;
 #pragma unroll
                 for (int w = 0; w < W; ++w) {
-                    const T o = wrate * y[IR + l * W + w];
-                    dy[IR + l * W + w] = inflow - o;
+                    const T o = wrate * y0[IR + l * W + w];
+                    dy[0][IR + l * W + w] = inflow - o;
                     inflow = o;
                 }
                 back_s += inflow;
             } else {
-                dy[IR + l * W] = g_i;
+                dy[0][IR + l * W] = g_i;
 #pragma unroll
-                for (int w = 1; w < W; ++w) dy[IR + l * W + w] = T(0);
+                for (int w = 1; w < W; ++w) dy[0][IR + l * W + w] = T(0);
             }
-            if constexpr (HAS_C) dy[IC + l] = flux;
+            if constexpr (HAS_C) dy[0][IC + l] = flux;
         }
-        dy[0] = back_s - out_s;
+        dy[0][0] = back_s - out_s;
+
+        // ---- JVP planes: the same expression tree, linearised
+        if constexpr (ND > 0) {
+#pragma unroll
+            for (int j = 0; j < ND; ++j) {
+                const T(&u)[NV] = y[1 + j];
+                T(&du)[NV] = dy[1 + j];
+                T dse = 0, dsi = 0, dsr = 0;
+#pragma unroll
+                for (int l = 0; l < S; ++l) {
+                    if constexpr (HAS_E) dse += u[IE + l];
+                    dsi += u[II + l];
+#pragma unroll
+                    for (int w = 0; w < W; ++w) dsr += u[IR + l * W + w];
+                }
+                const T dN = ((u[0] + dse) + dsi) + dsr;
+                const T dinvN = normalize ? -(invN * invN) * dN : T(0); // pad: invN == 0
+                T dseason = T(0);
+                if (seasonal)
+                    dseason = damp[j] * sin_arg + amp * cos_arg * (dw_season[j] * t + dphase[j]);
+                T dx[S], dacc[S];
+#pragma unroll
+                for (int l = 0; l < S; ++l) dx[l] = u[II + l] * invN + y0[II + l] * dinvN;
+                contract(dx, dacc);
+                T dout_s = 0, dback_s = 0;
+#pragma unroll
+                for (int l = 0; l < S; ++l) {
+                    const T bs = beta[l] * season;
+                    const T dbs = dbeta[j][l] * season + beta[l] * dseason;
+                    const T dfoi = dbs * acc[l] + bs * dacc[l];
+                    const T dflux = dfoi * y0[0] + foi[l] * u[0];
+                    const T dg_i = dgamma[j][l] * y0[II + l] + gamma[l] * u[II + l];
+                    dout_s += dflux;
+                    if constexpr (HAS_E) {
+                        const T ds_e = dsigma[j][l] * y0[IE + l] + sigma[l] * u[IE + l];
+                        du[IE + l] = dflux - ds_e;
+                        du[II + l] = ds_e - dg_i;
+                    } else {
+                        du[II + l] = dflux - dg_i;
+                    }
+                    if constexpr (HAS_WANE) {
+                        T dinflow = dg_i;
+#pragma unroll
+                        for (int w = 0; w < W; ++w) {
+                            const T d_o = T(W) * (domega[j][l] * y0[IR + l * W + w] +
+                                                  omega[l] * u[IR + l * W + w]);
+                            du[IR + l * W + w] = dinflow - d_o;
+                            dinflow = d_o;
+                        }
+                        dback_s += dinflow;
+                    } else {
+                        du[IR + l * W] = dg_i;
+#pragma unroll
+                        for (int w = 1; w < W; ++w) du[IR + l * W + w] = T(0);
+                    }
+                    if constexpr (HAS_C) du[IC + l] = dflux;
+                }
+                du[0] = dback_s - dout_s;
+            }
+        }
     }
 
     // Base b of the all-gather covers the four lane offsets {o, o^1, o^2, o^3} with
@@ -349,7 +437,7 @@ struct Solver {
 
     // dense output at theta in [0,1] for the accepted step (y -> y1), k = stage derivatives
     struct Dense {
-        T b[7]; // Tsit5: b_i(theta); Dopri5: theta powers folded below
+        T b[7]; // Tsit5: b_i(theta)
         T theta;
     };
     __device__ __forceinline__ static void dense_prepare(T th, Dense &d) {
@@ -398,27 +486,70 @@ struct Solver {
         }
     }
 
-    // interpolate + store one compartment block [FIRST, FIRST+CNT) of this lane
+    // interpolate + store one compartment block [FIRST, FIRST+CNT) of one plane of this lane
     template <int FIRST, int CNT>
     __device__ __forceinline__ static void save_block(const Dense &d, T dt, const T (&y)[NV],
-                                                      const T (&y1)[NV], const T (&k)[7][NV],
-                                                      T *dst, bool vec_ok) {
+                                                      const T (&y1)[NV], const T (&k)[7][NC][NV],
+                                                      int plane, T *dst, bool vec_ok) {
         T v[CNT];
 #pragma unroll
         for (int q = 0; q < CNT; ++q) {
             const int j = FIRST + q;
-#ifdef DYN_DIAG_NOMATH
-            v[q] = y[j] + d.theta;
-#else
-            v[q] = dense_eval(d, dt, y[j], y1[j], k[0][j], k[1][j], k[2][j], k[3][j], k[4][j],
-                              k[5][j], k[6][j]);
-#endif
+            v[q] = dense_eval(d, dt, y[j], y1[j], k[0][plane][j], k[1][plane][j], k[2][plane][j],
+                              k[3][plane][j], k[4][plane][j], k[5][plane][j], k[6][plane][j]);
         }
-#ifdef DYN_DIAG_NOSTORE
-        if (v[0] == T(-12345.678)) store_run<T, CNT>(dst, v, vec_ok);
-#else
         store_run<T, CNT>(dst, v, vec_ok);
-#endif
+    }
+
+    // one saved row of one plane
+    template <int PLANE>
+    __device__ __forceinline__ static void save_row(const KArgs<T> &ka, const Dense &dn, T dt,
+                                                    const T (&y)[NC][NV], const T (&yt)[NC][NV],
+                                                    const T (&k)[7][NC][NV], T *row, int a,
+                                                    bool vec_ok) {
+        if (ka.save_off[0] >= 0)
+            save_block<0, 1>(dn, dt, y[PLANE], yt[PLANE], k, PLANE, row + ka.save_off[0] + a, false);
+        if constexpr (HAS_E)
+            if (ka.save_off[1] >= 0)
+                save_block<IE, S>(dn, dt, y[PLANE], yt[PLANE], k, PLANE,
+                                  row + ka.save_off[1] + a * S, vec_ok);
+        if (ka.save_off[2] >= 0)
+            save_block<II, S>(dn, dt, y[PLANE], yt[PLANE], k, PLANE, row + ka.save_off[2] + a * S,
+                              vec_ok);
+        if (ka.save_off[3] >= 0)
+            save_block<IR, S * W>(dn, dt, y[PLANE], yt[PLANE], k, PLANE,
+                                  row + ka.save_off[3] + a * S * W, vec_ok);
+        if constexpr (HAS_C)
+            if (ka.save_off[4] >= 0)
+                save_block<IC, S>(dn, dt, y[PLANE], yt[PLANE], k, PLANE,
+                                  row + ka.save_off[4] + a * S, vec_ok);
+    }
+
+    __device__ __forceinline__ static void fill_row(const KArgs<T> &ka, T *row, int a, T v) {
+        if (ka.save_off[0] >= 0) row[ka.save_off[0] + a] = v;
+        if constexpr (HAS_E)
+            if (ka.save_off[1] >= 0)
+                for (int q = 0; q < S; ++q) row[ka.save_off[1] + a * S + q] = v;
+        if (ka.save_off[2] >= 0)
+            for (int q = 0; q < S; ++q) row[ka.save_off[2] + a * S + q] = v;
+        if (ka.save_off[3] >= 0)
+            for (int q = 0; q < S * W; ++q) row[ka.save_off[3] + a * S * W + q] = v;
+        if constexpr (HAS_C)
+            if (ka.save_off[4] >= 0)
+                for (int q = 0; q < S; ++q) row[ka.save_off[4] + a * S + q] = v;
+    }
+
+    template <int PLANE>
+    __device__ __forceinline__ static void save_tangents(const KArgs<T> &ka, const Dense &dn, T dt,
+                                                         const T (&y)[NC][NV],
+                                                         const T (&yt)[NC][NV],
+                                                         const T (&k)[7][NC][NV], T *drow, int a,
+                                                         bool vec_ok) {
+        if constexpr (PLANE < NC) {
+            save_row<PLANE>(ka, dn, dt, y, yt, k, drow + (int64_t)(PLANE - 1) * ka.d_saved, a,
+                            vec_ok);
+            save_tangents<PLANE + 1>(ka, dn, dt, y, yt, k, drow, a, vec_ok);
+        }
     }
 
     __device__ __forceinline__ static void run(const KArgs<T> &ka) {
@@ -438,26 +569,55 @@ struct Solver {
 
         // ---- flat-state offsets (compartment-major layout)
         const int offE = A, offI = A + A * NE, offR = offI + A * S, offC = offR + A * S * W;
-        const int D = offC + A * NC;
+        const int D = offC + A * NCU;
 
         // ---- per-trajectory parameters (broadcast loads inside the lane group)
         {
             const T *p = ka.params + traj * ka.P;
+            constexpr int oS = 2, oW = 2 + (HAS_E ? 1 : 0), oSe = 2 + (HAS_E ? 1 : 0) + (HAS_WANE ? 1 : 0);
 #pragma unroll
             for (int l = 0; l < S; ++l) {
                 L.beta[l] = p[l];
                 L.gamma[l] = p[S + l];
-                L.sigma[l] = HAS_E ? p[2 * S + l] : T(0);
-                L.omega[l] = HAS_WANE ? p[(2 + (HAS_E ? 1 : 0)) * S + l] : T(0);
+                L.sigma[l] = HAS_E ? p[oS * S + l] : T(0);
+                L.omega[l] = HAS_WANE ? p[oW * S + l] : T(0);
             }
             L.amp = T(0);
             L.phase = T(0);
             L.w_season = T(0);
+            T period = T(1);
             if (L.seasonal) {
-                const T *sp = p + (2 + (HAS_E ? 1 : 0) + (HAS_WANE ? 1 : 0)) * S;
+                const T *sp = p + oSe * S;
                 L.amp = sp[0];
                 L.phase = sp[1];
-                L.w_season = T(6.283185307179586476925286766559) / sp[2];
+                period = sp[2];
+                L.w_season = T(6.283185307179586476925286766559) / period;
+            }
+#pragma unroll
+            for (int j = 0; j < NDA; ++j) {
+#pragma unroll
+                for (int l = 0; l < S; ++l)
+                    L.dbeta[j][l] = L.dgamma[j][l] = L.dsigma[j][l] = L.domega[j][l] = T(0);
+                L.damp[j] = L.dphase[j] = L.dw_season[j] = T(0);
+            }
+            if constexpr (ND > 0) {
+#pragma unroll
+                for (int j = 0; j < ND; ++j) {
+                    const T *dp = ka.dparams + (traj * ND + j) * ka.P;
+#pragma unroll
+                    for (int l = 0; l < S; ++l) {
+                        L.dbeta[j][l] = dp[l];
+                        L.dgamma[j][l] = dp[S + l];
+                        if constexpr (HAS_E) L.dsigma[j][l] = dp[oS * S + l];
+                        if constexpr (HAS_WANE) L.domega[j][l] = dp[oW * S + l];
+                    }
+                    if (L.seasonal) {
+                        const T *dsp = dp + oSe * S;
+                        L.damp[j] = dsp[0];
+                        L.dphase[j] = dsp[1];
+                        L.dw_season[j] = -L.w_season / period * dsp[2]; // d(2 pi / period)
+                    }
+                }
             }
         }
         // ---- contact row, pre-permuted to the xor-exchange order
@@ -467,19 +627,27 @@ struct Solver {
             L.Cx[k] = (!L.pad && b < A) ? ka.contact[aa * A + b] : T(0);
         }
 
-        // ---- initial state
-        T y[NV], yt[NV], k[7][NV];
-        {
-            const T *y0 = ka.y0 + (ka.y0_batched ? traj * D : 0);
-            y[0] = L.pad ? T(0) : y0[aa];
+        // ---- initial state (plane 0) and its seeds (planes 1..ND)
+        T y[NC][NV], yt[NC][NV], k[7][NC][NV];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const T *src;
+            bool zero = L.pad;
+            if (c == 0) {
+                src = ka.y0 + (ka.y0_batched ? traj * D : 0);
+            } else {
+                zero = zero || ka.dy0 == nullptr;
+                src = ka.dy0 + ((ka.dy0_batched ? traj * ND : 0) + (c - 1)) * (int64_t)D;
+            }
+            y[c][0] = zero ? T(0) : src[aa];
 #pragma unroll
             for (int l = 0; l < S; ++l) {
-                if constexpr (HAS_E) y[IE + l] = L.pad ? T(0) : y0[offE + aa * S + l];
-                y[II + l] = L.pad ? T(0) : y0[offI + aa * S + l];
+                if constexpr (HAS_E) y[c][IE + l] = zero ? T(0) : src[offE + aa * S + l];
+                y[c][II + l] = zero ? T(0) : src[offI + aa * S + l];
 #pragma unroll
                 for (int w = 0; w < W; ++w)
-                    y[IR + l * W + w] = L.pad ? T(0) : y0[offR + (aa * S + l) * W + w];
-                if constexpr (HAS_C) y[IC + l] = L.pad ? T(0) : y0[offC + aa * S + l];
+                    y[c][IR + l * W + w] = zero ? T(0) : src[offR + (aa * S + l) * W + w];
+                if constexpr (HAS_C) y[c][IC + l] = zero ? T(0) : src[offC + aa * S + l];
             }
         }
 
@@ -492,12 +660,12 @@ struct Solver {
         if (constant) {
             tnext = tprev + ka.constant_dt;
         } else {
-            // Hairer-Norsett-Wanner II.4 starting step (diffrax _select_initial_step)
+            // Hairer-Norsett-Wanner II.4 starting step (diffrax _select_initial_step), primal only
             T s0 = 0, s1 = 0;
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
-                const T sc = atol + M::abs(y[v]) * rtol;
-                const T q0 = y[v] / sc, q1 = k[0][v] / sc;
+                const T sc = atol + M::abs(y[0][v]) * rtol;
+                const T q0 = y[0][v] / sc, q1 = k[0][0][v] / sc;
                 s0 += q0 * q0;
                 s1 += q1 * q1;
             }
@@ -505,13 +673,15 @@ struct Solver {
             const bool small = (d0 < T(1e-5)) || (d1 < T(1e-5));
             const T h0 = small ? T(1e-6) : T(0.01) * (d0 / d1);
 #pragma unroll
-            for (int v = 0; v < NV; ++v) yt[v] = y[v] + h0 * k[0][v];
+            for (int c = 0; c < NC; ++c)
+#pragma unroll
+                for (int v = 0; v < NV; ++v) yt[c][v] = y[c][v] + h0 * k[0][c][v];
             L.rhs(tprev + h0, yt, k[1]);
             T s2 = 0;
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
-                const T sc = atol + M::abs(y[v]) * rtol;
-                const T q2 = (k[1][v] - k[0][v]) / sc;
+                const T sc = atol + M::abs(y[0][v]) * rtol;
+                const T q2 = (k[1][0][v] - k[0][0][v]) / sc;
                 s2 += q2 * q2;
             }
             const T d2 = M::sqrt(group_sum<G>(s2) / Dn) / h0;
@@ -539,6 +709,7 @@ struct Solver {
         int32_t n_acc = 0, n_rej = 0, st = ST_OK;
         bool done = !(tprev < t_end);
         T *const out_traj = ka.out + traj * (int64_t)n_save * ka.d_saved;
+        T *const dout_traj = ND > 0 ? ka.dout + traj * (int64_t)n_save * ND * ka.d_saved : nullptr;
         const bool vec_ok = ka.vec_ok != 0;
 
 #ifdef DYN_DIAG_ROUNDS
@@ -553,29 +724,31 @@ struct Solver {
 #pragma unroll
             for (int sg = 1; sg < 7; ++sg) {
 #pragma unroll
-                for (int v = 0; v < NV; ++v) {
-                    T acc = T(TB::a[sg][0]) * k[0][v];
+                for (int c = 0; c < NC; ++c)
 #pragma unroll
-                    for (int q = 1; q < sg; ++q)
-                        if (TB::a[sg][q] != 0.0) acc += T(TB::a[sg][q]) * k[q][v];
-                    yt[v] = y[v] + dt * acc;
-                }
+                    for (int v = 0; v < NV; ++v) {
+                        T acc = T(TB::a[sg][0]) * k[0][c][v];
+#pragma unroll
+                        for (int q = 1; q < sg; ++q)
+                            if (TB::a[sg][q] != 0.0) acc += T(TB::a[sg][q]) * k[q][c][v];
+                        yt[c][v] = y[c][v] + dt * acc;
+                    }
                 L.rhs(tprev + T(TB::c[sg]) * dt, yt, k[sg]);
             }
             // after stage 7, yt == y1 (a[6][:] == b) and k[6] == f(tnext, y1)
 
-            // ---- embedded error, RMS norm over the whole state, I-controller
+            // ---- embedded error, RMS norm over the whole (primal) state, I-controller
             bool keep = true, finite = true;
             T factor = T(1);
             if (!constant) {
                 T ss = 0;
 #pragma unroll
                 for (int v = 0; v < NV; ++v) {
-                    T e = T(TB::berr[0]) * k[0][v];
+                    T e = T(TB::berr[0]) * k[0][0][v];
 #pragma unroll
                     for (int q = 1; q < 7; ++q)
-                        if (TB::berr[q] != 0.0) e += T(TB::berr[q]) * k[q][v];
-                    const T ym = M::max(M::abs(y[v]), M::abs(yt[v]));
+                        if (TB::berr[q] != 0.0) e += T(TB::berr[q]) * k[q][0][v];
+                    const T ym = M::max(M::abs(y[0][v]), M::abs(yt[0][v]));
                     const T r = (dt * e) * M::rcp_fast(atol + ym * rtol);
                     ss += r * r;
                 }
@@ -590,7 +763,7 @@ struct Solver {
             } else {
                 T chk = 0;
 #pragma unroll
-                for (int v = 0; v < NV; ++v) chk += yt[v] - yt[v];
+                for (int v = 0; v < NV; ++v) chk += yt[0][v] - yt[0][v];
                 chk = group_sum<G>(chk);
                 finite = (chk == T(0));
             }
@@ -613,23 +786,12 @@ struct Solver {
                     Dense dn;
                     dense_prepare((ts_next - tprev) * inv_dt, dn);
                     if (writer) {
-                        T *row = out_traj + (int64_t)save_idx * ka.d_saved;
-                        if (ka.save_off[0] >= 0)
-                            save_block<0, 1>(dn, dt, y, yt, k, row + ka.save_off[0] + a, false);
-                        if constexpr (HAS_E)
-                            if (ka.save_off[1] >= 0)
-                                save_block<IE, S>(dn, dt, y, yt, k, row + ka.save_off[1] + a * S,
-                                                  vec_ok);
-                        if (ka.save_off[2] >= 0)
-                            save_block<II, S>(dn, dt, y, yt, k, row + ka.save_off[2] + a * S,
-                                              vec_ok);
-                        if (ka.save_off[3] >= 0)
-                            save_block<IR, S * W>(dn, dt, y, yt, k,
-                                                  row + ka.save_off[3] + a * S * W, vec_ok);
-                        if constexpr (HAS_C)
-                            if (ka.save_off[4] >= 0)
-                                save_block<IC, S>(dn, dt, y, yt, k, row + ka.save_off[4] + a * S,
-                                                  vec_ok);
+                        save_row<0>(ka, dn, dt, y, yt, k, out_traj + (int64_t)save_idx * ka.d_saved,
+                                    a, vec_ok);
+                        if constexpr (ND > 0)
+                            save_tangents<1>(ka, dn, dt, y, yt, k,
+                                             dout_traj + (int64_t)save_idx * ND * ka.d_saved, a,
+                                             vec_ok);
                     }
                     ++save_idx;
                     ts_next = ts_next2;
@@ -641,10 +803,12 @@ struct Solver {
             // ---- commit / reject
             if (accept) {
 #pragma unroll
-                for (int v = 0; v < NV; ++v) {
-                    y[v] = yt[v];
-                    k[0][v] = k[6][v];
-                }
+                for (int c = 0; c < NC; ++c)
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) {
+                        y[c][v] = yt[c][v];
+                        k[0][c][v] = k[6][c][v];
+                    }
                 ++n_acc;
             } else if (act && finite) {
                 ++n_rej;
@@ -670,19 +834,11 @@ struct Solver {
         // rows never reached (failed solves): +inf, like diffrax's unfilled SaveAt buffer
         if (writer) {
             for (; save_idx < n_save; ++save_idx) {
-                T *row = out_traj + (int64_t)save_idx * ka.d_saved;
-                const T v = M::inf();
-                if (ka.save_off[0] >= 0) row[ka.save_off[0] + a] = v;
-                if constexpr (HAS_E)
-                    if (ka.save_off[1] >= 0)
-                        for (int q = 0; q < S; ++q) row[ka.save_off[1] + a * S + q] = v;
-                if (ka.save_off[2] >= 0)
-                    for (int q = 0; q < S; ++q) row[ka.save_off[2] + a * S + q] = v;
-                if (ka.save_off[3] >= 0)
-                    for (int q = 0; q < S * W; ++q) row[ka.save_off[3] + a * S * W + q] = v;
-                if constexpr (HAS_C)
-                    if (ka.save_off[4] >= 0)
-                        for (int q = 0; q < S; ++q) row[ka.save_off[4] + a * S + q] = v;
+                fill_row(ka, out_traj + (int64_t)save_idx * ka.d_saved, a, M::inf());
+                if constexpr (ND > 0)
+                    for (int j = 0; j < ND; ++j)
+                        fill_row(ka, dout_traj + ((int64_t)save_idx * ND + j) * ka.d_saved, a,
+                                 M::inf());
             }
             if (a == 0) {
                 ka.status[traj] = st;
@@ -697,20 +853,20 @@ struct Solver {
     }
 };
 
-template <typename T, int METHOD, int G, int S, bool HAS_E, bool HAS_WANE, bool HAS_C, int W>
+template <typename T, int METHOD, int G, int S, bool HAS_E, bool HAS_WANE, bool HAS_C, int W, int ND>
 __global__ void __launch_bounds__(64)
 solve_kernel(const KArgs<T> ka) {
-    Solver<T, METHOD, G, S, HAS_E, HAS_WANE, HAS_C, W>::run(ka);
+    Solver<T, METHOD, G, S, HAS_E, HAS_WANE, HAS_C, W, ND>::run(ka);
 }
 
 // host-side launcher, one explicit instantiation per compiled shape (instances.def)
-template <typename T, int METHOD, int G, int S, bool HAS_E, bool HAS_WANE, bool HAS_C, int W>
+template <typename T, int METHOD, int G, int S, bool HAS_E, bool HAS_WANE, bool HAS_C, int W, int ND>
 hipError_t launch(const KArgs<T> &ka, hipStream_t stream) {
     constexpr int TPW = 64 / G;
     const int64_t blocks = (ka.B + TPW - 1) / TPW;
     if (blocks <= 0) return hipSuccess;
     const size_t lds = (size_t)ka.n_save * sizeof(T); // save grid staged in LDS
-    hipLaunchKernelGGL((solve_kernel<T, METHOD, G, S, HAS_E, HAS_WANE, HAS_C, W>),
+    hipLaunchKernelGGL((solve_kernel<T, METHOD, G, S, HAS_E, HAS_WANE, HAS_C, W, ND>),
                        dim3((unsigned)blocks), dim3(64), lds, stream, ka);
     return hipGetLastError();
 }

@@ -40,6 +40,7 @@ class BatchResult:
     n_reject: torch.Tensor  # [B] int32
     saved: tuple            # names of the saved compartments, in row order
     sizes: tuple            # flat size of each saved compartment
+    dys: Optional[torch.Tensor] = None  # [B, n_save, n_dir, D_saved] tangents (solve_batch_jvp)
 
 
 def require_gpu() -> torch.device:
@@ -74,12 +75,17 @@ def solve_batch(model: ModelDesc, y0, params, contact, t1: float, save_ts, *, t0
                 atol: float = 1e-6, max_steps: int = 10**6, constant_dt: float = 0.0,
                 jump_ts: Sequence[float] = (), save_mask: Optional[Sequence[bool]] = None,
                 out: Optional[torch.Tensor] = None, stats_out: Optional[tuple] = None,
-                stream: Optional[torch.cuda.Stream] = None) -> BatchResult:
+                stream: Optional[torch.cuda.Stream] = None, dparams=None, dy0=None,
+                dout: Optional[torch.Tensor] = None) -> BatchResult:
     """Integrate B parameter samples of ``model`` over [t0, t1] on the current GPU.
 
     Replaces the per-sample ``diffeqsolve`` call of dynode.simulation.simulate
     (/root/reference/src/dynode/simulation/odes.py:133-144).  Asynchronous: work is enqueued
     on ``stream`` (default: torch's current stream); nothing is synchronised here.
+
+    With ``dparams`` ([B, n_dir, P] seed directions, optionally ``dy0`` [n_dir, D] / [B, n_dir, D])
+    the forward-mode tangents of the saved trajectory are computed in the same launch
+    (``dyn_solve_batch_jvp``) and returned as ``BatchResult.dys`` [B, n_save, n_dir, D_saved].
     """
     device = require_gpu()
     L = _abi.lib()
@@ -106,22 +112,47 @@ def solve_batch(model: ModelDesc, y0, params, contact, t1: float, save_ts, *, t0
         status, n_acc, n_rej = stats[0], stats[1], stats[2]
     else:
         status, n_acc, n_rej = stats_out
+    n_dir = 0
+    dparams_t = dy0_t = None
+    if dparams is not None:
+        dparams_t = _dev(dparams, dtype, device)
+        if dparams_t.dim() != 3 or dparams_t.shape[0] != B or dparams_t.shape[2] != P:
+            raise ValueError(f"dparams must have shape [B={B}, n_dir, P={P}], got {tuple(dparams_t.shape)}")
+        n_dir = dparams_t.shape[1]
+        if dy0 is not None:
+            dy0_t = _dev(dy0, dtype, device)
+            if tuple(dy0_t.shape) not in ((n_dir, D), (B, n_dir, D)):
+                raise ValueError(f"dy0 must have shape {(n_dir, D)} or {(B, n_dir, D)}")
+        if dout is None:
+            dout = torch.empty((B, n_save, n_dir, d_saved), dtype=dtype, device=device)
+        elif tuple(dout.shape) != (B, n_save, n_dir, d_saved) or dout.dtype != dtype or not dout.is_contiguous():
+            raise ValueError("`dout` must be a contiguous [B, n_save, n_dir, D_saved] tensor of `dtype`")
     if B == 0:  # empty batch: nothing to enqueue (zero-size tensors have null data pointers)
-        return BatchResult(out, status, n_acc, n_rej, saved, sizes)
+        return BatchResult(out, status, n_acc, n_rej, saved, sizes, dout)
     jt = np.ascontiguousarray(jump_ts, dtype=np.float64)
     opts = _abi.SolverOptsC(
         _METHODS[method], _DTYPES[dtype], float(rtol), float(atol), int(max_steps),
         float(constant_dt),
         jt.ctypes.data_as(ctypes.POINTER(ctypes.c_double)) if jt.size else None, int(jt.size))
     s = stream if stream is not None else torch.cuda.current_stream(device)
-    rc = L.dyn_solve_batch(
-        ctypes.byref(model.c()), ctypes.byref(opts), y0_t.data_ptr(), int(batched),
-        params_t.data_ptr(), contact_t.data_ptr(), B, float(t0), float(t1), ts_t.data_ptr(),
-        n_save, mask_c, out.data_ptr(), status.data_ptr(), n_acc.data_ptr(), n_rej.data_ptr(),
-        ctypes.c_void_p(s.cuda_stream))
+    if n_dir == 0:
+        rc = L.dyn_solve_batch(
+            ctypes.byref(model.c()), ctypes.byref(opts), y0_t.data_ptr(), int(batched),
+            params_t.data_ptr(), contact_t.data_ptr(), B, float(t0), float(t1), ts_t.data_ptr(),
+            n_save, mask_c, out.data_ptr(), status.data_ptr(), n_acc.data_ptr(), n_rej.data_ptr(),
+            ctypes.c_void_p(s.cuda_stream))
+    else:
+        rc = L.dyn_solve_batch_jvp(
+            ctypes.byref(model.c()), ctypes.byref(opts), y0_t.data_ptr(), int(batched),
+            params_t.data_ptr(), contact_t.data_ptr(), B, float(t0), float(t1), ts_t.data_ptr(),
+            n_save, mask_c, n_dir, dparams_t.data_ptr(),
+            dy0_t.data_ptr() if dy0_t is not None else None,
+            int(dy0_t is not None and dy0_t.dim() == 3), out.data_ptr(), dout.data_ptr(),
+            status.data_ptr(), n_acc.data_ptr(), n_rej.data_ptr(), ctypes.c_void_p(s.cuda_stream))
     if rc != 0:
         raise SolveError(rc, L.dyn_last_error().decode())
     # keep inputs alive until the stream has consumed them
-    for t in (y0_t, params_t, contact_t, ts_t):
-        t.record_stream(s)
-    return BatchResult(out, status, n_acc, n_rej, saved, sizes)
+    for t in (y0_t, params_t, contact_t, ts_t, dparams_t, dy0_t):
+        if t is not None:
+            t.record_stream(s)
+    return BatchResult(out, status, n_acc, n_rej, saved, sizes, dout)

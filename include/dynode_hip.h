@@ -88,7 +88,7 @@ enum {
     DYN_ERR_OPTS = -4,
     DYN_ERR_TOL = -5,
     DYN_ERR_JUMP = -6,
-    DYN_ERR_UNSUPPORTED = -7, /* shape not compiled into the library */
+    DYN_ERR_UNSUPPORTED = -7, /* shape / option not compiled into the library */
     DYN_ERR_LAUNCH = -8       /* hipLaunchKernel failed */
 };
 
@@ -122,6 +122,28 @@ int dyn_solve_batch(const dyn_model_desc *m, const dyn_solver_opts *opts, const 
                     double t0, double t1, const void *save_ts, int32_t n_save,
                     const uint8_t *save_mask, void *ys_out, int32_t *status, int32_t *n_accept,
                     int32_t *n_reject, void *stream);
+
+/*
+ * Batched solve + forward-mode tangents: value and directional derivatives of the saved
+ * trajectory with respect to the parameters / initial state, for n_dir directions at once.
+ * This is the gradient-solve under the reference's NUTS loop, where numpyro takes
+ * value_and_grad of the potential through diffeqsolve (src/dynode/infer/inference.py:149-163,
+ * examples/sir_infer_parameters.py:21-39).  Tangents are propagated through the SAME accepted
+ * steps as the primal (step sizes and error control see the primal only), i.e. they are the
+ * exact derivative of the computed trajectory -- what differentiating through diffrax yields.
+ *   dparams [B][n_dir][P]     seed directions of the parameter vector                 device
+ *   dy0     NULL (zero), [n_dir][D] (dy0_is_batched = 0) or [B][n_dir][D]              device
+ *   dys_out [B][n_save][n_dir][D_saved]                                                device
+ * Everything else as dyn_solve_batch.
+ */
+int dyn_solve_batch_jvp(const dyn_model_desc *m, const dyn_solver_opts *opts, const void *y0,
+                        int32_t y0_is_batched, const void *params, const void *contact, int64_t B,
+                        double t0, double t1, const void *save_ts, int32_t n_save,
+                        const uint8_t *save_mask, int32_t n_dir, const void *dparams,
+                        const void *dy0, int32_t dy0_is_batched, void *ys_out, void *dys_out,
+                        int32_t *status, int32_t *n_accept, int32_t *n_reject, void *stream);
+/* 1 if a tangent kernel for (model shape, method, dtype, n_dir) is compiled in */
+int32_t dyn_is_supported_jvp(const dyn_model_desc *m, const dyn_solver_opts *o, int32_t n_dir);
 
 #ifdef __cplusplus
 }

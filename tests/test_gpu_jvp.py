@@ -1,0 +1,95 @@
+"""Forward-mode tangents of the solve (dyn_solve_batch_jvp), the gradient-solve under NUTS.
+
+Checker: finite differences of the fp64 ORACLE primal.  With ConstantStepSize the discrete solve
+is a smooth map of the parameters, so central differences match the kernel's tangents to FD
+accuracy -- this pins "tangent == exact derivative of the computed trajectory".  With the adaptive
+controller at tight tolerances both converge to the true sensitivity.
+"""
+
+import numpy as np
+import pytest
+import torch
+
+import helpers as H
+from dynode_amd import ModelDesc, synthetic
+from dynode_amd.engine import solve_batch
+
+pytestmark = pytest.mark.gpu
+O = H.O
+
+
+def fd_oracle(m, y0, p, C, t1, ts, dp, dy0=None, eps=1e-6, **kw):
+    """Central difference of the oracle along direction (dp, dy0), fp64."""
+    dy0 = np.zeros_like(y0) if dy0 is None else dy0
+    up, _, _, _ = O.solve(H.omodel(m), y0 + eps * dy0, p + eps * dp, C, t1, ts, dtype=np.float64, **kw)
+    dn, _, _, _ = O.solve(H.omodel(m), y0 - eps * dy0, p - eps * dp, C, t1, ts, dtype=np.float64, **kw)
+    return (up - dn) / (2 * eps)
+
+
+CASES = [
+    (ModelDesc(n_age=2), 2), (ModelDesc(n_age=1), 2), (ModelDesc(n_age=8), 2),
+    (ModelDesc(n_age=1, has_e=True, has_wane=True), 4), (ModelDesc(n_age=1, has_e=True, has_wane=True), 1),
+    (ModelDesc(n_age=2, n_strain=3, has_e=True, has_wane=True, has_c=True), 1),
+    (ModelDesc(n_age=1, has_e=True, has_wane=True, seasonal=True), 4),
+]
+
+
+def _workload(m, B, seed):
+    from test_gpu_parity import random_workload
+    return random_workload(m, B, seed, t1=80.0)
+
+
+@pytest.mark.parametrize("m,nd", CASES, ids=lambda v: str(v) if isinstance(v, int) else f"A{v.n_age}S{v.n_strain}e{int(v.has_e)}s{int(v.seasonal)}")
+def test_tangents_equal_derivative_of_the_discrete_solve(m, nd):
+    B = 11
+    y0, p, C, t1, ts = _workload(m, B, seed=7 + nd)
+    rng = np.random.default_rng(0)
+    dp = rng.normal(size=(B, nd, m.param_dim)) * 0.1 * np.abs(p)[:, None, :]
+    dy0 = rng.normal(size=(B, nd, m.state_dim))
+    r = solve_batch(m, y0, p, C, t1, ts, dtype=torch.float64, constant_dt=0.25, dparams=dp, dy0=dy0)
+    torch.cuda.synchronize()
+    want_y, _, _, _ = O.solve(H.omodel(m), y0, p, C, t1, ts, dtype=np.float64, constant_dt=0.25)
+    assert np.abs(r.ys.cpu().numpy() - want_y).max() / 1000 < 1e-11           # primal untouched by the tangents
+    dys = r.dys.cpu().numpy()
+    assert dys.shape == (B, len(ts), nd, m.state_dim)
+    for j in range(nd):
+        want = fd_oracle(m, y0, p, C, t1, ts, dp[:, j], dy0[:, j], eps=1e-6, constant_dt=0.25)
+        scale = np.abs(want).max() + 1e-12
+        assert np.abs(dys[:, :, j] - want).max() / scale < 2e-6, (j, np.abs(dys[:, :, j] - want).max() / scale)
+
+
+def test_adaptive_tangents_converge_to_the_true_sensitivity():
+    m = ModelDesc(n_age=2)
+    wl = synthetic.sir_two_age_literal(t1=100.0)
+    p = np.repeat(wl.params, 3, axis=0) * np.array([[1.0], [1.1], [0.9]])
+    dp = np.zeros((3, 2, 2)); dp[:, 0, 0] = 1.0; dp[:, 1, 1] = 1.0             # d/dbeta, d/dgamma
+    r = solve_batch(m, wl.y0, p, wl.contact, 100.0, wl.save_ts, dtype=torch.float64, rtol=1e-10, atol=1e-10, dparams=dp)
+    torch.cuda.synchronize()
+    for j in range(2):
+        want = fd_oracle(m, wl.y0, p, wl.contact, 100.0, wl.save_ts, dp[:, j], eps=1e-5, rtol=1e-12, atol=1e-12)
+        scale = np.abs(want).max()
+        assert np.abs(r.dys.cpu().numpy()[:, :, j] - want).max() / scale < 1e-6
+    # default tolerances, fp32: tangents stay within solver-tolerance distance of the truth
+    r32 = solve_batch(m, wl.y0, p, wl.contact, 100.0, wl.save_ts, dtype=torch.float32, dparams=dp)
+    torch.cuda.synchronize()
+    ref = r.dys.cpu().numpy()
+    assert np.abs(r32.dys.cpu().numpy() - ref).max() / np.abs(ref).max() < 2e-3
+    plain = solve_batch(m, wl.y0, p, wl.contact, 100.0, wl.save_ts, dtype=torch.float32).ys
+    assert float((r32.ys - plain).abs().max()) / 1000 < 1e-5     # same algorithm, separately compiled kernels
+
+
+def test_jvp_sub_save_and_failures():
+    m = ModelDesc(n_age=2)
+    wl = synthetic.sir_two_age_literal(t1=50.0)
+    dp = np.ones((1, 2, 2))
+    full = solve_batch(m, wl.y0, wl.params, wl.contact, 50.0, wl.save_ts, dtype=torch.float64, dparams=dp)
+    sub = solve_batch(m, wl.y0, wl.params, wl.contact, 50.0, wl.save_ts, dtype=torch.float64, dparams=dp,
+                      save_mask=(0, 0, 1))
+    assert sub.dys.shape == (1, 51, 2, 2) and torch.equal(sub.dys, full.dys[..., 4:])
+    bad = solve_batch(m, wl.y0, wl.params, wl.contact, 50.0, wl.save_ts, dtype=torch.float64, dparams=dp, max_steps=3)
+    torch.cuda.synchronize()
+    assert int(bad.status[0]) == 1 and bool(torch.isinf(bad.dys[0, -1]).all())
+    from dynode_amd.engine import SolveError
+    with pytest.raises(SolveError, match="UNSUPPORTED"):
+        solve_batch(ModelDesc(n_age=8, n_strain=4, has_e=True, has_wane=True, has_c=True), np.zeros(136),
+                    np.ones((1, 16)), np.eye(8), 10.0, [0.0, 10.0], dparams=np.ones((1, 2, 16)))
