@@ -1,0 +1,76 @@
+"""Differentiable batched solve: the fused kernel as a ``torch.autograd.Function``.
+
+The reference obtains d(log-posterior)/d(parameters) by letting numpyro differentiate through
+``diffeqsolve`` (examples/sir_infer_parameters.py:21-39 under
+src/dynode/infer/inference.py:149-163).  Here the kernel itself returns the Jacobian of the saved
+trajectory with respect to the P entries of the parameter vector (forward mode, identity seeds,
+``dyn_solve_batch_jvp``); the backward pass is one contraction with the incoming cotangent, so any
+torch code around ``simulate`` -- ``get_odeparams`` arithmetic, ``diff``/``clamp``, the Poisson
+log-likelihood -- is differentiated by torch autograd.
+"""
+
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from .. import _abi
+from ..engine import _DTYPES, _METHODS, solve_batch
+
+
+def _supported_nd(model, method: str, dtype, nd: int) -> bool:
+    opts = _abi.SolverOptsC(_METHODS[method], _DTYPES[dtype], 1e-5, 1e-6, 10**6, 0.0, None, 0)
+    return bool(_abi.lib().dyn_is_supported_jvp(ctypes.byref(model.c()), ctypes.byref(opts), nd))
+
+
+def direction_chunks(model, method: str, dtype, P: int) -> list:
+    """Split P seed directions into chunks the library has kernels for (largest first)."""
+    sizes = [n for n in range(P, 0, -1) if _supported_nd(model, method, dtype, n)]
+    if not sizes:
+        raise RuntimeError(f"no tangent kernel compiled for {model} (method={method}, dtype={dtype})")
+    chunks, left = [], P
+    while left:
+        n = next((s for s in sizes if s <= left), None)
+        if n is None:
+            raise RuntimeError(f"cannot tile {P} tangent directions with compiled kernels {sizes}")
+        chunks.append(n)
+        left -= n
+    return chunks
+
+
+class _DiffSolve(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, params, model, y0, contact, t1, save_ts, kw):
+        dtype = kw.get("dtype", torch.float32)
+        method = kw.get("method", "tsit5")
+        B, P = params.shape
+        pk = params.detach().to(dtype)
+        eye = torch.eye(P, dtype=dtype, device=params.device)
+        jac, res, start = [], None, 0
+        for n in direction_chunks(model, method, dtype, P):
+            seeds = eye[start:start + n].unsqueeze(0).expand(B, n, P).contiguous()
+            res = solve_batch(model, y0, pk, contact, t1, save_ts, dparams=seeds, **kw)
+            jac.append(res.dys)
+            start += n
+        J = jac[0] if len(jac) == 1 else torch.cat(jac, dim=2)     # [B, n_save, P, D_saved]
+        ctx.save_for_backward(J)
+        ctx.in_dtype = params.dtype
+        ctx.mark_non_differentiable(res.status, res.n_accept, res.n_reject)
+        ctx.meta = (res.saved, res.sizes)
+        return res.ys, res.status, res.n_accept, res.n_reject
+
+    @staticmethod
+    def backward(ctx, g_ys, *_unused):
+        (J,) = ctx.saved_tensors
+        g = torch.einsum("btd,btpd->bp", g_ys.to(J.dtype), J)
+        return g.to(ctx.in_dtype), None, None, None, None, None, None
+
+
+def solve_batch_diff(model, y0, params: torch.Tensor, contact, t1, save_ts, **kw):
+    """Like ``engine.solve_batch`` but differentiable with respect to ``params`` ([B, P] tensor)."""
+    from ..engine import BatchResult, save_mask_bytes
+
+    ys, status, n_acc, n_rej = _DiffSolve.apply(params, model, y0, contact, t1, save_ts, kw)
+    _, saved, sizes = save_mask_bytes(model, kw.get("save_mask"))
+    return BatchResult(ys, status, n_acc, n_rej, saved, sizes)

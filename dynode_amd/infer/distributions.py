@@ -1,10 +1,11 @@
 """The handful of distributions the reference's priors and likelihood use, under numpyro's names.
 
-numpyro is not available to this build; these are thin float64 wrappers over
-``torch.distributions`` (host side, priors and likelihoods only -- never on the solve path).
-Used by: examples/sir_infer_parameters.py:47-58 of the reference
-(``TransformedDistribution(Beta(0.5, 0.5), AffineTransform(1.5, 1))``,
-``TruncatedNormal(8, 2, low=2, high=15)``) and its ``Poisson`` likelihood (:34-38).
+numpyro is not available to this build.  These are small torch implementations (float64,
+autograd- and device-transparent: ``log_prob`` follows the device of its argument), used for
+priors and likelihoods only -- never on the solve path.  Reference call sites:
+examples/sir_infer_parameters.py:47-58 (``TransformedDistribution(Beta(0.5, 0.5),
+AffineTransform(1.5, 1))``, ``TruncatedNormal(8, 2, low=2, high=15)``) and the ``Poisson``
+likelihood (:34-38).
 """
 
 from __future__ import annotations
@@ -13,83 +14,104 @@ import math
 from types import SimpleNamespace
 
 import torch
-import torch.distributions as td
 
 _F = torch.float64
+_SQRT2 = math.sqrt(2.0)
 
 
-def _t(x):
-    return torch.as_tensor(x, dtype=_F)
+def _t(x, like=None):
+    t = x if isinstance(x, torch.Tensor) else torch.as_tensor(x, dtype=_F)
+    if like is not None and isinstance(like, torch.Tensor):
+        t = t.to(device=like.device)
+    return t.to(_F)
+
+
+def _ndtr(z):
+    return 0.5 * (1.0 + torch.erf(z / _SQRT2))
+
+
+def _ndtri(p):
+    return _SQRT2 * torch.erfinv(2.0 * p - 1.0)
 
 
 class Distribution:
-    """Minimal numpyro-like distribution: sample(rng, shape), log_prob(value), support."""
+    """Minimal numpyro-like distribution: sample(rng, shape), log_prob(value), support, icdf."""
 
     support = (-math.inf, math.inf)
 
     def sample(self, rng: torch.Generator, sample_shape=()):
-        raise NotImplementedError
+        u = torch.rand(tuple(sample_shape) + tuple(self.batch_shape), generator=rng, dtype=_F)
+        return self.icdf(u.clamp(1e-12, 1 - 1e-12))
+
+    batch_shape = ()
 
     def log_prob(self, value):
+        raise NotImplementedError
+
+    def icdf(self, q):
         raise NotImplementedError
 
     @property
     def median(self):
-        return self.icdf(_t(0.5))
-
-    def icdf(self, q):
-        raise NotImplementedError
+        return self.icdf(torch.tensor(0.5, dtype=_F))
 
 
-class _Wrapped(Distribution):
-    def __init__(self, base: td.Distribution, support):
-        self._base = base
-        self.support = support
-
-    def sample(self, rng, sample_shape=()):
-        # torch.distributions has no generator argument: draw uniforms with ours, then invert the cdf
-        u = torch.rand(tuple(sample_shape) + tuple(self._base.batch_shape), generator=rng, dtype=_F)
-        u = u.clamp(1e-12, 1 - 1e-12)
-        return self.icdf(u)
+class Normal(Distribution):
+    def __init__(self, loc=0.0, scale=1.0):
+        self.loc, self.scale = _t(loc), _t(scale)
+        self.batch_shape = torch.broadcast_shapes(self.loc.shape, self.scale.shape)
 
     def log_prob(self, value):
-        return self._base.log_prob(_t(value))
+        v = _t(value)
+        loc, scale = _t(self.loc, v), _t(self.scale, v)
+        z = (v - loc) / scale
+        return -0.5 * z * z - torch.log(scale) - 0.5 * math.log(2 * math.pi)
 
     def icdf(self, q):
-        return self._base.icdf(_t(q))
+        q = _t(q)
+        return _t(self.loc, q) + _t(self.scale, q) * _ndtri(q)
 
 
-class Normal(_Wrapped):
-    def __init__(self, loc=0.0, scale=1.0):
-        super().__init__(td.Normal(_t(loc), _t(scale)), (-math.inf, math.inf))
-
-
-class Uniform(_Wrapped):
+class Uniform(Distribution):
     def __init__(self, low=0.0, high=1.0):
-        super().__init__(td.Uniform(_t(low), _t(high)), (float(low), float(high)))
+        self.low, self.high = _t(low), _t(high)
+        self.support = (float(self.low.min()), float(self.high.max()))
+        self.batch_shape = torch.broadcast_shapes(self.low.shape, self.high.shape)
+
+    def log_prob(self, value):
+        v = _t(value)
+        lo, hi = _t(self.low, v), _t(self.high, v)
+        inside = (v >= lo) & (v <= hi)
+        return torch.where(inside, -torch.log(hi - lo), torch.full_like(v, -math.inf))
+
+    def icdf(self, q):
+        q = _t(q)
+        return _t(self.low, q) + (_t(self.high, q) - _t(self.low, q)) * q
 
 
 class Beta(Distribution):
     support = (0.0, 1.0)
 
     def __init__(self, concentration1, concentration0):
-        self._base = td.Beta(_t(concentration1), _t(concentration0))
+        self.a, self.b = _t(concentration1), _t(concentration0)
+        self.batch_shape = torch.broadcast_shapes(self.a.shape, self.b.shape)
 
     def sample(self, rng, sample_shape=()):
-        a, b = self._base.concentration1, self._base.concentration0
-        # ratio of gammas drawn with our generator (torch's Beta.sample takes no generator)
-        shape = tuple(sample_shape) + tuple(self._base.batch_shape)
-        ga = torch._standard_gamma(a.expand(shape).contiguous(), generator=rng) if hasattr(torch, "_standard_gamma") else None
-        gb = torch._standard_gamma(b.expand(shape).contiguous(), generator=rng)
+        shape = tuple(sample_shape) + tuple(self.batch_shape)
+        ga = torch._standard_gamma(self.a.expand(shape).contiguous(), generator=rng)
+        gb = torch._standard_gamma(self.b.expand(shape).contiguous(), generator=rng)
         return (ga / (ga + gb)).clamp(1e-12, 1 - 1e-12)
 
     def log_prob(self, value):
-        return self._base.log_prob(_t(value))
+        v = _t(value)
+        a, b = _t(self.a, v), _t(self.b, v)
+        lbeta = torch.lgamma(a) + torch.lgamma(b) - torch.lgamma(a + b)
+        return (a - 1.0) * torch.log(v) + (b - 1.0) * torch.log1p(-v) - lbeta
 
     def icdf(self, q):
-        # bisection on the regularised incomplete beta (median of Beta(.5,.5) = .5 etc.)
-        from scipy.stats import beta as sbeta
-        return _t(sbeta.ppf(_t(q).numpy(), self._base.concentration1.numpy(), self._base.concentration0.numpy()))
+        from scipy.stats import beta as sbeta  # host-side, used for medians / initial values only
+        q = _t(q)
+        return torch.as_tensor(sbeta.ppf(q.cpu().numpy(), self.a.numpy(), self.b.numpy()), dtype=_F)
 
 
 class TruncatedNormal(Distribution):
@@ -100,37 +122,38 @@ class TruncatedNormal(Distribution):
         self.low = -math.inf if low is None else float(low)
         self.high = math.inf if high is None else float(high)
         self.support = (self.low, self.high)
-        self._n = td.Normal(_t(0.0), _t(1.0))
-        self._a = self._n.cdf((_t(self.low) - self.loc) / self.scale)
-        self._b = self._n.cdf((_t(self.high) - self.loc) / self.scale)
+        self.batch_shape = torch.broadcast_shapes(self.loc.shape, self.scale.shape)
+        self._a = _ndtr((torch.tensor(self.low, dtype=_F) - self.loc) / self.scale)
+        self._b = _ndtr((torch.tensor(self.high, dtype=_F) - self.loc) / self.scale)
         self._logz = torch.log(self._b - self._a)
 
     def icdf(self, q):
-        return self.loc + self.scale * self._n.icdf(self._a + _t(q) * (self._b - self._a))
-
-    def sample(self, rng, sample_shape=()):
-        u = torch.rand(tuple(sample_shape) + tuple(self.loc.shape), generator=rng, dtype=_F).clamp(1e-12, 1 - 1e-12)
-        return self.icdf(u)
+        q = _t(q)
+        return _t(self.loc, q) + _t(self.scale, q) * _ndtri(_t(self._a, q) + q * _t(self._b - self._a, q))
 
     def log_prob(self, value):
         v = _t(value)
-        z = (v - self.loc) / self.scale
-        lp = -0.5 * z * z - 0.5 * math.log(2 * math.pi) - torch.log(self.scale) - self._logz
-        return torch.where((v >= self.low) & (v <= self.high), lp, _t(-math.inf))
+        loc, scale = _t(self.loc, v), _t(self.scale, v)
+        z = (v - loc) / scale
+        lp = -0.5 * z * z - 0.5 * math.log(2 * math.pi) - torch.log(scale) - _t(self._logz, v)
+        return torch.where((v >= self.low) & (v <= self.high), lp, torch.full_like(lp, -math.inf))
 
 
 class Poisson(Distribution):
     support = (0.0, math.inf)
 
     def __init__(self, rate):
-        self.rate = _t(rate)
+        self.rate = rate if isinstance(rate, torch.Tensor) else _t(rate)
+        self.batch_shape = tuple(self.rate.shape)
 
     def sample(self, rng, sample_shape=()):
-        return torch.poisson(self.rate.expand(tuple(sample_shape) + tuple(self.rate.shape)), generator=rng)
+        rate = self.rate.detach().to("cpu", _F)
+        return torch.poisson(rate.expand(tuple(sample_shape) + tuple(rate.shape)), generator=rng)
 
     def log_prob(self, value):
-        v = _t(value)
-        return v * torch.log(self.rate) - self.rate - torch.lgamma(v + 1.0)
+        rate = self.rate.to(_F)
+        v = _t(value, rate)
+        return v * torch.log(rate) - rate - torch.lgamma(v + 1.0)
 
 
 class AffineTransform:
@@ -157,13 +180,7 @@ class TransformedDistribution(Distribution):
         for t in self.transforms:
             lo, hi = sorted((t(lo), t(hi)))
         self.support = (lo, hi)
-
-    def _inv(self, y):
-        x, ladj = _t(y), 0.0
-        for t in reversed(self.transforms):
-            x = t.inv(x)
-            ladj += t.log_abs_det_jacobian()
-        return x, ladj
+        self.batch_shape = base_distribution.batch_shape
 
     def sample(self, rng, sample_shape=()):
         x = self.base.sample(rng, sample_shape)
@@ -172,7 +189,10 @@ class TransformedDistribution(Distribution):
         return x
 
     def log_prob(self, value):
-        x, ladj = self._inv(value)
+        x, ladj = _t(value), 0.0
+        for t in reversed(self.transforms):
+            x = t.inv(x)
+            ladj += t.log_abs_det_jacobian()
         return self.base.log_prob(x) - ladj
 
     def icdf(self, q):
@@ -183,3 +203,45 @@ class TransformedDistribution(Distribution):
 
 
 transforms = SimpleNamespace(AffineTransform=AffineTransform)
+
+
+# ---------------------------------------------------------------------- unconstraining bijections
+class Bijection:
+    """Map an unconstrained real z to the support of a distribution (numpyro's ``biject_to``)."""
+
+    def __init__(self, support):
+        self.lo, self.hi = support
+        self.kind = ("real" if math.isinf(self.lo) and math.isinf(self.hi) else
+                     "interval" if not (math.isinf(self.lo) or math.isinf(self.hi)) else
+                     "lower" if math.isinf(self.hi) else "upper")
+
+    def __call__(self, z):
+        if self.kind == "real":
+            return z
+        if self.kind == "interval":
+            return self.lo + (self.hi - self.lo) * torch.sigmoid(z)
+        if self.kind == "lower":
+            return self.lo + torch.exp(z)
+        return self.hi - torch.exp(z)
+
+    def inv(self, x):
+        x = _t(x)
+        if self.kind == "real":
+            return x
+        if self.kind == "interval":
+            u = ((x - self.lo) / (self.hi - self.lo)).clamp(1e-12, 1 - 1e-12)
+            return torch.log(u) - torch.log1p(-u)
+        if self.kind == "lower":
+            return torch.log(x - self.lo)
+        return torch.log(self.hi - x)
+
+    def log_abs_det_jacobian(self, z):
+        if self.kind == "real":
+            return torch.zeros_like(z)
+        if self.kind == "interval":
+            return math.log(self.hi - self.lo) + torch.nn.functional.logsigmoid(z) + torch.nn.functional.logsigmoid(-z)
+        return z
+
+
+def biject_to(support) -> Bijection:
+    return Bijection(support)

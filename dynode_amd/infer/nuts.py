@@ -1,0 +1,303 @@
+"""Batched No-U-Turn sampler: all chains advance in lockstep on one GPU.
+
+What numpyro does under ``MCMC(NUTS(model, dense_mass=True, max_tree_depth, init_to_median))``
+(reference src/dynode/infer/inference.py:149-163), re-designed for a GPU whose potential
+evaluation is ONE fused gradient-solve launch for every chain at once: the tree is built with the
+iterative (checkpointed) algorithm of Hoffman-Gelman / Phan et al. so that at any moment all
+chains are at the same tree depth and leaf index -- checkpoint bookkeeping is host arithmetic,
+per-chain differences (direction, U-turn, divergence, proposal choice) are masks.  Warm-up is
+Stan's windowed scheme: dual-averaging step size (target accept 0.8), dense mass matrix from
+Welford covariance with shrinkage, per chain (chains adapt independently, as in numpyro).
+
+Chains shard embarrassingly over GPUs (one process per GPU, `dynode_amd.sharding`); nothing here
+communicates.
+"""
+
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Callable, Optional
+
+import torch
+
+
+def _bdot(a, b):
+    return (a * b).sum(-1)
+
+
+def _mv(m, v):
+    return torch.einsum("cij,cj->ci", m, v)
+
+
+@dataclass
+class NUTSResult:
+    samples: torch.Tensor       # [C, num_samples, D] unconstrained
+    accept_prob: torch.Tensor   # [C, num_samples]
+    num_steps: torch.Tensor     # [C, num_samples] leapfrogs per transition
+    diverging: torch.Tensor     # [C, num_samples]
+    step_size: torch.Tensor     # [C]
+    inverse_mass: torch.Tensor  # [C, D, D]
+    potential_evals: int        # batched gradient-solves issued
+
+
+class _DualAveraging:
+    """Nesterov dual averaging on log step size, per chain (Stan / numpyro defaults)."""
+
+    def __init__(self, step_size, t0=10.0, kappa=0.75, gamma=0.05):
+        self.t0, self.kappa, self.gamma = t0, kappa, gamma
+        self.restart(step_size)
+
+    def restart(self, step_size):
+        self.mu = torch.log(10.0 * step_size)
+        self.x_bar = torch.zeros_like(step_size)
+        self.g_bar = torch.zeros_like(step_size)
+        self.t = 0
+
+    def update(self, g):
+        self.t += 1
+        w = 1.0 / (self.t + self.t0)
+        self.g_bar = (1 - w) * self.g_bar + w * g
+        x = self.mu - math.sqrt(self.t) / self.gamma * self.g_bar
+        wx = self.t ** (-self.kappa)
+        self.x_bar = (1 - wx) * self.x_bar + wx * x
+        return torch.exp(x), torch.exp(self.x_bar)
+
+
+class _Welford:
+    def __init__(self, C, D, device):
+        self.n = 0
+        self.mean = torch.zeros((C, D), dtype=torch.float64, device=device)
+        self.m2 = torch.zeros((C, D, D), dtype=torch.float64, device=device)
+
+    def update(self, x):
+        self.n += 1
+        d = x - self.mean
+        self.mean = self.mean + d / self.n
+        self.m2 = self.m2 + torch.einsum("ci,cj->cij", d, x - self.mean)
+
+    def covariance(self):
+        cov = self.m2 / (self.n - 1)
+        scaled = (self.n / (self.n + 5.0)) * cov
+        eye = torch.eye(cov.shape[-1], dtype=cov.dtype, device=cov.device)
+        return scaled + 1e-3 * (5.0 / (self.n + 5.0)) * eye
+
+
+def _adaptation_windows(num_warmup: int):
+    """Stan's schedule: 75-step initial buffer, doubling 25-step windows, 50-step final buffer."""
+    if num_warmup < 20:
+        return []
+    init, term, base = 75, 50, 25
+    if init + base + term > num_warmup:
+        init, term = int(0.15 * num_warmup), int(0.1 * num_warmup)
+        base = num_warmup - init - term
+    ends, start, size = [], init, base
+    while start + size <= num_warmup - term:
+        nxt = start + size
+        if nxt + 2 * size > num_warmup - term:   # stretch the last window to the final buffer
+            nxt = num_warmup - term
+        ends.append((start, nxt))
+        start, size = nxt, size * 2
+    return ends
+
+
+class BatchedNUTS:
+    """NUTS for C independent chains over a D-dimensional unconstrained space.
+
+    ``potential_and_grad(z [C, D]) -> (U [C], dU/dz [C, D])`` evaluates every chain in one call.
+    """
+
+    def __init__(self, potential_and_grad: Callable, max_tree_depth: int = 10, target_accept: float = 0.8,
+                 max_delta_energy: float = 1000.0, seed: int = 0):
+        self.pg = potential_and_grad
+        self.max_depth = int(max_tree_depth)
+        self.target = float(target_accept)
+        self.max_de = float(max_delta_energy)
+        self.seed = int(seed)
+        self.evals = 0
+
+    # -------------------------------------------------------------- pieces
+    def _eval(self, z):
+        self.evals += 1
+        u, g = self.pg(z)
+        bad = ~torch.isfinite(u) | ~torch.isfinite(g).all(-1)
+        u = torch.where(bad, torch.full_like(u, math.inf), u)
+        g = torch.where(bad[:, None], torch.zeros_like(g), g)
+        return u, g
+
+    def _kinetic(self, imm, r):
+        return 0.5 * _bdot(r, _mv(imm, r))
+
+    def _leapfrog(self, z, r, g, eps, imm):
+        r = r - 0.5 * eps[:, None] * g
+        z = z + eps[:, None] * _mv(imm, r)
+        u, g = self._eval(z)
+        r = r - 0.5 * eps[:, None] * g
+        return z, r, u, g
+
+    @staticmethod
+    def _is_turning(imm, r_left, r_right, r_sum):
+        rs = r_sum - 0.5 * (r_left + r_right)
+        return (_bdot(_mv(imm, r_left), rs) <= 0) | (_bdot(_mv(imm, r_right), rs) <= 0)
+
+    def _find_reasonable_step_size(self, z, u, g, imm, mm_sqrt, eps, gen):
+        """Double/halve each chain's step until the one-step accept probability crosses 0.8."""
+        C = z.shape[0]
+        r = _mv(mm_sqrt, torch.randn(z.shape, dtype=z.dtype, device=z.device, generator=gen))
+        e0 = u + self._kinetic(imm, r)
+        direction = torch.zeros(C, dtype=z.dtype, device=z.device)
+        active = torch.ones(C, dtype=torch.bool, device=z.device)
+        for _ in range(50):
+            _, r1, u1, _ = self._leapfrog(z, r, g, eps, imm)
+            de = u1 + self._kinetic(imm, r1) - e0
+            de = torch.where(torch.isnan(de), torch.full_like(de, math.inf), de)
+            d = torch.where(-de > math.log(self.target), torch.ones_like(de), -torch.ones_like(de))
+            first = direction == 0
+            direction = torch.where(first, d, direction)
+            active = active & (d == direction) & (eps > 1e-10) & (eps < 1e7)
+            if not bool(active.any()):
+                break
+            eps = torch.where(active, eps * (2.0 ** direction), eps)
+        return eps
+
+    # -------------------------------------------------------------- one transition for all chains
+    def _transition(self, z, u, g, eps, imm, mm_sqrt, gen):
+        C, D = z.shape
+        dev, dt = z.device, z.dtype
+        r0 = _mv(mm_sqrt, torch.randn((C, D), dtype=dt, device=dev, generator=gen))
+        e0 = u + self._kinetic(imm, r0)
+        zl, rl, gl = z.clone(), r0.clone(), g.clone()
+        zr, rr, gr = z.clone(), r0.clone(), g.clone()
+        zp, up, gp = z.clone(), u.clone(), g.clone()
+        weight = torch.zeros(C, dtype=dt, device=dev)          # log sum of exp(-delta energy)
+        r_sum = r0.clone()
+        turning = torch.zeros(C, dtype=torch.bool, device=dev)
+        diverging = torch.zeros(C, dtype=torch.bool, device=dev)
+        sum_acc = torch.zeros(C, dtype=dt, device=dev)
+        n_prop = torch.zeros(C, dtype=torch.long, device=dev)
+
+        for depth in range(self.max_depth):
+            alive = ~turning & ~diverging
+            if not bool(alive.any()):
+                break
+            right = torch.rand(C, device=dev, generator=gen) < 0.5
+            sgn = torch.where(right, torch.ones(C, dtype=dt, device=dev), -torch.ones(C, dtype=dt, device=dev))
+            # ---- subtree of 2^depth leaves grown from the chosen end (iterative, checkpointed)
+            zc = torch.where(right[:, None], zr, zl)
+            rc = torch.where(right[:, None], rr, rl)
+            gc = torch.where(right[:, None], gr, gl)
+            s_first_r = None
+            s_zp, s_up, s_gp = zc.clone(), up.clone(), gc.clone()
+            s_weight = torch.full((C,), -math.inf, dtype=dt, device=dev)
+            s_rsum = torch.zeros((C, D), dtype=dt, device=dev)
+            s_turn = torch.zeros(C, dtype=torch.bool, device=dev)
+            s_div = torch.zeros(C, dtype=torch.bool, device=dev)
+            s_acc = torch.zeros(C, dtype=dt, device=dev)
+            s_n = torch.zeros(C, dtype=torch.long, device=dev)
+            r_ck = torch.zeros((self.max_depth, C, D), dtype=dt, device=dev)
+            rs_ck = torch.zeros((self.max_depth, C, D), dtype=dt, device=dev)
+            for leaf in range(2 ** depth):
+                grow = alive & ~s_turn & ~s_div
+                if not bool(grow.any()):
+                    break
+                zn, rn, un, gn = self._leapfrog(zc, rc, gc, eps * sgn, imm)
+                de = un + self._kinetic(imm, rn) - e0
+                de = torch.where(torch.isnan(de), torch.full_like(de, math.inf), de)
+                lw = -de
+                div = de > self.max_de
+                acc = torch.exp(torch.clamp(-de, max=0.0))
+                if leaf == 0:
+                    s_first_r = rn.clone()
+                # uniform (multinomial) choice inside the subtree
+                new_w = torch.logaddexp(s_weight, lw)
+                take = torch.rand(C, device=dev, generator=gen).to(dt) < torch.exp(lw - new_w)
+                upd = grow
+                sel = upd & take
+                s_zp = torch.where(sel[:, None], zn, s_zp)
+                s_up = torch.where(sel, un, s_up)
+                s_gp = torch.where(sel[:, None], gn, s_gp)
+                s_weight = torch.where(upd, new_w, s_weight)
+                s_rsum = torch.where(upd[:, None], s_rsum + rn, s_rsum)
+                s_div = s_div | (upd & div)
+                s_acc = torch.where(upd, s_acc + acc, s_acc)
+                s_n = s_n + upd.long()
+                zc = torch.where(upd[:, None], zn, zc)
+                rc = torch.where(upd[:, None], rn, rc)
+                gc = torch.where(upd[:, None], gn, gc)
+                # U-turn checks of every balanced sub-subtree that this leaf completes
+                idx_max = bin(leaf >> 1).count("1")
+                trailing = 0
+                while (leaf >> trailing) & 1:
+                    trailing += 1
+                idx_min = idx_max - trailing + 1
+                if leaf % 2 == 0:
+                    r_ck[idx_max] = torch.where(upd[:, None], rn, r_ck[idx_max])
+                    rs_ck[idx_max] = torch.where(upd[:, None], s_rsum, rs_ck[idx_max])
+                else:
+                    t = torch.zeros(C, dtype=torch.bool, device=dev)
+                    for i in range(idx_max, idx_min - 1, -1):
+                        sub = s_rsum - rs_ck[i] + r_ck[i]
+                        t = t | self._is_turning(imm, r_ck[i], rn, sub)
+                    s_turn = s_turn | (upd & t)
+            # ---- merge the subtree into the trajectory (biased progressive sampling)
+            grew = alive & (s_n > 0)
+            ok = grew & ~s_turn & ~s_div
+            move = ok & (torch.rand(C, device=dev, generator=gen).to(dt) < torch.exp(torch.clamp(s_weight - weight, max=0.0)))
+            zp = torch.where(move[:, None], s_zp, zp)
+            up = torch.where(move, s_up, up)
+            gp = torch.where(move[:, None], s_gp, gp)
+            ext_r = grew & right
+            ext_l = grew & ~right
+            zr = torch.where(ext_r[:, None], zc, zr); rr = torch.where(ext_r[:, None], rc, rr); gr = torch.where(ext_r[:, None], gc, gr)
+            zl = torch.where(ext_l[:, None], zc, zl); rl = torch.where(ext_l[:, None], rc, rl); gl = torch.where(ext_l[:, None], gc, gl)
+            weight = torch.where(grew, torch.logaddexp(weight, s_weight), weight)
+            r_sum = torch.where(grew[:, None], r_sum + s_rsum, r_sum)
+            sum_acc = sum_acc + torch.where(grew, s_acc, torch.zeros_like(s_acc))
+            n_prop = n_prop + torch.where(grew, s_n, torch.zeros_like(s_n))
+            diverging = diverging | (grew & s_div)
+            turning = turning | (grew & (s_turn | self._is_turning(imm, rl, rr, r_sum)))
+        accept = sum_acc / n_prop.clamp_min(1).to(dt)
+        return zp, up, gp, accept, n_prop, diverging
+
+    # -------------------------------------------------------------- driver
+    def run(self, z0: torch.Tensor, num_warmup: int, num_samples: int, init_step_size: float = 1.0,
+            progress: Optional[Callable] = None) -> NUTSResult:
+        z = z0.clone().to(torch.float64)
+        C, D = z.shape
+        dev = z.device
+        gen = torch.Generator(device=dev).manual_seed(self.seed)
+        eye = torch.eye(D, dtype=torch.float64, device=dev).expand(C, D, D).contiguous()
+        imm, mm_sqrt = eye.clone(), eye.clone()
+        u, g = self._eval(z)
+        eps = torch.full((C,), float(init_step_size), dtype=torch.float64, device=dev)
+        eps = self._find_reasonable_step_size(z, u, g, imm, mm_sqrt, eps, gen)
+        da = _DualAveraging(eps)
+        windows = _adaptation_windows(num_warmup)
+        win_i, welford = 0, _Welford(C, D, dev)
+        out_z = torch.empty((C, num_samples, D), dtype=torch.float64, device=dev)
+        out_acc = torch.empty((C, num_samples), dtype=torch.float64, device=dev)
+        out_n = torch.empty((C, num_samples), dtype=torch.long, device=dev)
+        out_div = torch.empty((C, num_samples), dtype=torch.bool, device=dev)
+        eps_avg = eps.clone()
+        for it in range(num_warmup + num_samples):
+            warm = it < num_warmup
+            z, u, g, acc, n_prop, div = self._transition(z, u, g, eps, imm, mm_sqrt, gen)
+            if warm:
+                eps, eps_avg = da.update(self.target - acc)
+                if win_i < len(windows) and windows[win_i][0] <= it < windows[win_i][1]:
+                    welford.update(z)
+                    if it + 1 == windows[win_i][1]:
+                        imm = welford.covariance()
+                        mm_sqrt = torch.linalg.cholesky(torch.linalg.inv(imm))
+                        welford = _Welford(C, D, dev)
+                        win_i += 1
+                        eps = self._find_reasonable_step_size(z, u, g, imm, mm_sqrt, eps_avg, gen)
+                        da.restart(eps)
+                if it + 1 == num_warmup:
+                    eps = eps_avg
+            else:
+                j = it - num_warmup
+                out_z[:, j], out_acc[:, j], out_n[:, j], out_div[:, j] = z, acc, n_prop, div
+            if progress is not None:
+                progress(it, warm)
+        return NUTSResult(out_z, out_acc, out_n, out_div, eps, imm, self.evals)

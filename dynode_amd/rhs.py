@@ -165,6 +165,45 @@ class CompartmentalODE:
             cols.append(np.broadcast_to(a.reshape(-1, 1), (B, 1)))
         return np.ascontiguousarray(np.concatenate(cols, axis=1)), batch, seasonal
 
+    def param_tensor(self, p, device) -> "torch.Tensor":
+        """[B, P] parameter matrix built with torch ops, keeping the autograd graph of any field
+        that is a tensor requiring grad (used by the differentiable solve under NUTS)."""
+        names = ["beta", "gamma"] + (["sigma"] if self.has_e else []) + (["omega"] if self.has_wane else [])
+        strain_rank = 1 if self.multi_strain else 0
+        f64 = torch.float64
+
+        def tt(v):
+            return v.to(device=device, dtype=f64) if isinstance(v, torch.Tensor) else torch.as_tensor(
+                np.asarray(v, dtype=np.float64), device=device)
+
+        arrays = []
+        for n in names:
+            a = tt(getattr(p, n))
+            if not self.multi_strain and a.dim() == 1 and a.numel() == 1:
+                a = a.reshape(())
+            arrays.append(a)
+        seas = getattr(p, "seasonality_params", None)
+        seasonal = bool(self.seasonal) if self.seasonal is not None else seas is not None
+        extra = [tt(getattr(seas, n)) for n in ("forcing_amp", "forcing_phase", "forcing_period")] if seasonal else []
+        extra = [a.reshape(()) if a.numel() == 1 and a.dim() <= 1 else a for a in extra]
+        B = 1
+        for a in arrays:
+            if a.dim() == strain_rank + 1:
+                B = max(B, a.shape[0])
+        for a in extra:
+            if a.dim() == 1:
+                B = max(B, a.shape[0])
+        S = arrays[0].shape[-1] if self.multi_strain else 1
+        cols = [a.reshape(-1, S).expand(B, S) for a in arrays] + [a.reshape(-1, 1).expand(B, 1) for a in extra]
+        return torch.cat(cols, dim=1)
+
+    def wants_grad(self, p) -> bool:
+        leaves = [getattr(p, f.name) for f in fields(p)]
+        seas = getattr(p, "seasonality_params", None)
+        if seas is not None:
+            leaves += [seas.forcing_amp, seas.forcing_phase, seas.forcing_period]
+        return any(isinstance(v, torch.Tensor) and v.requires_grad for v in leaves)
+
     def _contact(self, p, A: int, contact_shape: tuple) -> np.ndarray:
         C = getattr(p, "contact_matrix", None)
         if C is None:

@@ -113,12 +113,19 @@ def simulate(ode, duration_days, initial_state: CompartmentState, ode_parameters
     if dtype is None:
         dtype = torch.float64 if _X64 else torch.float32
     sp = solver_parameters
-    res = solve_batch(
-        packed.model, packed.y0, packed.params, packed.contact, float(duration_days), saveat.ts, t0=0.0,
-        method=sp.solver_method.method, dtype=dtype, rtol=sp.ode_solver_rel_tolerance,
-        atol=sp.ode_solver_abs_tolerance, max_steps=sp.max_steps,
-        constant_dt=sp.constant_step_size if sp.constant_step_size > 0.0 else 0.0,
-        jump_ts=sp.discontinuity_points, save_mask=saveat.mask)
+    kw = dict(t0=0.0, method=sp.solver_method.method, dtype=dtype, rtol=sp.ode_solver_rel_tolerance,
+              atol=sp.ode_solver_abs_tolerance, max_steps=sp.max_steps,
+              constant_dt=sp.constant_step_size if sp.constant_step_size > 0.0 else 0.0,
+              jump_ts=sp.discontinuity_points, save_mask=saveat.mask)
+    if ode.wants_grad(ode_parameters):
+        # a parameter carries an autograd graph (NUTS potential): differentiable solve
+        from ..engine import require_gpu
+        from ..infer.autodiff import solve_batch_diff
+
+        params_t = ode.param_tensor(ode_parameters, require_gpu())
+        res = solve_batch_diff(packed.model, packed.y0, params_t, packed.contact, float(duration_days), saveat.ts, **kw)
+    else:
+        res = solve_batch(packed.model, packed.y0, packed.params, packed.contact, float(duration_days), saveat.ts, **kw)
 
     if throw:
         bad = int((res.status != _abi.STATUS_OK).sum())

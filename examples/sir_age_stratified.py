@@ -36,8 +36,9 @@ def get_config(r_0=2.0, infectious_period=7.0) -> SimulationConfig:
 def get_odeparams(config: SimulationConfig) -> SIR_ODEParams:
     tp = sample_then_resolve(config.parameters.transmission_params)
     strain = tp.strains[0]
-    return SIR_ODEParams(beta=np.asarray(strain.r0 / strain.infectious_period),
-                         gamma=np.asarray(1 / strain.infectious_period), contact_matrix=tp.contact_matrix)
+    # plain arithmetic: r0 / infectious_period may be floats, arrays or (under NUTS) torch tensors
+    return SIR_ODEParams(beta=strain.r0 / strain.infectious_period, gamma=1 / strain.infectious_period,
+                         contact_matrix=tp.contact_matrix)
 
 
 def run_simulation(config: SimulationConfig, tf):
