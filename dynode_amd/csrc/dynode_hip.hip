@@ -128,6 +128,12 @@ static int enqueue(const Entry *e, const dyn_model_desc *m, const dyn_solver_opt
         // nothing to write: still run (status / step counts are outputs too)
         ka.d_saved = pos;
     }
+    ka.n_jump = 0;
+    for (int j = 0; j < dyn::kMaxJumps; ++j) ka.jump_ts[j] = (T)0;
+    for (int j = 0; j < o->n_jump; ++j) {
+        // only points strictly inside (t0, t1) matter; sorted input is required (checked by caller)
+        if (o->jump_ts[j] > t0 && o->jump_ts[j] < t1) ka.jump_ts[ka.n_jump++] = (T)o->jump_ts[j];
+    }
     typedef hipError_t (*fn_t)(const KArgs<T> &, hipStream_t);
     const hipError_t err = ((fn_t)e->fn)(ka, stream);
     if (err != hipSuccess) {
@@ -213,11 +219,13 @@ static int solve_impl(const dyn_model_desc *m, const dyn_solver_opts *o, const v
                  n_save, DYN_MAX_SAVE_BYTES);
         return DYN_ERR_UNSUPPORTED;
     }
-    if (o->n_jump > 0) {
-        snprintf(dyn::tl_error, sizeof(dyn::tl_error),
-                 "discontinuity_points are not supported by the HIP path yet");
+    if (o->n_jump > dyn::kMaxJumps) {
+        snprintf(dyn::tl_error, sizeof(dyn::tl_error), "at most %d discontinuity_points are supported",
+                 dyn::kMaxJumps);
         return DYN_ERR_UNSUPPORTED;
     }
+    for (int j = 1; j < o->n_jump; ++j)
+        if (!(o->jump_ts[j] > o->jump_ts[j - 1])) return DYN_ERR_JUMP; /* must be strictly increasing */
     const dyn::Entry *e = dyn::find_entry(m, o->dtype, o->method, n_dir);
     if (!e) {
         snprintf(dyn::tl_error, sizeof(dyn::tl_error),

@@ -43,7 +43,11 @@ struct KArgs {
     const T *dy0;     // [ND][D] or [B][ND][D] seeds of the initial state, or nullptr (= 0)
     T *dout;          // [B][n_save][ND][D_saved]
     int32_t dy0_batched;
+    // discontinuity_points (ClipStepSizeController jump_ts), passed by value in the kernarg
+    int32_t n_jump;
+    T jump_ts[16];
 };
+constexpr int kMaxJumps = 16;
 
 // ---------------------------------------------------------------- math per precision
 template <typename T>
@@ -68,6 +72,7 @@ struct Mth<float> {
         return __builtin_amdgcn_exp2f(e * __builtin_amdgcn_logf(x));
     }
     static __device__ __forceinline__ float inf() { return __builtin_huge_valf(); }
+    static __device__ __forceinline__ float next(float x, float to) { return nextafterf(x, to); }
     static constexpr float clip_tol = 1e-6f; // diffrax _clip_to_end tolerance, float32
 };
 template <>
@@ -82,6 +87,7 @@ struct Mth<double> {
     static __device__ __forceinline__ double recip(double x) { return 1.0 / x; }
     static __device__ __forceinline__ double pow_fast(double x, double e) { return ::pow(x, e); }
     static __device__ __forceinline__ double inf() { return __builtin_huge_val(); }
+    static __device__ __forceinline__ double next(double x, double to) { return nextafter(x, to); }
     static constexpr double clip_tol = 1e-10;
 };
 
@@ -701,7 +707,27 @@ struct Solver {
         extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
         T *const ts_tab = reinterpret_cast<T *>(dyn_smem); // LDS address space: ds_read only
         for (int j = lane; j < n_save; j += 64) ts_tab[j] = ka.save_ts[j];
+        // discontinuity points follow the save grid in LDS (per-group index into the table)
+        T *const jt_tab = ts_tab + n_save;
+        const int n_jump = ka.n_jump;
+        if (n_jump > 0 && lane == 0) {
+#pragma unroll
+            for (int j = 0; j < kMaxJumps; ++j) jt_tab[j] = ka.jump_ts[j];
+        }
         __syncthreads();
+        // jump bookkeeping (restates oracle/dynode_oracle_impl.inc): steps are clipped to land just
+        // before a jump, restart just after it with FSAL recomputed and the unclipped step size
+        int jidx = 0;
+        bool at_jump = false;
+        T dt_unclipped = T(0);
+        if (n_jump > 0) {
+            while (jidx < n_jump && jt_tab[jidx] <= tprev) ++jidx;
+            if (jidx < n_jump && jt_tab[jidx] < tnext) {
+                dt_unclipped = tnext - tprev;
+                tnext = M::next(jt_tab[jidx], -M::inf());
+                at_jump = true;
+            }
+        }
         // next two save times kept in registers (the read of ts[idx+2] overlaps a whole round)
         T ts_next = n_save > 0 ? ts_tab[0] : M::inf();
         T ts_next2 = n_save > 1 ? ts_tab[1] : M::inf();
@@ -814,11 +840,40 @@ struct Solver {
                 ++n_rej;
             }
             // ---- next interval: prev_dt * factor, then diffeqsolve's clip-to-end
-            const T next_t0 = accept ? tnext : tprev;
+            T next_t0 = accept ? tnext : tprev;
             T next_t1 = next_t0 + (constant ? ka.constant_dt : dt * factor);
+            if (n_jump > 0) { // wave-uniform: no cost when discontinuity_points is empty
+                const bool landed = at_jump && accept;
+                if (landed) {
+                    // prev_dt is the controller's proposal before the jump clipped it
+                    next_t0 = M::next(jt_tab[jidx], M::inf());
+                    next_t1 = next_t0 + (constant ? ka.constant_dt : dt_unclipped * factor);
+                    ++jidx;
+                }
+                if (__any(landed)) { // FSAL is invalid across a jump: k[0] = f(t_jump+, y)
+                    L.rhs(next_t0, y, k[1]);
+                    if (landed) {
+#pragma unroll
+                        for (int c = 0; c < NC; ++c)
+#pragma unroll
+                            for (int v = 0; v < NV; ++v) k[0][c][v] = k[1][c][v];
+                    }
+                }
+                if (act) at_jump = false;
+                if (act && jidx < n_jump) {
+                    const T tj = jt_tab[jidx];
+                    if (tj < next_t1 && tj > next_t0) {
+                        dt_unclipped = next_t1 - next_t0;
+                        next_t1 = M::next(tj, -M::inf());
+                        at_jump = true;
+                    }
+                }
+            }
             const T tp = M::min(next_t0, t_end);
-            if (next_t1 > t_end - M::clip_tol)
+            if (next_t1 > t_end - M::clip_tol) {
                 next_t1 = accept ? t_end : tp + T(0.5) * (t_end - tp);
+                at_jump = false;
+            }
             if (!done) {
                 tprev = tp;
                 tnext = next_t1;
@@ -865,7 +920,7 @@ hipError_t launch(const KArgs<T> &ka, hipStream_t stream) {
     constexpr int TPW = 64 / G;
     const int64_t blocks = (ka.B + TPW - 1) / TPW;
     if (blocks <= 0) return hipSuccess;
-    const size_t lds = (size_t)ka.n_save * sizeof(T); // save grid staged in LDS
+    const size_t lds = ((size_t)ka.n_save + (ka.n_jump > 0 ? kMaxJumps : 0)) * sizeof(T); // LDS tables
     hipLaunchKernelGGL((solve_kernel<T, METHOD, G, S, HAS_E, HAS_WANE, HAS_C, W, ND>),
                        dim3((unsigned)blocks), dim3(64), lds, stream, ka);
     return hipGetLastError();

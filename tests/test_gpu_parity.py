@@ -245,8 +245,27 @@ def test_final_size_on_gpu(s0, i0):
     assert got[0, -1, 2] == pytest.approx(1 - s_inf, abs=2e-2)
 
 
-def test_unsupported_shape_and_jumps_fail_loudly():
+def test_unsupported_shape_fails_loudly():
     with pytest.raises(SolveError, match="UNSUPPORTED"):
         solve_batch(ModelDesc(n_age=8, n_strain=7), np.zeros(8 * 15), np.zeros((1, 14)), np.eye(8), 10.0, [0.0, 10.0])
-    with pytest.raises(SolveError, match="UNSUPPORTED"):
-        solve_batch(SIR1, [0.9, 0.1, 0], [[0.3, 0.1]], [[1.0]], 10.0, [0.0, 10.0], jump_ts=[5.0])
+    with pytest.raises(SolveError, match="UNSUPPORTED"):       # more jump points than the LDS table holds
+        solve_batch(SIR1, [0.9, 0.1, 0], [[0.3, 0.1]], [[1.0]], 100.0, [0.0, 100.0], jump_ts=list(np.arange(1.0, 40.0, 2.0)))
+    with pytest.raises(SolveError, match="JUMP"):               # must be strictly increasing
+        solve_batch(SIR1, [0.9, 0.1, 0], [[0.3, 0.1]], [[1.0]], 100.0, [0.0, 100.0], jump_ts=[50.0, 20.0])
+
+
+@pytest.mark.parametrize("m", [ModelDesc(n_age=1, has_e=True, has_wane=True, seasonal=True), ModelDesc(n_age=8),
+                               ModelDesc(n_age=2, n_strain=3, has_e=True, has_wane=True, has_c=True)],
+                         ids=["seirs_seasonal", "sir8", "multi2x3"])
+def test_discontinuity_points_match_oracle(m):
+    """odes.py:120-131: ClipStepSizeController(jump_ts=discontinuity_points)."""
+    y0, p, C, t1, ts = random_workload(m, 21, seed=3, t1=150.0)
+    jumps = [0.0, 30.0, 61.5, 61.75, 120.0, 150.0, 400.0]      # incl. the ends and one beyond t1
+    got, st, na, nr = hip(m, y0, p, C, t1, ts, dtype=F64, jump_ts=jumps)
+    want, st_o, na_o, nr_o = O.solve(H.omodel(m), y0, p, C, t1, ts, dtype=np.float64, jump_ts=jumps)
+    assert st.max() == 0 and np.abs(got - want).max() / 1000 < 1e-11
+    assert np.array_equal(na, na_o) and np.array_equal(nr, nr_o)
+    base, _, na0, _ = hip(m, y0, p, C, t1, ts, dtype=F64)
+    assert (na >= na0).all() and np.abs(got - base).max() / 1000 < 1e-4   # smooth RHS: jumps only cost steps
+    got32, st32, _, _ = hip(m, y0, p, C, t1, ts, dtype=F32, jump_ts=jumps)
+    assert st32.max() == 0 and np.abs(got32 - want).max() / 1000 < 1e-5
