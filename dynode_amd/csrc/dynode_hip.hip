@@ -5,12 +5,13 @@
 #include "solve_kernel.hpp"
 
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 namespace dyn {
 
-#define X(T, METHOD, G, S, E, WN, C, W, ND) \
-    extern template hipError_t launch<T, METHOD, G, S, E, WN, C, W, ND>(const KArgs<T> &, hipStream_t);
+#define X(T, METHOD, G, S, E, WN, C, W, ND, SPL) \
+    extern template hipError_t launch<T, METHOD, G, S, E, WN, C, W, ND, SPL>(const KArgs<T> &, hipStream_t);
 #include "instances.def"
 #undef X
 
@@ -26,15 +27,15 @@ struct DType<double> {
 };
 
 struct Entry {
-    int dtype, method, G, S, E, WN, C, W, ND;
+    int dtype, method, G, S, E, WN, C, W, ND, SPL;
     void *fn; // hipError_t (*)(const KArgs<T>&, hipStream_t)
 };
 
 static const Entry kEntries[] = {
-#define X(T, METHOD, G, S, E, WN, C, W, ND)                   \
-    {DType<T>::id, METHOD, G, S, E, WN, C, W, ND,             \
+#define X(T, METHOD, G, S, E, WN, C, W, ND, SPL)              \
+    {DType<T>::id, METHOD, G, S, E, WN, C, W, ND, SPL,        \
      (void *)(hipError_t(*)(const KArgs<T> &, hipStream_t)) & \
-         launch<T, METHOD, G, S, E, WN, C, W, ND>},
+         launch<T, METHOD, G, S, E, WN, C, W, ND, SPL>},
 #include "instances.def"
 #undef X
 };
@@ -48,14 +49,20 @@ static int group_width(int A) {
 
 static const Entry *find_entry(const dyn_model_desc *m, int dtype, int method, int nd = 0) {
     const int G = group_width(m->n_age);
+    // DYNODE_HIP_SPL=<n> (tuning aid): prefer the variant with n strains per lane
+    const char *env = getenv("DYNODE_HIP_SPL");
+    const int want_spl = env ? atoi(env) : 0;
+    const Entry *first = nullptr;
     for (int i = 0; i < kNumEntries; ++i) {
         const Entry &e = kEntries[i];
         if (e.dtype == dtype && e.method == method && e.G == G && e.S == m->n_strain &&
             e.E == (m->has_e != 0) && e.WN == (m->has_wane != 0) && e.C == (m->has_c != 0) &&
-            e.W == m->n_wane && e.ND == nd)
-            return &e;
+            e.W == m->n_wane && e.ND == nd) {
+            if (!first) first = &e;
+            if (want_spl > 0 && e.SPL == want_spl) return &e;
+        }
     }
-    return nullptr;
+    return first;
 }
 
 static thread_local char tl_error[256] = "";
@@ -185,7 +192,9 @@ int32_t dyn_param_dim(const dyn_model_desc *m) {
 
 int32_t dyn_trajectories_per_wave(const dyn_model_desc *m) {
     if (dyn::check_model(m)) return 0;
-    return 64 / dyn::group_width(m->n_age);
+    const dyn::Entry *e = dyn::find_entry(m, DYN_F32, DYN_TSIT5, 0);
+    const int gs = e ? e->S / e->SPL : 1;
+    return 64 / (dyn::group_width(m->n_age) * gs);
 }
 
 int32_t dyn_is_supported(const dyn_model_desc *m, const dyn_solver_opts *o) {

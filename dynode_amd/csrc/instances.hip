@@ -7,8 +7,8 @@
 #endif
 
 namespace dyn {
-#define X(T, METHOD, G, S, E, WN, C, W, ND) \
-    template hipError_t launch<T, METHOD, G, S, E, WN, C, W, ND>(const KArgs<T> &, hipStream_t);
+#define X(T, METHOD, G, S, E, WN, C, W, ND, SPL) \
+    template hipError_t launch<T, METHOD, G, S, E, WN, C, W, ND, SPL>(const KArgs<T> &, hipStream_t);
 #include "instances.def"
 #undef X
 } // namespace dyn

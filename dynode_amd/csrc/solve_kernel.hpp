@@ -236,10 +236,23 @@ __device__ __forceinline__ T group_sum(T v) {
     return v;
 }
 
-// store CNT contiguous values; 16-byte vector stores when the host proved alignment
+// store CNT contiguous values; 16-byte (or 8-byte) vector stores when the host proved alignment
 template <typename T, int CNT>
 __device__ __forceinline__ void store_run(T *p, const T (&v)[CNT], bool vec_ok) {
     constexpr int PER = 16 / sizeof(T);
+    if constexpr (sizeof(T) == 4 && CNT % 4 != 0 && CNT % 2 == 0) {
+        if (vec_ok) {
+            typedef T vec2_t __attribute__((ext_vector_type(2)));
+#pragma unroll
+            for (int q = 0; q < CNT / 2; ++q) {
+                vec2_t pk;
+                pk[0] = v[2 * q];
+                pk[1] = v[2 * q + 1];
+                *reinterpret_cast<vec2_t *>(p + 2 * q) = pk;
+            }
+            return;
+        }
+    }
     if constexpr (CNT % PER == 0) {
         if (vec_ok) {
             typedef T vec_t __attribute__((ext_vector_type(PER)));
@@ -264,8 +277,18 @@ __device__ __forceinline__ void store_run(T *p, const T (&v)[CNT], bool vec_ok) 
 // accept/reject decision come from the primal alone (what jax.grad through diffrax does: the
 // controller is under stop_gradient), so the tangents are the exact derivative of the computed
 // trajectory ("discretise-then-optimise"), see dyn_solve_batch_jvp in include/dynode_hip.h.
-template <typename T, int METHOD, int G, int S, bool HAS_E, bool HAS_WANE, bool HAS_C, int W, int ND>
+// Lane mapping: a trajectory owns GA x GS lanes -- GA = power of two >= n_age "age lanes" (low bits
+// of the lane id) times GS = S / SPL "strain lanes"; lane (a, h) holds s_a (replicated over h) and
+// the e/i/r/c values of age a for its SPL strains h*SPL .. h*SPL+SPL-1.  SPL == S is the plain
+// one-lane-per-age mapping; splitting the strains (SPL < S) divides the per-lane state, trading
+// replicated control arithmetic for occupancy and smaller lock-step groups.
+template <typename T, int METHOD, int GA, int ST, bool HAS_E, bool HAS_WANE, bool HAS_C, int W, int ND, int SPL>
 struct Solver {
+    static_assert(ST % SPL == 0, "strains per lane must divide the strain count");
+    static constexpr int S = SPL;        // strains held by one lane (all per-lane arrays use S)
+    static constexpr int GS = ST / SPL;  // strain lanes
+    static constexpr int G = GA * GS;    // lanes per trajectory
+    static_assert(G <= 64 && (GS & (GS - 1)) == 0, "lane group must be a power of two <= 64");
     static constexpr int NE = HAS_E ? S : 0;
     static constexpr int NCU = HAS_C ? S : 0;
     static constexpr int NV = 1 + NE + S + S * W + NCU;
@@ -278,23 +301,33 @@ struct Solver {
 
     // per-lane model data
     T beta[S], gamma[S], sigma[S], omega[S];
-    T Cx[G]; // Cx[k] = contact[a][a ^ k] (0 outside the matrix)
+    T Cx[GA]; // Cx[k] = contact[a][a ^ k] (0 outside the matrix)
     T amp, phase, w_season;
     // parameter seeds per direction
     T dbeta[NDA][S], dgamma[NDA][S], dsigma[NDA][S], domega[NDA][S];
     T damp[NDA], dphase[NDA], dw_season[NDA];
     bool pad, normalize, seasonal;
+    bool lead; // strain lane 0: owns the replicated s for norms and stores
+
+    // sum over the strain lanes of the group (identical result in every lane)
+    __device__ __forceinline__ static T strain_sum(T v) {
+        if constexpr (GS >= 2) v += xchg_xor<GA>(v);
+        if constexpr (GS >= 4) v += xchg_xor<2 * GA>(v);
+        if constexpr (GS >= 8) v += xchg_xor<4 * GA>(v);
+        if constexpr (GS >= 16) v += xchg_xor<8 * GA>(v);
+        return v;
+    }
 
     // acc_l = sum_k Cx[k] * x_l[lane ^ k]: all-gather over the lane group fused with the
     // pre-permuted contact row
     __device__ __forceinline__ void contract(const T (&x)[S], T (&acc)[S]) const {
 #pragma unroll
         for (int l = 0; l < S; ++l) acc[l] = T(0);
-        if constexpr (G < 4) {
+        if constexpr (GA < 4) {
 #pragma unroll
             for (int l = 0; l < S; ++l) {
                 acc[l] = Cx[0] * x[l];
-                if constexpr (G == 2) acc[l] += Cx[1] * xchg_xor<1>(x[l]);
+                if constexpr (GA == 2) acc[l] += Cx[1] * xchg_xor<1>(x[l]);
             }
         } else {
             gather_base<0>(x, acc);
@@ -313,7 +346,7 @@ struct Solver {
 #pragma unroll
             for (int w = 0; w < W; ++w) sr += y0[IR + l * W + w];
         }
-        const T N = ((y0[0] + se) + si) + sr;
+        const T N = y0[0] + strain_sum((se + si) + sr);
         T invN = T(1);
         if (normalize) invN = pad ? T(0) : M::recip(N);
         T season = T(1), sin_arg = T(0), cos_arg = T(0);
@@ -358,7 +391,7 @@ struct Solver {
             }
             if constexpr (HAS_C) dy[0][IC + l] = flux;
         }
-        dy[0][0] = back_s - out_s;
+        dy[0][0] = strain_sum(back_s - out_s);
 
         // ---- JVP planes: the same expression tree, linearised
         if constexpr (ND > 0) {
@@ -374,7 +407,7 @@ struct Solver {
 #pragma unroll
                     for (int w = 0; w < W; ++w) dsr += u[IR + l * W + w];
                 }
-                const T dN = ((u[0] + dse) + dsi) + dsr;
+                const T dN = u[0] + strain_sum((dse + dsi) + dsr);
                 const T dinvN = normalize ? -(invN * invN) * dN : T(0); // pad: invN == 0
                 T dseason = T(0);
                 if (seasonal)
@@ -416,7 +449,7 @@ struct Solver {
                     }
                     if constexpr (HAS_C) du[IC + l] = dflux;
                 }
-                du[0] = dback_s - dout_s;
+                du[0] = strain_sum(dback_s - dout_s);
             }
         }
     }
@@ -438,7 +471,7 @@ struct Solver {
                           Cx[off ^ 3]);
         if constexpr (S % 2 == 1)
             fma_quad_one(acc[S - 1], xb[S - 1], Cx[off], Cx[off ^ 1], Cx[off ^ 2], Cx[off ^ 3]);
-        if constexpr ((BASE + 1) * 4 < G) gather_base<BASE + 1>(x, acc);
+        if constexpr ((BASE + 1) * 4 < GA) gather_base<BASE + 1>(x, acc);
     }
 
     // dense output at theta in [0,1] for the accepted step (y -> y1), k = stage derivatives
@@ -508,41 +541,43 @@ struct Solver {
     }
 
     // one saved row of one plane
+    // `as` = a * ST + h * SPL: position of this lane's first strain inside an [A, ST] block
     template <int PLANE>
     __device__ __forceinline__ static void save_row(const KArgs<T> &ka, const Dense &dn, T dt,
                                                     const T (&y)[NC][NV], const T (&yt)[NC][NV],
-                                                    const T (&k)[7][NC][NV], T *row, int a,
-                                                    bool vec_ok) {
-        if (ka.save_off[0] >= 0)
+                                                    const T (&k)[7][NC][NV], T *row, int a, int as,
+                                                    bool lead, bool vec_ok) {
+        if (ka.save_off[0] >= 0 && lead)
             save_block<0, 1>(dn, dt, y[PLANE], yt[PLANE], k, PLANE, row + ka.save_off[0] + a, false);
         if constexpr (HAS_E)
             if (ka.save_off[1] >= 0)
-                save_block<IE, S>(dn, dt, y[PLANE], yt[PLANE], k, PLANE,
-                                  row + ka.save_off[1] + a * S, vec_ok);
+                save_block<IE, S>(dn, dt, y[PLANE], yt[PLANE], k, PLANE, row + ka.save_off[1] + as,
+                                  vec_ok);
         if (ka.save_off[2] >= 0)
-            save_block<II, S>(dn, dt, y[PLANE], yt[PLANE], k, PLANE, row + ka.save_off[2] + a * S,
+            save_block<II, S>(dn, dt, y[PLANE], yt[PLANE], k, PLANE, row + ka.save_off[2] + as,
                               vec_ok);
         if (ka.save_off[3] >= 0)
             save_block<IR, S * W>(dn, dt, y[PLANE], yt[PLANE], k, PLANE,
-                                  row + ka.save_off[3] + a * S * W, vec_ok);
+                                  row + ka.save_off[3] + as * W, vec_ok);
         if constexpr (HAS_C)
             if (ka.save_off[4] >= 0)
-                save_block<IC, S>(dn, dt, y[PLANE], yt[PLANE], k, PLANE,
-                                  row + ka.save_off[4] + a * S, vec_ok);
+                save_block<IC, S>(dn, dt, y[PLANE], yt[PLANE], k, PLANE, row + ka.save_off[4] + as,
+                                  vec_ok);
     }
 
-    __device__ __forceinline__ static void fill_row(const KArgs<T> &ka, T *row, int a, T v) {
-        if (ka.save_off[0] >= 0) row[ka.save_off[0] + a] = v;
+    __device__ __forceinline__ static void fill_row(const KArgs<T> &ka, T *row, int a, int as,
+                                                    bool lead, T v) {
+        if (ka.save_off[0] >= 0 && lead) row[ka.save_off[0] + a] = v;
         if constexpr (HAS_E)
             if (ka.save_off[1] >= 0)
-                for (int q = 0; q < S; ++q) row[ka.save_off[1] + a * S + q] = v;
+                for (int q = 0; q < S; ++q) row[ka.save_off[1] + as + q] = v;
         if (ka.save_off[2] >= 0)
-            for (int q = 0; q < S; ++q) row[ka.save_off[2] + a * S + q] = v;
+            for (int q = 0; q < S; ++q) row[ka.save_off[2] + as + q] = v;
         if (ka.save_off[3] >= 0)
-            for (int q = 0; q < S * W; ++q) row[ka.save_off[3] + a * S * W + q] = v;
+            for (int q = 0; q < S * W; ++q) row[ka.save_off[3] + as * W + q] = v;
         if constexpr (HAS_C)
             if (ka.save_off[4] >= 0)
-                for (int q = 0; q < S; ++q) row[ka.save_off[4] + a * S + q] = v;
+                for (int q = 0; q < S; ++q) row[ka.save_off[4] + as + q] = v;
     }
 
     template <int PLANE>
@@ -550,17 +585,18 @@ struct Solver {
                                                          const T (&y)[NC][NV],
                                                          const T (&yt)[NC][NV],
                                                          const T (&k)[7][NC][NV], T *drow, int a,
-                                                         bool vec_ok) {
+                                                         int as, bool lead, bool vec_ok) {
         if constexpr (PLANE < NC) {
-            save_row<PLANE>(ka, dn, dt, y, yt, k, drow + (int64_t)(PLANE - 1) * ka.d_saved, a,
-                            vec_ok);
-            save_tangents<PLANE + 1>(ka, dn, dt, y, yt, k, drow, a, vec_ok);
+            save_row<PLANE>(ka, dn, dt, y, yt, k, drow + (int64_t)(PLANE - 1) * ka.d_saved, a, as,
+                            lead, vec_ok);
+            save_tangents<PLANE + 1>(ka, dn, dt, y, yt, k, drow, a, as, lead, vec_ok);
         }
     }
 
     __device__ __forceinline__ static void run(const KArgs<T> &ka) {
         const int lane = threadIdx.x & 63;
-        const int a = lane % G;
+        const int a = lane % GA;          // age lane
+        const int h = (lane / GA) % GS;   // strain lane: strains h*SPL .. h*SPL+SPL-1
         const int grp = lane / G;
         int64_t traj = (int64_t)blockIdx.x * TPW + grp;
         const bool valid_traj = traj < ka.B;
@@ -568,14 +604,17 @@ struct Solver {
         const int A = ka.A;
         Solver L;
         L.pad = a >= A;
+        L.lead = h == 0;
         L.normalize = ka.normalize != 0;
         L.seasonal = ka.seasonal != 0;
         const int aa = L.pad ? 0 : a;
         const bool writer = valid_traj && !L.pad;
+        const int s0 = h * SPL; // first global strain of this lane
 
         // ---- flat-state offsets (compartment-major layout)
-        const int offE = A, offI = A + A * NE, offR = offI + A * S, offC = offR + A * S * W;
-        const int D = offC + A * NCU;
+        const int offE = A, offI = A + (HAS_E ? A * ST : 0), offR = offI + A * ST,
+                  offC = offR + A * ST * W;
+        const int D = offC + (HAS_C ? A * ST : 0);
 
         // ---- per-trajectory parameters (broadcast loads inside the lane group)
         {
@@ -583,17 +622,17 @@ struct Solver {
             constexpr int oS = 2, oW = 2 + (HAS_E ? 1 : 0), oSe = 2 + (HAS_E ? 1 : 0) + (HAS_WANE ? 1 : 0);
 #pragma unroll
             for (int l = 0; l < S; ++l) {
-                L.beta[l] = p[l];
-                L.gamma[l] = p[S + l];
-                L.sigma[l] = HAS_E ? p[oS * S + l] : T(0);
-                L.omega[l] = HAS_WANE ? p[oW * S + l] : T(0);
+                L.beta[l] = p[s0 + l];
+                L.gamma[l] = p[ST + s0 + l];
+                L.sigma[l] = HAS_E ? p[oS * ST + s0 + l] : T(0);
+                L.omega[l] = HAS_WANE ? p[oW * ST + s0 + l] : T(0);
             }
             L.amp = T(0);
             L.phase = T(0);
             L.w_season = T(0);
             T period = T(1);
             if (L.seasonal) {
-                const T *sp = p + oSe * S;
+                const T *sp = p + oSe * ST;
                 L.amp = sp[0];
                 L.phase = sp[1];
                 period = sp[2];
@@ -612,13 +651,13 @@ struct Solver {
                     const T *dp = ka.dparams + (traj * ND + j) * ka.P;
 #pragma unroll
                     for (int l = 0; l < S; ++l) {
-                        L.dbeta[j][l] = dp[l];
-                        L.dgamma[j][l] = dp[S + l];
-                        if constexpr (HAS_E) L.dsigma[j][l] = dp[oS * S + l];
-                        if constexpr (HAS_WANE) L.domega[j][l] = dp[oW * S + l];
+                        L.dbeta[j][l] = dp[s0 + l];
+                        L.dgamma[j][l] = dp[ST + s0 + l];
+                        if constexpr (HAS_E) L.dsigma[j][l] = dp[oS * ST + s0 + l];
+                        if constexpr (HAS_WANE) L.domega[j][l] = dp[oW * ST + s0 + l];
                     }
                     if (L.seasonal) {
-                        const T *dsp = dp + oSe * S;
+                        const T *dsp = dp + oSe * ST;
                         L.damp[j] = dsp[0];
                         L.dphase[j] = dsp[1];
                         L.dw_season[j] = -L.w_season / period * dsp[2]; // d(2 pi / period)
@@ -628,7 +667,7 @@ struct Solver {
         }
         // ---- contact row, pre-permuted to the xor-exchange order
 #pragma unroll
-        for (int k = 0; k < G; ++k) {
+        for (int k = 0; k < GA; ++k) {
             const int b = a ^ k;
             L.Cx[k] = (!L.pad && b < A) ? ka.contact[aa * A + b] : T(0);
         }
@@ -648,12 +687,12 @@ struct Solver {
             y[c][0] = zero ? T(0) : src[aa];
 #pragma unroll
             for (int l = 0; l < S; ++l) {
-                if constexpr (HAS_E) y[c][IE + l] = zero ? T(0) : src[offE + aa * S + l];
-                y[c][II + l] = zero ? T(0) : src[offI + aa * S + l];
+                const int sg = aa * ST + s0 + l; // (age, global strain)
+                if constexpr (HAS_E) y[c][IE + l] = zero ? T(0) : src[offE + sg];
+                y[c][II + l] = zero ? T(0) : src[offI + sg];
 #pragma unroll
-                for (int w = 0; w < W; ++w)
-                    y[c][IR + l * W + w] = zero ? T(0) : src[offR + (aa * S + l) * W + w];
-                if constexpr (HAS_C) y[c][IC + l] = zero ? T(0) : src[offC + aa * S + l];
+                for (int w = 0; w < W; ++w) y[c][IR + l * W + w] = zero ? T(0) : src[offR + sg * W + w];
+                if constexpr (HAS_C) y[c][IC + l] = zero ? T(0) : src[offC + sg];
             }
         }
 
@@ -667,15 +706,17 @@ struct Solver {
             tnext = tprev + ka.constant_dt;
         } else {
             // Hairer-Norsett-Wanner II.4 starting step (diffrax _select_initial_step), primal only
-            T s0 = 0, s1 = 0;
+            // the replicated s (element 0) enters every norm once: only the lead strain lane counts it
+            const T w_s = L.lead ? T(1) : T(0);
+            T n0 = 0, n1 = 0;
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
                 const T sc = atol + M::abs(y[0][v]) * rtol;
                 const T q0 = y[0][v] / sc, q1 = k[0][0][v] / sc;
-                s0 += q0 * q0;
-                s1 += q1 * q1;
+                n0 += (v == 0 ? w_s : T(1)) * (q0 * q0);
+                n1 += (v == 0 ? w_s : T(1)) * (q1 * q1);
             }
-            const T d0 = M::sqrt(group_sum<G>(s0) / Dn), d1 = M::sqrt(group_sum<G>(s1) / Dn);
+            const T d0 = M::sqrt(group_sum<G>(n0) / Dn), d1 = M::sqrt(group_sum<G>(n1) / Dn);
             const bool small = (d0 < T(1e-5)) || (d1 < T(1e-5));
             const T h0 = small ? T(1e-6) : T(0.01) * (d0 / d1);
 #pragma unroll
@@ -688,7 +729,7 @@ struct Solver {
             for (int v = 0; v < NV; ++v) {
                 const T sc = atol + M::abs(y[0][v]) * rtol;
                 const T q2 = (k[1][0][v] - k[0][0][v]) / sc;
-                s2 += q2 * q2;
+                s2 += (v == 0 ? w_s : T(1)) * (q2 * q2);
             }
             const T d2 = M::sqrt(group_sum<G>(s2) / Dn) / h0;
             const T max_d = M::max(d1, d2);
@@ -737,6 +778,7 @@ struct Solver {
         T *const out_traj = ka.out + traj * (int64_t)n_save * ka.d_saved;
         T *const dout_traj = ND > 0 ? ka.dout + traj * (int64_t)n_save * ND * ka.d_saved : nullptr;
         const bool vec_ok = ka.vec_ok != 0;
+        const int as = a * ST + s0;
 
 #ifdef DYN_DIAG_ROUNDS
         int diag_iters = 0, diag_rounds = 0;
@@ -776,7 +818,10 @@ struct Solver {
                         if (TB::berr[q] != 0.0) e += T(TB::berr[q]) * k[q][0][v];
                     const T ym = M::max(M::abs(y[0][v]), M::abs(yt[0][v]));
                     const T r = (dt * e) * M::rcp_fast(atol + ym * rtol);
-                    ss += r * r;
+                    if (GS > 1 && v == 0)
+                        ss += L.lead ? r * r : T(0);
+                    else
+                        ss += r * r;
                 }
                 const T err = M::sqrt(group_sum<G>(ss) / Dn);
                 keep = err < T(1);
@@ -813,11 +858,11 @@ struct Solver {
                     dense_prepare((ts_next - tprev) * inv_dt, dn);
                     if (writer) {
                         save_row<0>(ka, dn, dt, y, yt, k, out_traj + (int64_t)save_idx * ka.d_saved,
-                                    a, vec_ok);
+                                    a, as, L.lead, vec_ok);
                         if constexpr (ND > 0)
                             save_tangents<1>(ka, dn, dt, y, yt, k,
-                                             dout_traj + (int64_t)save_idx * ND * ka.d_saved, a,
-                                             vec_ok);
+                                             dout_traj + (int64_t)save_idx * ND * ka.d_saved, a, as,
+                                             L.lead, vec_ok);
                     }
                     ++save_idx;
                     ts_next = ts_next2;
@@ -889,13 +934,13 @@ struct Solver {
         // rows never reached (failed solves): +inf, like diffrax's unfilled SaveAt buffer
         if (writer) {
             for (; save_idx < n_save; ++save_idx) {
-                fill_row(ka, out_traj + (int64_t)save_idx * ka.d_saved, a, M::inf());
+                fill_row(ka, out_traj + (int64_t)save_idx * ka.d_saved, a, as, L.lead, M::inf());
                 if constexpr (ND > 0)
                     for (int j = 0; j < ND; ++j)
-                        fill_row(ka, dout_traj + ((int64_t)save_idx * ND + j) * ka.d_saved, a,
-                                 M::inf());
+                        fill_row(ka, dout_traj + ((int64_t)save_idx * ND + j) * ka.d_saved, a, as,
+                                 L.lead, M::inf());
             }
-            if (a == 0) {
+            if (a == 0 && L.lead) {
                 ka.status[traj] = st;
 #ifdef DYN_DIAG_ROUNDS
                 n_acc = diag_iters;
@@ -908,20 +953,20 @@ struct Solver {
     }
 };
 
-template <typename T, int METHOD, int G, int S, bool HAS_E, bool HAS_WANE, bool HAS_C, int W, int ND>
+template <typename T, int METHOD, int GA, int ST, bool HAS_E, bool HAS_WANE, bool HAS_C, int W, int ND, int SPL>
 __global__ void __launch_bounds__(64)
 solve_kernel(const KArgs<T> ka) {
-    Solver<T, METHOD, G, S, HAS_E, HAS_WANE, HAS_C, W, ND>::run(ka);
+    Solver<T, METHOD, GA, ST, HAS_E, HAS_WANE, HAS_C, W, ND, SPL>::run(ka);
 }
 
 // host-side launcher, one explicit instantiation per compiled shape (instances.def)
-template <typename T, int METHOD, int G, int S, bool HAS_E, bool HAS_WANE, bool HAS_C, int W, int ND>
+template <typename T, int METHOD, int GA, int ST, bool HAS_E, bool HAS_WANE, bool HAS_C, int W, int ND, int SPL>
 hipError_t launch(const KArgs<T> &ka, hipStream_t stream) {
-    constexpr int TPW = 64 / G;
+    constexpr int TPW = 64 / (GA * (ST / SPL));
     const int64_t blocks = (ka.B + TPW - 1) / TPW;
     if (blocks <= 0) return hipSuccess;
     const size_t lds = ((size_t)ka.n_save + (ka.n_jump > 0 ? kMaxJumps : 0)) * sizeof(T); // LDS tables
-    hipLaunchKernelGGL((solve_kernel<T, METHOD, G, S, HAS_E, HAS_WANE, HAS_C, W, ND>),
+    hipLaunchKernelGGL((solve_kernel<T, METHOD, GA, ST, HAS_E, HAS_WANE, HAS_C, W, ND, SPL>),
                        dim3((unsigned)blocks), dim3(64), lds, stream, ka);
     return hipGetLastError();
 }

@@ -49,6 +49,9 @@ def random_workload(m, B, seed, t1=200.0):
     y0[:, :A] = 990 * w
     off_i = A + (A * S if m.has_e else 0)
     y0[:, off_i:off_i + A * S] = (10 * w[None, :, None] * rng.dirichlet(np.ones(S), B)[:, None, :]).reshape(B, -1)
+    if W > 1:  # some mass in every waning stage so the chain is exercised
+        off_r = off_i + A * S
+        y0[:, off_r:off_r + A * S * W] = rng.uniform(0.0, 0.5, (B, A * S * W))
     return y0, params, C, t1, synthetic.save_grid(t1)
 
 
@@ -62,6 +65,8 @@ SHAPES = [
     ModelDesc(n_age=8, n_strain=4, has_e=True, has_wane=True, has_c=True),
     ModelDesc(n_age=8, n_strain=4, has_e=True, has_wane=True, has_c=True, seasonal=True),
     ModelDesc(n_age=5, n_strain=4, has_e=True, has_wane=True, has_c=True),
+    ModelDesc(n_age=8, n_strain=4, has_e=True, has_wane=True, has_c=True, n_wane=8),   # D = 360, strains split over lanes
+    ModelDesc(n_age=6, n_strain=4, has_e=True, has_wane=True, has_c=True, n_wane=2),
 ]
 
 
@@ -75,7 +80,7 @@ def _supported(m, dtype, method):
 
 @pytest.mark.parametrize("method", ["tsit5", "dopri5"])
 @pytest.mark.parametrize("dtype", [F64, F32])
-@pytest.mark.parametrize("m", SHAPES, ids=lambda m: f"A{m.n_age}S{m.n_strain}e{int(m.has_e)}w{int(m.has_wane)}c{int(m.has_c)}s{int(m.seasonal)}")
+@pytest.mark.parametrize("m", SHAPES, ids=lambda m: f"A{m.n_age}S{m.n_strain}e{int(m.has_e)}w{int(m.has_wane)}c{int(m.has_c)}s{int(m.seasonal)}W{m.n_wane}")
 def test_hip_matches_oracle(m, dtype, method):
     if not _supported(m, dtype, method):
         pytest.skip("shape not compiled for this dtype/method")
@@ -116,7 +121,8 @@ def test_hip_vs_scipy_ground_truth(name):
 
 # ------------------------------------------------------------------ BASELINE sizes, property checks
 @pytest.mark.parametrize("wl", [synthetic.sir_age_stratified(4096, seed=0), synthetic.seirs_multi_strain(16384, seed=1),
-                                synthetic.seirs_multi_strain(8192, seed=5, seasonal=True)], ids=lambda w: w.name)
+                                synthetic.seirs_multi_strain(8192, seed=5, seasonal=True),
+                                synthetic.seirs_multi_strain(4096, seed=1, W=8)], ids=lambda w: f"{w.name}_D{w.model.state_dim}")
 def test_full_size_properties(wl):
     m = wl.model
     r = solve_batch(m, wl.y0, wl.params, wl.contact, wl.t1, wl.save_ts, dtype=F32)
