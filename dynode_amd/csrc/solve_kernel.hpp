@@ -350,7 +350,7 @@ struct Solver {
         T invN = T(1);
         if (normalize) invN = pad ? T(0) : M::recip(N);
         T season = T(1), sin_arg = T(0), cos_arg = T(0);
-        if (seasonal) {
+        if (__builtin_expect(seasonal, 0)) {
             const T arg = w_season * t + phase;
             sin_arg = M::sin(arg);
             if constexpr (ND > 0) cos_arg = M::cos(arg);
