@@ -43,7 +43,10 @@ class seed(_Handler):
     def process(self, msg):
         if msg["type"] == "sample" and msg["value"] is None and msg["gen"] is None:
             msg["gen"] = self.gen
-            if self.batch and not msg["sample_shape"]:
+            # one draw per batch member: prior sites are unbatched and get a sample_shape; sites whose
+            # distribution already depends on batched values (e.g. the likelihood) are batched already
+            shape = tuple(getattr(msg["fn"], "batch_shape", ()))
+            if self.batch and not msg["sample_shape"] and not (shape and shape[0] == self.batch):
                 msg["sample_shape"] = (self.batch,)
 
 
