@@ -7,7 +7,7 @@ import pytest
 import torch
 from scipy import stats
 
-from dynode_amd.infer.nuts import BatchedNUTS, _adaptation_windows
+from dynode_amd.infer.nuts import BatchedNUTS, LockstepNUTS, _adaptation_windows
 
 
 def gaussian_target(cov):
@@ -26,10 +26,11 @@ def test_adaptation_windows_follow_stans_schedule():
     assert _adaptation_windows(10) == []
 
 
-def test_correlated_gaussian_moments_and_marginals():
+@pytest.mark.parametrize("sampler", [BatchedNUTS, LockstepNUTS], ids=["async", "lockstep"])
+def test_correlated_gaussian_moments_and_marginals(sampler):
     torch.manual_seed(0)
     cov = torch.tensor([[4.0, 1.8], [1.8, 1.0]], dtype=torch.float64)    # strongly correlated, unequal scales
-    nuts = BatchedNUTS(gaussian_target(cov), max_tree_depth=8, seed=1)
+    nuts = sampler(gaussian_target(cov), max_tree_depth=8, seed=1)
     res = nuts.run(torch.randn(32, 2, dtype=torch.float64), num_warmup=300, num_samples=300)
     x = res.samples.reshape(-1, 2)
     assert res.samples.shape == (32, 300, 2) and int(res.diverging.sum()) == 0
@@ -64,3 +65,13 @@ def test_tree_depth_limit_and_divergence_flag():
     thin = res.samples[:, ::5, 0].reshape(-1).numpy()
     # density ~ exp(-x^4/4): symmetric, |x| rarely beyond 2.5
     assert abs(np.mean(thin)) < 0.25 and np.mean(np.abs(thin) > 2.5) < 0.02
+
+
+def test_async_needs_far_fewer_gradient_solves_than_lockstep():
+    cov = torch.tensor([[4.0, 1.8], [1.8, 1.0]], dtype=torch.float64)
+    z0 = torch.randn(64, 2, dtype=torch.float64, generator=torch.Generator().manual_seed(3))
+    a = BatchedNUTS(gaussian_target(cov), max_tree_depth=8, seed=2).run(z0, 150, 100)
+    b = LockstepNUTS(gaussian_target(cov), max_tree_depth=8, seed=2).run(z0, 150, 100)
+    per_chain = float(a.num_steps.double().mean())
+    assert a.potential_evals < 0.6 * b.potential_evals
+    assert a.potential_evals < 250 * (per_chain + 1) * 2.0          # ~ leapfrogs of the slowest chain, not the sum of maxima
