@@ -90,11 +90,17 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: there is no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # DYNODE_BENCH_REHEARSAL=1: rehearse the N > 1 code path on a box with ONE GPU (all ranks on
+    # cuda:0, gloo instead of RCCL, which refuses two ranks on one device).  Never set by the driver.
+    rehearsal = os.environ.get("DYNODE_BENCH_REHEARSAL") == "1"
+    torch.cuda.set_device(0 if rehearsal else local_rank)
+    dev = torch.device("cuda", 0 if rehearsal else local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     # ---- synthetic workload: same recipe on every rank, rank-offset seed (weak scaling)
     gen = synthetic.WORKLOADS[args.workload]
@@ -138,10 +144,11 @@ def main():
     steps_mean = float((stats[1] + stats[2]).float().mean())
 
     if world > 1:
-        t = torch.tensor([elapsed, kern_ms], dtype=torch.float64, device=dev)
+        cdev = torch.device("cpu") if rehearsal else dev
+        t = torch.tensor([elapsed, kern_ms], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kern_ms = float(t[0]), float(t[1])
-        okt = torch.tensor([int(ok)], device=dev)
+        okt = torch.tensor([int(ok)], device=cdev)
         dist.all_reduce(okt, op=dist.ReduceOp.MIN)
         ok = bool(okt.item())
 

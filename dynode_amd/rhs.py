@@ -236,9 +236,8 @@ class CompartmentalODE:
             raise ValueError(f"compartment s has shape {s.shape}; expected rank {self.contact_ndim}")
         contact_shape = s.shape[1:] if sbatch is not None else s.shape
         A = int(np.prod(contact_shape))
-        S = params.shape[1] // (2 + int(self.has_e) + int(self.has_wane)) if self.multi_strain else 1
-        if self.multi_strain:
-            S = (params.shape[1] - (3 if seasonal else 0)) // (2 + int(self.has_e) + int(self.has_wane))
+        per_strain = 2 + int(self.has_e) + int(self.has_wane)       # beta, gamma (, sigma) (, omega)
+        S = (params.shape[1] - (3 if seasonal else 0)) // per_strain if self.multi_strain else 1
         batch = pbatch if pbatch is not None else sbatch
         if pbatch is not None and sbatch is not None and pbatch != sbatch:
             raise ValueError(f"batch of parameters ({pbatch}) and of initial_state ({sbatch}) differ")
