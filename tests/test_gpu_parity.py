@@ -57,7 +57,8 @@ def random_workload(m, B, seed, t1=200.0):
 
 SHAPES = [
     ModelDesc(n_age=1), ModelDesc(n_age=2), ModelDesc(n_age=3), ModelDesc(n_age=6), ModelDesc(n_age=8),
-    ModelDesc(n_age=13),
+    ModelDesc(n_age=13), ModelDesc(n_age=24), ModelDesc(n_age=33), ModelDesc(n_age=64),
+    ModelDesc(n_age=12, has_e=True, has_wane=True), ModelDesc(n_age=3, n_strain=4, has_e=True, has_wane=True, has_c=True),
     ModelDesc(n_age=1, has_e=True, has_wane=True), ModelDesc(n_age=1, has_e=True, has_wane=True, seasonal=True),
     ModelDesc(n_age=2, has_e=True, has_wane=True), ModelDesc(n_age=7, has_e=True, has_wane=True),
     ModelDesc(n_age=2, n_strain=3, has_e=True, has_wane=True, has_c=True),
