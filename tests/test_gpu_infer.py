@@ -111,3 +111,19 @@ def test_predictive_is_one_batched_solve(data):
     assert set(pp) == {"inf_incidence"} and pp["inf_incidence"].shape == (5, 100, 2)
     # Poisson draws around the noiseless incidence the data were generated from
     assert abs(float(pp["inf_incidence"].mean()) - float(data.mean())) < 0.2 * float(data.mean())
+
+
+def test_svi_gaussian_fit_lands_on_the_posterior(data):
+    """reference inference.py:244-302 (SVIProcess: AutoMultivariateNormal + Adam(0.1) + ELBO)."""
+    from dynode_amd.infer.inference import SVIProcess
+
+    proc = SVIProcess(numpyro_model=ex.model, num_iterations=400, num_samples=2000, num_particles=16, progress_bar=False)
+    res = proc.infer(config=ex.get_config(), tf=100, obs_data=data)
+    assert float(res.losses[-50:].mean()) < float(res.losses[:20].mean())          # the ELBO improved
+    post = proc.get_samples()
+    assert set(post) == {"strains_0_r0", "strains_0_infectious_period"} and post["strains_0_r0"].shape == (2000,)
+    # a Gaussian in the unconstrained space cannot match the ridge exactly; its centre must
+    assert abs(float(post["strains_0_r0"].median()) - 2.04) < 0.12
+    assert abs(float(post["strains_0_infectious_period"].median()) - 7.2) < 0.5
+    with pytest.raises(AssertionError):
+        SVIProcess(numpyro_model=ex.model, num_iterations=1, num_samples=1).get_samples()
