@@ -35,7 +35,7 @@ batch = batch or defaults[workload]
 
 lines = [f"# rocprofv3 summary `{tag}` -- bench.py --workload {workload} (B={batch} per GPU)", ""]
 if stats:
-    lines += ["## kernel-trace --stats (20 timed + 3 warm-up launches)", "",
+    lines += ["## kernel-trace --stats (50 timed + 5 warm-up launches, the default bench.py command)", "",
               "| kernel | calls | avg ns | min ns | max ns | % of GPU time |", "|---|---|---|---|---|---|",
               f"| `{stats['Name'][:90]}` | {stats['Calls']} | {float(stats['AverageNs']):.0f} | {stats['MinNs']} | {stats['MaxNs']} | {stats['Percentage']} |", ""]
 if meta:
