@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--workload", default="cfg3", choices=["cfg2", "cfg3", "cfg3w8", "cfg5"])
     ap.add_argument("--batch", type=int, default=0, help="trajectories per GPU (0 = config default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the short cfg2/cfg5 side measurements (N=1 only)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="trajectories in the CPU sample (0 = auto)")
     return ap.parse_args()
 
@@ -198,6 +199,32 @@ def main():
                 "algorithmic_bytes_per_trajectory": bytes_traj,
             },
         }
+        if world == 1 and not args.no_extra and args.workload == "cfg3":
+            # the other single-GPU configs of BASELINE.json, 20 launches each (not the headline value)
+            line["other_workloads"] = {}
+            for name in ("cfg2", "cfg5", "cfg3w8"):
+                w2 = synthetic.WORKLOADS[name]()
+                a = [torch.as_tensor(x, dtype=f32, device=dev) for x in (w2.y0, w2.params, w2.contact, w2.save_ts)]
+                o2 = torch.empty((w2.B, w2.n_save, w2.model.state_dim), dtype=f32, device=dev)
+                st2 = torch.empty((3, w2.B), dtype=torch.int32, device=dev)
+                run = lambda: solve_batch(w2.model, a[0], a[1], a[2], w2.t1, a[3], dtype=f32, out=o2,
+                                          stats_out=(st2[0], st2[1], st2[2]))
+                for _ in range(3):
+                    run()
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(20):
+                    run()
+                e1.record()
+                torch.cuda.synchronize()
+                ms = e0.elapsed_time(e1) / 20
+                gbs = w2.bytes_per_trajectory(4) * w2.B / (ms * 1e-3) / 1e9
+                line["other_workloads"][name] = {
+                    "workload": f"{w2.name}: A={w2.model.n_age} S={w2.model.n_strain} W={w2.model.n_wane} D={w2.model.state_dim}, B={w2.B}",
+                    "trajectories_per_s": w2.B / (ms * 1e-3), "ms_per_launch": ms, "hbm_frac": gbs / HBM_PEAK_GBS,
+                    "all_status_ok": int(st2[0].max()) == 0}
+                del o2
         if world == 1 and not args.no_cpu_baseline:
             sample = args.cpu_sample or (4096 if m.state_dim >= 100 else 16384)
             line["cpu_baseline"] = cpu_baseline(wl, min(sample, B))

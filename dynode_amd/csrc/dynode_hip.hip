@@ -141,6 +141,25 @@ static int enqueue(const Entry *e, const dyn_model_desc *m, const dyn_solver_opt
         // only points strictly inside (t0, t1) matter; sorted input is required (checked by caller)
         if (o->jump_ts[j] > t0 && o->jump_ts[j] < t1) ka.jump_ts[ka.n_jump++] = (T)o->jump_ts[j];
     }
+    // Small, save-heavy batches leave most SIMDs idle and are bound by the serial latency of one
+    // trajectory's dense output: replicate each trajectory over 2^r lane groups (<= 8) while the
+    // grid still fits in one resident round (~2 waves per SIMD on 1024 SIMDs).
+    {
+        const int tpw = 64 / (group_width(m->n_age) * (e->S / e->SPL));
+        const int64_t waves = (B + tpw - 1) / tpw;
+        int r = 0;
+        const char *env = getenv("DYNODE_HIP_REPLICAS_LOG2");
+        if (env) {
+            r = atoi(env);
+        } else if (n_save >= 64) {
+            // measured: tiny states (<= 5 values per lane: SIR, SEIRS) gain up to 4 waves per SIMD
+            // (cfg 2: 0.37 -> 0.19 ms); register-heavy VALU-bound shapes do not (cfg 5: 0.72 -> 0.89 ms)
+            const int nv = 1 + e->SPL * (e->E + 1 + e->W + e->C);
+            if (nv <= 5)
+                while (r < 3 && (waves << (r + 1)) <= 4096) ++r;
+        }
+        ka.rep_log2 = r < 0 ? 0 : (r > 3 ? 3 : r);
+    }
     typedef hipError_t (*fn_t)(const KArgs<T> &, hipStream_t);
     const hipError_t err = ((fn_t)e->fn)(ka, stream);
     if (err != hipSuccess) {

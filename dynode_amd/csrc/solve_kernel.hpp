@@ -46,6 +46,10 @@ struct KArgs {
     // discontinuity_points (ClipStepSizeController jump_ts), passed by value in the kernarg
     int32_t n_jump;
     T jump_ts[16];
+    // Replication for small batches: 2^rep_log2 lane groups integrate the SAME trajectory
+    // (bit-identical redundant stepping on otherwise idle SIMDs) and split its save times
+    // round-robin, which divides the serial dense-output latency of a trajectory.
+    int32_t rep_log2;
 };
 constexpr int kMaxJumps = 16;
 
@@ -295,6 +299,9 @@ struct Solver {
     static constexpr int IE = 1, II = 1 + NE, IR = II + S, IC = IR + S * W;
     static constexpr int TPW = 64 / G;
     static constexpr int NC = 1 + ND;          // planes
+    // Small states are latency-bound by the serial save rounds: interpolate SU save times per
+    // round (all computed for ILP, stores predicated) instead of one.
+    static constexpr int SU = (NV * NC <= 4) ? 4 : (NV * NC <= 9 ? 2 : 1);
     static constexpr int NDA = ND > 0 ? ND : 1; // array extent for tangent-only data
     using M = Mth<T>;
     using TB = Tab<METHOD>;
@@ -598,7 +605,10 @@ struct Solver {
         const int a = lane % GA;          // age lane
         const int h = (lane / GA) % GS;   // strain lane: strains h*SPL .. h*SPL+SPL-1
         const int grp = lane / G;
-        int64_t traj = (int64_t)blockIdx.x * TPW + grp;
+        const int64_t gslot = (int64_t)blockIdx.x * TPW + grp;
+        const int R = 1 << ka.rep_log2;                 // replicas per trajectory
+        const int rep = (int)(gslot & (R - 1));         // this group's replica number
+        int64_t traj = gslot >> ka.rep_log2;
         const bool valid_traj = traj < ka.B;
         if (!valid_traj) traj = ka.B - 1; // duplicate a real trajectory, never store
         const int A = ka.A;
@@ -739,7 +749,7 @@ struct Solver {
         }
         tnext = M::min(tnext, t_end);
 
-        int save_idx = 0;
+        int save_idx = rep; // replica r owns save times r, r + R, r + 2R, ...
         const int n_save = ka.n_save;
         // The save grid lives in LDS: a global load inside the save loop would share the
         // in-order vmcnt counter with the output stores, and waiting for it would drain every
@@ -770,8 +780,8 @@ struct Solver {
             }
         }
         // next two save times kept in registers (the read of ts[idx+2] overlaps a whole round)
-        T ts_next = n_save > 0 ? ts_tab[0] : M::inf();
-        T ts_next2 = n_save > 1 ? ts_tab[1] : M::inf();
+        T ts_next = save_idx < n_save ? ts_tab[save_idx] : M::inf();
+        T ts_next2 = save_idx + R < n_save ? ts_tab[save_idx + R] : M::inf();
         int64_t steps = 0;
         int32_t n_acc = 0, n_rej = 0, st = ST_OK;
         bool done = !(tprev < t_end);
@@ -849,7 +859,42 @@ struct Solver {
             // ---- SaveAt(ts): dense output at every save time in (tprev, tnext]
             bool pending = accept && (save_idx < n_save) && (ts_next <= tnext);
             const T inv_dt = M::recip(dt);
-            while (__any(pending)) {
+            if constexpr (SU > 1) {
+                while (__any(pending)) {
+                    if (pending) {
+                        T tsu[SU];
+                        bool pu[SU];
+                        Dense dn[SU];
+                        tsu[0] = ts_next;
+#pragma unroll
+                        for (int q = 1; q < SU; ++q)
+                            tsu[q] = save_idx + q * R < n_save ? ts_tab[save_idx + q * R] : M::inf();
+                        int cnt = 0;
+#pragma unroll
+                        for (int q = 0; q < SU; ++q) {
+                            pu[q] = tsu[q] <= tnext; // increasing grid: the saved ones form a prefix
+                            cnt += pu[q] ? 1 : 0;
+                            dense_prepare(((pu[q] ? tsu[q] : tprev) - tprev) * inv_dt, dn[q]);
+                        }
+#pragma unroll
+                        for (int q = 0; q < SU; ++q) {
+                            if (pu[q] && writer) {
+                                save_row<0>(ka, dn[q], dt, y, yt, k,
+                                            out_traj + (int64_t)(save_idx + q * R) * ka.d_saved, a,
+                                            as, L.lead, vec_ok);
+                                if constexpr (ND > 0)
+                                    save_tangents<1>(ka, dn[q], dt, y, yt, k,
+                                                     dout_traj + (int64_t)(save_idx + q * R) * ND * ka.d_saved,
+                                                     a, as, L.lead, vec_ok);
+                            }
+                        }
+                        save_idx += cnt * R;
+                        ts_next = save_idx < n_save ? ts_tab[save_idx] : M::inf();
+                    }
+                    pending = accept && (save_idx < n_save) && (ts_next <= tnext);
+                }
+            }
+            while (SU == 1 && __any(pending)) {
 #ifdef DYN_DIAG_ROUNDS
                 ++diag_rounds;
 #endif
@@ -864,9 +909,9 @@ struct Solver {
                                              dout_traj + (int64_t)save_idx * ND * ka.d_saved, a, as,
                                              L.lead, vec_ok);
                     }
-                    ++save_idx;
+                    save_idx += R;
                     ts_next = ts_next2;
-                    ts_next2 = save_idx + 1 < n_save ? ts_tab[save_idx + 1] : M::inf();
+                    ts_next2 = save_idx + R < n_save ? ts_tab[save_idx + R] : M::inf();
                 }
                 pending = accept && (save_idx < n_save) && (ts_next <= tnext);
             }
@@ -933,14 +978,14 @@ struct Solver {
 
         // rows never reached (failed solves): +inf, like diffrax's unfilled SaveAt buffer
         if (writer) {
-            for (; save_idx < n_save; ++save_idx) {
+            for (; save_idx < n_save; save_idx += R) {
                 fill_row(ka, out_traj + (int64_t)save_idx * ka.d_saved, a, as, L.lead, M::inf());
                 if constexpr (ND > 0)
                     for (int j = 0; j < ND; ++j)
                         fill_row(ka, dout_traj + ((int64_t)save_idx * ND + j) * ka.d_saved, a, as,
                                  L.lead, M::inf());
             }
-            if (a == 0 && L.lead) {
+            if (a == 0 && L.lead && rep == 0) {
                 ka.status[traj] = st;
 #ifdef DYN_DIAG_ROUNDS
                 n_acc = diag_iters;
@@ -963,7 +1008,7 @@ solve_kernel(const KArgs<T> ka) {
 template <typename T, int METHOD, int GA, int ST, bool HAS_E, bool HAS_WANE, bool HAS_C, int W, int ND, int SPL>
 hipError_t launch(const KArgs<T> &ka, hipStream_t stream) {
     constexpr int TPW = 64 / (GA * (ST / SPL));
-    const int64_t blocks = (ka.B + TPW - 1) / TPW;
+    const int64_t blocks = ((ka.B << ka.rep_log2) + TPW - 1) / TPW;
     if (blocks <= 0) return hipSuccess;
     const size_t lds = ((size_t)ka.n_save + (ka.n_jump > 0 ? kMaxJumps : 0)) * sizeof(T); // LDS tables
     hipLaunchKernelGGL((solve_kernel<T, METHOD, GA, ST, HAS_E, HAS_WANE, HAS_C, W, ND, SPL>),

@@ -8,9 +8,9 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 50 --warmup 5 --no-cpu-baseline $*"
+ARGS="--steps 50 --warmup 5 --no-cpu-baseline --no-extra $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$ROOT/bench.py" $ARGS > "$OUT/trace.log" 2>&1 || { echo "trace failed"; tail -5 "$OUT/trace.log"; exit 1; }
-PARGS="--steps 4 --warmup 1 --no-cpu-baseline $*"
+PARGS="--steps 4 --warmup 1 --no-cpu-baseline --no-extra $*"
 i=0
 for C in "FETCH_SIZE" "WRITE_SIZE" \
   "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY" \
