@@ -52,10 +52,27 @@ def require_gpu() -> torch.device:
     return torch.device("cuda", torch.cuda.current_device())
 
 
+_CONST_CACHE: "dict[tuple, torch.Tensor]" = {}
+_CONST_CACHE_MAX_BYTES = 1 << 16   # only small, typically constant inputs (y0, contact matrix, save grid)
+
+
 def _dev(x, dtype, device) -> torch.Tensor:
+    """Device tensor of ``x``.  Small host arrays are cached by content, so loops that pass the same
+    constants again and again (NUTS: y0, contact matrix, save grid at every gradient-solve) do not
+    pay a blocking host-to-device copy per call -- which also keeps the call HIP-graph capturable."""
     if isinstance(x, torch.Tensor):
         return x.to(device=device, dtype=dtype).contiguous()
-    return torch.as_tensor(np.ascontiguousarray(x), dtype=dtype, device=device).contiguous()
+    arr = np.ascontiguousarray(x)
+    if arr.nbytes <= _CONST_CACHE_MAX_BYTES:
+        key = (arr.dtype.str, arr.shape, arr.tobytes(), dtype, str(device))
+        hit = _CONST_CACHE.get(key)
+        if hit is None:
+            if len(_CONST_CACHE) > 256:
+                _CONST_CACHE.clear()
+            hit = torch.as_tensor(arr, dtype=dtype, device=device).contiguous()
+            _CONST_CACHE[key] = hit
+        return hit
+    return torch.as_tensor(arr, dtype=dtype, device=device).contiguous()
 
 
 def save_mask_bytes(model: ModelDesc, save_mask: Optional[Sequence[bool]]):

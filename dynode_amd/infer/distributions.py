@@ -19,10 +19,25 @@ _F = torch.float64
 _SQRT2 = math.sqrt(2.0)
 
 
+_DEV_CACHE: dict = {}
+
+
 def _t(x, like=None):
+    """float64 tensor of ``x`` on the device of ``like``.  Device copies of (constant) distribution
+    parameters are cached, so evaluating a log-density in a sampler loop issues no host-to-device
+    copies (and stays HIP-graph capturable)."""
     t = x if isinstance(x, torch.Tensor) else torch.as_tensor(x, dtype=_F)
-    if like is not None and isinstance(like, torch.Tensor):
-        t = t.to(device=like.device)
+    if like is not None and isinstance(like, torch.Tensor) and t.device != like.device:
+        if t.requires_grad:
+            return t.to(device=like.device, dtype=_F)
+        key = (id(t), str(like.device))
+        hit = _DEV_CACHE.get(key)
+        if hit is None or hit[0] is not t:
+            if len(_DEV_CACHE) > 512:
+                _DEV_CACHE.clear()
+            hit = (t, t.to(device=like.device, dtype=_F))
+            _DEV_CACHE[key] = hit
+        return hit[1]
     return t.to(_F)
 
 

@@ -88,7 +88,8 @@ def _apply(msg):
 
 def sample(name: str, fn, obs=None, rng_key: Optional[int] = None, sample_shape=()):
     gen = torch.Generator().manual_seed(int(rng_key)) if rng_key is not None else None
-    value = None if obs is None else torch.as_tensor(obs, dtype=torch.float64)
+    value = None if obs is None else (obs.to(torch.float64) if isinstance(obs, torch.Tensor)
+                                      else torch.as_tensor(obs, dtype=torch.float64))
     return _apply({"type": "sample", "name": name, "fn": fn, "value": value, "is_observed": obs is not None,
                    "gen": gen, "sample_shape": tuple(sample_shape)})
 

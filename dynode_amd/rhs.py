@@ -221,12 +221,41 @@ class CompartmentalODE:
             raise ValueError(f"contact_matrix has shape {C.shape}, expected {(A, A)}")
         return np.ascontiguousarray(C)
 
-    def pack(self, initial_state, p) -> Packed:
-        """Flatten (initial_state, params) into the kernel's layout."""
+    def _param_meta(self, p):
+        """(P, batch, seasonal) from SHAPES only -- no device-to-host copy of tensor-valued fields."""
+        names = ["beta", "gamma"] + (["sigma"] if self.has_e else []) + (["omega"] if self.has_wane else [])
+        strain_rank = 1 if self.multi_strain else 0
+        batch, S = None, 1
+        for n in names:
+            shape = tuple(getattr(getattr(p, n), "shape", ()))
+            if not self.multi_strain and len(shape) == 1 and shape[0] == 1:
+                shape = ()
+            if len(shape) == strain_rank + 1:
+                batch = shape[0]
+            if self.multi_strain:
+                S = shape[-1]
+        seas = getattr(p, "seasonality_params", None)
+        seasonal = bool(self.seasonal) if self.seasonal is not None else seas is not None
+        if seasonal:
+            for n in ("forcing_amp", "forcing_phase", "forcing_period"):
+                shape = tuple(getattr(getattr(seas, n), "shape", ()))
+                if len(shape) == 1 and shape[0] > 1:
+                    batch = shape[0]
+        P = S * len(names) + (3 if seasonal else 0)
+        return P, batch, seasonal
+
+    def pack(self, initial_state, p, with_params: bool = True) -> Packed:
+        """Flatten (initial_state, params) into the kernel's layout.  ``with_params=False`` leaves
+        ``Packed.params`` as a zero placeholder of the right shape (the differentiable path builds
+        the parameter matrix on the device with :meth:`param_tensor`)."""
         if len(initial_state) != len(self.compartments):
             raise ValueError(f"{self.__name__} expects compartments {self.compartments}, got "
                              f"{len(initial_state)} arrays")
-        params, pbatch, seasonal = self._param_matrix(p)
+        if with_params:
+            params, pbatch, seasonal = self._param_matrix(p)
+        else:
+            P, pbatch, seasonal = self._param_meta(p)
+            params = np.zeros((pbatch or 1, P))
         arrs = [_np(a) for a in initial_state]
         s = arrs[0]
         sbatch = None

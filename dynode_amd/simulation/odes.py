@@ -108,7 +108,8 @@ def simulate(ode, duration_days, initial_state: CompartmentState, ode_parameters
     assert isinstance(duration_days, (int, float)) and not isinstance(duration_days, bool), (
         "tf must be of type int or float")
 
-    packed = ode.pack(initial_state, ode_parameters)
+    differentiable = ode.wants_grad(ode_parameters)
+    packed = ode.pack(initial_state, ode_parameters, with_params=not differentiable)
     saveat = build_saveat(0.0, duration_days, save_step, sub_save_indices, len(initial_state))
     if dtype is None:
         dtype = torch.float64 if _X64 else torch.float32
@@ -117,8 +118,11 @@ def simulate(ode, duration_days, initial_state: CompartmentState, ode_parameters
               atol=sp.ode_solver_abs_tolerance, max_steps=sp.max_steps,
               constant_dt=sp.constant_step_size if sp.constant_step_size > 0.0 else 0.0,
               jump_ts=sp.discontinuity_points, save_mask=saveat.mask)
-    if ode.wants_grad(ode_parameters):
-        # a parameter carries an autograd graph (NUTS potential): differentiable solve
+    if differentiable:
+        # a parameter carries an autograd graph (NUTS / SVI potential): differentiable solve.  No
+        # host synchronisation here: a failed trajectory leaves +inf rows, which turn the
+        # log-density non-finite and are rejected by the sampler like a divergence.
+        throw = False
         from ..engine import require_gpu
         from ..infer.autodiff import solve_batch_diff
 
@@ -156,5 +160,6 @@ def simulate(ode, duration_days, initial_state: CompartmentState, ode_parameters
         "num_rejected_steps": unb(res.n_reject),
         "max_steps": sp.max_steps,
     }
-    ts = torch.as_tensor(saveat.ts, dtype=res.ys.dtype, device=res.ys.device)
+    from ..engine import _dev
+    ts = _dev(saveat.ts, res.ys.dtype, res.ys.device)
     return Solution(ts=ts, ys=tuple(ys), stats=stats, result=unb(res.status), t0=0.0, t1=float(duration_days))
