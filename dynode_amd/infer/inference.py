@@ -25,7 +25,7 @@ from pydantic import BaseModel, ConfigDict, Field, PositiveInt, PrivateAttr
 from .. import sharding
 from . import handlers
 from .distributions import biject_to
-from .nuts import BatchedNUTS, NUTSResult
+from .nuts import BatchedNUTS, GraphNUTS, NUTSResult
 
 
 def init_to_median(num_samples: int = 15):
@@ -198,10 +198,13 @@ class MCMCProcess(InferenceProcess):
         local = hi - lo
         pot = Potential(self.numpyro_model, kwargs, self.inference_prngkey, device)
         z0 = pot.initial(self.num_chains, self.nuts_init_strategy, self.inference_prngkey)[lo:hi]
-        pg = pot.graphed(local) if self.mcmc_kwargs.get("hip_graph", True) else pot.potential_and_grad
-        sampler = BatchedNUTS(pg, max_tree_depth=self.nuts_max_tree_depth,
-                              target_accept=self.nuts_kwargs.get("target_accept_prob", 0.8),
-                              seed=self.inference_prngkey + 7919 * rank)
+        # default: the whole sampler iteration (model, gradient-solve kernel, autograd, tree and
+        # adaptation bookkeeping) is captured once as a HIP graph and replayed
+        # mcmc_kwargs={"hip_graph": False} selects the eager asynchronous sampler
+        cls = GraphNUTS if self.mcmc_kwargs.get("hip_graph", True) else BatchedNUTS
+        sampler = cls(pot.potential_and_grad, max_tree_depth=self.nuts_max_tree_depth,
+                      target_accept=self.nuts_kwargs.get("target_accept_prob", 0.8),
+                      seed=self.inference_prngkey + 7919 * rank)
         total = self.num_warmup + self.num_samples
 
         def progress(it, warm):

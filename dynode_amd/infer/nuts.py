@@ -511,3 +511,257 @@ class BatchedNUTS(LockstepNUTS):
                 r_ck = torch.where(fresh, torch.zeros_like(r_ck), r_ck)
                 rs_ck = torch.where(fresh, torch.zeros_like(rs_ck), rs_ck)
         return NUTSResult(out_z, out_acc, out_n, out_div, eps, imm, self.evals)
+
+
+class GraphNUTS(LockstepNUTS):
+    """`BatchedNUTS` with the whole iteration as ONE HIP-graph replay.
+
+    The asynchronous sampler's iteration is a pure tensor program: state tensors in, state tensors
+    out, every data-dependent decision a mask.  Written that way it can be captured once -- the
+    potential (the user's model function, the fused gradient-solve kernel, autograd), the leapfrog,
+    tree bookkeeping, adaptation and sample recording together -- and replayed; the host only draws
+    a block of random numbers and checks for completion every `block` iterations.  Mass-matrix
+    updates are computed in the graph and applied (with their Cholesky factor and the step-size
+    restart) at the next block boundary, i.e. at most `block` iterations late, which is immaterial
+    for warm-up.  On CPU tensors the same step function runs eagerly (used by the tests).
+    """
+
+    def __init__(self, *args, block: int = 16, use_graph: bool = True, **kw):
+        super().__init__(*args, **kw)
+        self.block, self.use_graph = int(block), bool(use_graph)
+
+    # ---------------------------------------------------------------- one iteration, pure function
+    def _step(self, S: dict, K: dict, ru, rn):
+        """S: state tensors, K: constants, ru [3, C] uniforms, rn [C, D] normals -> new state dict."""
+        C, D, Dm, dt = K["C"], K["D"], self.max_depth, torch.float64
+        N = dict(S)  # new state (entries replaced below)
+        active = S["it"] < K["total"]
+        imm, mm_sqrt = S["imm"], S["mm_sqrt"]
+        # ---- one leapfrog for every chain from its subtree frontier
+        zn, rn_, un, gn = self._leapfrog(S["zc"], S["rc"], S["gc"], S["eps"] * S["sgn"], imm)
+        de = un + self._kinetic(imm, rn_) - S["e0"]
+        de = torch.where(torch.isnan(de), torch.full_like(de, math.inf), de)
+        lw, div = -de, de > self.max_de
+        acc = torch.exp(torch.clamp(-de, max=0.0))
+        new_w = torch.logaddexp(S["s_weight"], lw)
+        sel = active & (ru[0] < torch.exp(lw - new_w))
+        s_zp = torch.where(sel[:, None], zn, S["s_zp"]); s_up = torch.where(sel, un, S["s_up"])
+        s_gp = torch.where(sel[:, None], gn, S["s_gp"])
+        s_weight = torch.where(active, new_w, S["s_weight"])
+        s_rsum = torch.where(active[:, None], S["s_rsum"] + rn_, S["s_rsum"])
+        s_div = S["s_div"] | (active & div)
+        s_acc = S["s_acc"] + torch.where(active, acc, torch.zeros_like(acc))
+        s_n = S["s_n"] + active.long()
+        zc = torch.where(active[:, None], zn, S["zc"]); rc = torch.where(active[:, None], rn_, S["rc"])
+        gc = torch.where(active[:, None], gn, S["gc"])
+        # ---- checkpointed U-turn test, leaf index per chain
+        leaf = S["leaf"]
+        idx_max = torch.zeros_like(leaf)
+        for b in range(Dm):
+            idx_max = idx_max + ((leaf >> (b + 1)) & 1)
+        ones, trailing = torch.ones_like(leaf), torch.zeros_like(leaf)
+        for b in range(Dm):
+            ones = ones & ((leaf >> b) & 1)
+            trailing = trailing + ones
+        idx_min = idx_max - trailing + 1
+        even = (leaf & 1) == 0
+        lv = K["levels"]
+        wmask = (active & even)[None, :, None] & (lv[:, None, None] == idx_max[None, :, None])     # [Dm, C, 1]
+        r_ck = torch.where(wmask, rn_[None], S["r_ck"])
+        rs_ck = torch.where(wmask, s_rsum[None], S["rs_ck"])
+        in_range = (lv[:, None] <= idx_max[None, :]) & (lv[:, None] >= idx_min[None, :])
+        rs = (s_rsum[None] - rs_ck + r_ck) - 0.5 * (r_ck + rn_[None])
+        vl = torch.einsum("cij,lcj->lci", imm, r_ck)
+        vr = _mv(imm, rn_)
+        turn_l = ((vl * rs).sum(-1) <= 0) | ((vr[None] * rs).sum(-1) <= 0)
+        s_turn = S["s_turn"] | (active & ~even & (turn_l & in_range).any(0))
+        leaf = leaf + active.long()
+        # ---- subtree complete -> merge into the tree
+        depth = S["depth"]
+        sub_done = active & (s_turn | s_div | (leaf >= (torch.ones_like(depth) << depth)))
+        ok = sub_done & ~s_turn & ~s_div
+        move = ok & (ru[1] < torch.exp(torch.clamp(s_weight - S["weight"], max=0.0)))
+        zp = torch.where(move[:, None], s_zp, S["zp"]); up = torch.where(move, s_up, S["up"])
+        gp = torch.where(move[:, None], s_gp, S["gp"])
+        er, el = (sub_done & S["right"])[:, None], (sub_done & ~S["right"])[:, None]
+        zr, rr, gr = torch.where(er, zc, S["zr"]), torch.where(er, rc, S["rr"]), torch.where(er, gc, S["gr"])
+        zl, rl, gl = torch.where(el, zc, S["zl"]), torch.where(el, rc, S["rl"]), torch.where(el, gc, S["gl"])
+        weight = torch.where(sub_done, torch.logaddexp(S["weight"], s_weight), S["weight"])
+        r_sum = torch.where(sub_done[:, None], S["r_sum"] + s_rsum, S["r_sum"])
+        sum_acc = S["sum_acc"] + torch.where(sub_done, s_acc, torch.zeros_like(s_acc))
+        n_prop = S["n_prop"] + torch.where(sub_done, s_n, torch.zeros_like(s_n))
+        depth = depth + sub_done.long()
+        stop = sub_done & (s_turn | s_div | self._is_turning(imm, rl, rr, r_sum) | (depth >= Dm))
+        # ---- transition complete: adapt, record, next transition
+        it = S["it"]
+        warm = it < K["num_warmup"]
+        a_prob = sum_acc / n_prop.clamp_min(1).to(dt)
+        z = torch.where(stop[:, None], zp, S["z"]); u = torch.where(stop, up, S["u"]); g = torch.where(stop[:, None], gp, S["g"])
+        upd = stop & warm
+        t1 = S["da_t"] + 1.0
+        w = 1.0 / (t1 + 10.0)
+        gbar = (1 - w) * S["da_gbar"] + w * (self.target - a_prob)
+        x = S["da_mu"] - torch.sqrt(t1) / 0.05 * gbar
+        wx = t1 ** (-0.75)
+        xbar = (1 - wx) * S["da_xbar"] + wx * x
+        N["da_t"] = torch.where(upd, t1, S["da_t"]); N["da_gbar"] = torch.where(upd, gbar, S["da_gbar"])
+        N["da_xbar"] = torch.where(upd, xbar, S["da_xbar"])
+        eps = torch.where(upd, torch.exp(x), S["eps"])
+        eps_avg = torch.where(upd, torch.exp(xbar), S["eps_avg"])
+        wi = S["wi"]
+        ws, we = K["w_start"][wi], K["w_end"][wi]
+        in_win = upd & (it >= ws) & (it < we)
+        n1 = S["wf_n"] + 1.0
+        d = z - S["wf_mean"]
+        mean1 = S["wf_mean"] + d / n1[:, None]
+        m21 = S["wf_m2"] + torch.einsum("ci,cj->cij", d, z - mean1)
+        wf_n = torch.where(in_win, n1, S["wf_n"]); wf_mean = torch.where(in_win[:, None], mean1, S["wf_mean"])
+        wf_m2 = torch.where(in_win[:, None, None], m21, S["wf_m2"])
+        close = in_win & (it + 1 == we)
+        nn = wf_n.clamp_min(2.0)
+        reg = (nn / (nn + 5.0))[:, None, None] * (wf_m2 / (nn - 1.0)[:, None, None]) + \
+            1e-3 * (5.0 / (nn + 5.0))[:, None, None] * K["eye"]
+        N["pend_cov"] = torch.where(close[:, None, None], reg, S["pend_cov"])
+        N["need_mm"] = S["need_mm"] | close
+        N["wf_n"] = torch.where(close, torch.zeros_like(wf_n), wf_n)
+        N["wf_mean"] = torch.where(close[:, None], torch.zeros_like(wf_mean), wf_mean)
+        N["wf_m2"] = torch.where(close[:, None, None], torch.zeros_like(wf_m2), wf_m2)
+        N["wi"] = wi + close.long()
+        N["eps"] = torch.where(upd & (it + 1 == K["num_warmup"]), eps_avg, eps)
+        N["eps_avg"] = eps_avg
+        rec = stop & ~warm
+        j = (it - K["num_warmup"]).clamp(0, K["num_samples"] - 1)
+        jz = j.view(C, 1, 1).expand(C, 1, D)
+        N["out_z"] = S["out_z"].scatter(1, jz, torch.where(rec[:, None], z, S["out_z"].gather(1, jz)[:, 0]).unsqueeze(1))
+        j1 = j.view(C, 1)
+        N["out_acc"] = S["out_acc"].scatter(1, j1, torch.where(rec, a_prob, S["out_acc"].gather(1, j1)[:, 0]).unsqueeze(1))
+        N["out_n"] = S["out_n"].scatter(1, j1, torch.where(rec, n_prop, S["out_n"].gather(1, j1)[:, 0]).unsqueeze(1))
+        N["out_div"] = S["out_div"].scatter(1, j1, torch.where(rec, s_div, S["out_div"].gather(1, j1)[:, 0]).unsqueeze(1))
+        N["it"] = it + stop.long()
+        N["z"], N["u"], N["g"] = z, u, g
+        # new tree for the chains that finished a transition
+        r0 = _mv(mm_sqrt, rn)
+        sm, sv = stop[:, None], stop
+        N["e0"] = torch.where(sv, u + self._kinetic(imm, r0), S["e0"])
+        N["zl"], N["rl"], N["gl"] = torch.where(sm, z, zl), torch.where(sm, r0, rl), torch.where(sm, g, gl)
+        N["zr"], N["rr"], N["gr"] = torch.where(sm, z, zr), torch.where(sm, r0, rr), torch.where(sm, g, gr)
+        N["zp"], N["up"], N["gp"] = torch.where(sm, z, zp), torch.where(sv, u, up), torch.where(sm, g, gp)
+        N["weight"] = torch.where(sv, torch.zeros_like(weight), weight)
+        N["r_sum"] = torch.where(sm, r0, r_sum)
+        N["sum_acc"] = torch.where(sv, torch.zeros_like(sum_acc), sum_acc)
+        N["n_prop"] = torch.where(sv, torch.zeros_like(n_prop), n_prop)
+        N["depth"] = torch.where(sv, torch.zeros_like(depth), depth)
+        # new subtree for the chains that finished one (next doubling or first of a new transition)
+        right = torch.where(sub_done, ru[2] < 0.5, S["right"])
+        N["right"] = right
+        N["sgn"] = torch.where(right, torch.ones_like(S["sgn"]), -torch.ones_like(S["sgn"]))
+        sd, sdv = sub_done[:, None], sub_done
+        N["leaf"] = torch.where(sdv, torch.zeros_like(leaf), leaf)
+        N["zc"] = torch.where(sd, torch.where(right[:, None], N["zr"], N["zl"]), zc)
+        N["rc"] = torch.where(sd, torch.where(right[:, None], N["rr"], N["rl"]), rc)
+        N["gc"] = torch.where(sd, torch.where(right[:, None], N["gr"], N["gl"]), gc)
+        N["s_zp"] = torch.where(sd, N["zp"], s_zp); N["s_up"] = torch.where(sdv, N["up"], s_up)
+        N["s_gp"] = torch.where(sd, N["gp"], s_gp)
+        N["s_weight"] = torch.where(sdv, torch.full_like(s_weight, -math.inf), s_weight)
+        N["s_rsum"] = torch.where(sd, torch.zeros_like(s_rsum), s_rsum)
+        N["s_turn"] = s_turn & ~sdv
+        N["s_div"] = s_div & ~sdv
+        N["s_acc"] = torch.where(sdv, torch.zeros_like(s_acc), s_acc)
+        N["s_n"] = torch.where(sdv, torch.zeros_like(s_n), s_n)
+        fresh = sub_done[None, :, None]
+        N["r_ck"] = torch.where(fresh, torch.zeros_like(r_ck), r_ck)
+        N["rs_ck"] = torch.where(fresh, torch.zeros_like(rs_ck), rs_ck)
+        return N
+
+    # ---------------------------------------------------------------- driver
+    def run(self, z0: torch.Tensor, num_warmup: int, num_samples: int, init_step_size: float = 1.0,
+            progress: Optional[Callable] = None) -> NUTSResult:
+        C, D = z0.shape
+        dev, dt, Dm = z0.device, torch.float64, self.max_depth
+        total = num_warmup + num_samples
+        gen = torch.Generator(device=dev).manual_seed(self.seed)
+        z = z0.clone().to(dt)
+        eye = torch.eye(D, dtype=dt, device=dev).expand(C, D, D).contiguous()
+        u, g = self._eval(z)
+        eps = self._find_reasonable_step_size(z, u, g, eye, eye,
+                                              torch.full((C,), float(init_step_size), dtype=dt, device=dev), gen)
+        windows = _adaptation_windows(num_warmup)
+        K = dict(C=C, D=D, total=total, num_warmup=num_warmup, num_samples=num_samples, eye=eye,
+                 levels=torch.arange(Dm, device=dev),
+                 w_start=torch.tensor([w[0] for w in windows] + [total + 1], device=dev),
+                 w_end=torch.tensor([w[1] for w in windows] + [total + 2], device=dev))
+        zf = lambda *s: torch.zeros(s, dtype=dt, device=dev)
+        zl_ = lambda *s: torch.zeros(s, dtype=torch.long, device=dev)
+        zb = lambda *s: torch.zeros(s, dtype=torch.bool, device=dev)
+        r0 = torch.randn((C, D), dtype=dt, device=dev, generator=gen)
+        right = torch.rand(C, device=dev, generator=gen) < 0.5
+        S = dict(z=z, u=u, g=g, eps=eps, eps_avg=eps.clone(), da_mu=torch.log(10.0 * eps), da_xbar=zf(C), da_gbar=zf(C),
+                 da_t=zf(C), imm=eye.clone(), mm_sqrt=eye.clone(), wi=zl_(C), wf_n=zf(C), wf_mean=zf(C, D), wf_m2=zf(C, D, D),
+                 it=zl_(C), pend_cov=eye.clone(), need_mm=zb(C),
+                 e0=u + 0.5 * (r0 * r0).sum(-1), zl=z.clone(), rl=r0.clone(), gl=g.clone(), zr=z.clone(), rr=r0.clone(),
+                 gr=g.clone(), zp=z.clone(), up=u.clone(), gp=g.clone(), weight=zf(C), r_sum=r0.clone(), sum_acc=zf(C),
+                 n_prop=zl_(C), depth=zl_(C), right=right,
+                 sgn=torch.where(right, torch.ones(C, dtype=dt, device=dev), -torch.ones(C, dtype=dt, device=dev)),
+                 leaf=zl_(C), zc=z.clone(), rc=r0.clone(), gc=g.clone(), s_zp=z.clone(), s_up=u.clone(), s_gp=g.clone(),
+                 s_weight=torch.full((C,), -math.inf, dtype=dt, device=dev), s_rsum=zf(C, D), s_turn=zb(C), s_div=zb(C),
+                 s_acc=zf(C), s_n=zl_(C), r_ck=zf(Dm, C, D), rs_ck=zf(Dm, C, D),
+                 out_z=zf(C, num_samples, D), out_acc=zf(C, num_samples), out_n=zl_(C, num_samples),
+                 out_div=zb(C, num_samples))
+        S = {k: v.contiguous() for k, v in S.items()}
+        Kb = self.block
+        ru_buf = torch.zeros((Kb, 3, C), dtype=dt, device=dev)
+        rn_buf = torch.zeros((Kb, C, D), dtype=dt, device=dev)
+        kidx = torch.zeros(1, dtype=torch.long, device=dev)
+
+        def one_step():
+            ru = ru_buf.index_select(0, kidx)[0]
+            rn = rn_buf.index_select(0, kidx)[0]
+            new = self._step(S, K, ru, rn)
+            for key, val in new.items():
+                if val is not S[key]:
+                    S[key].copy_(val)
+            kidx.add_(1)
+
+        graph = None
+        blocks = 0
+        while True:
+            if not bool((S["it"] < total).any()):
+                break
+            # ---- block boundary (host): fresh randoms, deferred mass-matrix updates, progress
+            ru_buf.copy_(torch.rand((Kb, 3, C), device=dev, generator=gen).to(dt))
+            rn_buf.copy_(torch.randn((Kb, C, D), dtype=dt, device=dev, generator=gen))
+            kidx.zero_()
+            if bool(S["need_mm"].any()):
+                need = S["need_mm"]
+                imm = torch.where(need[:, None, None], S["pend_cov"], S["imm"])
+                S["imm"].copy_(imm)
+                S["mm_sqrt"].copy_(torch.where(need[:, None, None], torch.linalg.cholesky(torch.linalg.inv(imm)), S["mm_sqrt"]))
+                warm = need & (S["it"] < num_warmup)          # restart dual averaging around the running average
+                S["eps"].copy_(torch.where(warm, S["eps_avg"], S["eps"]))
+                S["da_mu"].copy_(torch.where(warm, torch.log(10.0 * S["eps_avg"]), S["da_mu"]))
+                for key in ("da_t", "da_gbar", "da_xbar"):
+                    S[key].copy_(torch.where(warm, torch.zeros_like(S[key]), S[key]))
+                S["need_mm"].zero_()
+            if self.use_graph and dev.type == "cuda" and graph is None and blocks >= 1:
+                try:
+                    torch.cuda.synchronize()
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph):
+                        one_step()
+                    kidx.zero_()                          # capture does not execute
+                except Exception as err:  # pragma: no cover - depends on the model
+                    torch.cuda.synchronize()
+                    print(f"[dynode_amd] NUTS iteration not graph-capturable ({type(err).__name__}: {str(err)[:120]}); eager")
+                    graph, self.use_graph = None, False
+                    kidx.zero_()
+            for _ in range(Kb):
+                if graph is not None:
+                    graph.replay()
+                else:
+                    one_step()
+            self.evals += Kb if graph is not None else 0
+            blocks += 1
+            if progress is not None:
+                m = int(S["it"].min())
+                progress(max(m - 1, 0), m <= num_warmup)
+        return NUTSResult(S["out_z"], S["out_acc"], S["out_n"], S["out_div"], S["eps"], S["imm"], self.evals)

@@ -7,7 +7,7 @@ import pytest
 import torch
 from scipy import stats
 
-from dynode_amd.infer.nuts import BatchedNUTS, LockstepNUTS, _adaptation_windows
+from dynode_amd.infer.nuts import BatchedNUTS, GraphNUTS, LockstepNUTS, _adaptation_windows
 
 
 def gaussian_target(cov):
@@ -26,7 +26,7 @@ def test_adaptation_windows_follow_stans_schedule():
     assert _adaptation_windows(10) == []
 
 
-@pytest.mark.parametrize("sampler", [BatchedNUTS, LockstepNUTS], ids=["async", "lockstep"])
+@pytest.mark.parametrize("sampler", [BatchedNUTS, LockstepNUTS, GraphNUTS], ids=["async", "lockstep", "graph-step"])
 def test_correlated_gaussian_moments_and_marginals(sampler):
     torch.manual_seed(0)
     cov = torch.tensor([[4.0, 1.8], [1.8, 1.0]], dtype=torch.float64)    # strongly correlated, unequal scales
