@@ -88,8 +88,12 @@ def allreduce_ensemble_moments(ys_local: torch.Tensor) -> tuple:
     Sums are accumulated in float64 and all-reduced: 2 x n_save x D doubles per rank (cfg 5:
     800 KB) instead of gathering the 13 GB ensemble.
     """
-    s1 = ys_local.double().sum(dim=0)
-    s2 = (ys_local.double() ** 2).sum(dim=0)
+    # float64 accumulation without a float64 (or squared) copy of the multi-GB ensemble: the
+    # squares are formed in blocks of 1024 trajectories (a ~200 MB temporary for cfg 3)
+    s1 = ys_local.sum(dim=0, dtype=torch.float64)
+    s2 = torch.zeros_like(s1)
+    for lo in range(0, ys_local.shape[0], 1024):
+        s2 += ys_local[lo:lo + 1024].square().sum(dim=0, dtype=torch.float64)
     n = torch.tensor([float(ys_local.shape[0])], dtype=torch.float64, device=ys_local.device)
     rank, size = world()
     if size > 1:
