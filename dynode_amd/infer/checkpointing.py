@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import datetime
 
+from ..utils import date_to_sim_day
 from . import handlers
 
 
@@ -24,7 +25,8 @@ def checkpoint_compartment_sizes(config, solution, save_final_timesteps: bool = 
         for name, idx in comps:
             handlers.deterministic("final_timestep_%s" % name, at(solution.ys[idx], idx, -1))
     for date in compartment_save_dates:
-        sim_day = (date - config.initializer.initialize_date).days if isinstance(date, datetime.date) else int(date)
+        sim_day = (date_to_sim_day(date, config.initializer.initialize_date) if isinstance(date, datetime.date)
+                   else int(date))
         n_days = solution.ts.shape[0]
         if 0 <= sim_day < n_days:
             tag = date.strftime("%Y_%m_%d") if isinstance(date, datetime.date) else f"day_{sim_day}"

@@ -9,11 +9,7 @@ import numpy as np
 from dynode_amd import (Bin, Compartment, Dimension, Initializer, Params, SimulationConfig, SolverParams, Strain,
                         TransmissionParams, simulate)
 from dynode_amd.rhs import SEIRS_MultiStrain_ODEParams, seirs_multi_strain_ode  # noqa: F401
-
-
-def vectorize_objects(objs, target):
-    """[getattr(o, target) for o in objs] -- reference utils/utils.py:10-38."""
-    return [getattr(o, target) for o in objs]
+from dynode_amd.utils import vectorize_objects
 
 
 class SEIRSStratifiedInitializer(Initializer):
