@@ -1,11 +1,13 @@
-"""Type aliases of the drop-in surface (mirrors /root/reference/src/dynode/typing/typing.py:11-39).
+"""Aliases used across the drop-in surface.
 
-The reference's arrays are ``jax.Array``; here a compartment array is a ``torch.Tensor``
-(device memory) or a ``numpy.ndarray`` on the way in.
+Counterpart of the reference's ``dynode.typing`` (src/dynode/typing/typing.py:11-39); where the
+reference says ``jax.Array`` a compartment here is a ``torch.Tensor`` in HBM (results) or a
+``numpy.ndarray`` / ``torch.Tensor`` (inputs).
 """
 
 from __future__ import annotations
 
+import re
 from typing import Annotated, Any, Callable, Tuple, Union
 
 import numpy as np
@@ -13,28 +15,36 @@ import torch
 from annotated_types import Ge, Le
 from pydantic import BeforeValidator
 
+# ---- arrays and state tuples
 ArrayLike = Union[np.ndarray, torch.Tensor]
-CompartmentState = Tuple[ArrayLike, ...]
-CompartmentGradients = Tuple[ArrayLike, ...]
-CompartmentTimeseries = CompartmentState
+CompartmentState = Tuple[ArrayLike, ...]        # one array per compartment, in config order
+CompartmentGradients = CompartmentState
+CompartmentTimeseries = CompartmentState         # the same with a leading time axis
+ObservedData = Union[CompartmentState, ArrayLike]
+ODE_Eqns = Callable[[Any, CompartmentState, Any], CompartmentGradients]   # (t, state, params) -> d(state)/dt
+
+# ---- constrained scalars
 UnitIntervalFloat = Annotated[float, Ge(0.0), Le(1.0)]
-ODE_Eqns = Callable[[Any, CompartmentState, Any], CompartmentGradients]
-ObservedData = Union[Tuple[ArrayLike, ...], ArrayLike]
+
+_NAME = re.compile(r"[A-Za-z_][A-Za-z0-9_]*\Z")
 
 
-def _verify_name(name: str) -> str:
-    """No leading digit, no spaces, alphanumerics/underscores only (typing.py:27-36)."""
-    if name[0].isnumeric():
+def _check_identifier(name: str) -> str:
+    """Names of compartments, dimensions, bins and strains become attributes of ``config.idx``, so
+    they must look like identifiers: letters, digits, underscores, no leading digit, no spaces.
+    Same three rejections (and messages) as the reference's validator."""
+    if _NAME.match(name):
+        return name
+    if name[:1].isdigit():
         raise ValueError("Name can not start with a number.")
     if " " in name:
         raise ValueError("Name can not have spaces.")
-    if not all(ch.isalnum() or ch == "_" for ch in name):
-        raise ValueError("Name can only contain alphanumerics or underscores.")
-    return name
+    raise ValueError("Name can only contain alphanumerics or underscores.")
 
 
-DynodeName = Annotated[str, BeforeValidator(_verify_name)]
+DynodeName = Annotated[str, BeforeValidator(_check_identifier)]
 
 
 def is_array(x: Any) -> bool:
+    """True for the array types ``simulate`` accepts as compartment values."""
     return isinstance(x, (np.ndarray, torch.Tensor))

@@ -1,46 +1,69 @@
-"""Minimal SIR model on dynode_amd -- counterpart of the reference's examples/sir.py.
+"""Single-population SIR on dynode_amd (the smallest model of the family).
 
-Same structure as the reference example (Initializer, get_config, get_odeparams, simulate);
-the only change a user makes is the import line and using the ``sir_ode`` descriptor.
+Covers the same ground as the reference's ``examples/sir.py`` -- an Initializer, a
+SimulationConfig, a parameter container, one ``simulate`` call -- and then shows what the GPU
+engine adds: the same call with a vector of R0 values integrates all of them in one launch.
 """
 
 from datetime import date
 
 import numpy as np
 
-from dynode_amd import (Bin, Compartment, Dimension, Initializer, Params, SimulationConfig, SolverParams, Strain,
-                        TransmissionParams, simulate)
-from dynode_amd.rhs import SIR_ODEParams, sir_ode  # noqa: F401
+import dynode_amd as dyn
+from dynode_amd.rhs import SIR_ODEParams, sir_ode
+
+POPULATION = 1
 
 
-class SimpleSIRInitializer(Initializer):
+class SimpleSIRInitializer(dyn.Initializer):
+    """Fractions of one unit population: 90 % susceptible, 10 % infectious unless told otherwise."""
+
     def __init__(self):
-        super().__init__(description="Simple SIR initializer", initialize_date=date(2022, 2, 11), population_size=1)
+        super().__init__(description="fractions of a unit population", initialize_date=date(2022, 2, 11),
+                         population_size=POPULATION)
 
     def get_initial_state(self, s_0=0.9, i_0=0.1, r_0=0.0, **kwargs):
-        return (np.array([s_0]), np.array([i_0]), np.array([r_0]))
+        return tuple(np.array([float(v)]) for v in (s_0, i_0, r_0))
 
 
-def get_config(r_0=2.0, infectious_period=7.0) -> SimulationConfig:
-    dimension = Dimension(name="age", bins=[Bin(name="all")])
-    comps = [Compartment(name=n, dimensions=[dimension]) for n in ("s", "i", "r")]
-    strain = [Strain(strain_name="test", r0=r_0, infectious_period=infectious_period)]
-    params = Params(solver_params=SolverParams(),
-                    transmission_params=TransmissionParams(strains=strain, strain_interactions={"test": {"test": 1.0}},
-                                                           contact_matrix=np.array([[1.0]])))
-    return SimulationConfig(compartments=comps, initializer=SimpleSIRInitializer(), parameters=params)
+def get_config(r_0=2.0, infectious_period=7.0) -> dyn.SimulationConfig:
+    everyone = dyn.Dimension(name="age", bins=[dyn.Bin(name="all")])
+    transmission = dyn.TransmissionParams(
+        strains=[dyn.Strain(strain_name="test", r0=r_0, infectious_period=infectious_period)],
+        strain_interactions={"test": {"test": 1.0}},
+        contact_matrix=np.ones((1, 1)),
+    )
+    return dyn.SimulationConfig(
+        compartments=[dyn.Compartment(name=c, dimensions=[everyone]) for c in "sir"],
+        initializer=SimpleSIRInitializer(),
+        parameters=dyn.Params(solver_params=dyn.SolverParams(), transmission_params=transmission),
+    )
 
 
-def get_odeparams(config: SimulationConfig) -> SIR_ODEParams:
+def get_odeparams(config: dyn.SimulationConfig) -> SIR_ODEParams:
+    """beta = R0 / T_inf, gamma = 1 / T_inf."""
     strain = config.parameters.transmission_params.strains[0]
-    return SIR_ODEParams(beta=np.array(strain.r0 / strain.infectious_period), gamma=np.array(1.0 / strain.infectious_period))
+    t_inf = strain.infectious_period
+    return SIR_ODEParams(beta=np.asarray(strain.r0 / t_inf), gamma=np.asarray(1.0 / t_inf))
+
+
+def main():
+    config = get_config()
+    state0 = config.initializer.get_initial_state()
+    solver = config.parameters.solver_params
+    sol = dyn.simulate(ode=sir_ode, duration_days=150, initial_state=state0, ode_parameters=get_odeparams(config),
+                       solver_parameters=solver)
+    s, i, r = (c.squeeze().cpu().numpy() for c in sol.ys)
+    print("day      S       I       R")
+    for day in (0, 30, 60, 90, 150):
+        print(f"{day:3d}  {s[day]:.4f}  {i[day]:.4f}  {r[day]:.4f}")
+    # the batched extension: 1000 values of R0 in one launch, final sizes back as one tensor
+    r0 = np.linspace(1.1, 4.0, 1000)
+    sweep = dyn.simulate(ode=sir_ode, duration_days=300, initial_state=state0,
+                         ode_parameters=SIR_ODEParams(beta=r0 / 7.0, gamma=np.asarray(1 / 7.0)), solver_parameters=solver)
+    final = sweep.ys[config.idx.r][:, -1, 0].cpu().numpy()
+    print("final size for R0 = 1.1, 2.0, 4.0:", final[0].round(3), final[310].round(3), final[-1].round(3))
 
 
 if __name__ == "__main__":
-    config = get_config()
-    sol = simulate(ode=sir_ode, duration_days=150, initial_state=config.initializer.get_initial_state(),
-                   ode_parameters=get_odeparams(config), solver_parameters=config.parameters.solver_params)
-    s, i, r = [arr.squeeze().cpu().numpy() for arr in sol.ys]
-    print("day   S      I      R")
-    for d in (0, 30, 60, 90, 150):
-        print(f"{d:3d} {s[d]:.4f} {i[d]:.4f} {r[d]:.4f}")
+    main()
