@@ -47,13 +47,33 @@ def parse():
     return ap.parse_args()
 
 
+def effective_cpus() -> int:
+    """CPUs this process may actually use: affinity mask capped by the cgroup CPU quota (a GPU box
+    exposes every host thread in the mask but grants the job a 16-CPU share)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    env = os.environ.get("DYNODE_BENCH_CPUS")
+    return int(env) if env else n
+
+
 def cpu_baseline(wl, sample: int):
     """Time the oracle (CPU restatement, fp32, OpenMP over trajectories) on a bounded sample."""
     import numpy as np
 
     from oracle import oracle as O  # checker/baseline only; never on the product path
 
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = effective_cpus()
     m = wl.model
     om = O.Model(m.n_age, m.n_strain, m.has_e, m.has_wane, m.has_c, m.n_wane, m.normalize, m.seasonal)
     y0 = wl.y0[:sample] if wl.y0.ndim == 2 else wl.y0
@@ -226,7 +246,7 @@ def main():
                     "all_status_ok": int(st2[0].max()) == 0}
                 del o2
         if world == 1 and not args.no_cpu_baseline:
-            sample = args.cpu_sample or (4096 if m.state_dim >= 100 else 16384)
+            sample = args.cpu_sample or (16384 if m.state_dim >= 100 else 65536)
             line["cpu_baseline"] = cpu_baseline(wl, min(sample, B))
         print(json.dumps(line), flush=True)
     if world > 1:
