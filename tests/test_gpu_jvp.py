@@ -92,4 +92,34 @@ def test_jvp_sub_save_and_failures():
     from dynode_amd.engine import SolveError
     with pytest.raises(SolveError, match="UNSUPPORTED"):
         solve_batch(ModelDesc(n_age=8, n_strain=4, has_e=True, has_wane=True, has_c=True), np.zeros(136),
-                    np.ones((1, 16)), np.eye(8), 10.0, [0.0, 10.0], dparams=np.ones((1, 2, 16)))
+                    np.ones((1, 16)), np.eye(8), 10.0, [0.0, 10.0], dparams=np.ones((1, 3, 16)))   # no 3-direction kernel
+
+
+def test_gradient_of_a_multi_strain_model_through_simulate():
+    """Directions are tiled over the compiled tangent kernels: 12 parameters of the 2-age x 3-strain
+    example (1 direction per launch) and 16 of the 8 x 4 model (2 per launch, strains split over lanes)."""
+    from dynode_amd import rhs, simulate
+    from examples import seirs_multi_strain_age_stratified as ex
+
+    for cfg in (ex.get_config(),
+                ex.get_config(r0s=(2.0, 2.5, 1.8, 2.2), infectious_periods=(7.0, 6.0, 8.0, 7.5),
+                              latent_periods=(3.0, 2.5, 4.0, 3.0), waning_periods=(60.0, 80.0, 50.0, 70.0),
+                              contact_matrix=np.eye(8) * 0.5 + 0.5 / 8, age_names=tuple(f"a{k}" for k in range(8)),
+                              age_demographics=tuple([0.125] * 8))):
+        p = ex.get_odeparams(cfg)
+        y0 = cfg.initializer.get_initial_state(cfg)
+        beta = torch.tensor(p.beta, dtype=torch.float64, device="cuda", requires_grad=True)
+
+        def loss(b):
+            q = rhs.SEIRS_MultiStrain_ODEParams(beta=b, gamma=p.gamma, sigma=p.sigma, omega=p.omega,
+                                                contact_matrix=p.contact_matrix)
+            sol = simulate(rhs.seirs_multi_strain_ode, 60, y0, q, cfg.parameters.solver_params, dtype=torch.float64)
+            return sol.ys[cfg.idx.c][-1].sum()          # cumulative incidence at day 60
+
+        val = loss(beta)
+        (grad,) = torch.autograd.grad(val, beta)
+        eps = 1e-6
+        fd = torch.stack([(loss(beta.detach() + eps * torch.eye(len(beta), dtype=torch.float64, device="cuda")[j])
+                           - loss(beta.detach() - eps * torch.eye(len(beta), dtype=torch.float64, device="cuda")[j])) / (2 * eps)
+                          for j in range(len(beta))])
+        assert torch.allclose(grad, fd.detach(), rtol=5e-4), (grad, fd)
