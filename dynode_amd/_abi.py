@@ -28,7 +28,20 @@ EXPORTED_SYMBOLS = (
     "dyn_abi_version", "dyn_state_dim", "dyn_param_dim", "dyn_n_compartments",
     "dyn_compartment_offsets", "dyn_is_supported", "dyn_trajectories_per_wave",
     "dyn_last_error", "dyn_solve_batch", "dyn_solve_batch_jvp", "dyn_is_supported_jvp",
+    "dyn_nuts_advance", "dyn_nuts_state_size", "dyn_philox4x32_10",
 )
+
+NUTS_MAX_DIM, NUTS_MAX_DEPTH, NUTS_MAX_WINDOWS = 8, 10, 16
+# pointer members of dyn_nuts_state, in declaration order (include/dynode_hip.h)
+NUTS_POINTER_FIELDS = (
+    "z_eval", "u_new", "g_new", "z", "u", "g", "eps", "eps_avg", "da_mu", "da_xbar", "da_gbar", "da_t",
+    "imm", "mm_sqrt", "wf_n", "wf_mean", "wf_m2", "e0", "zl", "rl", "gl", "zr", "rr", "gr", "zp", "up", "gp",
+    "weight", "r_sum", "sum_acc", "sgn", "zc", "rc", "gc", "r_half", "s_zp", "s_up", "s_gp", "s_weight",
+    "s_rsum", "s_acc", "r_ck", "rs_ck", "it", "wi", "n_prop", "depth", "right", "leaf", "s_turn", "s_div",
+    "s_n", "rng_ctr", "pool", "pool_ro", "pend", "out_z", "out_acc", "out_n", "out_div",
+)
+NUTS_INT32_FIELDS = ("it", "wi", "n_prop", "depth", "right", "leaf", "s_turn", "s_div", "s_n", "out_n", "out_div", "pend")
+NUTS_INT64_FIELDS = ("rng_ctr", "pool", "pool_ro")
 
 
 class ModelDescC(ctypes.Structure):
@@ -47,6 +60,13 @@ class SolverOptsC(ctypes.Structure):
         ("jump_ts", ctypes.POINTER(ctypes.c_double)),
         ("n_jump", ctypes.c_int32),
     ]
+
+
+class NutsStateC(ctypes.Structure):
+    _fields_ = ([(n, ctypes.c_int32) for n in ("n_chains", "dim", "max_depth", "num_warmup", "num_samples", "n_windows", "pooled")]
+                + [("w_start", ctypes.c_int32 * NUTS_MAX_WINDOWS), ("w_end", ctypes.c_int32 * NUTS_MAX_WINDOWS),
+                   ("seed", ctypes.c_uint64), ("target_accept", ctypes.c_double), ("max_delta_energy", ctypes.c_double)]
+                + [(n, ctypes.c_void_p) for n in NUTS_POINTER_FIELDS])
 
 
 @dataclass(frozen=True)
@@ -132,5 +152,10 @@ def lib() -> ctypes.CDLL:
             ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
             ctypes.c_void_p,
         ]
+        L.dyn_nuts_advance.restype = ctypes.c_int
+        L.dyn_nuts_advance.argtypes = [ctypes.POINTER(NutsStateC), ctypes.c_void_p]
+        L.dyn_nuts_state_size.restype = ctypes.c_int32
+        L.dyn_philox4x32_10.restype = None
+        L.dyn_philox4x32_10.argtypes = [ctypes.POINTER(ctypes.c_uint32)] * 3
         _lib = L
     return _lib

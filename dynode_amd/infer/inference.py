@@ -25,7 +25,7 @@ from pydantic import BaseModel, ConfigDict, Field, PositiveInt, PrivateAttr
 from .. import sharding
 from . import handlers
 from .distributions import biject_to
-from .nuts import BatchedNUTS, GraphNUTS, NUTSResult
+from .nuts import BatchedNUTS, GraphNUTS, KernelNUTS, NUTSResult
 
 
 def init_to_median(num_samples: int = 15):
@@ -198,13 +198,20 @@ class MCMCProcess(InferenceProcess):
         local = hi - lo
         pot = Potential(self.numpyro_model, kwargs, self.inference_prngkey, device)
         z0 = pot.initial(self.num_chains, self.nuts_init_strategy, self.inference_prngkey)[lo:hi]
-        # default: the whole sampler iteration (model, gradient-solve kernel, autograd, tree and
-        # adaptation bookkeeping) is captured once as a HIP graph and replayed
-        # mcmc_kwargs={"hip_graph": False} selects the eager asynchronous sampler
-        cls = GraphNUTS if self.mcmc_kwargs.get("hip_graph", True) else BatchedNUTS
+        # default ("kernel"): an iteration = the potential (model, fused gradient-solve kernel,
+        # autograd) + ONE hand-written sampler kernel (dyn_nuts_advance), captured as a HIP graph.
+        # Mass-matrix windows are pooled over the chains of this GPU by default
+        # (mcmc_kwargs={"adaptation": "per_chain"} gives numpyro's chain-by-chain adaptation).
+        # mcmc_kwargs={"sampler": "graph"} replays the torch-op sampler step instead,
+        # {"sampler": "eager"} (or the older {"hip_graph": False}) runs it op by op.
+        kind = self.mcmc_kwargs.get("sampler", "kernel" if self.mcmc_kwargs.get("hip_graph", True) else "eager")
+        if kind == "kernel" and (pot.dim > 8 or self.nuts_max_tree_depth > 10):
+            kind = "graph"
+        cls = {"kernel": KernelNUTS, "graph": GraphNUTS, "eager": BatchedNUTS}[kind]
+        extra = {"adaptation": self.mcmc_kwargs.get("adaptation", "pooled")} if kind == "kernel" else {}
         sampler = cls(pot.potential_and_grad, max_tree_depth=self.nuts_max_tree_depth,
                       target_accept=self.nuts_kwargs.get("target_accept_prob", 0.8),
-                      seed=self.inference_prngkey + 7919 * rank)
+                      seed=self.inference_prngkey + 7919 * rank, **extra)
         total = self.num_warmup + self.num_samples
 
         def progress(it, warm):

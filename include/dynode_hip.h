@@ -145,6 +145,62 @@ int dyn_solve_batch_jvp(const dyn_model_desc *m, const dyn_solver_opts *opts, co
 /* 1 if a tangent kernel for (model shape, method, dtype, n_dir) is compiled in */
 int32_t dyn_is_supported_jvp(const dyn_model_desc *m, const dyn_solver_opts *o, int32_t n_dir);
 
+/*
+ * One NUTS sampler iteration for n_chains independent chains (one GPU thread per chain).
+ * Under numpyro the transition kernel is traced together with the model
+ * (src/dynode/infer/inference.py:149-163: MCMC(NUTS(model, dense_mass=True, max_tree_depth=5,
+ * init_strategy=init_to_median), ...)); here the model's potential and gradient are evaluated by
+ * the caller (any program that reads z_eval and writes u_new / g_new, e.g. a HIP graph around
+ * dyn_solve_batch_jvp) and this call does everything else a chain does between two potential
+ * evaluations: second half of the leapfrog, energy error, multinomial / biased-progressive
+ * proposal choice, checkpointed U-turn test, tree doubling, dual-averaging step size, windowed
+ * dense mass matrix with its Cholesky factor, recording the draw, momentum refresh, and the first
+ * half of the next leapfrog (which produces the next z_eval).  Chains advance asynchronously:
+ * every call costs every unfinished chain exactly one gradient.  All arrays are device arrays,
+ * row-major with the chain index first; real = float64.
+ */
+#define DYN_NUTS_MAX_DIM 8
+#define DYN_NUTS_MAX_DEPTH 10
+#define DYN_NUTS_MAX_WINDOWS 16
+typedef struct dyn_nuts_state {
+    int32_t n_chains, dim, max_depth;  /* dim <= DYN_NUTS_MAX_DIM, max_depth <= DYN_NUTS_MAX_DEPTH */
+    int32_t num_warmup, num_samples;
+    int32_t n_windows;                 /* slow adaptation windows [w_start, w_end) in transitions */
+    int32_t pooled;                    /* 0: every chain adapts its own mass matrix (numpyro);
+                                          1: window statistics pooled over the chains of this call */
+    int32_t w_start[DYN_NUTS_MAX_WINDOWS], w_end[DYN_NUTS_MAX_WINDOWS];
+    uint64_t seed;                     /* Philox key; stream = (seed, chain, per-chain counter) */
+    double target_accept, max_delta_energy;
+    /* exchange with the potential: position to evaluate, value and gradient there */
+    double *z_eval;                    /* [C][D]  written by this call */
+    const double *u_new, *g_new;       /* [C], [C][D]  read by this call (non-finite = divergent) */
+    /* chain state */
+    double *z, *u, *g;                 /* current draw, its potential and gradient */
+    double *eps, *eps_avg, *da_mu, *da_xbar, *da_gbar, *da_t;      /* dual averaging  [C] */
+    double *imm, *mm_sqrt;             /* inverse mass matrix, chol(mass)   [C][D][D] */
+    double *wf_n, *wf_mean, *wf_m2;    /* Welford accumulators of the open window */
+    /* trajectory (tree) state */
+    double *e0, *zl, *rl, *gl, *zr, *rr, *gr, *zp, *up, *gp, *weight, *r_sum, *sum_acc, *sgn;
+    /* subtree under construction */
+    double *zc, *rc, *gc, *r_half, *s_zp, *s_up, *s_gp, *s_weight, *s_rsum, *s_acc;
+    double *r_ck, *rs_ck;              /* U-turn checkpoints  [C][max_depth][D] */
+    int32_t *it, *wi, *n_prop, *depth, *right, *leaf, *s_turn, *s_div, *s_n;   /* [C] */
+    int64_t *rng_ctr;                  /* [C] */
+    /* pooled adaptation (pooled = 1): fixed-point sums per window, zero-initialised by the caller */
+    int64_t *pool, *pool_ro;               /* [W][1 + D + D*D]: count, sum, sum of outer products;
+                                              pool_ro = copy made after each launch (what chains read) */
+    int32_t *pend;                         /* [C] window whose pooled matrix is still to be applied, +1 */
+    /* post-warm-up draws */
+    double *out_z, *out_acc;           /* [C][num_samples][D], [C][num_samples] */
+    int32_t *out_n, *out_div;          /* [C][num_samples] leapfrogs per draw, divergence flag */
+} dyn_nuts_state;
+int dyn_nuts_advance(const dyn_nuts_state *st, void *stream);
+/* sizeof(dyn_nuts_state), for binding checks */
+int32_t dyn_nuts_state_size(void);
+/* the sampler's random-number block function (host copy, for known-answer tests):
+ * Philox4x32-10, ctr[4], key[2] -> out[4] */
+void dyn_philox4x32_10(const uint32_t *ctr, const uint32_t *key, uint32_t *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -105,3 +105,40 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(_abi, "LIB_PATH", "/nonexistent/libdynode_hip.so")
     with pytest.raises(_abi.HipLibraryMissing):
         _abi.lib()
+
+
+def test_sampler_state_struct_matches_the_header_and_rng_known_answers():
+    lib = _abi.lib()
+    assert lib.dyn_nuts_state_size() == ctypes.sizeof(_abi.NutsStateC)
+    text = open(os.path.join(H.ROOT, "include", "dynode_hip.h")).read()
+    body = text[text.index("typedef struct dyn_nuts_state"):text.index("} dyn_nuts_state;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    ptrs = []
+    for decl in re.findall(r"(?:const\s+)?(?:double|int32_t|int64_t)\s+(\*[^;]+);", body):
+        ptrs += [n.strip().lstrip("*") for n in decl.split(",")]
+    assert tuple(ptrs) == _abi.NUTS_POINTER_FIELDS
+    for name, val in (("DYN_NUTS_MAX_DIM", _abi.NUTS_MAX_DIM), ("DYN_NUTS_MAX_DEPTH", _abi.NUTS_MAX_DEPTH),
+                      ("DYN_NUTS_MAX_WINDOWS", _abi.NUTS_MAX_WINDOWS)):
+        assert int(re.search(rf"#define {name} (\d+)", text).group(1)) == val
+
+    # Philox4x32-10 known-answer vectors of the Random123 distribution (kat_vectors)
+    def philox(ctr, key):
+        c, k, o = (ctypes.c_uint32 * 4)(*ctr), (ctypes.c_uint32 * 2)(*key), (ctypes.c_uint32 * 4)()
+        lib.dyn_philox4x32_10(c, k, o)
+        return tuple(o)
+    assert philox([0] * 4, [0] * 2) == (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)
+    assert philox([0xffffffff] * 4, [0xffffffff] * 2) == (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)
+    assert philox([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]) == (
+        0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1)
+
+
+def test_sampler_entry_validates_before_launching():
+    lib = _abi.lib()
+    assert lib.dyn_nuts_advance(None, None) == -1
+    st = _abi.NutsStateC()
+    st.n_chains, st.dim, st.max_depth = 4, 9, 5           # dimension above DYN_NUTS_MAX_DIM
+    assert lib.dyn_nuts_advance(ctypes.byref(st), None) == -3
+    st.dim, st.max_depth = 2, 11
+    assert lib.dyn_nuts_advance(ctypes.byref(st), None) == -3
+    st.max_depth, st.n_chains = 5, 0                      # no chains: nothing to do, no launch
+    assert lib.dyn_nuts_advance(ctypes.byref(st), None) == 0

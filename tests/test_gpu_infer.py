@@ -68,9 +68,11 @@ def _grid_marginals(data):
     return (r0.numpy(), np.cumsum(p.sum(1).numpy())), (ti.numpy(), np.cumsum(p.sum(0).numpy()))
 
 
-def test_nuts_posterior_matches_grid_quadrature(data):
+@pytest.mark.parametrize("sampler,adaptation", [("kernel", "pooled"), ("kernel", "per_chain"), ("graph", "per_chain")])
+def test_nuts_posterior_matches_grid_quadrature(data, sampler, adaptation):
     process = MCMCProcess(numpyro_model=ex.model, num_warmup=250, num_samples=250, num_chains=48,
-                          nuts_max_tree_depth=10, progress_bar=False)
+                          nuts_max_tree_depth=10, progress_bar=False,
+                          mcmc_kwargs={"sampler": sampler, "adaptation": adaptation})
     mcmc = process.infer(config=ex.get_config(), tf=100, obs_data=data)
     post = process.get_samples(group_by_chain=True)
     assert set(post) == {"strains_0_r0", "strains_0_infectious_period"}
@@ -127,3 +129,43 @@ def test_svi_gaussian_fit_lands_on_the_posterior(data):
     assert abs(float(post["strains_0_infectious_period"].median()) - 7.2) < 0.5
     with pytest.raises(AssertionError):
         SVIProcess(numpyro_model=ex.model, num_iterations=1, num_samples=1).get_samples()
+
+
+@pytest.mark.parametrize("adaptation", ["per_chain", "pooled"])
+def test_sampler_kernel_on_a_correlated_gaussian(adaptation):
+    """dyn_nuts_advance against an analytic target (the CPU tests of tests/test_nuts.py, on the kernel)."""
+    from dynode_amd.infer.nuts import KernelNUTS
+
+    dev = torch.device("cuda")
+    cov = torch.tensor([[4.0, 1.8, 0.0], [1.8, 1.0, 0.0], [0.0, 0.0, 0.25]], dtype=torch.float64, device=dev)
+    prec = torch.linalg.inv(cov)
+
+    def pg(z):
+        g = z @ prec
+        return 0.5 * (z * g).sum(-1), g
+
+    torch.manual_seed(0)
+    z0 = torch.randn(64, 3, dtype=torch.float64, device=dev)
+    res = KernelNUTS(pg, max_tree_depth=8, seed=1, adaptation=adaptation).run(z0, num_warmup=300, num_samples=300)
+    x = res.samples.reshape(-1, 3)
+    assert res.samples.shape == (64, 300, 3) and int(res.diverging.sum()) == 0
+    assert 0.6 < float(res.accept_prob.mean()) < 0.95
+    assert int(res.num_steps.min()) >= 1 and int(res.num_steps.max()) <= 2 ** 8
+    assert torch.allclose(x.mean(0), torch.zeros(3, dtype=torch.float64, device=dev), atol=0.06)
+    assert torch.allclose(torch.cov(x.T), cov, rtol=0.1, atol=0.06)
+    assert torch.allclose(res.inverse_mass.mean(0), cov, rtol=0.35, atol=0.3)
+    if adaptation == "pooled":          # most chains end with (nearly) the same, well-estimated matrix
+        assert float((res.inverse_mass[:, 0, 0] - 4.0).abs().median()) < 0.3
+        assert float((res.inverse_mass[:, 2, 2] - 0.25).abs().median()) < 0.02
+    for d, sd in ((0, 2.0), (1, 1.0), (2, 0.5)):
+        thin = res.samples[:, ::10, d].reshape(-1).cpu().numpy()
+        assert stats.kstest(thin, "norm", args=(0.0, sd)).pvalue > 1e-3
+    # same seed -> same draws; chains differ from each other
+    again = KernelNUTS(pg, max_tree_depth=8, seed=1, adaptation=adaptation).run(z0, num_warmup=300, num_samples=300)
+    assert torch.equal(again.samples, res.samples) and not torch.equal(res.samples[0], res.samples[1])
+    # a potential that is non-finite away from the origin: flagged divergent, chain stays put
+    def wall(z):
+        u = torch.where(z.abs().amax(-1) > 3.0, torch.full_like(z[:, 0], float("nan")), 0.5 * (z * z).sum(-1))
+        return u, z.clone()
+    r2 = KernelNUTS(wall, max_tree_depth=6, seed=3).run(torch.zeros(16, 2, dtype=torch.float64, device=dev), 100, 100)
+    assert bool(torch.isfinite(r2.samples).all()) and float(r2.samples.abs().max()) <= 3.0

@@ -19,6 +19,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1000)
     ap.add_argument("--samples", type=int, default=1000)
     ap.add_argument("--depth", type=int, default=10)
+    ap.add_argument("--sampler", default="kernel", choices=["kernel", "graph", "eager"])
+    ap.add_argument("--adaptation", default="pooled", choices=["per_chain", "pooled"])
     args = ap.parse_args()
     import numpy as np, torch, torch.distributed as dist
     from scipy import stats
@@ -34,7 +36,8 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", torch.cuda.current_device()))
     data = ex.synthetic_incidence(100)
     proc = MCMCProcess(numpyro_model=ex.model, num_warmup=args.warmup, num_samples=args.samples, num_chains=args.chains,
-                       nuts_max_tree_depth=args.depth, progress_bar=(rank == 0))
+                       nuts_max_tree_depth=args.depth, progress_bar=(rank == 0),
+                       mcmc_kwargs={"sampler": args.sampler, "adaptation": args.adaptation})
     torch.cuda.synchronize()
     if world > 1: dist.barrier()
     t0 = time.perf_counter()
@@ -49,20 +52,25 @@ def main():
         g0 = torch.linspace(1.5 + 1e-4, 2.5 - 1e-4, 401, dtype=torch.float64); g1 = torch.linspace(4.5, 10.5, 481, dtype=torch.float64)
         lp = log_posterior_grid(pot, [g0, g1]).cpu(); odes.enable_x64(False)
         p = torch.exp(lp - lp.max()); p = p / p.sum()
-        ks = {}
+        ks, quad = {}, {}
         for name, grid, cdf in (("strains_0_r0", g0.numpy(), np.cumsum(p.sum(1).numpy())),
                                 ("strains_0_infectious_period", g1.numpy(), np.cumsum(p.sum(0).numpy()))):
             thin = post[name][:, ::20].reshape(-1).cpu().numpy()
             ks[name] = float(stats.kstest(thin, lambda x: np.interp(x, grid, cdf)).pvalue)
+            pdf = np.diff(np.concatenate([[0.0], cdf]))
+            mean = float((grid * pdf).sum())
+            quad[name] = {"mean": mean, "sd": float(np.sqrt(((grid - mean) ** 2 * pdf).sum())),
+                          "sample_mean": float(post[name].mean()), "sample_sd": float(post[name].std()),
+                          "max_cdf_gap": float(stats.kstest(thin, lambda x: np.interp(x, grid, cdf)).statistic)}
         n_trans = args.chains * (args.warmup + args.samples)
         print(json.dumps({
             "workload": "cfg4 sir_infer_parameters: NUTS, 2-age SIR, tf=100, Poisson incidence",
-            "n_gpus": world, "chains": args.chains, "warmup": args.warmup, "samples": args.samples,
+            "sampler": args.sampler, "adaptation": args.adaptation, "n_gpus": world, "chains": args.chains, "warmup": args.warmup, "samples": args.samples,
             "seconds": el, "transitions_per_s": n_trans / el,
             "gradient_solves_per_s_per_gpu": mcmc.nuts.potential_evals / el,
             "chain_gradient_evals_per_s": mcmc.nuts.potential_evals * (args.chains / world) * world / el,
             "mean_leapfrogs_per_transition": float(mcmc.nuts.num_steps.double().mean()),
-            "divergences_rank0": int(mcmc.nuts.diverging.sum()), "ks_pvalues_vs_quadrature": ks,
+            "divergences_rank0": int(mcmc.nuts.diverging.sum()), "ks_pvalues_vs_quadrature": ks, "moments_vs_quadrature": quad,
             "posterior_mean": {k: float(v.mean()) for k, v in post.items()},
         }), flush=True)
     if world > 1:
