@@ -154,6 +154,36 @@ class MCMCResult:
         return text
 
 
+class InferenceGroups:
+    """What ``to_arviz`` returns when arviz is not installed: the groups of an
+    ``arviz.InferenceData`` as plain dicts of tensors, every variable with leading
+    ``(chain, draw)`` axes (``chain`` = 1 for SVI, prior and predictive groups, as
+    ``az.from_numpyro`` lays them out).  ``to_inference_data()`` converts when arviz is present."""
+
+    GROUPS = ("posterior", "posterior_predictive", "prior", "log_likelihood", "sample_stats", "observed_data")
+
+    def __init__(self, **groups):
+        for g in self.GROUPS:
+            setattr(self, g, dict(groups.get(g) or {}))
+
+    def groups(self) -> list:
+        return [g for g in self.GROUPS if getattr(self, g)]
+
+    def __repr__(self):
+        return "InferenceGroups(" + ", ".join(f"{g}: {sorted(getattr(self, g))}" for g in self.groups()) + ")"
+
+    def to_inference_data(self):
+        import arviz as az  # noqa: F401  (optional dependency)
+
+        conv = lambda d: {k: v.detach().cpu().numpy() for k, v in d.items()}
+        return az.from_dict(**{g: conv(getattr(self, g)) for g in self.groups()})
+
+
+def _as_draws(d: dict) -> dict:
+    """(n, ...) -> (1, n, ...): a single "chain" axis in front, arviz's layout for unchained groups."""
+    return {k: v.unsqueeze(0) for k, v in d.items() if isinstance(v, torch.Tensor)}
+
+
 class InferenceProcess(BaseModel):
     """Abstract inference process (reference inference.py:29-117)."""
 
@@ -170,6 +200,44 @@ class InferenceProcess(BaseModel):
 
     def get_samples(self, group_by_chain=False, exclude_deterministic=True) -> dict:
         raise NotImplementedError("get_samples() process not implemented, please use a subclass.")
+
+    def to_arviz(self):
+        raise NotImplementedError("to_arviz() process not implemented, please use a subclass.")
+
+    # ---- shared by the subclasses' to_arviz (reference inference.py:208-241, 368-405)
+    def _predictive_groups(self, posterior_flat: dict, num_prior: int) -> dict:
+        """posterior predictive (the model re-run on the posterior draws) and prior predictive, each
+        as ONE batched solve, plus the pointwise log-likelihood of the observed sites."""
+        from .predictive import Predictive
+
+        kw = self._inferer_kwargs
+        post_pred = Predictive(self.numpyro_model, posterior_samples=posterior_flat, return_observed=True)(
+            rng_key=self.inference_prngkey, **kw)
+        prior = Predictive(self.numpyro_model, num_samples=num_prior, return_observed=True)(
+            rng_key=self.inference_prngkey, **kw)
+        n = next(iter(posterior_flat.values())).shape[0]
+        data = {k: torch.as_tensor(v, dtype=torch.float64) for k, v in posterior_flat.items()}
+        loglik, observed = {}, {}
+        with torch.no_grad(), handlers.substitute(data), handlers.trace() as tr:
+            self.numpyro_model(**kw)
+        for name, site in tr.sites.items():
+            if site["type"] == "sample" and site["is_observed"]:
+                lp = site["fn"].log_prob(site["value"])
+                loglik[name] = lp if lp.dim() and lp.shape[0] == n else lp.expand((n,) + tuple(lp.shape))
+                observed[name] = site["value"]
+        for name, obs in observed.items():           # numpyro reports observed sites once per draw
+            for grp, m in ((post_pred, n), (prior, num_prior)):
+                if name in grp and tuple(grp[name].shape) == tuple(obs.shape):
+                    grp[name] = obs.expand((m,) + tuple(obs.shape))
+        return dict(posterior_predictive=_as_draws(post_pred), prior=_as_draws(prior), log_likelihood=loglik,
+                    observed_data=observed)
+
+    @staticmethod
+    def _finish_arviz(groups: "InferenceGroups"):
+        try:
+            return groups.to_inference_data()
+        except ImportError:
+            return groups
 
 
 class MCMCProcess(InferenceProcess):
@@ -237,6 +305,23 @@ class MCMCProcess(InferenceProcess):
                 return {}
             samples = gathered
         return {n: (v if group_by_chain else v.reshape((-1,) + tuple(v.shape[2:]))) for n, v in samples.items()}
+
+    def to_arviz(self):
+        """Posterior, posterior predictive, prior, pointwise log-likelihood and sampler statistics in
+        arviz's layout (reference inference.py:208-241).  Returns ``arviz.InferenceData`` when arviz
+        is importable, else an `InferenceGroups` with the same groups."""
+        if not self._inference_complete:
+            raise AssertionError("Inference process not completed, please call infer() first.")
+        posterior = self.get_samples(group_by_chain=True)
+        C, N = next(iter(posterior.values())).shape[:2]
+        flat = {k: v.reshape((C * N,) + tuple(v.shape[2:])) for k, v in posterior.items()}
+        g = self._predictive_groups(flat, self.num_samples)
+        g["posterior_predictive"] = {k: v.reshape((C, N) + tuple(v.shape[2:])) for k, v in g["posterior_predictive"].items()}
+        g["log_likelihood"] = {k: v.reshape((C, N) + tuple(v.shape[1:])) for k, v in g["log_likelihood"].items()}
+        nuts = self._inferer.nuts
+        stats = {"diverging": nuts.diverging, "acceptance_rate": nuts.accept_prob, "n_steps": nuts.num_steps,
+                 "step_size": nuts.step_size[:, None].expand(C, N)}
+        return self._finish_arviz(InferenceGroups(posterior=posterior, sample_stats=stats, **g))
 
     def _deterministic_sites(self) -> dict:
         """Replay the model over the posterior draws to collect ``deterministic`` sites."""
@@ -360,5 +445,17 @@ class SVIProcess(InferenceProcess):
         return samples
 
 
-__all__ = ["Adam", "AutoMultivariateNormal", "InferenceProcess", "MCMCProcess", "MCMCResult", "Potential", "SVIProcess",
+    def to_arviz(self):
+        """Posterior predictive, prior (``num_iterations`` draws, as the reference does) and pointwise
+        log-likelihood (reference inference.py:368-405); the guide's draws are reported as a
+        one-chain posterior group as well."""
+        if not self._inference_complete:
+            raise AssertionError("Inference process not completed, please call infer() first.")
+        flat = self.get_samples()
+        g = self._predictive_groups(flat, self.num_iterations)
+        g["log_likelihood"] = _as_draws(g["log_likelihood"])
+        return self._finish_arviz(InferenceGroups(posterior=_as_draws(flat), **g))
+
+
+__all__ = ["Adam", "AutoMultivariateNormal", "InferenceGroups", "InferenceProcess", "MCMCProcess", "MCMCResult", "Potential", "SVIProcess",
            "SVIResult", "init_to_median", "init_to_sample", "log_posterior_grid"]

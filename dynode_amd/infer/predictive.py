@@ -18,7 +18,7 @@ from . import handlers
 
 class Predictive:
     def __init__(self, model: Callable, posterior_samples: Optional[dict] = None, num_samples: Optional[int] = None,
-                 exclude_deterministic: bool = True):
+                 exclude_deterministic: bool = True, return_observed: bool = False):
         if posterior_samples is None and num_samples is None:
             raise ValueError("either posterior_samples or num_samples must be given")
         self.model = model
@@ -30,6 +30,9 @@ class Predictive:
             num_samples = sizes.pop()
         self.num_samples = int(num_samples)
         self.exclude_deterministic = exclude_deterministic
+        # numpyro's Predictive also reports observed sites (their value is the observation); off by
+        # default here because callers normally pass ``obs_data=None`` to get predictive draws
+        self.return_observed = return_observed
 
     def __call__(self, rng_key: int = 0, **model_kwargs) -> dict:
         """Run the model; unobserved sample sites not in ``posterior_samples`` are drawn from their
@@ -42,7 +45,7 @@ class Predictive:
         for name, site in tr.sites.items():
             if site["type"] == "deterministic" and self.exclude_deterministic:
                 continue
-            if site["type"] == "sample" and site["is_observed"]:
+            if site["type"] == "sample" and site["is_observed"] and not self.return_observed:
                 continue
             if name in data:
                 continue

@@ -129,6 +129,14 @@ def test_svi_gaussian_fit_lands_on_the_posterior(data):
     assert abs(float(post["strains_0_infectious_period"].median()) - 7.2) < 0.5
     with pytest.raises(AssertionError):
         SVIProcess(numpyro_model=ex.model, num_iterations=1, num_samples=1).get_samples()
+    with pytest.raises(AssertionError):
+        SVIProcess(numpyro_model=ex.model, num_iterations=1, num_samples=1).to_arviz()
+    idata = proc.to_arviz()                          # reference inference.py:368-405
+    if hasattr(idata, "log_likelihood") and isinstance(idata.log_likelihood, dict):
+        assert idata.posterior["strains_0_r0"].shape == (1, 2000)
+        assert idata.prior["strains_0_r0"].shape == (1, 400)                     # num_iterations prior draws
+        assert idata.posterior_predictive["inf_incidence"].shape == (1, 2000, 100, 2)
+        assert idata.log_likelihood["inf_incidence"].shape == (1, 2000, 100, 2)
 
 
 @pytest.mark.parametrize("adaptation", ["per_chain", "pooled"])
@@ -169,3 +177,36 @@ def test_sampler_kernel_on_a_correlated_gaussian(adaptation):
         return u, z.clone()
     r2 = KernelNUTS(wall, max_tree_depth=6, seed=3).run(torch.zeros(16, 2, dtype=torch.float64, device=dev), 100, 100)
     assert bool(torch.isfinite(r2.samples).all()) and float(r2.samples.abs().max()) <= 3.0
+
+
+def test_to_arviz_groups_have_arviz_layout(data):
+    """to_arviz (reference inference.py:208-241): posterior / posterior_predictive / prior /
+    log_likelihood / sample_stats with (chain, draw) leading axes; predictive groups are one batched solve."""
+    from dynode_amd.infer.inference import InferenceGroups
+
+    with pytest.raises(AssertionError):
+        MCMCProcess(numpyro_model=ex.model, num_warmup=1, num_samples=1, num_chains=1, nuts_max_tree_depth=1).to_arviz()
+    process = MCMCProcess(numpyro_model=ex.model, num_warmup=60, num_samples=40, num_chains=6,
+                          nuts_max_tree_depth=6, progress_bar=False)
+    process.infer(config=ex.get_config(), tf=100, obs_data=data)
+    idata = process.to_arviz()
+    if not isinstance(idata, InferenceGroups):       # arviz installed: the conversion is arviz's own
+        assert {"posterior", "posterior_predictive", "prior", "log_likelihood", "sample_stats"} <= set(idata.groups())
+        return
+    assert idata.groups() == ["posterior", "posterior_predictive", "prior", "log_likelihood", "sample_stats", "observed_data"]
+    assert idata.posterior["strains_0_r0"].shape == (6, 40)
+    assert idata.posterior_predictive["inf_incidence"].shape == (6, 40, 100, 2)
+    assert idata.prior["strains_0_r0"].shape == (1, 40) and idata.prior["inf_incidence"].shape == (1, 40, 100, 2)
+    ll = idata.log_likelihood["inf_incidence"]
+    assert ll.shape == (6, 40, 100, 2) and bool(torch.isfinite(ll).all())
+    # the pointwise log-likelihood sums to the observed part of the log joint at the same draws
+    post = process.get_samples()
+    pot = process._inferer.potential
+    z = torch.stack([pot.bij[n].inv(post[n]) for n in pot.latent], dim=1).to(pot.device)
+    with torch.no_grad():
+        lj, _ = pot.log_joint(z)
+        prior_part = sum(pot.latent[n].log_prob(post[n].to(pot.device)) + pot.bij[n].log_abs_det_jacobian(z[:, i])
+                         for i, n in enumerate(pot.latent))
+    assert torch.allclose(ll.reshape(240, -1).sum(-1).to(lj.device), lj - prior_part, rtol=1e-9, atol=1e-6)
+    assert idata.sample_stats["diverging"].shape == (6, 40) and idata.sample_stats["step_size"].shape == (6, 40)
+    assert torch.equal(idata.observed_data["inf_incidence"].cpu(), torch.as_tensor(data, dtype=torch.float64).cpu())
