@@ -154,6 +154,29 @@ def test_full_size_properties(wl):
     assert np.abs(ys[torch.as_tensor(idx, device="cuda")].cpu().numpy() - want).max() / 1000.0 < 1e-5
 
 
+def test_output_offsets_beyond_2_to_the_31():
+    """cfg 5's global batch on ONE GPU: 65536 x 366 x 136 = 3.26e9 floats (13 GB), element offsets
+    above 2^31 (and byte offsets above 2^33); the trajectories at the far end must still be right."""
+    wl = synthetic.seirs_multi_strain(65536, seed=5, seasonal=True)
+    m = wl.model
+    assert wl.B * 366 * m.state_dim > 2 ** 31
+    r = solve_batch(m, wl.y0, wl.params, wl.contact, wl.t1, wl.save_ts, dtype=F32)
+    torch.cuda.synchronize()
+    assert int(r.status.max()) == 0 and r.ys.shape == (65536, 366, 136)
+    idx = np.concatenate([np.arange(0, 8), np.arange(43000, 43008), np.arange(wl.B - 16, wl.B)])   # 43000*366*136 > 2^31
+    y0s = wl.y0[idx] if wl.y0.ndim == 2 else wl.y0
+    want, _, _, _ = O.solve(H.omodel(m), y0s, wl.params[idx], wl.contact, wl.t1, wl.save_ts, dtype=np.float32, n_threads=8)
+    got = r.ys[torch.as_tensor(idx, device="cuda")].cpu().numpy()
+    assert np.abs(got - want).max() / 1000.0 < 1e-5
+    # every trajectory conserves mass, checked in chunks to keep temporaries small
+    n_pop = m.state_dim - m.n_age * m.n_strain
+    for lo in range(0, wl.B, 8192):
+        total = r.ys[lo:lo + 8192, :, :n_pop].sum(-1, dtype=torch.float64)
+        assert float((total - 1000.0).abs().max()) < 5e-3
+    del r
+    torch.cuda.empty_cache()
+
+
 # ------------------------------------------------------------------ edge cases of the boundary
 SIR1 = ModelDesc(n_age=1)
 UNNORM = ModelDesc(n_age=1, normalize=False)
