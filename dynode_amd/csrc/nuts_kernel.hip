@@ -19,7 +19,6 @@
 
 namespace dynnuts {
 
-constexpr int MAXD = DYN_NUTS_MAX_DIM;
 constexpr double POOL_SCALE = 1073741824.0; // 2^30 fixed point for the pooled window sums
 
 // Philox4x32-10 (Salmon et al. 2011), counter = (ctr_lo, ctr_hi, chain, 0), key = seed
@@ -60,31 +59,38 @@ __device__ inline double logaddexp(double a, double b) {
     return m + log1p(exp(-fabs(a - b)));
 }
 
-// y = M v for a row-major D x D matrix
-__device__ inline void matvec(const double *M, const double *v, double *y, int D) {
+// y = M v for a row-major D x D matrix (D is a compile-time constant: everything stays in registers)
+template <int D>
+__device__ inline void matvec(const double *M, const double *v, double *y) {
+#pragma unroll
     for (int i = 0; i < D; ++i) {
         double a = 0;
+#pragma unroll
         for (int j = 0; j < D; ++j) a += M[i * D + j] * v[j];
         y[i] = a;
     }
 }
-__device__ inline double dot(const double *a, const double *b, int D) {
+template <int D>
+__device__ inline double dot(const double *a, const double *b) {
     double s = 0;
+#pragma unroll
     for (int i = 0; i < D; ++i) s += a[i] * b[i];
     return s;
 }
-__device__ inline bool is_turning(const double *imm, const double *rl, const double *rr,
-                                  const double *rsum, int D) {
-    double rs[MAXD], vl[MAXD], vr[MAXD];
+template <int D>
+__device__ inline bool is_turning(const double *imm, const double *rl, const double *rr, const double *rsum) {
+    double rs[D], vl[D], vr[D];
+#pragma unroll
     for (int i = 0; i < D; ++i) rs[i] = rsum[i] - 0.5 * (rl[i] + rr[i]);
-    matvec(imm, rl, vl, D);
-    matvec(imm, rr, vr, D);
-    return dot(vl, rs, D) <= 0.0 || dot(vr, rs, D) <= 0.0;
+    matvec<D>(imm, rl, vl);
+    matvec<D>(imm, rr, vr);
+    return dot<D>(vl, rs) <= 0.0 || dot<D>(vr, rs) <= 0.0;
 }
 
 // mm_sqrt = chol(inv(imm)) for a symmetric positive definite D x D (Gauss-Jordan + Cholesky)
-__device__ inline void mass_sqrt(const double *imm, double *out, int D) {
-    double a[MAXD * MAXD], inv[MAXD * MAXD];
+template <int D>
+__device__ inline void mass_sqrt(const double *imm, double *out) {
+    double a[D * D], inv[D * D];
     for (int i = 0; i < D * D; ++i) a[i] = imm[i];
     for (int i = 0; i < D; ++i)
         for (int j = 0; j < D; ++j) inv[i * D + j] = i == j ? 1.0 : 0.0;
@@ -106,9 +112,10 @@ __device__ inline void mass_sqrt(const double *imm, double *out, int D) {
         }
 }
 
+template <int D>
 __global__ void __launch_bounds__(64) nuts_advance(const dyn_nuts_state st) {
     const int c = blockIdx.x * 64 + threadIdx.x;
-    const int C = st.n_chains, D = st.dim, Dm = st.max_depth;
+    const int C = st.n_chains, Dm = st.max_depth;
     if (c >= C) return;
     const int total = st.num_warmup + st.num_samples;
     int it = st.it[c];
@@ -124,12 +131,12 @@ __global__ void __launch_bounds__(64) nuts_advance(const dyn_nuts_state st) {
     const double un = st.u_new[c];
     const double *gn = st.g_new + (int64_t)c * D;
     const double *zn = st.z_eval + (int64_t)c * D;
-    double rn[MAXD], tmp[MAXD];
+    double rn[D], tmp[D];
     bool bad = !isfinite(un);
     for (int i = 0; i < D; ++i) bad = bad || !isfinite(gn[i]);
     for (int i = 0; i < D; ++i) rn[i] = V(r_half)[i] - 0.5 * eps_signed * (bad ? 0.0 : gn[i]);
-    matvec(imm, rn, tmp, D);
-    double de = (bad ? INFINITY : un) + 0.5 * dot(rn, tmp, D) - st.e0[c];
+    matvec<D>(imm, rn, tmp);
+    double de = (bad ? INFINITY : un) + 0.5 * dot<D>(rn, tmp) - st.e0[c];
     if (isnan(de)) de = INFINITY;
     const double lw = -de;
     const bool div = de > st.max_delta_energy;
@@ -162,9 +169,9 @@ __global__ void __launch_bounds__(64) nuts_advance(const dyn_nuts_state st) {
         for (int i = 0; i < D; ++i) { r_ck[idx_max * D + i] = rn[i]; rs_ck[idx_max * D + i] = s_rsum[i]; }
     } else {
         for (int l = idx_max; l >= idx_min; --l) {
-            double sub[MAXD];
+            double sub[D];
             for (int i = 0; i < D; ++i) sub[i] = s_rsum[i] - rs_ck[l * D + i] + r_ck[l * D + i];
-            s_turn = s_turn || is_turning(imm, r_ck + l * D, rn, sub, D);
+            s_turn = s_turn || is_turning<D>(imm, r_ck + l * D, rn, sub);
         }
     }
     ++leaf;
@@ -187,7 +194,7 @@ __global__ void __launch_bounds__(64) nuts_advance(const dyn_nuts_state st) {
         st.sum_acc[c] += s_acc;
         st.n_prop[c] += s_n;
         ++depth;
-        stop = s_turn || s_div || is_turning(imm, V(rl), V(rr), V(r_sum), D) || depth >= Dm;
+        stop = s_turn || s_div || is_turning<D>(imm, V(rl), V(rr), V(r_sum)) || depth >= Dm;
     }
 
     double eps = st.eps[c];
@@ -213,14 +220,14 @@ __global__ void __launch_bounds__(64) nuts_advance(const dyn_nuts_state st) {
                 // (pool_ro = the pool as it stood after the previous launch: no concurrent writers)
                 const int64_t *pw = st.pool_ro + (int64_t)(st.pend[c] - 1) * (1 + D + D * D);
                 const double N = (double)pw[0], nn = fmax(N, 2.0);
-                double mu[MAXD], cand[MAXD * MAXD], chol[MAXD * MAXD];
+                double mu[D], cand[D * D], chol[D * D];
                 for (int i = 0; i < D; ++i) mu[i] = (double)pw[1 + i] / POOL_SCALE / N;
                 for (int i = 0; i < D; ++i)
                     for (int j = 0; j < D; ++j) {
                         const double cov = ((double)pw[1 + D + i * D + j] / POOL_SCALE - N * mu[i] * mu[j]) / (nn - 1.0);
                         cand[i * D + j] = (nn / (nn + 5.0)) * cov + (i == j ? 1e-3 * (5.0 / (nn + 5.0)) : 0.0);
                     }
-                mass_sqrt(cand, chol, D);
+                mass_sqrt<D>(cand, chol);
                 bool good = N >= 2.0;
                 for (int i = 0; i < D * D; ++i) good = good && isfinite(cand[i]) && isfinite(chol[i]);
                 for (int i = 0; i < D; ++i) good = good && chol[i * D + i] > 0.0 && cand[i * D + i] > 0.0;
@@ -236,7 +243,7 @@ __global__ void __launch_bounds__(64) nuts_advance(const dyn_nuts_state st) {
             const int wi = st.wi[c];
             if (wi < st.n_windows && it >= st.w_start[wi] && it < st.w_end[wi]) {
                 const double n1 = st.wf_n[c] + 1.0;
-                double d0[MAXD];
+                double d0[D];
                 double *mean = V(wf_mean), *m2 = M2(wf_m2);
                 for (int i = 0; i < D; ++i) { d0[i] = z[i] - mean[i]; mean[i] += d0[i] / n1; }
                 for (int i = 0; i < D; ++i)
@@ -262,7 +269,7 @@ __global__ void __launch_bounds__(64) nuts_advance(const dyn_nuts_state st) {
                             for (int j = 0; j < D; ++j)
                                 imm[i * D + j] = (nn / (nn + 5.0)) * m2[i * D + j] / (nn - 1.0) +
                                                  (i == j ? 1e-3 * (5.0 / (nn + 5.0)) : 0.0);
-                        mass_sqrt(imm, mms, D);
+                        mass_sqrt<D>(imm, mms);
                         eps = st.eps_avg[c]; // restart dual averaging around the running average
                         st.da_mu[c] = log(10.0 * eps);
                         st.da_t[c] = 0.0; st.da_gbar[c] = 0.0; st.da_xbar[c] = 0.0;
@@ -284,11 +291,11 @@ __global__ void __launch_bounds__(64) nuts_advance(const dyn_nuts_state st) {
         st.eps[c] = eps;
         st.it[c] = ++it;
         // fresh momentum r0 = chol(M) * normal, new trajectory = the single point (z, r0)
-        double nrm[MAXD], r0[MAXD];
+        double nrm[D], r0[D];
         for (int i = 0; i < D; ++i) nrm[i] = rng.normal();
-        matvec(mms, nrm, r0, D);
-        matvec(imm, r0, tmp, D);
-        st.e0[c] = st.u[c] + 0.5 * dot(r0, tmp, D);
+        matvec<D>(mms, nrm, r0);
+        matvec<D>(imm, r0, tmp);
+        st.e0[c] = st.u[c] + 0.5 * dot<D>(r0, tmp);
         for (int i = 0; i < D; ++i) {
             V(zl)[i] = V(zr)[i] = V(zp)[i] = z[i];
             V(rl)[i] = V(rr)[i] = V(r_sum)[i] = r0[i];
@@ -325,9 +332,9 @@ __global__ void __launch_bounds__(64) nuts_advance(const dyn_nuts_state st) {
 
     // ---- first half of the next leapfrog: r_half, and the position the potential is needed at
     const double es = eps * (go_right ? 1.0 : -1.0);
-    double rh[MAXD];
+    double rh[D];
     for (int i = 0; i < D; ++i) rh[i] = rc[i] - 0.5 * es * gc[i];
-    matvec(imm, rh, tmp, D);
+    matvec<D>(imm, rh, tmp);
     for (int i = 0; i < D; ++i) {
         V(r_half)[i] = rh[i];
         st.z_eval[(int64_t)c * D + i] = (it >= total) ? z[i] : zc[i] + es * tmp[i];
@@ -356,7 +363,11 @@ extern "C" int dyn_nuts_advance(const dyn_nuts_state *st, void *stream) {
     if (st->n_chains == 0) return 0;
     const unsigned blocks = (unsigned)((st->n_chains + 63) / 64);
     if (st->pooled && (!st->pool || !st->pool_ro || !st->pend)) return DYN_ERR_NULL;
-    hipLaunchKernelGGL(dynnuts::nuts_advance, dim3(blocks), dim3(64), 0, (hipStream_t)stream, *st);
+    using Kern = void (*)(const dyn_nuts_state);
+    static const Kern kernels[DYN_NUTS_MAX_DIM] = {
+        dynnuts::nuts_advance<1>, dynnuts::nuts_advance<2>, dynnuts::nuts_advance<3>, dynnuts::nuts_advance<4>,
+        dynnuts::nuts_advance<5>, dynnuts::nuts_advance<6>, dynnuts::nuts_advance<7>, dynnuts::nuts_advance<8>};
+    hipLaunchKernelGGL(kernels[st->dim - 1], dim3(blocks), dim3(64), 0, (hipStream_t)stream, *st);
     if (hipGetLastError() != hipSuccess) return DYN_ERR_LAUNCH;
     if (st->pooled && st->n_windows > 0) {
         // readers of the next launch see the pool as it stands now, never a half-updated one
