@@ -28,8 +28,11 @@ EXPORTED_SYMBOLS = (
     "dyn_abi_version", "dyn_state_dim", "dyn_param_dim", "dyn_n_compartments",
     "dyn_compartment_offsets", "dyn_is_supported", "dyn_trajectories_per_wave",
     "dyn_last_error", "dyn_solve_batch", "dyn_solve_batch_jvp", "dyn_is_supported_jvp",
-    "dyn_nuts_advance", "dyn_nuts_state_size", "dyn_philox4x32_10",
+    "dyn_nuts_advance", "dyn_nuts_state_size", "dyn_philox4x32_10", "dyn_latent_sites",
 )
+
+MAX_SITES = 8
+DIST_NORMAL, DIST_UNIFORM, DIST_BETA, DIST_TRUNCNORMAL = 0, 1, 2, 3
 
 NUTS_MAX_DIM, NUTS_MAX_DEPTH, NUTS_MAX_WINDOWS = 8, 10, 16
 # pointer members of dyn_nuts_state, in declaration order (include/dynode_hip.h)
@@ -60,6 +63,12 @@ class SolverOptsC(ctypes.Structure):
         ("jump_ts", ctypes.POINTER(ctypes.c_double)),
         ("n_jump", ctypes.c_int32),
     ]
+
+
+class SiteDescC(ctypes.Structure):
+    _fields_ = [("dist", ctypes.c_int32), ("reserved", ctypes.c_int32), ("p", ctypes.c_double * 4),
+                ("base_lo", ctypes.c_double), ("base_hi", ctypes.c_double), ("aff_loc", ctypes.c_double),
+                ("aff_scale", ctypes.c_double), ("lo", ctypes.c_double), ("hi", ctypes.c_double)]
 
 
 class NutsStateC(ctypes.Structure):
@@ -157,5 +166,7 @@ def lib() -> ctypes.CDLL:
         L.dyn_nuts_state_size.restype = ctypes.c_int32
         L.dyn_philox4x32_10.restype = None
         L.dyn_philox4x32_10.argtypes = [ctypes.POINTER(ctypes.c_uint32)] * 3
+        L.dyn_latent_sites.restype = ctypes.c_int
+        L.dyn_latent_sites.argtypes = [ctypes.POINTER(SiteDescC), ctypes.c_int32, ctypes.c_int64] + [ctypes.c_void_p] * 6
         _lib = L
     return _lib

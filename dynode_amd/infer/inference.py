@@ -58,6 +58,14 @@ class Potential:
         self.deterministic = [n for n, s in tr.sites.items() if s["type"] == "deterministic"]
         self.bij = OrderedDict((n, biject_to(d.support)) for n, d in self.latent.items())
         self.dim = len(self.latent)
+        # bijections + log priors + log-Jacobians of all latent sites as one kernel launch, when every
+        # site is in the fused families (fused_sites.py); otherwise the generic torch path below
+        self.site_table = None
+        self._ones: dict = {}
+        if torch.device(device).type == "cuda":
+            from . import fused_sites
+
+            self.site_table = fused_sites.build_table(self.latent.values())
 
     def constrain(self, z: torch.Tensor) -> "OrderedDict[str, torch.Tensor]":
         return OrderedDict((n, b(z[..., i])) for i, (n, b) in enumerate(self.bij.items()))
@@ -74,13 +82,21 @@ class Potential:
 
     def log_joint(self, z: torch.Tensor):
         """(log p(x, obs) + log|dx/dz|) per chain, and the trace."""
-        x = self.constrain(z)
-        with handlers.substitute(x), handlers.trace() as tr:
-            self.model(**self.kwargs)
         C = z.shape[0]
-        total = torch.zeros(C, dtype=torch.float64, device=z.device)
-        for i, (name, b) in enumerate(self.bij.items()):
-            total = total + self.latent[name].log_prob(x[name]) + b.log_abs_det_jacobian(z[:, i])
+        if self.site_table is not None and z.is_cuda and z.dim() == 2 and z.dtype == torch.float64:
+            from .fused_sites import LatentSites
+
+            x_all, total = LatentSites.apply(z, self.site_table)
+            x = OrderedDict(zip(self.bij, x_all.unbind(-1)))
+            with handlers.substitute(x), handlers.trace() as tr:
+                self.model(**self.kwargs)
+        else:
+            x = self.constrain(z)
+            with handlers.substitute(x), handlers.trace() as tr:
+                self.model(**self.kwargs)
+            total = torch.zeros(C, dtype=torch.float64, device=z.device)
+            for i, (name, b) in enumerate(self.bij.items()):
+                total = total + self.latent[name].log_prob(x[name]) + b.log_abs_det_jacobian(z[:, i])
         for name, s in tr.sites.items():
             if s["type"] == "sample" and s["is_observed"]:
                 lp = s["fn"].log_prob(s["value"].to(z.device))
@@ -90,7 +106,10 @@ class Potential:
     def potential_and_grad(self, z: torch.Tensor):
         z = z.detach().requires_grad_(True)
         lj, _ = self.log_joint(z)
-        (g,) = torch.autograd.grad(lj.sum(), z)
+        ones = self._ones.get(lj.shape[0])
+        if ones is None or ones.device != lj.device:
+            ones = self._ones[lj.shape[0]] = torch.ones_like(lj)
+        (g,) = torch.autograd.grad(lj, z, ones)
         return -lj.detach(), -g
 
     def graphed(self, chains: int):

@@ -201,6 +201,29 @@ int32_t dyn_nuts_state_size(void);
  * Philox4x32-10, ctr[4], key[2] -> out[4] */
 void dyn_philox4x32_10(const uint32_t *ctr, const uint32_t *key, uint32_t *out);
 
+/*
+ * Latent (prior) sites of a NUTS model in one launch: for every chain map the unconstrained
+ * coordinates z to the constrained values x (numpyro's biject_to of the site's support) and return
+ * lp = sum over sites of [log prior(x_i) + log |dx_i/dz_i|] with the derivatives a backward pass
+ * needs.  Replaces the per-op evaluation of the reference's priors
+ * (examples/sir_infer_parameters.py:47-58) inside the traced potential.
+ *   sites   [n_sites]  HOST descriptors;  z, x, dx_dz, dlp_dz [C][n_sites], lp [C]  device, float64
+ *   dlp_dz = d lp / d z_i (prior and Jacobian terms), dx_dz = d x_i / d z_i
+ */
+#define DYN_MAX_SITES 8
+enum { DYN_DIST_NORMAL = 0, DYN_DIST_UNIFORM = 1, DYN_DIST_BETA = 2, DYN_DIST_TRUNCNORMAL = 3 };
+typedef struct dyn_site_desc {
+    int32_t dist;            /* base distribution */
+    int32_t reserved;
+    double p[4];             /* normal {loc, scale}; uniform {low, high}; beta {a, b, log B(a,b)};
+                                truncated normal {loc, scale, log Z} */
+    double base_lo, base_hi; /* truncation bounds of the base (truncated normal), else unused */
+    double aff_loc, aff_scale; /* site value = aff_loc + aff_scale * base (composed AffineTransforms) */
+    double lo, hi;           /* support of the site value (+-INFINITY allowed): selects the bijection */
+} dyn_site_desc;
+int dyn_latent_sites(const dyn_site_desc *sites, int32_t n_sites, int64_t C, const double *z, double *x,
+                     double *lp, double *dx_dz, double *dlp_dz, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

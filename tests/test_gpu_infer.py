@@ -11,7 +11,7 @@ import torch
 from scipy import stats
 
 from dynode_amd.infer import handlers
-from dynode_amd.infer.inference import MCMCProcess, Potential, log_posterior_grid
+from dynode_amd.infer.inference import MCMCProcess, Potential, init_to_median, log_posterior_grid
 from dynode_amd.simulation import odes
 from examples import sir_infer_parameters as ex
 
@@ -210,3 +210,54 @@ def test_to_arviz_groups_have_arviz_layout(data):
     assert torch.allclose(ll.reshape(240, -1).sum(-1).to(lj.device), lj - prior_part, rtol=1e-9, atol=1e-6)
     assert idata.sample_stats["diverging"].shape == (6, 40) and idata.sample_stats["step_size"].shape == (6, 40)
     assert torch.equal(idata.observed_data["inf_incidence"].cpu(), torch.as_tensor(data, dtype=torch.float64).cpu())
+
+
+def test_fused_latent_sites_match_the_torch_definitions():
+    """dyn_latent_sites (bijection + log prior + log-Jacobian of every site in one launch) against
+    the op-by-op definitions in dynode_amd/infer/distributions.py, values and gradients."""
+    from dynode_amd.infer import distributions as dist
+    from dynode_amd.infer import fused_sites
+    from dynode_amd.infer.distributions import biject_to
+
+    T = dist.TransformedDistribution
+    A = dist.transforms.AffineTransform
+    families = [
+        [dist.Normal(0.3, 1.7), dist.Uniform(-2.0, 5.0), dist.Beta(0.5, 0.5), dist.Beta(2.0, 3.5),
+         T(dist.Beta(0.5, 0.5), A(1.5, 1)), dist.TruncatedNormal(loc=8, scale=2, low=2, high=15)],
+        [dist.TruncatedNormal(0.0, 1.0, low=0.5), dist.TruncatedNormal(1.0, 2.0, high=3.0),
+         T(dist.Normal(0.0, 1.0), [A(2.0, -3.0)]), T(dist.Beta(3.0, 1.5), [A(0.0, 2.0), A(1.0, -0.5)])],
+    ]
+    dev = torch.device("cuda")
+    gen = torch.Generator().manual_seed(0)
+    for dists in families:
+        table = fused_sites.build_table(dists)
+        assert table is not None and table[1] == len(dists)
+        z = ((torch.rand((257, len(dists)), generator=gen, dtype=torch.float64) - 0.5) * 12.0).to(dev)
+        w1 = torch.rand(257, generator=gen, dtype=torch.float64).to(dev)
+        w2 = torch.rand((257, len(dists)), generator=gen, dtype=torch.float64).to(dev)
+        za = z.clone().requires_grad_(True)
+        x_f, lp_f = fused_sites.LatentSites.apply(za, table)
+        (g_f,) = torch.autograd.grad((lp_f * w1).sum() + (x_f * w2).sum(), za)
+        zb = z.clone().requires_grad_(True)
+        bij = [biject_to(d.support) for d in dists]
+        x_t = torch.stack([b(zb[:, i]) for i, b in enumerate(bij)], dim=1)
+        lp_t = sum(d.log_prob(x_t[:, i]) + b.log_abs_det_jacobian(zb[:, i]) for i, (d, b) in enumerate(zip(dists, bij)))
+        (g_t,) = torch.autograd.grad((lp_t * w1).sum() + (x_t * w2).sum(), zb)
+        assert torch.allclose(x_f, x_t, rtol=1e-13, atol=1e-13)
+        assert torch.allclose(lp_f, lp_t, rtol=1e-12, atol=1e-11)
+        assert torch.allclose(g_f, g_t, rtol=1e-10, atol=1e-10)
+    # outside the fused families: tensor-valued parameters, other distributions, too many sites
+    assert fused_sites.describe(dist.Normal(torch.zeros(2), 1.0)) is None
+    assert fused_sites.describe(dist.Poisson(torch.ones(3))) is None
+    assert fused_sites.build_table([dist.Normal(0.0, 1.0)] * 9) is None
+
+
+def test_potential_with_fused_sites_equals_the_generic_path(data):
+    pot = Potential(ex.model, dict(config=ex.get_config(), tf=100, obs_data=data), 0, torch.device("cuda"))
+    assert pot.site_table is not None                      # the example's priors are in the fused families
+    z = pot.initial(32, init_to_median, 0) + 0.3 * torch.randn(32, 2, dtype=torch.float64, generator=torch.Generator().manual_seed(1)).cuda()
+    u1, g1 = pot.potential_and_grad(z)
+    table, pot.site_table = pot.site_table, None
+    u2, g2 = pot.potential_and_grad(z)
+    pot.site_table = table
+    assert torch.allclose(u1, u2, rtol=1e-12, atol=1e-9) and torch.allclose(g1, g2, rtol=1e-9, atol=1e-8)
