@@ -118,14 +118,64 @@ __global__ void __launch_bounds__(64) nuts_advance(const dyn_nuts_state st) {
     const int C = st.n_chains, Dm = st.max_depth;
     if (c >= C) return;
     const int total = st.num_warmup + st.num_samples;
-    int it = st.it[c];
-    if (it >= total) return; // finished chains idle
-#define V(f) (st.f + (int64_t)c * D)
-#define M2(f) (st.f + (int64_t)c * D * D)
-    double *z = V(z), *g = V(g), *zc = V(zc), *rc = V(rc), *gc = V(gc);
-    double *imm = M2(imm), *mms = M2(mm_sqrt);
-    const double eps_signed = st.eps[c] * st.sgn[c];
-    Philox rng{(uint32_t)st.seed, (uint32_t)(st.seed >> 32), (uint64_t)st.rng_ctr[c], (uint32_t)c};
+    if (st.it[c] >= total) return; // finished chains idle
+    // Scalars of this chain live in registers for the whole call (loaded here, stored at the end);
+    // the per-chain vectors are disjoint, which the restrict qualifiers tell the compiler, so loads
+    // are not serialised behind the stores of earlier phases.
+    double L_u = st.u[c];
+    double L_eps = st.eps[c];
+    double L_eps_avg = st.eps_avg[c];
+    double L_da_mu = st.da_mu[c];
+    double L_da_xbar = st.da_xbar[c];
+    double L_da_gbar = st.da_gbar[c];
+    double L_da_t = st.da_t[c];
+    double L_wf_n = st.wf_n[c];
+    double L_e0 = st.e0[c];
+    double L_up = st.up[c];
+    double L_weight = st.weight[c];
+    double L_sum_acc = st.sum_acc[c];
+    double L_sgn = st.sgn[c];
+    double L_s_up = st.s_up[c];
+    double L_s_weight = st.s_weight[c];
+    double L_s_acc = st.s_acc[c];
+    int L_it = st.it[c];
+    int L_wi = st.wi[c];
+    int L_n_prop = st.n_prop[c];
+    int L_depth = st.depth[c];
+    int L_right = st.right[c];
+    int L_leaf = st.leaf[c];
+    int L_s_turn = st.s_turn[c];
+    int L_s_div = st.s_div[c];
+    int L_s_n = st.s_n[c];
+    int L_pend = st.pooled ? st.pend[c] : 0;
+    int64_t L_rng_ctr = st.rng_ctr[c];
+    double *__restrict__ const p_g = st.g + (int64_t)c * D;
+    double *__restrict__ const p_gc = st.gc + (int64_t)c * D;
+    double *__restrict__ const p_gl = st.gl + (int64_t)c * D;
+    double *__restrict__ const p_gp = st.gp + (int64_t)c * D;
+    double *__restrict__ const p_gr = st.gr + (int64_t)c * D;
+    double *__restrict__ const p_r_half = st.r_half + (int64_t)c * D;
+    double *__restrict__ const p_r_sum = st.r_sum + (int64_t)c * D;
+    double *__restrict__ const p_rc = st.rc + (int64_t)c * D;
+    double *__restrict__ const p_rl = st.rl + (int64_t)c * D;
+    double *__restrict__ const p_rr = st.rr + (int64_t)c * D;
+    double *__restrict__ const p_s_gp = st.s_gp + (int64_t)c * D;
+    double *__restrict__ const p_s_rsum = st.s_rsum + (int64_t)c * D;
+    double *__restrict__ const p_s_zp = st.s_zp + (int64_t)c * D;
+    double *__restrict__ const p_wf_mean = st.wf_mean + (int64_t)c * D;
+    double *__restrict__ const p_z = st.z + (int64_t)c * D;
+    double *__restrict__ const p_zc = st.zc + (int64_t)c * D;
+    double *__restrict__ const p_zl = st.zl + (int64_t)c * D;
+    double *__restrict__ const p_zp = st.zp + (int64_t)c * D;
+    double *__restrict__ const p_zr = st.zr + (int64_t)c * D;
+    double *__restrict__ const p_imm = st.imm + (int64_t)c * D * D;
+    double *__restrict__ const p_mm_sqrt = st.mm_sqrt + (int64_t)c * D * D;
+    double *__restrict__ const p_wf_m2 = st.wf_m2 + (int64_t)c * D * D;
+    int it = L_it;
+    double *__restrict__ const z = p_z, *__restrict__ const g = p_g, *__restrict__ const zc = p_zc, *__restrict__ const rc = p_rc,
+           *__restrict__ const gc = p_gc, *__restrict__ const imm = p_imm, *__restrict__ const mms = p_mm_sqrt;
+    const double eps_signed = L_eps * L_sgn;
+    Philox rng{(uint32_t)st.seed, (uint32_t)(st.seed >> 32), (uint64_t)L_rng_ctr, (uint32_t)c};
 
     // ---- finish the leapfrog started by the previous launch: second momentum half step
     const double un = st.u_new[c];
@@ -134,37 +184,37 @@ __global__ void __launch_bounds__(64) nuts_advance(const dyn_nuts_state st) {
     double rn[D], tmp[D];
     bool bad = !isfinite(un);
     for (int i = 0; i < D; ++i) bad = bad || !isfinite(gn[i]);
-    for (int i = 0; i < D; ++i) rn[i] = V(r_half)[i] - 0.5 * eps_signed * (bad ? 0.0 : gn[i]);
+    for (int i = 0; i < D; ++i) rn[i] = p_r_half[i] - 0.5 * eps_signed * (bad ? 0.0 : gn[i]);
     matvec<D>(imm, rn, tmp);
-    double de = (bad ? INFINITY : un) + 0.5 * dot<D>(rn, tmp) - st.e0[c];
+    double de = (bad ? INFINITY : un) + 0.5 * dot<D>(rn, tmp) - L_e0;
     if (isnan(de)) de = INFINITY;
     const double lw = -de;
     const bool div = de > st.max_delta_energy;
     const double acc = exp(fmin(-de, 0.0));
 
     // ---- grow the subtree by this leaf (multinomial choice inside the subtree)
-    double s_weight = st.s_weight[c];
+    double s_weight = L_s_weight;
     const double new_w = logaddexp(s_weight, lw);
     if (rng.uniform() < exp(lw - new_w)) {
-        for (int i = 0; i < D; ++i) { V(s_zp)[i] = zn[i]; V(s_gp)[i] = bad ? 0.0 : gn[i]; }
-        st.s_up[c] = bad ? INFINITY : un;
+        for (int i = 0; i < D; ++i) { p_s_zp[i] = zn[i]; p_s_gp[i] = bad ? 0.0 : gn[i]; }
+        L_s_up = bad ? INFINITY : un;
     }
     s_weight = new_w;
-    double *s_rsum = V(s_rsum);
+    double *s_rsum = p_s_rsum;
     for (int i = 0; i < D; ++i) s_rsum[i] += rn[i];
-    bool s_div = st.s_div[c] != 0 || div;
-    const double s_acc = st.s_acc[c] + acc;
-    const int s_n = st.s_n[c] + 1;
+    bool s_div = L_s_div != 0 || div;
+    const double s_acc = L_s_acc + acc;
+    const int s_n = L_s_n + 1;
     for (int i = 0; i < D; ++i) { zc[i] = zn[i]; rc[i] = rn[i]; gc[i] = bad ? 0.0 : gn[i]; }
 
     // ---- checkpointed U-turn test
-    int leaf = st.leaf[c];
+    int leaf = L_leaf;
     const int idx_max = __popc((unsigned)(leaf >> 1));
     int trailing = 0;
     while ((leaf >> trailing) & 1) ++trailing;
     const int idx_min = idx_max - trailing + 1;
     double *r_ck = st.r_ck + (int64_t)c * Dm * D, *rs_ck = st.rs_ck + (int64_t)c * Dm * D;
-    bool s_turn = st.s_turn[c] != 0;
+    bool s_turn = L_s_turn != 0;
     if ((leaf & 1) == 0) {
         for (int i = 0; i < D; ++i) { r_ck[idx_max * D + i] = rn[i]; rs_ck[idx_max * D + i] = s_rsum[i]; }
     } else {
@@ -177,48 +227,48 @@ __global__ void __launch_bounds__(64) nuts_advance(const dyn_nuts_state st) {
     ++leaf;
 
     // ---- subtree complete -> merge into the trajectory (biased progressive sampling)
-    int depth = st.depth[c];
-    const bool right = st.right[c] != 0;
+    int depth = L_depth;
+    const bool right = L_right != 0;
     const bool sub_done = s_turn || s_div || leaf >= (1 << depth);
     bool stop = false;
     if (sub_done) {
         const bool ok = !s_turn && !s_div;
-        if (ok && rng.uniform() < exp(fmin(s_weight - st.weight[c], 0.0))) {
-            for (int i = 0; i < D; ++i) { V(zp)[i] = V(s_zp)[i]; V(gp)[i] = V(s_gp)[i]; }
-            st.up[c] = st.s_up[c];
+        if (ok && rng.uniform() < exp(fmin(s_weight - L_weight, 0.0))) {
+            for (int i = 0; i < D; ++i) { p_zp[i] = p_s_zp[i]; p_gp[i] = p_s_gp[i]; }
+            L_up = L_s_up;
         }
-        double *ze = right ? V(zr) : V(zl), *re = right ? V(rr) : V(rl), *ge = right ? V(gr) : V(gl);
+        double *ze = right ? p_zr : p_zl, *re = right ? p_rr : p_rl, *ge = right ? p_gr : p_gl;
         for (int i = 0; i < D; ++i) { ze[i] = zc[i]; re[i] = rc[i]; ge[i] = gc[i]; }
-        st.weight[c] = logaddexp(st.weight[c], s_weight);
-        for (int i = 0; i < D; ++i) V(r_sum)[i] += s_rsum[i];
-        st.sum_acc[c] += s_acc;
-        st.n_prop[c] += s_n;
+        L_weight = logaddexp(L_weight, s_weight);
+        for (int i = 0; i < D; ++i) p_r_sum[i] += s_rsum[i];
+        L_sum_acc += s_acc;
+        L_n_prop += s_n;
         ++depth;
-        stop = s_turn || s_div || is_turning<D>(imm, V(rl), V(rr), V(r_sum)) || depth >= Dm;
+        stop = s_turn || s_div || is_turning<D>(imm, p_rl, p_rr, p_r_sum) || depth >= Dm;
     }
 
-    double eps = st.eps[c];
+    double eps = L_eps;
     if (stop) {
         // ---- transition complete: adapt, record, next transition
         const bool warm = it < st.num_warmup;
-        const int n_prop = st.n_prop[c];
-        const double a_prob = st.sum_acc[c] / (double)(n_prop > 0 ? n_prop : 1);
-        for (int i = 0; i < D; ++i) { z[i] = V(zp)[i]; g[i] = V(gp)[i]; }
-        st.u[c] = st.up[c];
+        const int n_prop = L_n_prop;
+        const double a_prob = L_sum_acc / (double)(n_prop > 0 ? n_prop : 1);
+        for (int i = 0; i < D; ++i) { z[i] = p_zp[i]; g[i] = p_gp[i]; }
+        L_u = L_up;
         if (warm) {
             // dual averaging (Stan / numpyro constants: t0 = 10, kappa = 0.75, gamma = 0.05)
-            const double t1 = st.da_t[c] + 1.0, w = 1.0 / (t1 + 10.0);
-            const double gbar = (1.0 - w) * st.da_gbar[c] + w * (st.target_accept - a_prob);
-            const double x = st.da_mu[c] - sqrt(t1) / 0.05 * gbar;
+            const double t1 = L_da_t + 1.0, w = 1.0 / (t1 + 10.0);
+            const double gbar = (1.0 - w) * L_da_gbar + w * (st.target_accept - a_prob);
+            const double x = L_da_mu - sqrt(t1) / 0.05 * gbar;
             const double wx = pow(t1, -0.75);
-            const double xbar = (1.0 - wx) * st.da_xbar[c] + wx * x;
-            st.da_t[c] = t1; st.da_gbar[c] = gbar; st.da_xbar[c] = xbar;
+            const double xbar = (1.0 - wx) * L_da_xbar + wx * x;
+            L_da_t = t1; L_da_gbar = gbar; L_da_xbar = xbar;
             eps = exp(x);
-            st.eps_avg[c] = exp(xbar);
-            if (st.pooled && st.pend[c] > 0) {
+            L_eps_avg = exp(xbar);
+            if (st.pooled && L_pend > 0) {
                 // pooled window statistics of every chain that has closed this window so far
                 // (pool_ro = the pool as it stood after the previous launch: no concurrent writers)
-                const int64_t *pw = st.pool_ro + (int64_t)(st.pend[c] - 1) * (1 + D + D * D);
+                const int64_t *pw = st.pool_ro + (int64_t)(L_pend - 1) * (1 + D + D * D);
                 const double N = (double)pw[0], nn = fmax(N, 2.0);
                 double mu[D], cand[D * D], chol[D * D];
                 for (int i = 0; i < D; ++i) mu[i] = (double)pw[1 + i] / POOL_SCALE / N;
@@ -233,22 +283,22 @@ __global__ void __launch_bounds__(64) nuts_advance(const dyn_nuts_state st) {
                 for (int i = 0; i < D; ++i) good = good && chol[i * D + i] > 0.0 && cand[i * D + i] > 0.0;
                 if (good) {
                     for (int i = 0; i < D * D; ++i) { imm[i] = cand[i]; mms[i] = chol[i]; }
-                    eps = st.eps_avg[c];
-                    st.da_mu[c] = log(10.0 * eps);
-                    st.da_t[c] = 0.0; st.da_gbar[c] = 0.0; st.da_xbar[c] = 0.0;
+                    eps = L_eps_avg;
+                    L_da_mu = log(10.0 * eps);
+                    L_da_t = 0.0; L_da_gbar = 0.0; L_da_xbar = 0.0;
                 }
-                st.pend[c] = 0;
+                L_pend = 0;
             }
             // windowed dense mass matrix (Welford), applied with its Cholesky factor at window end
-            const int wi = st.wi[c];
+            const int wi = L_wi;
             if (wi < st.n_windows && it >= st.w_start[wi] && it < st.w_end[wi]) {
-                const double n1 = st.wf_n[c] + 1.0;
+                const double n1 = L_wf_n + 1.0;
                 double d0[D];
-                double *mean = V(wf_mean), *m2 = M2(wf_m2);
+                double *mean = p_wf_mean, *m2 = p_wf_m2;
                 for (int i = 0; i < D; ++i) { d0[i] = z[i] - mean[i]; mean[i] += d0[i] / n1; }
                 for (int i = 0; i < D; ++i)
                     for (int j = 0; j < D; ++j) m2[i * D + j] += d0[i] * (z[j] - mean[j]);
-                st.wf_n[c] = n1;
+                L_wf_n = n1;
                 if (it + 1 == st.w_end[wi]) {
                     if (st.pooled) {
                         // contribute this chain's window to the pool (fixed point: the sums do not
@@ -262,7 +312,7 @@ __global__ void __launch_bounds__(64) nuts_advance(const dyn_nuts_state st) {
                         for (int i = 0; i < D; ++i)
                             for (int j = 0; j < D; ++j)
                                 add(pw + 1 + D + i * D + j, m2[i * D + j] + n1 * mean[i] * mean[j]);
-                        st.pend[c] = wi + 1;
+                        L_pend = wi + 1;
                     } else {
                         const double nn = fmax(n1, 2.0);
                         for (int i = 0; i < D; ++i)
@@ -270,17 +320,17 @@ __global__ void __launch_bounds__(64) nuts_advance(const dyn_nuts_state st) {
                                 imm[i * D + j] = (nn / (nn + 5.0)) * m2[i * D + j] / (nn - 1.0) +
                                                  (i == j ? 1e-3 * (5.0 / (nn + 5.0)) : 0.0);
                         mass_sqrt<D>(imm, mms);
-                        eps = st.eps_avg[c]; // restart dual averaging around the running average
-                        st.da_mu[c] = log(10.0 * eps);
-                        st.da_t[c] = 0.0; st.da_gbar[c] = 0.0; st.da_xbar[c] = 0.0;
+                        eps = L_eps_avg; // restart dual averaging around the running average
+                        L_da_mu = log(10.0 * eps);
+                        L_da_t = 0.0; L_da_gbar = 0.0; L_da_xbar = 0.0;
                     }
-                    st.wf_n[c] = 0.0;
+                    L_wf_n = 0.0;
                     for (int i = 0; i < D; ++i) mean[i] = 0.0;
                     for (int i = 0; i < D * D; ++i) m2[i] = 0.0;
-                    st.wi[c] = wi + 1;
+                    L_wi = wi + 1;
                 }
             }
-            if (it + 1 == st.num_warmup) eps = st.eps_avg[c];
+            if (it + 1 == st.num_warmup) eps = L_eps_avg;
         } else {
             const int j = it - st.num_warmup;
             for (int i = 0; i < D; ++i) st.out_z[((int64_t)c * st.num_samples + j) * D + i] = z[i];
@@ -288,47 +338,47 @@ __global__ void __launch_bounds__(64) nuts_advance(const dyn_nuts_state st) {
             st.out_n[(int64_t)c * st.num_samples + j] = n_prop;
             st.out_div[(int64_t)c * st.num_samples + j] = s_div ? 1 : 0;
         }
-        st.eps[c] = eps;
-        st.it[c] = ++it;
+        L_eps = eps;
+        L_it = ++it;
         // fresh momentum r0 = chol(M) * normal, new trajectory = the single point (z, r0)
         double nrm[D], r0[D];
         for (int i = 0; i < D; ++i) nrm[i] = rng.normal();
         matvec<D>(mms, nrm, r0);
         matvec<D>(imm, r0, tmp);
-        st.e0[c] = st.u[c] + 0.5 * dot<D>(r0, tmp);
+        L_e0 = L_u + 0.5 * dot<D>(r0, tmp);
         for (int i = 0; i < D; ++i) {
-            V(zl)[i] = V(zr)[i] = V(zp)[i] = z[i];
-            V(rl)[i] = V(rr)[i] = V(r_sum)[i] = r0[i];
-            V(gl)[i] = V(gr)[i] = V(gp)[i] = g[i];
+            p_zl[i] = p_zr[i] = p_zp[i] = z[i];
+            p_rl[i] = p_rr[i] = p_r_sum[i] = r0[i];
+            p_gl[i] = p_gr[i] = p_gp[i] = g[i];
         }
-        st.up[c] = st.u[c];
-        st.weight[c] = 0.0; st.sum_acc[c] = 0.0; st.n_prop[c] = 0;
+        L_up = L_u;
+        L_weight = 0.0; L_sum_acc = 0.0; L_n_prop = 0;
         depth = 0;
     }
-    st.depth[c] = depth;
+    L_depth = depth;
 
     bool go_right = right;
     if (sub_done) {
         // ---- next subtree (next doubling, or the first of a new transition)
         go_right = rng.uniform() < 0.5;
-        st.right[c] = go_right ? 1 : 0;
-        st.sgn[c] = go_right ? 1.0 : -1.0;
-        const double *ze = go_right ? V(zr) : V(zl), *re = go_right ? V(rr) : V(rl), *ge = go_right ? V(gr) : V(gl);
+        L_right = go_right ? 1 : 0;
+        L_sgn = go_right ? 1.0 : -1.0;
+        const double *ze = go_right ? p_zr : p_zl, *re = go_right ? p_rr : p_rl, *ge = go_right ? p_gr : p_gl;
         for (int i = 0; i < D; ++i) { zc[i] = ze[i]; rc[i] = re[i]; gc[i] = ge[i]; }
-        for (int i = 0; i < D; ++i) { V(s_zp)[i] = V(zp)[i]; V(s_gp)[i] = V(gp)[i]; s_rsum[i] = 0.0; }
-        st.s_up[c] = st.up[c];
+        for (int i = 0; i < D; ++i) { p_s_zp[i] = p_zp[i]; p_s_gp[i] = p_gp[i]; s_rsum[i] = 0.0; }
+        L_s_up = L_up;
         s_weight = -INFINITY;
-        st.s_acc[c] = 0.0; st.s_n[c] = 0;
+        L_s_acc = 0.0; L_s_n = 0;
         s_turn = false; s_div = false;
         leaf = 0;
         for (int i = 0; i < Dm * D; ++i) { r_ck[i] = 0.0; rs_ck[i] = 0.0; }
     } else {
-        st.s_acc[c] = s_acc; st.s_n[c] = s_n;
+        L_s_acc = s_acc; L_s_n = s_n;
     }
-    st.s_weight[c] = s_weight;
-    st.s_turn[c] = s_turn ? 1 : 0;
-    st.s_div[c] = s_div ? 1 : 0;
-    st.leaf[c] = leaf;
+    L_s_weight = s_weight;
+    L_s_turn = s_turn ? 1 : 0;
+    L_s_div = s_div ? 1 : 0;
+    L_leaf = leaf;
 
     // ---- first half of the next leapfrog: r_half, and the position the potential is needed at
     const double es = eps * (go_right ? 1.0 : -1.0);
@@ -336,12 +386,36 @@ __global__ void __launch_bounds__(64) nuts_advance(const dyn_nuts_state st) {
     for (int i = 0; i < D; ++i) rh[i] = rc[i] - 0.5 * es * gc[i];
     matvec<D>(imm, rh, tmp);
     for (int i = 0; i < D; ++i) {
-        V(r_half)[i] = rh[i];
+        p_r_half[i] = rh[i];
         st.z_eval[(int64_t)c * D + i] = (it >= total) ? z[i] : zc[i] + es * tmp[i];
     }
     st.rng_ctr[c] = (int64_t)rng.ctr;
-#undef V
-#undef M2
+    st.u[c] = L_u;
+    st.eps[c] = L_eps;
+    st.eps_avg[c] = L_eps_avg;
+    st.da_mu[c] = L_da_mu;
+    st.da_xbar[c] = L_da_xbar;
+    st.da_gbar[c] = L_da_gbar;
+    st.da_t[c] = L_da_t;
+    st.wf_n[c] = L_wf_n;
+    st.e0[c] = L_e0;
+    st.up[c] = L_up;
+    st.weight[c] = L_weight;
+    st.sum_acc[c] = L_sum_acc;
+    st.sgn[c] = L_sgn;
+    st.s_up[c] = L_s_up;
+    st.s_weight[c] = L_s_weight;
+    st.s_acc[c] = L_s_acc;
+    st.it[c] = L_it;
+    st.wi[c] = L_wi;
+    st.n_prop[c] = L_n_prop;
+    st.depth[c] = L_depth;
+    st.right[c] = L_right;
+    st.leaf[c] = L_leaf;
+    st.s_turn[c] = L_s_turn;
+    st.s_div[c] = L_s_div;
+    st.s_n[c] = L_s_n;
+    if (st.pooled) st.pend[c] = L_pend;
 }
 
 } // namespace dynnuts

@@ -39,6 +39,21 @@ def direction_chunks(model, method: str, dtype, P: int) -> list:
     return chunks
 
 
+_SEEDS: dict = {}
+
+
+def _identity_seeds(B: int, P: int, start: int, n: int, dtype, device) -> torch.Tensor:
+    """[B, n, P] rows start..start+n of the identity for every batch member (constant: cached)."""
+    key = (B, P, start, n, dtype, str(device))
+    t = _SEEDS.get(key)
+    if t is None:
+        if len(_SEEDS) > 64:
+            _SEEDS.clear()
+        t = torch.eye(P, dtype=dtype, device=device)[start:start + n].unsqueeze(0).expand(B, n, P).contiguous()
+        _SEEDS[key] = t
+    return t
+
+
 class _DiffSolve(torch.autograd.Function):
     @staticmethod
     def forward(ctx, params, model, y0, contact, t1, save_ts, kw):
@@ -46,10 +61,10 @@ class _DiffSolve(torch.autograd.Function):
         method = kw.get("method", "tsit5")
         B, P = params.shape
         pk = params.detach().to(dtype)
-        eye = torch.eye(P, dtype=dtype, device=params.device)
+        ctx.set_materialize_grads(False)          # no zero tensors for the integer outputs' "gradients"
         jac, res, start = [], None, 0
         for n in direction_chunks(model, method, dtype, P):
-            seeds = eye[start:start + n].unsqueeze(0).expand(B, n, P).contiguous()
+            seeds = _identity_seeds(B, P, start, n, dtype, params.device)
             res = solve_batch(model, y0, pk, contact, t1, save_ts, dparams=seeds, **kw)
             jac.append(res.dys)
             start += n
@@ -63,6 +78,8 @@ class _DiffSolve(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_ys, *_unused):
         (J,) = ctx.saved_tensors
+        if g_ys is None:
+            return None, None, None, None, None, None, None
         g = torch.einsum("btd,btpd->bp", g_ys.to(J.dtype), J)
         return g.to(ctx.in_dtype), None, None, None, None, None, None
 

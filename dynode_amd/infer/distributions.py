@@ -27,18 +27,20 @@ def _t(x, like=None):
     parameters are cached, so evaluating a log-density in a sampler loop issues no host-to-device
     copies (and stays HIP-graph capturable)."""
     t = x if isinstance(x, torch.Tensor) else torch.as_tensor(x, dtype=_F)
-    if like is not None and isinstance(like, torch.Tensor) and t.device != like.device:
-        if t.requires_grad:
-            return t.to(device=like.device, dtype=_F)
-        key = (id(t), str(like.device))
-        hit = _DEV_CACHE.get(key)
-        if hit is None or hit[0] is not t:
-            if len(_DEV_CACHE) > 512:
-                _DEV_CACHE.clear()
-            hit = (t, t.to(device=like.device, dtype=_F))
-            _DEV_CACHE[key] = hit
-        return hit[1]
-    return t.to(_F)
+    dev = like.device if isinstance(like, torch.Tensor) else t.device
+    if t.device == dev and t.dtype == _F:
+        return t
+    if t.requires_grad or t.numel() > (1 << 20):
+        return t.to(device=dev, dtype=_F)
+    # constant that needs a device copy and/or a float64 conversion: do it once
+    key = (id(t), str(dev))
+    hit = _DEV_CACHE.get(key)
+    if hit is None or hit[0] is not t or hit[2] != t._version:
+        if len(_DEV_CACHE) > 512:
+            _DEV_CACHE.clear()
+        hit = (t, t.to(device=dev, dtype=_F), t._version)
+        _DEV_CACHE[key] = hit
+    return hit[1]
 
 
 def _ndtr(z):
@@ -154,6 +156,23 @@ class TruncatedNormal(Distribution):
         return torch.where((v >= self.low) & (v <= self.high), lp, torch.full_like(lp, -math.inf))
 
 
+_LGAMMA_CACHE: dict = {}
+
+
+def _lgamma1p(v: torch.Tensor) -> torch.Tensor:
+    """lgamma(v + 1); cached for constant tensors (observed counts scored once per gradient)."""
+    if v.requires_grad:
+        return torch.lgamma(v + 1.0)
+    key = (id(v), v.data_ptr(), v._version)
+    hit = _LGAMMA_CACHE.get(key)
+    if hit is None or hit[0] is not v:
+        if len(_LGAMMA_CACHE) > 64:
+            _LGAMMA_CACHE.clear()
+        hit = (v, torch.lgamma(v + 1.0))
+        _LGAMMA_CACHE[key] = hit
+    return hit[1]
+
+
 class Poisson(Distribution):
     support = (0.0, math.inf)
 
@@ -168,7 +187,7 @@ class Poisson(Distribution):
     def log_prob(self, value):
         rate = self.rate.to(_F)
         v = _t(value, rate)
-        return v * torch.log(rate) - rate - torch.lgamma(v + 1.0)
+        return v * torch.log(rate) - rate - _lgamma1p(v)
 
 
 class AffineTransform:

@@ -31,6 +31,16 @@ def enable_x64(flag: bool = True) -> None:
     _X64 = bool(flag)
 
 
+class _LazyStats(dict):
+    """``Solution.stats``; ``num_steps`` (= accepted + rejected) is added on first access."""
+
+    def __missing__(self, key):
+        if key == "num_steps":
+            self[key] = self["num_accepted_steps"] + self["num_rejected_steps"]
+            return self[key]
+        raise KeyError(key)
+
+
 class SolverError(RuntimeError):
     """The solve did not reach t1 (max_steps exhausted or non-finite state); the reference raises
     from diffeqsolve in the same situations (params.py:51-55)."""
@@ -154,12 +164,13 @@ def simulate(ode, duration_days, initial_state: CompartmentState, ode_parameters
         ys.append(block if batched else block[0])
         pos += size
     unb = (lambda t: t) if batched else (lambda t: t[0])
-    stats = {
-        "num_steps": unb(res.n_accept + res.n_reject),
+    stats = _LazyStats({
         "num_accepted_steps": unb(res.n_accept),
         "num_rejected_steps": unb(res.n_reject),
         "max_steps": sp.max_steps,
-    }
+    })
+    if not differentiable:        # inside a sampler's potential nobody reads it: one launch less per gradient
+        stats["num_steps"]
     from ..engine import _dev
     ts = _dev(saveat.ts, res.ys.dtype, res.ys.device)
     return Solution(ts=ts, ys=tuple(ys), stats=stats, result=unb(res.status), t0=0.0, t1=float(duration_days))

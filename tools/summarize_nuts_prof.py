@@ -53,4 +53,11 @@ with open(os.path.join(root, "profiles", f"{tag}_nuts_iteration.md"), "w") as f:
     f.write(f"- total GPU kernel time {total / 1e9:.2f} s; everything else is the model's torch program (constrain, priors, likelihood, autograd)\n")
     if bench:
         f.write(f"- traced run: {bench.get('seconds', 0):.2f} s, {bench.get('transitions_per_s', 0):.0f} transitions/s, KS p {bench.get('ks_pvalues_vs_quadrature')}\n")
+    a, b = sel[len(sel) // 2], sel[len(sel) // 2 + 1]
+    f.write("\nKernel sequence of one steady-state iteration (start us, duration us, kernel):\n\n```\n")
+    t0 = int(tr[a]["End_Timestamp"])
+    for r in tr[a + 1:b + 1]:
+        f.write("%8.1f %6.1f  %s\n" % ((int(r["Start_Timestamp"]) - t0) / 1e3, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3,
+                                       short(r["Kernel_Name"])[:90]))
+    f.write("```\n")
 print(open(os.path.join(root, "profiles", f"{tag}_nuts_iteration.md")).read())
