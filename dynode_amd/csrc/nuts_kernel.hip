@@ -330,7 +330,21 @@ __global__ void __launch_bounds__(64) nuts_advance(const dyn_nuts_state st) {
                     L_wi = wi + 1;
                 }
             }
-            if (it + 1 == st.num_warmup) eps = L_eps_avg;
+            if (it + 1 == st.num_warmup) {
+                eps = L_eps_avg;
+                if (st.pooled) {
+                    // final step size = geometric mean over the chains that have finished warm-up so
+                    // far (they share one mass matrix, so the ideal step is the same; the 50-transition
+                    // final buffer alone leaves a factor ~2 of dual-averaging noise between chains)
+                    const int64_t stride = 1 + D + D * D;
+                    int64_t *pw = st.pool + (int64_t)st.n_windows * stride;
+                    const int64_t *pr = st.pool_ro + (int64_t)st.n_windows * stride;
+                    const double le = log(L_eps_avg);
+                    atomicAdd((unsigned long long *)pw, 1ull);
+                    atomicAdd((unsigned long long *)(pw + 1), (unsigned long long)llrint(le * POOL_SCALE));
+                    eps = exp(((double)pr[1] / POOL_SCALE + le) / ((double)pr[0] + 1.0));
+                }
+            }
         } else {
             const int j = it - st.num_warmup;
             for (int i = 0; i < D; ++i) st.out_z[((int64_t)c * st.num_samples + j) * D + i] = z[i];
@@ -443,9 +457,9 @@ extern "C" int dyn_nuts_advance(const dyn_nuts_state *st, void *stream) {
         dynnuts::nuts_advance<5>, dynnuts::nuts_advance<6>, dynnuts::nuts_advance<7>, dynnuts::nuts_advance<8>};
     hipLaunchKernelGGL(kernels[st->dim - 1], dim3(blocks), dim3(64), 0, (hipStream_t)stream, *st);
     if (hipGetLastError() != hipSuccess) return DYN_ERR_LAUNCH;
-    if (st->pooled && st->n_windows > 0) {
+    if (st->pooled) {
         // readers of the next launch see the pool as it stands now, never a half-updated one
-        const size_t bytes = sizeof(int64_t) * (size_t)st->n_windows * (size_t)(1 + st->dim + st->dim * st->dim);
+        const size_t bytes = sizeof(int64_t) * (size_t)(st->n_windows + 1) * (size_t)(1 + st->dim + st->dim * st->dim);
         if (hipMemcpyAsync(st->pool_ro, st->pool, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess)
             return DYN_ERR_LAUNCH;
     }

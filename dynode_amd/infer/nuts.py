@@ -780,7 +780,8 @@ class KernelNUTS(LockstepNUTS):
     ``adaptation="per_chain"`` is numpyro's behaviour: every chain estimates its own dense mass
     matrix from its own window.  ``"pooled"`` merges the window statistics of all chains of this
     call (order-independent fixed-point sums, so runs stay reproducible) and every chain uses the
-    merged estimate: with an asynchronous batch the run lasts as long as its slowest chain, and
+    merged estimate (and ends warm-up with the geometric mean of the final step sizes of the chains
+    that finished before it): with an asynchronous batch the run lasts as long as its slowest chain, and
     a chain whose own window caught a rare tail excursion otherwise ends warm-up with a several
     times too small step (measured on cfg 4, 1024 chains: slowest chain 17.9 leapfrogs per draw
     against a mean of 4.7).  Warm-up draws are discarded either way; after warm-up each chain's
@@ -832,8 +833,8 @@ class KernelNUTS(LockstepNUTS):
                  z_eval=z + (eps * sgn)[:, None] * r_half, u_new=zf(C), g_new=zf(C, D),
                  it=zi(C), wi=zi(C), n_prop=zi(C), depth=zi(C), right=right.to(torch.int32), leaf=zi(C), s_turn=zi(C),
                  s_div=zi(C), s_n=zi(C), rng_ctr=torch.zeros(C, dtype=torch.int64, device=dev),
-                 pool=torch.zeros((W, 1 + D + D * D), dtype=torch.int64, device=dev),
-                 pool_ro=torch.zeros((W, 1 + D + D * D), dtype=torch.int64, device=dev), pend=zi(C),
+                 pool=torch.zeros((W + 1, 1 + D + D * D), dtype=torch.int64, device=dev),
+                 pool_ro=torch.zeros((W + 1, 1 + D + D * D), dtype=torch.int64, device=dev), pend=zi(C),
                  out_z=zf(C, num_samples, D), out_acc=zf(C, num_samples), out_n=zi(C, num_samples),
                  out_div=zi(C, num_samples))
         S = {k: v.contiguous() for k, v in S.items()}

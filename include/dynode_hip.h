@@ -187,7 +187,8 @@ typedef struct dyn_nuts_state {
     int32_t *it, *wi, *n_prop, *depth, *right, *leaf, *s_turn, *s_div, *s_n;   /* [C] */
     int64_t *rng_ctr;                  /* [C] */
     /* pooled adaptation (pooled = 1): fixed-point sums per window, zero-initialised by the caller */
-    int64_t *pool, *pool_ro;               /* [W][1 + D + D*D]: count, sum, sum of outer products;
+    int64_t *pool, *pool_ro;               /* [W + 1][1 + D + D*D]: per window count, sum, sum of outer
+                                              products; row W: count and sum of log final step sizes;
                                               pool_ro = copy made after each launch (what chains read) */
     int32_t *pend;                         /* [C] window whose pooled matrix is still to be applied, +1 */
     /* post-warm-up draws */

@@ -62,6 +62,11 @@ def main():
             quad[name] = {"mean": mean, "sd": float(np.sqrt(((grid - mean) ** 2 * pdf).sum())),
                           "sample_mean": float(post[name].mean()), "sample_sd": float(post[name].std()),
                           "max_cdf_gap": float(stats.kstest(thin, lambda x: np.interp(x, grid, cdf)).statistic)}
+            allx = post[name].reshape(-1).cpu().numpy()
+            for k in (-3.0, -2.0, 2.0, 3.0):                    # tail masses beyond mean + k sd: quadrature vs draws
+                cut = mean + k * quad[name]["sd"]
+                pq = float(np.interp(cut, grid, cdf))
+                quad[name][f"tail_{k:+.0f}sd"] = [pq if k < 0 else 1.0 - pq, float((allx < cut).mean() if k < 0 else (allx > cut).mean())]
         n_trans = args.chains * (args.warmup + args.samples)
         print(json.dumps({
             "workload": "cfg4 sir_infer_parameters: NUTS, 2-age SIR, tf=100, Poisson incidence",
