@@ -152,6 +152,7 @@ class MCMCResult:
 
     def __init__(self, potential: Potential, nuts: NUTSResult, num_chains: int):
         self.potential, self.nuts, self.num_chains = potential, nuts, num_chains
+        self.num_samples = int(nuts.samples.shape[1])       # numpyro's MCMC.num_samples
 
     def get_samples(self, group_by_chain: bool = False) -> dict:
         x = self.potential.constrain(self.nuts.samples)            # [C, N] per site

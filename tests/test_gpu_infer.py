@@ -261,3 +261,41 @@ def test_potential_with_fused_sites_equals_the_generic_path(data):
     u2, g2 = pot.potential_and_grad(z)
     pot.site_table = table
     assert torch.allclose(u1, u2, rtol=1e-12, atol=1e-9) and torch.allclose(g1, g2, rtol=1e-9, atol=1e-8)
+
+
+def test_reference_inference_process_tests_on_a_conjugate_model():
+    """reference tests/test_infer/test_inference_processes.py (model without an ODE: completes,
+    sample keys and counts), plus the conjugate-normal posterior the reference does not check."""
+    from dynode_amd.infer import distributions as dist
+    from dynode_amd.infer.inference import SVIProcess
+
+    y = torch.as_tensor(np.random.default_rng(0).standard_normal(128))
+
+    def model(y):
+        dist_loc = handlers.sample("dist_loc", dist.Normal(1, 1))
+        handlers.sample("obs", dist.Normal(dist_loc[..., None], 1), obs=y)    # [..., None]: one row per chain
+
+    mcmc_process = MCMCProcess(numpyro_model=model, num_samples=10, num_chains=1, num_warmup=10, progress_bar=False,
+                               nuts_max_tree_depth=10)
+    mcmc_process.infer(y=y)                                                   # completes, no raises
+    proc = MCMCProcess(numpyro_model=model, num_samples=100, num_chains=1, num_warmup=50, progress_bar=False,
+                       nuts_max_tree_depth=10)
+    mcmc = proc.infer(y=y)
+    samples = mcmc.get_samples()
+    assert "dist_loc" in samples.keys() and len(samples["dist_loc"]) == mcmc.num_samples == 100
+    # conjugate posterior: N((1 + sum y) / 129, 1 / 129)
+    big = MCMCProcess(numpyro_model=model, num_samples=500, num_chains=16, num_warmup=300, progress_bar=False,
+                      nuts_max_tree_depth=10)
+    big.infer(y=y)
+    draws = big.get_samples()["dist_loc"].cpu().numpy()
+    mean, sd = (1.0 + float(y.sum())) / 129.0, (1.0 / 129.0) ** 0.5
+    assert abs(draws.mean() - mean) < 4 * sd / np.sqrt(2000) and abs(draws.std() / sd - 1) < 0.06
+    assert stats.kstest(big.get_samples(group_by_chain=True)["dist_loc"][:, ::5].reshape(-1).cpu().numpy(), "norm", args=(mean, sd)).pvalue > 1e-3
+    svi = SVIProcess(numpyro_model=model, num_iterations=10, num_samples=10, progress_bar=False)
+    svi.infer(y=y)
+    s = svi.get_samples()
+    assert "dist_loc" in s.keys() and len(s["dist_loc"]) == svi.num_samples
+    fit = SVIProcess(numpyro_model=model, num_iterations=300, num_samples=2000, progress_bar=False)
+    fit.infer(y=y)
+    s = fit.get_samples()["dist_loc"].cpu().numpy()
+    assert abs(s.mean() - mean) < 0.05 and abs(s.std() / sd - 1) < 0.35
