@@ -9,6 +9,6 @@ from ._abi import ModelDesc  # noqa: F401
 from .config import (AgeBin, Bin, Compartment, DeterministicParameter, Dimension, Dopri5,  # noqa: F401
                      Initializer, Params, SimulationConfig, SolverParams, Strain, TransmissionParams, Tsit5)
 from .infer.inference import MCMCProcess, SVIProcess  # noqa: F401
-from .simulation import AbstractODEParams, Solution, SolverError, simulate  # noqa: F401
+from .simulation import AbstractODEParams, PoissonObservation, Solution, SolverError, simulate  # noqa: F401
 
 __version__ = "0.1.0"

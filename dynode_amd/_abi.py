@@ -29,6 +29,7 @@ EXPORTED_SYMBOLS = (
     "dyn_compartment_offsets", "dyn_is_supported", "dyn_trajectories_per_wave",
     "dyn_last_error", "dyn_solve_batch", "dyn_solve_batch_jvp", "dyn_is_supported_jvp",
     "dyn_nuts_advance", "dyn_nuts_state_size", "dyn_philox4x32_10", "dyn_latent_sites",
+    "dyn_solve_batch_loglik",
 )
 
 MAX_SITES = 8
@@ -160,6 +161,13 @@ def lib() -> ctypes.CDLL:
             ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32,
             ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
             ctypes.c_void_p,
+        ]
+        L.dyn_solve_batch_loglik.restype = ctypes.c_int
+        L.dyn_solve_batch_loglik.argtypes = [
+            pm, po, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
+            ctypes.c_double, ctypes.c_double, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+            ctypes.c_double, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32,
+            ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
         ]
         L.dyn_nuts_advance.restype = ctypes.c_int
         L.dyn_nuts_advance.argtypes = [ctypes.POINTER(NutsStateC), ctypes.c_void_p]

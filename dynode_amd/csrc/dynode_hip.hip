@@ -74,14 +74,30 @@ static int check_model(const dyn_model_desc *m) {
     return 0;
 }
 
+// fused observation likelihood (dyn_solve_batch_loglik)
+struct LLArgs {
+    const void *obs;
+    int32_t slot, mode, row;
+    double floor;
+    double *ll_out, *dll_out;
+};
+
 template <typename T>
 static int enqueue(const Entry *e, const dyn_model_desc *m, const dyn_solver_opts *o,
                    const void *y0, int32_t y0_is_batched, const void *params, const void *contact,
                    int64_t B, double t0, double t1, const void *save_ts, int32_t n_save,
                    const uint8_t *save_mask, void *ys_out, int32_t *status, int32_t *n_accept,
                    int32_t *n_reject, hipStream_t stream, const void *dparams = nullptr,
-                   const void *dy0 = nullptr, int32_t dy0_is_batched = 0, void *dys_out = nullptr) {
+                   const void *dy0 = nullptr, int32_t dy0_is_batched = 0, void *dys_out = nullptr,
+                   const LLArgs *ll = nullptr) {
     KArgs<T> ka;
+    ka.obs = ll ? (const T *)ll->obs : nullptr;
+    ka.ll_out = ll ? ll->ll_out : nullptr;
+    ka.dll_out = ll ? ll->dll_out : nullptr;
+    ka.ll_slot = ll ? ll->slot : 0;
+    ka.ll_mode = ll ? ll->mode : 0;
+    ka.ll_row = ll ? ll->row : 0;
+    ka.ll_floor = ll ? (T)ll->floor : (T)0;
     ka.dparams = (const T *)dparams;
     ka.dy0 = (const T *)dy0;
     ka.dout = (T *)dys_out;
@@ -159,6 +175,17 @@ static int enqueue(const Entry *e, const dyn_model_desc *m, const dyn_solver_opt
                 while (r < 3 && (waves << (r + 1)) <= 4096) ++r;
         }
         ka.rep_log2 = r < 0 ? 0 : (r > 3 ? 3 : r);
+        if (ll) { // the replicas of a trajectory must share a wave (LDS table, lane reductions)
+            const int lanes = group_width(m->n_age) * (e->S / e->SPL);
+            while (ka.rep_log2 > 0 && (lanes << ka.rep_log2) > 64) --ka.rep_log2;
+        }
+        if (ll && ka.rep_log2 > 0) {
+            // replicated trajectories park their interpolated observable in LDS (solve_kernel.hpp);
+            // fall back to unreplicated in-order scoring if that table does not fit
+            const size_t tab = (size_t)(64 >> ka.rep_log2) * (size_t)n_save * (size_t)(e->SPL * e->W) *
+                               (size_t)(1 + e->ND) * sizeof(T);
+            if (tab + (size_t)(n_save + dyn::kMaxJumps) * sizeof(T) > 60 * 1024) ka.rep_log2 = 0;
+        }
     }
     typedef hipError_t (*fn_t)(const KArgs<T> &, hipStream_t);
     const hipError_t err = ((fn_t)e->fn)(ka, stream);
@@ -228,13 +255,14 @@ static int solve_impl(const dyn_model_desc *m, const dyn_solver_opts *o, const v
                       double t0, double t1, const void *save_ts, int32_t n_save,
                       const uint8_t *save_mask, void *ys_out, int32_t *status, int32_t *n_accept,
                       int32_t *n_reject, void *stream, int32_t n_dir, const void *dparams,
-                      const void *dy0, int32_t dy0_is_batched, void *dys_out) {
+                      const void *dy0, int32_t dy0_is_batched, void *dys_out,
+                      const dyn::LLArgs *ll = nullptr) {
     dyn::tl_error[0] = 0;
     int rc = dyn::check_model(m);
     if (rc) return rc;
     if (!o || !y0 || !params || !contact || !status || !n_accept || !n_reject) return DYN_ERR_NULL;
-    if (B < 0 || n_save < 0 || (n_save > 0 && (!save_ts || !ys_out))) return DYN_ERR_SIZE;
-    if (n_dir < 0 || (n_dir > 0 && (!dparams || (n_save > 0 && !dys_out)))) return DYN_ERR_NULL;
+    if (B < 0 || n_save < 0 || (n_save > 0 && (!save_ts || (!ys_out && !ll)))) return DYN_ERR_SIZE;
+    if (n_dir < 0 || (n_dir > 0 && (!dparams || (n_save > 0 && !dys_out && !ll)))) return DYN_ERR_NULL;
     if ((o->method != DYN_TSIT5 && o->method != DYN_DOPRI5) ||
         (o->dtype != DYN_F32 && o->dtype != DYN_F64))
         return DYN_ERR_OPTS;
@@ -267,10 +295,10 @@ static int solve_impl(const dyn_model_desc *m, const dyn_solver_opts *o, const v
     if (o->dtype == DYN_F64)
         return dyn::enqueue<double>(e, m, o, y0, y0_is_batched, params, contact, B, t0, t1,
                                     save_ts, n_save, save_mask, ys_out, status, n_accept, n_reject,
-                                    (hipStream_t)stream, dparams, dy0, dy0_is_batched, dys_out);
+                                    (hipStream_t)stream, dparams, dy0, dy0_is_batched, dys_out, ll);
     return dyn::enqueue<float>(e, m, o, y0, y0_is_batched, params, contact, B, t0, t1, save_ts,
                                n_save, save_mask, ys_out, status, n_accept, n_reject,
-                               (hipStream_t)stream, dparams, dy0, dy0_is_batched, dys_out);
+                               (hipStream_t)stream, dparams, dy0, dy0_is_batched, dys_out, ll);
 }
 
 int dyn_solve_batch(const dyn_model_desc *m, const dyn_solver_opts *o, const void *y0,
@@ -293,6 +321,42 @@ int dyn_solve_batch_jvp(const dyn_model_desc *m, const dyn_solver_opts *o, const
     return solve_impl(m, o, y0, y0_is_batched, params, contact, B, t0, t1, save_ts, n_save,
                       save_mask, ys_out, status, n_accept, n_reject, stream, n_dir, dparams, dy0,
                       dy0_is_batched, dys_out);
+}
+
+int dyn_solve_batch_loglik(const dyn_model_desc *m, const dyn_solver_opts *o, const void *y0,
+                           int32_t y0_is_batched, const void *params, const void *contact, int64_t B,
+                           double t0, double t1, const void *save_ts, int32_t n_save,
+                           int32_t obs_compartment, int32_t obs_mode, double rate_floor, const void *obs,
+                           int32_t n_dir, const void *dparams, const void *dy0, int32_t dy0_is_batched,
+                           double *logp_out, double *dlogp_out, int32_t *status, int32_t *n_accept,
+                           int32_t *n_reject, void *stream) {
+    if (n_dir < 1) return DYN_ERR_SIZE;
+    if (!m || !obs || !logp_out || !dlogp_out) return DYN_ERR_NULL;
+    int rc = dyn::check_model(m);
+    if (rc) return rc;
+    if (obs_mode < 0 || obs_mode > 1 || !(rate_floor > 0.0)) return DYN_ERR_OPTS;
+    if (n_save < 1 + obs_mode) return DYN_ERR_SIZE;
+    int32_t off[8];
+    const int ncomp = dyn_compartment_offsets(m, off);
+    if (obs_compartment < 0 || obs_compartment >= ncomp) return DYN_ERR_MODEL;
+    // compartment index (reference order s, (e), i, r, (c)) -> kernel slot 0 s, 1 e, 2 i, 3 r, 4 c
+    int slot_of[5], n = 0;
+    slot_of[n++] = 0;
+    if (m->has_e) slot_of[n++] = 1;
+    slot_of[n++] = 2;
+    slot_of[n++] = 3;
+    if (m->has_c) slot_of[n++] = 4;
+    dyn::LLArgs ll;
+    ll.obs = obs;
+    ll.slot = slot_of[obs_compartment];
+    ll.mode = obs_mode;
+    ll.row = off[obs_compartment + 1] - off[obs_compartment];
+    ll.floor = rate_floor;
+    ll.ll_out = logp_out;
+    ll.dll_out = dlogp_out;
+    return solve_impl(m, o, y0, y0_is_batched, params, contact, B, t0, t1, save_ts, n_save, nullptr,
+                      nullptr, status, n_accept, n_reject, stream, n_dir, dparams, dy0, dy0_is_batched,
+                      nullptr, &ll);
 }
 
 int32_t dyn_is_supported_jvp(const dyn_model_desc *m, const dyn_solver_opts *o, int32_t n_dir) {

@@ -38,6 +38,14 @@ struct KArgs {
     T t0, t1, rtol, atol, constant_dt;
     int32_t y0_batched, n_save, A, P, normalize, seasonal, d_saved, vec_ok;
     int32_t save_off[5]; // offset of s,e,i,r,c inside a saved row; -1 = not saved
+    // fused observation likelihood (tangent kernels only; obs == nullptr: off)
+    const T *obs;        // [n_obs][ll_row] observed counts, shared by the batch
+    double *ll_out;      // [B] sum of obs * log(rate) - rate
+    double *dll_out;     // [B][ND] its directional derivatives
+    int32_t ll_slot;     // observed compartment: 0 s, 1 e, 2 i, 3 r, 4 c
+    int32_t ll_mode;     // 0: rate = value at each save time; 1: rate = increment between save times
+    int32_t ll_row;      // values per observation row
+    T ll_floor;          // rate = max(rate, floor) (the reference clamps incidence at 1e-6)
     // forward-mode tangents (dyn_solve_batch_jvp); unused when the kernel's ND == 0
     const T *dparams; // [B][ND][P] seed directions of the parameter vector
     const T *dy0;     // [ND][D] or [B][ND][D] seeds of the initial state, or nullptr (= 0)
@@ -75,6 +83,8 @@ struct Mth<float> {
     static __device__ __forceinline__ float pow_fast(float x, float e) {
         return __builtin_amdgcn_exp2f(e * __builtin_amdgcn_logf(x));
     }
+    // natural log through v_log_f32 (fused Poisson likelihood terms; sums are kept in float64)
+    static __device__ __forceinline__ float log(float x) { return __builtin_amdgcn_logf(x) * 0.69314718055994530942f; }
     static __device__ __forceinline__ float inf() { return __builtin_huge_valf(); }
     static __device__ __forceinline__ float next(float x, float to) { return nextafterf(x, to); }
     static constexpr float clip_tol = 1e-6f; // diffrax _clip_to_end tolerance, float32
@@ -90,6 +100,7 @@ struct Mth<double> {
     static __device__ __forceinline__ double rcp_fast(double x) { return 1.0 / x; }
     static __device__ __forceinline__ double recip(double x) { return 1.0 / x; }
     static __device__ __forceinline__ double pow_fast(double x, double e) { return ::pow(x, e); }
+    static __device__ __forceinline__ double log(double x) { return ::log(x); }
     static __device__ __forceinline__ double inf() { return __builtin_huge_val(); }
     static __device__ __forceinline__ double next(double x, double to) { return nextafter(x, to); }
     static constexpr double clip_tol = 1e-10;
@@ -547,6 +558,97 @@ struct Solver {
         store_run<T, CNT>(dst, v, vec_ok);
     }
 
+    // ---- fused observation likelihood (Poisson log-likelihood of the reference's model(),
+    // examples/sir_infer_parameters.py:30-38: incidence = max(diff(R), 1e-6), obs ~ Poisson(incidence);
+    // lgamma(obs + 1) is the host's).  Unreplicated trajectories accumulate while they save (each
+    // group walks its save times in order); replicated ones (small states, save times interleaved
+    // over the replicas) park the interpolated values in an LDS table and score them after the solve.
+    static constexpr int LLMAX = S * W;
+    struct LL {
+        T prev[NC][LLMAX];
+        double acc;
+        double dacc[NC];   // [0] unused
+    };
+    // one Poisson term and its tangents: terms in the solve's own precision (fp32: v_log_f32 /
+    // v_rcp_f32), sums in float64; the gradient passes the floor where inc >= floor (clamp convention)
+    __device__ __forceinline__ static void ll_term(const KArgs<T> &ka, LL &ll, T o, const T (&inc)[NC]) {
+        const T rate = inc[0] > ka.ll_floor ? inc[0] : ka.ll_floor;
+        ll.acc += (double)(o * M::log(rate) - rate);
+        const double coef = inc[0] >= ka.ll_floor ? (double)(o * M::recip(rate) - T(1)) : 0.0;
+#pragma unroll
+        for (int c = 1; c < NC; ++c) ll.dacc[c] += coef * (double)inc[c];
+    }
+    template <int FIRST, int CNT>
+    __device__ __forceinline__ static void ll_block(const KArgs<T> &ka, const Dense &d, T dt, const T (&y)[NC][NV],
+                                                    const T (&yt)[NC][NV], const T (&k)[7][NC][NV], LL &ll,
+                                                    int j, int off, T *tab_row) {
+        const bool have = ka.ll_mode == 0 || j > 0;
+        const T *orow = ka.obs + (int64_t)(ka.ll_mode == 0 ? j : (j > 0 ? j - 1 : 0)) * ka.ll_row + off;
+#pragma unroll
+        for (int q = 0; q < CNT; ++q) {
+            const int e = FIRST + q;
+            T v[NC];
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+                v[c] = dense_eval(d, dt, y[c][e], yt[c][e], k[0][c][e], k[1][c][e], k[2][c][e], k[3][c][e],
+                                  k[4][c][e], k[5][c][e], k[6][c][e]);
+            if (tab_row != nullptr) {
+#pragma unroll
+                for (int c = 0; c < NC; ++c) tab_row[q * NC + c] = v[c];
+            } else {
+                if (have) {
+                    T inc[NC];
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) inc[c] = ka.ll_mode == 0 ? v[c] : v[c] - ll.prev[c][q];
+                    ll_term(ka, ll, orow[q], inc);
+                }
+#pragma unroll
+                for (int c = 0; c < NC; ++c) ll.prev[c][q] = v[c];
+            }
+        }
+    }
+    __device__ __forceinline__ static void ll_row(const KArgs<T> &ka, const Dense &d, T dt, const T (&y)[NC][NV],
+                                                  const T (&yt)[NC][NV], const T (&k)[7][NC][NV], LL &ll, int j,
+                                                  int a, int as, bool lead, T *tab_row) {
+        switch (ka.ll_slot) {
+        case 0:
+            if (lead) ll_block<0, 1>(ka, d, dt, y, yt, k, ll, j, a, tab_row);
+            break;
+        case 1:
+            if constexpr (HAS_E) ll_block<IE, S>(ka, d, dt, y, yt, k, ll, j, as, tab_row);
+            break;
+        case 2:
+            ll_block<II, S>(ka, d, dt, y, yt, k, ll, j, as, tab_row);
+            break;
+        case 3:
+            ll_block<IR, S * W>(ka, d, dt, y, yt, k, ll, j, as * W, tab_row);
+            break;
+        default:
+            if constexpr (HAS_C) ll_block<IC, S>(ka, d, dt, y, yt, k, ll, j, as, tab_row);
+            break;
+        }
+    }
+    // table mode, after the solve: replica `rep` scores observation rows rep, rep + R, ...
+    __device__ __forceinline__ static void ll_from_table(const KArgs<T> &ka, LL &ll, const T *tab_lane, int row_stride,
+                                                         int n_save, int rep, int R, int a, int as, bool lead) {
+        const int slot = ka.ll_slot;
+        const int cnt = slot == 0 ? 1 : (slot == 3 ? S * W : S);
+        const int off = slot == 0 ? a : (slot == 3 ? as * W : as);
+        if (slot == 0 && !lead) return;
+        const int n_obs = n_save - ka.ll_mode;
+        for (int r = rep; r < n_obs; r += R) {
+            const int j = r + ka.ll_mode;
+            const T *now = tab_lane + (int64_t)j * row_stride, *before = tab_lane + (int64_t)(j - ka.ll_mode) * row_stride;
+            for (int q = 0; q < cnt; ++q) {
+                T inc[NC];
+#pragma unroll
+                for (int c = 0; c < NC; ++c)
+                    inc[c] = ka.ll_mode == 0 ? now[q * NC + c] : now[q * NC + c] - before[q * NC + c];
+                ll_term(ka, ll, ka.obs[(int64_t)r * ka.ll_row + off + q], inc);
+            }
+        }
+    }
+
     // one saved row of one plane
     // `as` = a * ST + h * SPL: position of this lane's first strain inside an [A, ST] block
     template <int PLANE>
@@ -751,6 +853,11 @@ struct Solver {
 
         int save_idx = rep; // replica r owns save times r, r + R, r + 2R, ...
         const int n_save = ka.n_save;
+        bool fused_ll = false, ll_table = false;
+        if constexpr (ND > 0) {
+            fused_ll = ka.obs != nullptr;
+            ll_table = fused_ll && R > 1;
+        }
         // The save grid lives in LDS: a global load inside the save loop would share the
         // in-order vmcnt counter with the output stores, and waiting for it would drain every
         // store of the previous round (measured: the dominant stall of the save path).
@@ -761,6 +868,10 @@ struct Solver {
         // discontinuity points follow the save grid in LDS (per-group index into the table)
         T *const jt_tab = ts_tab + n_save;
         const int n_jump = ka.n_jump;
+        // likelihood table (replicated trajectories): [trajectory slot][save index][lane of group][LLMAX][planes]
+        constexpr int LL_ROW = G * LLMAX * NC;
+        T *const ll_tab = jt_tab + (n_jump > 0 ? kMaxJumps : 0);
+        T *const ll_lane = ll_tab + ((int64_t)((lane / G) >> ka.rep_log2) * n_save * LL_ROW + (lane % G) * (LLMAX * NC));
         if (n_jump > 0 && lane == 0) {
 #pragma unroll
             for (int j = 0; j < kMaxJumps; ++j) jt_tab[j] = ka.jump_ts[j];
@@ -789,6 +900,16 @@ struct Solver {
         T *const dout_traj = ND > 0 ? ka.dout + traj * (int64_t)n_save * ND * ka.d_saved : nullptr;
         const bool vec_ok = ka.vec_ok != 0;
         const int as = a * ST + s0;
+        LL ll;
+        if constexpr (ND > 0) {
+            ll.acc = 0.0;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                ll.dacc[c] = 0.0;
+#pragma unroll
+                for (int q = 0; q < LLMAX; ++q) ll.prev[c][q] = T(0);
+            }
+        }
 
 #ifdef DYN_DIAG_ROUNDS
         int diag_iters = 0, diag_rounds = 0;
@@ -878,7 +999,11 @@ struct Solver {
                         }
 #pragma unroll
                         for (int q = 0; q < SU; ++q) {
-                            if (pu[q] && writer) {
+                            if (ND > 0 && fused_ll) {
+                                if (pu[q] && writer)
+                                    ll_row(ka, dn[q], dt, y, yt, k, ll, save_idx + q * R, a, as, L.lead,
+                                           ll_table ? ll_lane + (int64_t)(save_idx + q * R) * LL_ROW : nullptr);
+                            } else if (pu[q] && writer) {
                                 save_row<0>(ka, dn[q], dt, y, yt, k,
                                             out_traj + (int64_t)(save_idx + q * R) * ka.d_saved, a,
                                             as, L.lead, vec_ok);
@@ -901,7 +1026,11 @@ struct Solver {
                 if (pending) {
                     Dense dn;
                     dense_prepare((ts_next - tprev) * inv_dt, dn);
-                    if (writer) {
+                    if (ND > 0 && fused_ll) {
+                        if (writer)
+                            ll_row(ka, dn, dt, y, yt, k, ll, save_idx, a, as, L.lead,
+                                   ll_table ? ll_lane + (int64_t)save_idx * LL_ROW : nullptr);
+                    } else if (writer) {
                         save_row<0>(ka, dn, dt, y, yt, k, out_traj + (int64_t)save_idx * ka.d_saved,
                                     a, as, L.lead, vec_ok);
                         if constexpr (ND > 0)
@@ -976,6 +1105,37 @@ struct Solver {
             }
         }
 
+        if constexpr (ND > 0) {
+            if (fused_ll) { // wave-uniform
+                // sum over the lanes of the trajectory; a failed solve scores -inf (rejected by the sampler)
+                // (the replicas of a trajectory are adjacent lane groups of the same wave)
+                int unfinished = (st != ST_OK || save_idx < n_save) ? 1 : 0;
+                if (ll_table) {
+                    __syncthreads(); // every replica's table entries are visible
+                    if (writer && !unfinished) ll_from_table(ka, ll, ll_lane, LL_ROW, n_save, rep, R, a, as, L.lead);
+                }
+                const int span = G * R;
+                double tot = writer ? ll.acc : 0.0;
+                for (int off = span / 2; off > 0; off >>= 1) tot += __shfl_xor(tot, off);
+                double dtot[NC];
+#pragma unroll
+                for (int c = 1; c < NC; ++c) {
+                    dtot[c] = writer ? ll.dacc[c] : 0.0;
+                    for (int off = span / 2; off > 0; off >>= 1) dtot[c] += __shfl_xor(dtot[c], off);
+                }
+                for (int off = span / 2; off > 0; off >>= 1) unfinished |= __shfl_xor(unfinished, off);
+                const bool ok = unfinished == 0;
+                if (writer && a == 0 && L.lead && rep == 0) {
+                    ka.ll_out[traj] = ok ? tot : -__builtin_inf();
+#pragma unroll
+                    for (int c = 1; c < NC; ++c) ka.dll_out[traj * ND + (c - 1)] = ok ? dtot[c] : 0.0;
+                    ka.status[traj] = st;
+                    ka.n_acc[traj] = n_acc;
+                    ka.n_rej[traj] = n_rej;
+                }
+                return;
+            }
+        }
         // rows never reached (failed solves): +inf, like diffrax's unfilled SaveAt buffer
         if (writer) {
             for (; save_idx < n_save; save_idx += R) {
@@ -1010,7 +1170,9 @@ hipError_t launch(const KArgs<T> &ka, hipStream_t stream) {
     constexpr int TPW = 64 / (GA * (ST / SPL));
     const int64_t blocks = ((ka.B << ka.rep_log2) + TPW - 1) / TPW;
     if (blocks <= 0) return hipSuccess;
-    const size_t lds = ((size_t)ka.n_save + (ka.n_jump > 0 ? kMaxJumps : 0)) * sizeof(T); // LDS tables
+    size_t lds = ((size_t)ka.n_save + (ka.n_jump > 0 ? kMaxJumps : 0)) * sizeof(T); // LDS tables
+    if (ND > 0 && ka.obs != nullptr && ka.rep_log2 > 0) // likelihood table of the replicated trajectories of a wave
+        lds += (size_t)(64 >> ka.rep_log2) * ka.n_save * (SPL * W) * (1 + ND) * sizeof(T);
     hipLaunchKernelGGL((solve_kernel<T, METHOD, GA, ST, HAS_E, HAS_WANE, HAS_C, W, ND, SPL>),
                        dim3((unsigned)blocks), dim3(64), lds, stream, ka);
     return hipGetLastError();

@@ -173,3 +173,72 @@ def solve_batch(model: ModelDesc, y0, params, contact, t1: float, save_ts, *, t0
         if t is not None:
             t.record_stream(s)
     return BatchResult(out, status, n_acc, n_rej, saved, sizes, dout)
+
+
+def solve_batch_loglik(model: ModelDesc, y0, params, contact, t1: float, save_ts, obs, obs_compartment: int, *,
+                       dparams, increments: bool = True, floor: float = 1e-6, dy0=None, t0: float = 0.0,
+                       method: str = "tsit5", dtype: torch.dtype = torch.float32, rtol: float = 1e-5,
+                       atol: float = 1e-6, max_steps: int = 10**6, constant_dt: float = 0.0,
+                       jump_ts: Sequence[float] = (), stream: Optional[torch.cuda.Stream] = None):
+    """Tangent solve with the Poisson observation likelihood fused in (``dyn_solve_batch_loglik``):
+    returns ``(logp [B], dlogp [B, n_dir], status, n_accept, n_reject)`` and writes no trajectory.
+
+    ``logp = sum(obs * log(rate) - rate)`` with ``rate = max(v, floor)``, ``v`` the compartment
+    ``obs_compartment`` at the save times (``increments=False``, ``len(save_ts)`` rows of ``obs``) or
+    its increments between them (``increments=True``, one row fewer); the constant
+    ``-lgamma(obs + 1)`` is left to the caller.  ``dparams`` [B, n_dir, P] are the seed directions.
+    """
+    device = require_gpu()
+    L = _abi.lib()
+    D, P, A = model.state_dim, model.param_dim, model.n_age
+    params_t = _dev(params, dtype, device).reshape(-1, P)
+    B = params_t.shape[0]
+    y0_t = _dev(y0, dtype, device)
+    batched = y0_t.dim() == 2
+    if tuple(y0_t.shape) != ((B, D) if batched else (D,)):
+        raise ValueError(f"y0 has shape {tuple(y0_t.shape)}, expected {(D,)} or {(B, D)}")
+    contact_t = _dev(contact, dtype, device)
+    if contact_t.numel() != A * A:
+        raise ValueError(f"contact matrix must have {A}x{A} entries")
+    ts_t = _dev(save_ts, dtype, device).reshape(-1)
+    n_save = ts_t.shape[0]
+    sizes = model.compartment_sizes
+    if not 0 <= obs_compartment < len(sizes):
+        raise ValueError(f"obs_compartment {obs_compartment} out of range for {model.compartment_names}")
+    n_obs = n_save - int(bool(increments))
+    obs_t = _dev(obs, dtype, device).reshape(-1)
+    if n_obs < 1 or obs_t.numel() != n_obs * sizes[obs_compartment]:
+        raise ValueError(f"obs must hold {n_obs} rows of {sizes[obs_compartment]} values "
+                         f"({'increments between' if increments else 'values at'} the {n_save} save times), got {obs_t.numel()} values")
+    dparams_t = _dev(dparams, dtype, device)
+    if dparams_t.dim() != 3 or dparams_t.shape[0] != B or dparams_t.shape[2] != P:
+        raise ValueError(f"dparams must have shape [B={B}, n_dir, P={P}], got {tuple(dparams_t.shape)}")
+    n_dir = dparams_t.shape[1]
+    dy0_t = None
+    if dy0 is not None:
+        dy0_t = _dev(dy0, dtype, device)
+        if tuple(dy0_t.shape) not in ((n_dir, D), (B, n_dir, D)):
+            raise ValueError(f"dy0 must have shape {(n_dir, D)} or {(B, n_dir, D)}")
+    logp = torch.empty(B, dtype=torch.float64, device=device)
+    dlogp = torch.empty((B, n_dir), dtype=torch.float64, device=device)
+    stats = torch.empty((3, B), dtype=torch.int32, device=device)
+    if B == 0:
+        return logp, dlogp, stats[0], stats[1], stats[2]
+    jt = np.ascontiguousarray(jump_ts, dtype=np.float64)
+    opts = _abi.SolverOptsC(
+        _METHODS[method], _DTYPES[dtype], float(rtol), float(atol), int(max_steps), float(constant_dt),
+        jt.ctypes.data_as(ctypes.POINTER(ctypes.c_double)) if jt.size else None, int(jt.size))
+    s = stream if stream is not None else torch.cuda.current_stream(device)
+    rc = L.dyn_solve_batch_loglik(
+        ctypes.byref(model.c()), ctypes.byref(opts), y0_t.data_ptr(), int(batched), params_t.data_ptr(),
+        contact_t.data_ptr(), B, float(t0), float(t1), ts_t.data_ptr(), n_save, int(obs_compartment),
+        int(bool(increments)), float(floor), obs_t.data_ptr(), n_dir, dparams_t.data_ptr(),
+        dy0_t.data_ptr() if dy0_t is not None else None, int(dy0_t is not None and dy0_t.dim() == 3),
+        logp.data_ptr(), dlogp.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(),
+        ctypes.c_void_p(s.cuda_stream))
+    if rc != 0:
+        raise SolveError(rc, L.dyn_last_error().decode())
+    for t in (y0_t, params_t, contact_t, ts_t, obs_t, dparams_t, dy0_t):
+        if t is not None:
+            t.record_stream(s)
+    return logp, dlogp, stats[0], stats[1], stats[2]

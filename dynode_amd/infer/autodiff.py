@@ -16,7 +16,7 @@ import ctypes
 import torch
 
 from .. import _abi
-from ..engine import _DTYPES, _METHODS, solve_batch
+from ..engine import _DTYPES, _METHODS, solve_batch, solve_batch_loglik
 
 
 def _supported_nd(model, method: str, dtype, nd: int) -> bool:
@@ -91,3 +91,44 @@ def solve_batch_diff(model, y0, params: torch.Tensor, contact, t1, save_ts, **kw
     ys, status, n_acc, n_rej = _DiffSolve.apply(params, model, y0, contact, t1, save_ts, kw)
     _, saved, sizes = save_mask_bytes(model, kw.get("save_mask"))
     return BatchResult(ys, status, n_acc, n_rej, saved, sizes)
+
+
+class _DiffLogLik(torch.autograd.Function):
+    """Poisson observation log-likelihood of the solve, fused into the tangent kernel
+    (``dyn_solve_batch_loglik``): value [B] and, for backward, d value / d params [B, P]."""
+
+    @staticmethod
+    def forward(ctx, params, model, y0, contact, t1, save_ts, obs, comp, increments, floor, kw):
+        dtype = kw.get("dtype", torch.float32)
+        method = kw.get("method", "tsit5")
+        B, P = params.shape
+        pk = params.detach().to(dtype)
+        ctx.set_materialize_grads(False)
+        grads, logp, stats, start = [], None, None, 0
+        for n in direction_chunks(model, method, dtype, P):
+            seeds = _identity_seeds(B, P, start, n, dtype, params.device)
+            lp, dlp, st, na, nr = solve_batch_loglik(model, y0, pk, contact, t1, save_ts, obs, comp, dparams=seeds,
+                                                     increments=increments, floor=floor, **kw)
+            logp = lp if logp is None else logp
+            stats = (st, na, nr)
+            grads.append(dlp)
+            start += n
+        G = grads[0] if len(grads) == 1 else torch.cat(grads, dim=1)      # [B, P]
+        ctx.save_for_backward(G)
+        ctx.in_dtype = params.dtype
+        ctx.mark_non_differentiable(*stats)
+        return (logp,) + stats
+
+    @staticmethod
+    def backward(ctx, g, *_unused):
+        (G,) = ctx.saved_tensors
+        if g is None:
+            return (None,) * 11
+        return ((g.unsqueeze(-1) * G).to(ctx.in_dtype),) + (None,) * 10
+
+
+def solve_loglik_diff(model, y0, params: torch.Tensor, contact, t1, save_ts, obs, obs_compartment: int, *,
+                      increments: bool = True, floor: float = 1e-6, **kw):
+    """``(logp [B], status, n_accept, n_reject)``, differentiable with respect to ``params``."""
+    return _DiffLogLik.apply(params, model, y0, contact, t1, save_ts, obs, int(obs_compartment), bool(increments),
+                             float(floor), kw)

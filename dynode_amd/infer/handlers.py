@@ -88,10 +88,17 @@ def _apply(msg):
 
 def sample(name: str, fn, obs=None, rng_key: Optional[int] = None, sample_shape=()):
     gen = torch.Generator().manual_seed(int(rng_key)) if rng_key is not None else None
-    value = None if obs is None else (obs.to(torch.float64) if isinstance(obs, torch.Tensor)
-                                      else torch.as_tensor(obs, dtype=torch.float64))
+    # tensors are kept as given (log_prob converts, with a cache for constants): no copy per evaluation
+    value = None if obs is None else (obs if isinstance(obs, torch.Tensor) else torch.as_tensor(obs, dtype=torch.float64))
     return _apply({"type": "sample", "name": name, "fn": fn, "value": value, "is_observed": obs is not None,
                    "gen": gen, "sample_shape": tuple(sample_shape)})
+
+
+def factor(name: str, log_factor):
+    """Add ``log_factor`` (a tensor, one value per chain) to the log joint -- ``numpyro.factor``.
+    Used with likelihoods that are computed inside the solve kernel (``simulate(..., observe=...)``)."""
+    return _apply({"type": "factor", "name": name, "fn": None, "value": log_factor, "is_observed": True,
+                   "gen": None, "sample_shape": ()})
 
 
 def deterministic(name: str, value):

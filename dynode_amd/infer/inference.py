@@ -101,6 +101,8 @@ class Potential:
             if s["type"] == "sample" and s["is_observed"]:
                 lp = s["fn"].log_prob(s["value"].to(z.device))
                 total = total + lp.reshape(C, -1).sum(-1)
+            elif s["type"] == "factor":
+                total = total + s["value"].reshape(C, -1).sum(-1)
         return total, tr
 
     def potential_and_grad(self, z: torch.Tensor):

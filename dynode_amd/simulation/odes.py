@@ -70,6 +70,25 @@ class Solution:
     result: torch.Tensor = None      # per-trajectory status (0 ok, 1 max_steps, 2 non-finite)
     t0: float = 0.0
     t1: float = 0.0
+    log_likelihood: Optional[torch.Tensor] = None   # only with ``simulate(..., observe=...)``
+
+
+@dataclass
+class PoissonObservation:
+    """Observation model scored INSIDE the solve kernel (``simulate(..., observe=...)``).
+
+    ``data ~ Poisson(max(v, floor))`` where ``v`` is compartment ``compartment`` of the state at the
+    save times (``increments=False``; ``data`` has one row per save time) or its increase from one
+    save time to the next (``increments=True``; one row fewer) -- the likelihood of the reference's
+    model(): ``incidence = max(diff(R), 1e-6)``, ``obs ~ Poisson(incidence)``
+    (examples/sir_infer_parameters.py:30-38).  No trajectory is written to memory; the solution
+    carries ``log_likelihood`` (differentiable with respect to the ODE parameters) instead of ``ys``.
+    """
+
+    compartment: int
+    data: object                      # array-like [n_obs, *compartment_shape]
+    increments: bool = True
+    floor: float = 1e-6
 
 
 def build_saveat(start: float, stop, step: int = 1,
@@ -92,9 +111,54 @@ def build_saveat(start: float, stop, step: int = 1,
     return SaveAt(ts, mask)
 
 
+_OBS_CACHE: dict = {}
+
+
+def _observation_constants(data, dtype, device):
+    """(observations as a flat device tensor of the solve dtype, sum lgamma(data + 1)); cached per data object."""
+    key = (id(data), dtype, str(device))
+    hit = _OBS_CACHE.get(key)
+    if hit is None or hit[0] is not data:
+        if len(_OBS_CACHE) > 16:
+            _OBS_CACHE.clear()
+        t = data.detach() if isinstance(data, torch.Tensor) else torch.as_tensor(np.asarray(data))
+        t64 = t.to(device=device, dtype=torch.float64)
+        hit = (data, t64.to(dtype).contiguous(), torch.lgamma(t64 + 1.0).sum(), tuple(t.shape))
+        _OBS_CACHE[key] = hit
+    return hit[1], hit[2], hit[3]
+
+
+def _simulate_observed(ode, ode_parameters, packed, saveat, t1, kw, observe, differentiable, sp, n_comp):
+    from ..engine import require_gpu
+    from ..infer.autodiff import solve_loglik_diff
+
+    device = require_gpu()
+    comp = int(observe.compartment) % n_comp
+    obs_t, const, shape = _observation_constants(observe.data, kw["dtype"], device)
+    n_obs = len(saveat.ts) - int(bool(observe.increments))
+    if tuple(shape) != (n_obs,) + tuple(packed.shapes[comp]):
+        raise ValueError(f"observations have shape {tuple(shape)}; expected {(n_obs,) + tuple(packed.shapes[comp])} "
+                         f"({'increments between' if observe.increments else 'values at'} {len(saveat.ts)} save times)")
+    kw = {k: v for k, v in kw.items() if k != "save_mask"}
+    if differentiable:
+        params_t = ode.param_tensor(ode_parameters, device)
+    else:
+        params_t = torch.as_tensor(packed.params, dtype=torch.float64, device=device)
+    lp, status, n_acc, n_rej = solve_loglik_diff(packed.model, packed.y0, params_t, packed.contact, t1, saveat.ts, obs_t,
+                                                 comp, increments=observe.increments, floor=observe.floor, **kw)
+    lp = lp - const
+    batched = packed.batch is not None
+    unb = (lambda t: t) if batched else (lambda t: t[0])
+    stats = _LazyStats({"num_accepted_steps": unb(n_acc), "num_rejected_steps": unb(n_rej), "max_steps": sp.max_steps})
+    from ..engine import _dev
+    empty = torch.empty((lp.shape[0], len(saveat.ts), 0) if batched else (len(saveat.ts), 0), dtype=kw["dtype"], device=device)
+    return Solution(ts=_dev(saveat.ts, kw["dtype"], device), ys=tuple(empty for _ in range(n_comp)), stats=stats,
+                    result=unb(status), t0=0.0, t1=t1, log_likelihood=unb(lp))
+
+
 def simulate(ode, duration_days, initial_state: CompartmentState, ode_parameters, solver_parameters: SolverParams,
              sub_save_indices: Optional[Tuple[int, ...]] = None, save_step: int = 1, *, dtype=None,
-             throw: bool = True) -> Solution:
+             throw: bool = True, observe: Optional["PoissonObservation"] = None) -> Solution:
     """Solve ``ode`` for ``duration_days`` days from ``initial_state`` (reference odes.py:35-145).
 
     Parameters follow the reference one for one.  ``ode`` is a :class:`CompartmentalODE` descriptor
@@ -128,6 +192,9 @@ def simulate(ode, duration_days, initial_state: CompartmentState, ode_parameters
               atol=sp.ode_solver_abs_tolerance, max_steps=sp.max_steps,
               constant_dt=sp.constant_step_size if sp.constant_step_size > 0.0 else 0.0,
               jump_ts=sp.discontinuity_points, save_mask=saveat.mask)
+    if observe is not None:
+        return _simulate_observed(ode, ode_parameters, packed, saveat, float(duration_days), kw, observe,
+                                  differentiable, sp, len(initial_state))
     if differentiable:
         # a parameter carries an autograd graph (NUTS / SVI potential): differentiable solve.  No
         # host synchronisation here: a failed trajectory leaves +inf rows, which turn the

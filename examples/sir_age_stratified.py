@@ -41,9 +41,10 @@ def get_odeparams(config: SimulationConfig) -> SIR_ODEParams:
                          contact_matrix=tp.contact_matrix)
 
 
-def run_simulation(config: SimulationConfig, tf):
+def run_simulation(config: SimulationConfig, tf, observe=None):
     return simulate(ode=sir_ode, duration_days=tf, initial_state=config.initializer.get_initial_state(SIRConfig=config),
-                    ode_parameters=get_odeparams(config), solver_parameters=config.parameters.solver_params)
+                    ode_parameters=get_odeparams(config), solver_parameters=config.parameters.solver_params,
+                    observe=observe)
 
 
 if __name__ == "__main__":

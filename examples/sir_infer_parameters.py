@@ -28,6 +28,18 @@ def model(config: SimulationConfig, tf, obs_data):
     return solution
 
 
+def model_fused(config: SimulationConfig, tf, obs_data):
+    """The same model with the likelihood evaluated inside the solve kernel: the trajectory never
+    leaves the registers, the solve returns the Poisson log-likelihood of ``diff(R)`` and its
+    gradient (``dyn_solve_batch_loglik``).  Same posterior as :func:`model`."""
+    from dynode_amd import PoissonObservation
+
+    solution = run_simulation(config, tf, observe=PoissonObservation(compartment=config.idx.r, data=obs_data,
+                                                                     increments=True, floor=1e-6))
+    handlers.factor("inf_incidence", solution.log_likelihood)
+    return solution
+
+
 def get_config() -> SimulationConfig:
     """Static SIR config with the strain's r0 / infectious period replaced by priors (:42-59)."""
     sir_config = get_static_config(r_0=2.0, infectious_period=7.0)

@@ -142,6 +142,29 @@ int dyn_solve_batch_jvp(const dyn_model_desc *m, const dyn_solver_opts *opts, co
                         const uint8_t *save_mask, int32_t n_dir, const void *dparams,
                         const void *dy0, int32_t dy0_is_batched, void *ys_out, void *dys_out,
                         int32_t *status, int32_t *n_accept, int32_t *n_reject, void *stream);
+/*
+ * Tangent solve with the observation likelihood fused in: nothing of the trajectory is written to
+ * HBM (cfg 4: "D_saved = 0, likelihood fused").  For every batch member returns
+ *     logp  = sum_{j, x} obs[j][x] * log(rate[j][x]) - rate[j][x]          (Poisson, without the
+ *                                                        constant -lgamma(obs + 1), the caller's)
+ *     dlogp = its derivative along each of the n_dir seed directions
+ * where rate = max(v, rate_floor) and v is the observed compartment at save time j (obs_mode 0,
+ * n_save rows of observations) or its increment between save times j and j + 1 (obs_mode 1,
+ * n_save - 1 rows) -- the reference's model(): incidence = max(diff(R), 1e-6), obs ~ Poisson
+ * (examples/sir_infer_parameters.py:30-38).  The derivative passes through the floor where
+ * v >= rate_floor (the usual clamp / clip autodiff convention).  A failed solve scores logp = -inf.
+ *   obs_compartment  index into the state tuple (as dyn_compartment_offsets)
+ *   obs   [n_obs][size of that compartment]  same float type as the solve, shared by the batch   device
+ *   logp_out [B], dlogp_out [B][n_dir]  float64                                                  device
+ * Everything else as dyn_solve_batch_jvp.
+ */
+int dyn_solve_batch_loglik(const dyn_model_desc *m, const dyn_solver_opts *opts, const void *y0,
+                           int32_t y0_is_batched, const void *params, const void *contact, int64_t B,
+                           double t0, double t1, const void *save_ts, int32_t n_save,
+                           int32_t obs_compartment, int32_t obs_mode, double rate_floor, const void *obs,
+                           int32_t n_dir, const void *dparams, const void *dy0, int32_t dy0_is_batched,
+                           double *logp_out, double *dlogp_out, int32_t *status, int32_t *n_accept,
+                           int32_t *n_reject, void *stream);
 /* 1 if a tangent kernel for (model shape, method, dtype, n_dir) is compiled in */
 int32_t dyn_is_supported_jvp(const dyn_model_desc *m, const dyn_solver_opts *o, int32_t n_dir);
 

@@ -299,3 +299,41 @@ def test_reference_inference_process_tests_on_a_conjugate_model():
     fit.infer(y=y)
     s = fit.get_samples()["dist_loc"].cpu().numpy()
     assert abs(s.mean() - mean) < 0.05 and abs(s.std() / sd - 1) < 0.35
+
+
+def test_fused_observation_likelihood_matches_the_op_by_op_model(data):
+    """dyn_solve_batch_loglik (Poisson likelihood of diff(R) inside the tangent kernel) against the
+    reference-shaped model: simulate -> diff -> clamp -> Poisson.log_prob, values and gradients."""
+    kw = dict(config=ex.get_config(), tf=100, obs_data=data)
+    dev = torch.device("cuda")
+    pot_a = Potential(ex.model, kw, 0, dev)
+    pot_b = Potential(ex.model_fused, kw, 0, dev)
+    z = pot_a.initial(48, init_to_median, 0) + 0.4 * torch.randn(48, 2, dtype=torch.float64, generator=torch.Generator().manual_seed(2)).cuda()
+    ua, ga = pot_a.potential_and_grad(z)
+    ub, gb = pot_b.potential_and_grad(z)
+    # both evaluate the same fp32 solve; the fused path accumulates the 200 Poisson terms in float64
+    assert torch.allclose(ua, ub, rtol=1e-9, atol=5e-3), float((ua - ub).abs().max())
+    assert torch.allclose(ga, gb, rtol=5e-4, atol=2e-2), float((ga - gb).abs().max())
+    # float64 end to end: the two paths agree to rounding
+    odes.enable_x64(True)
+    try:
+        ua64, ga64 = Potential(ex.model, kw, 0, dev).potential_and_grad(z)
+        ub64, gb64 = Potential(ex.model_fused, kw, 0, dev).potential_and_grad(z)
+    finally:
+        odes.enable_x64(False)
+    assert torch.allclose(ua64, ub64, rtol=1e-12, atol=1e-8) and torch.allclose(ga64, gb64, rtol=1e-9, atol=1e-7)
+    # observations of the wrong length are refused
+    with pytest.raises(ValueError):
+        Potential(ex.model_fused, dict(config=ex.get_config(), tf=100, obs_data=data[:-1]), 0, dev)
+
+
+def test_nuts_with_fused_likelihood_matches_grid_quadrature(data):
+    process = MCMCProcess(numpyro_model=ex.model_fused, num_warmup=250, num_samples=250, num_chains=48,
+                          nuts_max_tree_depth=10, progress_bar=False)
+    mcmc = process.infer(config=ex.get_config(), tf=100, obs_data=data)
+    post = process.get_samples(group_by_chain=True)
+    assert int(mcmc.nuts.diverging.sum()) <= 5 and 0.6 < float(mcmc.nuts.accept_prob.mean()) < 0.97
+    (g_r0, cdf_r0), (g_ti, cdf_ti) = _grid_marginals(data)
+    for name, grid, cdf in (("strains_0_r0", g_r0, cdf_r0), ("strains_0_infectious_period", g_ti, cdf_ti)):
+        thin = post[name][:, ::10].reshape(-1).cpu().numpy()
+        assert stats.kstest(thin, lambda x: np.interp(x, grid, cdf)).pvalue > 1e-3

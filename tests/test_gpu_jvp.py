@@ -123,3 +123,72 @@ def test_gradient_of_a_multi_strain_model_through_simulate():
                            - loss(beta.detach() - eps * torch.eye(len(beta), dtype=torch.float64, device="cuda")[j])) / (2 * eps)
                           for j in range(len(beta))])
         assert torch.allclose(grad, fd.detach(), rtol=5e-4), (grad, fd)
+
+
+# ------------------------------------------------------------------ fused observation likelihood
+LL_CASES = [
+    # model, directions, observed compartment (index into the state tuple), increments?
+    (ModelDesc(n_age=2), 2, 2, True), (ModelDesc(n_age=2), 2, 1, False), (ModelDesc(n_age=1), 2, 0, False),
+    (ModelDesc(n_age=8), 2, 2, True), (ModelDesc(n_age=1, has_e=True, has_wane=True), 4, 1, False),
+    (ModelDesc(n_age=2, n_strain=3, has_e=True, has_wane=True, has_c=True), 1, 4, True),
+    (ModelDesc(n_age=2, n_strain=3, has_e=True, has_wane=True, has_c=True), 1, 2, False),
+    (ModelDesc(n_age=8, n_strain=4, has_e=True, has_wane=True, has_c=True), 2, 4, True),
+]
+
+
+@pytest.mark.parametrize("replicas", ["default", "0"])
+@pytest.mark.parametrize("m,nd,comp,inc", LL_CASES, ids=lambda v: str(v) if not isinstance(v, ModelDesc) else f"A{v.n_age}S{v.n_strain}e{int(v.has_e)}")
+def test_fused_poisson_likelihood_equals_scoring_the_saved_trajectory(m, nd, comp, inc, replicas, monkeypatch):
+    """dyn_solve_batch_loglik == Poisson log-likelihood (and its tangents) computed from the output of
+    dyn_solve_batch_jvp, in float64, for every compartment kind, both observation modes, and both
+    kernel paths (in-order accumulation / LDS table of replicated trajectories)."""
+    from dynode_amd.engine import solve_batch_loglik
+
+    if replicas != "default":
+        monkeypatch.setenv("DYNODE_HIP_REPLICAS_LOG2", replicas)
+    B = 37
+    y0, p, C, t1, ts = _workload(m, B, seed=11)
+    rng = np.random.default_rng(1)
+    dp = rng.normal(size=(B, nd, m.param_dim)) * 0.1 * np.abs(p)[:, None, :]
+    dy0 = rng.normal(size=(B, nd, m.state_dim))
+    ref = solve_batch(m, y0, p, C, t1, ts, dtype=torch.float64, dparams=dp, dy0=dy0)
+    off = np.concatenate([[0], np.cumsum(m.compartment_sizes)])
+    v = ref.ys[:, :, off[comp]:off[comp + 1]]                      # [B, n_save, size]
+    dv = ref.dys[:, :, :, off[comp]:off[comp + 1]]                 # [B, n_save, nd, size]
+    if inc:
+        v, dv = v[:, 1:] - v[:, :-1], dv[:, 1:] - dv[:, :-1]
+    floor = max(float(torch.quantile(v.flatten(), 0.1)), 0.05)     # a tenth of the rates sit on the floor
+    obs = torch.as_tensor(rng.poisson(np.clip(v[0].cpu().numpy(), 0.0, 50.0) + 0.5).astype(np.float64), device="cuda")
+    rate = torch.clamp(v, min=floor)
+    want = (obs * torch.log(rate) - rate).sum((1, 2))
+    coef = torch.where(v >= floor, obs / rate - 1.0, torch.zeros_like(rate))
+    dwant = (coef[:, :, None, :] * dv).sum((1, 3))
+    assert int((v < floor).sum()) > 0
+    lp, dlp, st, na, nr = solve_batch_loglik(m, y0, p, C, t1, ts, obs, comp, dparams=dp, dy0=dy0, increments=inc, floor=floor,
+                                             dtype=torch.float64)
+    torch.cuda.synchronize()
+    assert int(st.max()) == 0 and torch.equal(na, ref.n_accept) and torch.equal(nr, ref.n_reject)
+    assert torch.allclose(lp, want, rtol=1e-12, atol=1e-9), float((lp - want).abs().max())
+    assert torch.allclose(dlp, dwant, rtol=1e-10, atol=1e-8), float((dlp - dwant).abs().max())
+    # fp32 kernels: same quantity at fp32 accuracy
+    lp32, dlp32, st32, _, _ = solve_batch_loglik(m, y0, p, C, t1, ts, obs, comp, dparams=dp, dy0=dy0, increments=inc, floor=floor,
+                                                 dtype=torch.float32)
+    assert int(st32.max()) == 0
+    assert torch.allclose(lp32, want, rtol=2e-4, atol=2e-2), float((lp32 - want).abs().max())
+
+
+def test_fused_likelihood_argument_checks_and_failed_solves():
+    from dynode_amd.engine import SolveError, solve_batch_loglik
+
+    m = ModelDesc(n_age=2)
+    y0, p, C, t1, ts = _workload(m, 5, seed=3)
+    dp = np.zeros((5, 2, m.param_dim))
+    obs = np.ones((len(ts) - 1, 2))
+    with pytest.raises(ValueError):
+        solve_batch_loglik(m, y0, p, C, t1, ts, obs[:-1], 2, dparams=dp)            # one row short
+    with pytest.raises(ValueError):
+        solve_batch_loglik(m, y0, p, C, t1, ts, obs, 3, dparams=dp)                 # no such compartment
+    with pytest.raises(SolveError):
+        solve_batch_loglik(m, y0, p, C, t1, ts, obs, 2, dparams=dp, floor=0.0)      # the floor must be positive
+    lp, dlp, st, _, _ = solve_batch_loglik(m, y0, p, C, t1, ts, obs, 2, dparams=dp, max_steps=3)
+    assert bool((st == 1).all()) and bool(torch.isinf(lp).all()) and bool((lp < 0).all()) and bool((dlp == 0).all())

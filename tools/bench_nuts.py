@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--depth", type=int, default=10)
     ap.add_argument("--sampler", default="kernel", choices=["kernel", "graph", "eager"])
     ap.add_argument("--adaptation", default="pooled", choices=["per_chain", "pooled"])
+    ap.add_argument("--fused-likelihood", action="store_true", help="score the observations inside the solve kernel (examples model_fused)")
     args = ap.parse_args()
     import numpy as np, torch, torch.distributed as dist
     from scipy import stats
@@ -35,7 +36,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", torch.cuda.current_device()))
     data = ex.synthetic_incidence(100)
-    proc = MCMCProcess(numpyro_model=ex.model, num_warmup=args.warmup, num_samples=args.samples, num_chains=args.chains,
+    proc = MCMCProcess(numpyro_model=ex.model_fused if args.fused_likelihood else ex.model, num_warmup=args.warmup, num_samples=args.samples, num_chains=args.chains,
                        nuts_max_tree_depth=args.depth, progress_bar=(rank == 0),
                        mcmc_kwargs={"sampler": args.sampler, "adaptation": args.adaptation})
     torch.cuda.synchronize()
@@ -70,7 +71,7 @@ def main():
         n_trans = args.chains * (args.warmup + args.samples)
         print(json.dumps({
             "workload": "cfg4 sir_infer_parameters: NUTS, 2-age SIR, tf=100, Poisson incidence",
-            "sampler": args.sampler, "adaptation": args.adaptation, "n_gpus": world, "chains": args.chains, "warmup": args.warmup, "samples": args.samples,
+            "sampler": args.sampler, "adaptation": args.adaptation, "fused_likelihood": args.fused_likelihood, "n_gpus": world, "chains": args.chains, "warmup": args.warmup, "samples": args.samples,
             "seconds": el, "transitions_per_s": n_trans / el,
             "gradient_solves_per_s_per_gpu": mcmc.nuts.potential_evals / el,
             "chain_gradient_evals_per_s": mcmc.nuts.potential_evals * (args.chains / world) * world / el,
