@@ -93,7 +93,7 @@ def cpu_baseline(wl, sample: int):
     }
 
 
-def nuts_side_measurement(dev, chains=128, warmup=300, samples=300):
+def nuts_side_measurement(dev, chains=128, warmup=300, samples=300, fused=False):
     """cfg 4 in short form: NUTS on the 2-age SIR (tf=100, Poisson incidence), 128 chains on this GPU,
     300 + 300 transitions (BASELINE's cfg 4 runs 1000 + 1000; tools/bench_nuts.py is the full form).
     Unit of work = one gradient-solve (fused solve + tangents for every chain) per sampler iteration."""
@@ -103,7 +103,7 @@ def nuts_side_measurement(dev, chains=128, warmup=300, samples=300):
     from examples import sir_infer_parameters as ex
 
     data = ex.synthetic_incidence(100)
-    proc = MCMCProcess(numpyro_model=ex.model, num_warmup=warmup, num_samples=samples, num_chains=chains,
+    proc = MCMCProcess(numpyro_model=ex.model_fused if fused else ex.model, num_warmup=warmup, num_samples=samples, num_chains=chains,
                        nuts_max_tree_depth=10, progress_bar=False)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -111,7 +111,8 @@ def nuts_side_measurement(dev, chains=128, warmup=300, samples=300):
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     post = proc.get_samples()
-    return {"workload": f"cfg4 sir_infer_parameters: NUTS {chains} chains x ({warmup} warm-up + {samples} draws), tree depth 10",
+    return {"workload": f"cfg4 sir_infer_parameters: NUTS {chains} chains x ({warmup} warm-up + {samples} draws), tree depth 10"
+                        + (", Poisson likelihood fused into the solve kernel (examples model_fused)" if fused else ""),
             "seconds": el, "transitions_per_s": chains * (warmup + samples) / el,
             "gradient_solves_per_s": mcmc.nuts.potential_evals / el,
             "chain_gradients_per_s": mcmc.nuts.potential_evals * chains / el,
@@ -273,6 +274,7 @@ def main():
                     "all_status_ok": int(st2[0].max()) == 0}
                 del o2
             line["other_workloads"]["cfg4"] = nuts_side_measurement(dev)
+            line["other_workloads"]["cfg4_fused_likelihood"] = nuts_side_measurement(dev, fused=True)
         if world == 1 and not args.no_cpu_baseline:
             sample = args.cpu_sample or (16384 if m.state_dim >= 100 else 65536)
             line["cpu_baseline"] = cpu_baseline(wl, min(sample, B))

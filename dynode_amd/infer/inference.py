@@ -102,17 +102,18 @@ class Potential:
                 lp = s["fn"].log_prob(s["value"].to(z.device))
                 total = total + lp.reshape(C, -1).sum(-1)
             elif s["type"] == "factor":
-                total = total + s["value"].reshape(C, -1).sum(-1)
+                v = s["value"]
+                total = total + (v if v.dim() == 1 and v.shape[0] == C else v.reshape(C, -1).sum(-1))
         return total, tr
 
     def potential_and_grad(self, z: torch.Tensor):
         z = z.detach().requires_grad_(True)
         lj, _ = self.log_joint(z)
-        ones = self._ones.get(lj.shape[0])
-        if ones is None or ones.device != lj.device:
-            ones = self._ones[lj.shape[0]] = torch.ones_like(lj)
-        (g,) = torch.autograd.grad(lj, z, ones)
-        return -lj.detach(), -g
+        minus = self._ones.get(lj.shape[0])
+        if minus is None or minus.device != lj.device:
+            minus = self._ones[lj.shape[0]] = -torch.ones_like(lj)
+        (g,) = torch.autograd.grad(lj, z, minus)             # gradient of the potential U = -log joint
+        return -lj.detach(), g
 
     def graphed(self, chains: int):
         """``potential_and_grad`` for a fixed number of chains as ONE HIP-graph replay.
