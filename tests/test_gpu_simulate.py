@@ -110,12 +110,19 @@ def test_seirs_endemic_equilibrium(r0, ti, tl, tw):
     assert all(x[-100:].std() < 1e-4 for x in (s, e, i, r))
 
 
-def test_seasonal_seirs_keeps_oscillating():
-    """tests/test_seirs_seasonality_dynamics/test_seirs_seasonality_dynamics.py:19-42."""
-    cfg = ex_seirs.get_config()
-    sol = simulate(rhs.seirs_ode_seasonal, 1500, cfg.initializer.get_initial_state(),
-                   ex_seirs.get_seasonal_odeparams(cfg, 0.2, 0.0, 365.0), cfg.parameters.solver_params)
-    assert all(a.squeeze()[-100:].std() > 1e-4 for a in _np(sol))
+@pytest.mark.parametrize("r_0, infectious_period, latent_period, waning_period",
+                         [(2.0, 7.0, 3.0, 60.0), (3.0, 5.0, 2.0, 100.0)])
+def test_seasonal_seirs_keeps_oscillating(r_0, infectious_period, latent_period, waning_period):
+    """tests/test_seirs_seasonality_dynamics/test_seirs_seasonality_dynamics.py:19-42, through the same
+    module and names the reference's test imports (examples.seirs_seasonal_forcing)."""
+    from examples.seirs_seasonal_forcing import get_config, get_seirs_odeparams, seirs_ode_seasonal
+
+    config = get_config(r_0=r_0, infectious_period=infectious_period, latent_period=latent_period,
+                        waning_period=waning_period)
+    sol = simulate(ode=seirs_ode_seasonal, duration_days=1000, initial_state=config.initializer.get_initial_state(),
+                   ode_parameters=get_seirs_odeparams(config), solver_parameters=config.parameters.solver_params)
+    s, e, i, r = [a.squeeze() for a in _np(sol)]
+    assert s[-100:].std() > 1e-4 and e[-100:].std() > 1e-4 and i[-100:].std() > 1e-4 and r[-100:].std() > 1e-4
 
 
 # ------------------------------------------------------------------ the examples, vs the oracle
