@@ -1,20 +1,30 @@
-"""Config / plugin schema of the simulate path (mirrors dynode.config, boundary only).
+"""Config / plugin schema of the simulate path (the names ``dynode.config`` exports).
 
-Restated from the reference's behaviour, not copied: only what the hot path's front-end
-needs -- shapes, the recursive ``idx`` namespace, strain vectors, solver knobs.
-Reference: /root/reference/src/dynode/config/ ("boundary only" row).
+Restated from the reference's behaviour (tests/test_config.py mirrors what its tests pin), not
+copied: shapes and the recursive ``idx`` namespace, strain vectors, solver knobs, and the bin /
+dimension builders the reference's larger models are described with.
 """
 
-from .bins import AgeBin, Bin, DiscretizedPositiveIntBin
-from .deterministic_parameter import DeterministicParameter
-from .dimension import Dimension
-from .initializer import Initializer
-from .params import Dopri5, Params, SolverParams, Tsit5, TransmissionParams
-from .simulation_config import Compartment, SimulationConfig
-from .strains import Strain
+import importlib as _importlib
 
-__all__ = [
-    "AgeBin", "Bin", "DiscretizedPositiveIntBin", "DeterministicParameter", "Dimension",
-    "Initializer", "Dopri5", "Params", "SolverParams", "Tsit5", "TransmissionParams",
-    "Compartment", "SimulationConfig", "Strain",
-]
+# module -> public names, in dependency order
+_PUBLIC = {
+    "bins": ("Bin", "DiscretizedPositiveIntBin", "AgeBin", "WaneBin"),
+    "strains": ("Strain",),
+    "dimension": ("Dimension", "VaccinationDimension", "ImmuneHistoryDimension",
+                  "FullStratifiedImmuneHistoryDimension", "LastStrainImmuneHistoryDimension", "WaneDimension"),
+    "deterministic_parameter": ("DeterministicParameter",),
+    "placeholder_sample": ("PlaceholderSample", "SamplePlaceholderError"),
+    "simulation_date": ("set_dynode_init_date_flag", "get_dynode_init_date_flag", "simulation_day"),
+    "initializer": ("Initializer",),
+    "params": ("Tsit5", "Dopri5", "SolverParams", "TransmissionParams", "Params"),
+    "simulation_config": ("Compartment", "SimulationConfig"),
+}
+
+__all__ = []
+for _module, _names in _PUBLIC.items():
+    _loaded = _importlib.import_module(f"{__name__}.{_module}")
+    for _name in _names:
+        globals()[_name] = getattr(_loaded, _name)
+        __all__.append(_name)
+del _module, _names, _loaded, _name

@@ -2,7 +2,7 @@
 
 from __future__ import annotations
 
-from pydantic import BaseModel, Field, NonNegativeInt, model_validator
+from pydantic import BaseModel, Field, NonNegativeFloat, NonNegativeInt, PositiveFloat, model_validator
 
 from ..typing import DynodeName
 
@@ -34,3 +34,12 @@ class AgeBin(DiscretizedPositiveIntBin):
 
     def __init__(self, min_value, max_value, name=None):
         super().__init__(min_value, max_value, name if name is not None else f"a{min_value}_{max_value}")
+
+
+class WaneBin(Bin):
+    """One stage of waning immunity (reference bins.py:77-89): the mean number of days spent in
+    the stage (``math.inf`` = the stage is never left; waning rate = 1 / waiting_time) and the share
+    of immune protection its occupants keep."""
+
+    waiting_time: PositiveFloat = Field(description="mean days in this stage; math.inf = absorbing")
+    base_protection: NonNegativeFloat = Field(le=1.0, description="retained protection in [0, 1]")

@@ -88,6 +88,15 @@ class SimulationConfig(BaseModel):
                     f"dimension {dim.name} has different definitions across different compartments")
             else:
                 seen[dim.name] = dim
+        # immune-history axes must be generated from exactly the strains of transmission_params
+        # (reference simulation_config.py:170-206)
+        from .dimension import ImmuneHistoryDimension
+
+        strains = self.parameters.transmission_params.strains
+        for dim in self.flatten_dims():
+            if isinstance(dim, ImmuneHistoryDimension):
+                assert type(dim) is not ImmuneHistoryDimension and type(dim)(strains) == dim, (
+                    "Found immune states that dont correlate with strains from transmission_params")
         return self
 
     def get_compartment(self, compartment_name: str) -> Compartment:
