@@ -97,7 +97,29 @@ class SimulationConfig(BaseModel):
             if isinstance(dim, ImmuneHistoryDimension):
                 assert type(dim) is not ImmuneHistoryDimension and type(dim)(strains) == dim, (
                     "Found immune states that dont correlate with strains from transmission_params")
+        self._encode_introduction_ages(strains)
         return self
+
+    def _encode_introduction_ages(self, strains) -> None:
+        """Externally introduced strains name the age bins they arrive in; those must be age bins of
+        the model, and are turned into a 0/1 vector over the model's age axis
+        (``Strain.introduction_ages_mask_vector``; reference simulation_config.py:208-264)."""
+        from .bins import AgeBin
+
+        model_ages = [b for b in self.flatten_bins() if isinstance(b, AgeBin)]
+        for s in strains:
+            if s.is_introduced and s.introduction_ages is not None:
+                assert all(target in model_ages for target in s.introduction_ages), (
+                    f"{s.strain_name} attempts to introduce itself using {s.introduction_ages} age bins, "
+                    "but those are not found within the age structure of the model.")
+        if not any(s.introduction_ages is not None for s in strains):
+            return
+        age_axis = next((d.bins for d in self.flatten_dims() if isinstance(d.bins[0], AgeBin)), [])
+        assert len(age_axis) > 0, ("attempted to encode introduction_ages but could not find any age "
+                                   "structure in the compartments")
+        for s in strains:
+            wanted = s.introduction_ages or []
+            s.introduction_ages_mask_vector = [int(b in wanted) for b in age_axis]
 
     def get_compartment(self, compartment_name: str) -> Compartment:
         for comp in self.compartments:

@@ -256,3 +256,26 @@ def test_simulation_days_are_plain_ints_wherever_they_are_used(no_init_date):
     import torch
     gen = torch.Generator().manual_seed(0)
     assert -1 <= float(tn.sample(gen)) <= 1 and math.isfinite(float(n.sample(gen)))
+
+
+def test_introduced_strains_are_encoded_over_the_models_age_axis():
+    """reference simulation_config.py:208-264: introduction_ages -> 0/1 mask over the age bins; ages
+    that are not bins of the model are refused."""
+    ages = [config.AgeBin(min_value=0, max_value=17), config.AgeBin(min_value=18, max_value=64), config.AgeBin(min_value=65, max_value=99)]
+    intro = dict(is_introduced=True, introduction_time=100, introduction_percentage=0.1, introduction_scale=10)
+
+    def build(strains):
+        names = [s.strain_name for s in strains]
+        return config.SimulationConfig(
+            compartments=[C(name="s", dimensions=[D(name="age", bins=ages)])],
+            initializer=config.Initializer(description="x", initialize_date=date(2022, 2, 11), population_size=1000),
+            parameters=config.Params(
+                transmission_params=config.TransmissionParams(strains=strains, strain_interactions={a: {b: 1.0 for b in names} for a in names}),
+                solver_params=config.SolverParams()))
+
+    cfg = build([strain("resident"), strain("newcomer", introduction_ages=[ages[1], ages[2]], **intro)])
+    masks = [s.introduction_ages_mask_vector for s in cfg.parameters.transmission_params.strains]
+    assert masks == [[0, 0, 0], [0, 1, 1]]
+    assert build([strain("resident")]).parameters.transmission_params.strains[0].introduction_ages_mask_vector is None
+    with pytest.raises(ValidationError):
+        build([strain("newcomer", introduction_ages=[config.AgeBin(min_value=0, max_value=4)], **intro)])
