@@ -373,6 +373,27 @@ def log_posterior_grid(potential: Potential, grids: list) -> torch.Tensor:
 
 
 
+def marginal_cdfs_by_quadrature(potential: Potential, z_grids: list) -> list:
+    """Marginal posterior CDFs of every latent site by tensor-grid quadrature in the UNCONSTRAINED
+    coordinates (uniform grids ``z_grids``, one per site), returned as ``(x_grid, cdf, pmf)`` triples
+    in the constrained coordinate (``pmf`` = the probability mass of each grid cell).  Integrating in z keeps priors that are singular at the edge of
+    their support (the reference's Beta(0.5, 0.5) on r0) smooth: the density in z carries the
+    Jacobian, so no grid point sits on an integrable singularity."""
+    mesh = torch.meshgrid(*z_grids, indexing="ij")
+    z = torch.stack([m.reshape(-1) for m in mesh], dim=1).to(potential.device)
+    with torch.no_grad():
+        lj, _ = potential.log_joint(z)
+    p = torch.exp(lj - lj.max()).reshape(mesh[0].shape).cpu()
+    p = p / p.sum()
+    out = []
+    for i, (grid, bij) in enumerate(zip(z_grids, potential.bij.values())):
+        other = tuple(d for d in range(p.dim()) if d != i)
+        marginal = p.sum(other) if other else p
+        cdf = torch.cumsum(marginal, 0) - 0.5 * marginal            # midpoint rule
+        out.append((bij(grid.to(torch.float64)).cpu().numpy(), cdf.numpy(), marginal.numpy()))
+    return out
+
+
 class Adam:
     """Optimizer marker with numpyro's constructor (``numpyro.optim.Adam(step_size=0.1)``)."""
 
@@ -481,4 +502,4 @@ class SVIProcess(InferenceProcess):
 
 
 __all__ = ["Adam", "AutoMultivariateNormal", "InferenceGroups", "InferenceProcess", "MCMCProcess", "MCMCResult", "Potential", "SVIProcess",
-           "SVIResult", "init_to_median", "init_to_sample", "log_posterior_grid"]
+           "SVIResult", "init_to_median", "init_to_sample", "log_posterior_grid", "marginal_cdfs_by_quadrature"]

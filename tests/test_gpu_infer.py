@@ -53,19 +53,20 @@ def test_potential_gradient_matches_finite_differences(data):
 
 
 def _grid_marginals(data):
+    """Exact marginals by quadrature in the unconstrained coordinates (float64 solves)."""
+    from dynode_amd.infer.inference import marginal_cdfs_by_quadrature
+
     odes.enable_x64(True)
     try:
         pot = Potential(ex.model, dict(config=ex.get_config(), tf=100, obs_data=data), 0, torch.device("cuda"))
-        r0 = torch.linspace(1.5 + 1e-4, 2.5 - 1e-4, 401, dtype=torch.float64)   # the prior's whole support
-        ti = torch.linspace(4.5, 10.5, 481, dtype=torch.float64)
-        lp = log_posterior_grid(pot, [r0, ti]).cpu()
+        z_r0 = torch.linspace(-14.0, 14.0, 1401, dtype=torch.float64)      # r0 = 1.5 + sigmoid(z): out to 1e-6 of both edges
+        z_ti = torch.linspace(-6.0, 6.0, 1001, dtype=torch.float64)        # T_inf = 2 + 13 sigmoid(z): 2.03 .. 14.97
+        (g_r0, c_r0, _), (g_ti, c_ti, _) = marginal_cdfs_by_quadrature(pot, [z_r0, z_ti])
     finally:
         odes.enable_x64(False)
-    p = torch.exp(lp - lp.max())
-    p = p / p.sum()
-    # r0 spans the prior's whole support; only the infectious-period box can cut mass off
-    assert float(p[:, 0].sum() + p[:, -1].sum()) < 1e-6 and float(p[0].sum() + p[-1].sum()) < 5e-3
-    return (r0.numpy(), np.cumsum(p.sum(1).numpy())), (ti.numpy(), np.cumsum(p.sum(0).numpy()))
+    for cdf in (c_r0, c_ti):                                               # nothing is cut off at the grid edges
+        assert cdf[0] < 1e-6 and cdf[-1] > 1 - 1e-6
+    return (g_r0, c_r0), (g_ti, c_ti)
 
 
 @pytest.mark.parametrize("sampler,adaptation", [("kernel", "pooled"), ("kernel", "per_chain"), ("graph", "per_chain")])

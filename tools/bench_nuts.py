@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--depth", type=int, default=10)
     ap.add_argument("--sampler", default="kernel", choices=["kernel", "graph", "eager"])
     ap.add_argument("--adaptation", default="pooled", choices=["per_chain", "pooled"])
+    ap.add_argument("--target-accept", type=float, default=0.8)
     ap.add_argument("--fused-likelihood", action="store_true", help="score the observations inside the solve kernel (examples model_fused)")
     args = ap.parse_args()
     import numpy as np, torch, torch.distributed as dist
@@ -38,7 +39,8 @@ def main():
     data = ex.synthetic_incidence(100)
     proc = MCMCProcess(numpyro_model=ex.model_fused if args.fused_likelihood else ex.model, num_warmup=args.warmup, num_samples=args.samples, num_chains=args.chains,
                        nuts_max_tree_depth=args.depth, progress_bar=(rank == 0),
-                       mcmc_kwargs={"sampler": args.sampler, "adaptation": args.adaptation})
+                       mcmc_kwargs={"sampler": args.sampler, "adaptation": args.adaptation},
+                       nuts_kwargs={"target_accept_prob": args.target_accept})
     torch.cuda.synchronize()
     if world > 1: dist.barrier()
     t0 = time.perf_counter()
@@ -50,15 +52,13 @@ def main():
     if rank == 0:
         odes.enable_x64(True)
         pot = Potential(ex.model, dict(config=ex.get_config(), tf=100, obs_data=data), 0, torch.device("cuda"))
-        g0 = torch.linspace(1.5 + 1e-4, 2.5 - 1e-4, 401, dtype=torch.float64); g1 = torch.linspace(4.5, 10.5, 481, dtype=torch.float64)
-        lp = log_posterior_grid(pot, [g0, g1]).cpu(); odes.enable_x64(False)
-        p = torch.exp(lp - lp.max()); p = p / p.sum()
+        from dynode_amd.infer.inference import marginal_cdfs_by_quadrature
+        z0 = torch.linspace(-14.0, 14.0, 1401, dtype=torch.float64); z1 = torch.linspace(-6.0, 6.0, 1001, dtype=torch.float64)
+        (g0, c0, m0), (g1, c1, m1) = marginal_cdfs_by_quadrature(pot, [z0, z1]); odes.enable_x64(False)   # unconstrained-space grid
         ks, quad = {}, {}
-        for name, grid, cdf in (("strains_0_r0", g0.numpy(), np.cumsum(p.sum(1).numpy())),
-                                ("strains_0_infectious_period", g1.numpy(), np.cumsum(p.sum(0).numpy()))):
+        for name, grid, cdf, pdf in (("strains_0_r0", g0, c0, m0), ("strains_0_infectious_period", g1, c1, m1)):
             thin = post[name][:, ::20].reshape(-1).cpu().numpy()
             ks[name] = float(stats.kstest(thin, lambda x: np.interp(x, grid, cdf)).pvalue)
-            pdf = np.diff(np.concatenate([[0.0], cdf]))
             mean = float((grid * pdf).sum())
             quad[name] = {"mean": mean, "sd": float(np.sqrt(((grid - mean) ** 2 * pdf).sum())),
                           "sample_mean": float(post[name].mean()), "sample_sd": float(post[name].std()),
@@ -71,7 +71,7 @@ def main():
         n_trans = args.chains * (args.warmup + args.samples)
         print(json.dumps({
             "workload": "cfg4 sir_infer_parameters: NUTS, 2-age SIR, tf=100, Poisson incidence",
-            "sampler": args.sampler, "adaptation": args.adaptation, "fused_likelihood": args.fused_likelihood, "n_gpus": world, "chains": args.chains, "warmup": args.warmup, "samples": args.samples,
+            "sampler": args.sampler, "adaptation": args.adaptation, "fused_likelihood": args.fused_likelihood, "target_accept": args.target_accept, "n_gpus": world, "chains": args.chains, "warmup": args.warmup, "samples": args.samples,
             "seconds": el, "transitions_per_s": n_trans / el,
             "gradient_solves_per_s_per_gpu": mcmc.nuts.potential_evals / el,
             "chain_gradient_evals_per_s": mcmc.nuts.potential_evals * (args.chains / world) * world / el,
