@@ -48,9 +48,13 @@ NUTS_INT32_FIELDS = ("it", "wi", "n_prop", "depth", "right", "leaf", "s_turn", "
 NUTS_INT64_FIELDS = ("rng_ctr", "pool", "pool_ro")
 
 
+MAX_STRAINS = 8
+
+
 class ModelDescC(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in (
-        "n_age", "n_strain", "has_e", "has_wane", "has_c", "n_wane", "normalize", "seasonal")]
+        "n_age", "n_strain", "has_e", "has_wane", "has_c", "n_wane", "normalize", "seasonal", "has_intro",
+        "reserved")] + [("intro_age_mask", ctypes.c_uint64 * MAX_STRAINS)]
 
 
 class SolverOptsC(ctypes.Structure):
@@ -91,10 +95,14 @@ class ModelDesc:
     n_wane: int = 1
     normalize: bool = True
     seasonal: bool = False
+    has_intro: bool = False          # externally introduced strains (Strain.is_introduced)
+    intro_age_mask: tuple = ()       # per strain: bit a set = age bin a receives the introductions
 
     def c(self) -> ModelDescC:
+        masks = tuple(int(v) for v in self.intro_age_mask) + (0,) * (MAX_STRAINS - len(self.intro_age_mask))
         return ModelDescC(self.n_age, self.n_strain, int(self.has_e), int(self.has_wane),
-                          int(self.has_c), self.n_wane, int(self.normalize), int(self.seasonal))
+                          int(self.has_c), self.n_wane, int(self.normalize), int(self.seasonal),
+                          int(self.has_intro), 0, (ctypes.c_uint64 * MAX_STRAINS)(*masks))
 
     # pure-Python mirrors of dyn_state_dim & co (host logic must not need the .so)
     @property
@@ -113,7 +121,7 @@ class ModelDesc:
 
     @property
     def param_dim(self) -> int:
-        return self.n_strain * (2 + int(self.has_e) + int(self.has_wane)) + (
+        return self.n_strain * (2 + int(self.has_e) + int(self.has_wane) + (3 if self.has_intro else 0)) + (
             3 if self.seasonal else 0)
 
 

@@ -12,7 +12,10 @@ namespace dyn {
 
 #define X(T, METHOD, G, S, E, WN, C, W, ND, SPL) \
     extern template hipError_t launch<T, METHOD, G, S, E, WN, C, W, ND, SPL>(const KArgs<T> &, hipStream_t);
+#define XI(T, METHOD, G, S, E, WN, C, W, ND, SPL) \
+    extern template hipError_t launch<T, METHOD, G, S, E, WN, C, W, ND, SPL, true>(const KArgs<T> &, hipStream_t);
 #include "instances.def"
+#undef XI
 #undef X
 
 template <typename T>
@@ -27,16 +30,21 @@ struct DType<double> {
 };
 
 struct Entry {
-    int dtype, method, G, S, E, WN, C, W, ND, SPL;
+    int dtype, method, G, S, E, WN, C, W, ND, SPL, INTRO;
     void *fn; // hipError_t (*)(const KArgs<T>&, hipStream_t)
 };
 
 static const Entry kEntries[] = {
 #define X(T, METHOD, G, S, E, WN, C, W, ND, SPL)              \
-    {DType<T>::id, METHOD, G, S, E, WN, C, W, ND, SPL,        \
+    {DType<T>::id, METHOD, G, S, E, WN, C, W, ND, SPL, 0,     \
      (void *)(hipError_t(*)(const KArgs<T> &, hipStream_t)) & \
          launch<T, METHOD, G, S, E, WN, C, W, ND, SPL>},
+#define XI(T, METHOD, G, S, E, WN, C, W, ND, SPL)             \
+    {DType<T>::id, METHOD, G, S, E, WN, C, W, ND, SPL, 1,     \
+     (void *)(hipError_t(*)(const KArgs<T> &, hipStream_t)) & \
+         launch<T, METHOD, G, S, E, WN, C, W, ND, SPL, true>},
 #include "instances.def"
+#undef XI
 #undef X
 };
 static constexpr int kNumEntries = sizeof(kEntries) / sizeof(kEntries[0]);
@@ -57,7 +65,7 @@ static const Entry *find_entry(const dyn_model_desc *m, int dtype, int method, i
         const Entry &e = kEntries[i];
         if (e.dtype == dtype && e.method == method && e.G == G && e.S == m->n_strain &&
             e.E == (m->has_e != 0) && e.WN == (m->has_wane != 0) && e.C == (m->has_c != 0) &&
-            e.W == m->n_wane && e.ND == nd) {
+            e.W == m->n_wane && e.ND == nd && e.INTRO == (m->has_intro != 0)) {
             if (!first) first = &e;
             if (want_spl > 0 && e.SPL == want_spl) return &e;
         }
@@ -71,6 +79,7 @@ static int check_model(const dyn_model_desc *m) {
     if (!m) return DYN_ERR_NULL;
     if (m->n_age < 1 || m->n_age > 64 || m->n_strain < 1 || m->n_wane < 1) return DYN_ERR_MODEL;
     if (m->n_wane > 1 && !m->has_wane) return DYN_ERR_MODEL;
+    if (m->has_intro && m->n_strain > DYN_MAX_STRAINS) return DYN_ERR_MODEL;
     return 0;
 }
 
@@ -123,6 +132,7 @@ static int enqueue(const Entry *e, const dyn_model_desc *m, const dyn_solver_opt
     ka.P = dyn_param_dim(m);
     ka.normalize = m->normalize ? 1 : 0;
     ka.seasonal = m->seasonal ? 1 : 0;
+    for (int l = 0; l < DYN_MAX_STRAINS; ++l) ka.intro_mask[l] = m->has_intro ? m->intro_age_mask[l] : 0;
 
     // saved-row layout: saved compartments concatenated in state order
     int32_t off[8];
@@ -233,7 +243,8 @@ int32_t dyn_state_dim(const dyn_model_desc *m) {
 }
 
 int32_t dyn_param_dim(const dyn_model_desc *m) {
-    return m->n_strain * (2 + (m->has_e ? 1 : 0) + (m->has_wane ? 1 : 0)) + (m->seasonal ? 3 : 0);
+    return m->n_strain * (2 + (m->has_e ? 1 : 0) + (m->has_wane ? 1 : 0) + (m->has_intro ? 3 : 0)) +
+           (m->seasonal ? 3 : 0);
 }
 
 int32_t dyn_trajectories_per_wave(const dyn_model_desc *m) {
@@ -285,9 +296,9 @@ static int solve_impl(const dyn_model_desc *m, const dyn_solver_opts *o, const v
     const dyn::Entry *e = dyn::find_entry(m, o->dtype, o->method, n_dir);
     if (!e) {
         snprintf(dyn::tl_error, sizeof(dyn::tl_error),
-                 "no kernel compiled for A=%d S=%d e=%d wane=%d c=%d W=%d dtype=%d method=%d "
+                 "no kernel compiled for A=%d S=%d e=%d wane=%d c=%d W=%d intro=%d dtype=%d method=%d "
                  "tangent directions=%d",
-                 m->n_age, m->n_strain, m->has_e, m->has_wane, m->has_c, m->n_wane, o->dtype,
+                 m->n_age, m->n_strain, m->has_e, m->has_wane, m->has_c, m->n_wane, m->has_intro, o->dtype,
                  o->method, n_dir);
         return DYN_ERR_UNSUPPORTED;
     }

@@ -9,6 +9,9 @@
 namespace dyn {
 #define X(T, METHOD, G, S, E, WN, C, W, ND, SPL) \
     template hipError_t launch<T, METHOD, G, S, E, WN, C, W, ND, SPL>(const KArgs<T> &, hipStream_t);
+#define XI(T, METHOD, G, S, E, WN, C, W, ND, SPL) \
+    template hipError_t launch<T, METHOD, G, S, E, WN, C, W, ND, SPL, true>(const KArgs<T> &, hipStream_t);
 #include "instances.def"
+#undef XI
 #undef X
 } // namespace dyn

@@ -38,6 +38,7 @@ struct KArgs {
     T t0, t1, rtol, atol, constant_dt;
     int32_t y0_batched, n_save, A, P, normalize, seasonal, d_saved, vec_ok;
     int32_t save_off[5]; // offset of s,e,i,r,c inside a saved row; -1 = not saved
+    uint64_t intro_mask[8]; // per strain: bit a set = age bin a receives external introductions
     // fused observation likelihood (tangent kernels only; obs == nullptr: off)
     const T *obs;        // [n_obs][ll_row] observed counts, shared by the batch
     double *ll_out;      // [B] sum of obs * log(rate) - rate
@@ -83,6 +84,7 @@ struct Mth<float> {
     static __device__ __forceinline__ float pow_fast(float x, float e) {
         return __builtin_amdgcn_exp2f(e * __builtin_amdgcn_logf(x));
     }
+    static __device__ __forceinline__ float exp(float x) { return expf(x); } // external-introduction pulse
     // natural log through v_log_f32 (fused Poisson likelihood terms; sums are kept in float64)
     static __device__ __forceinline__ float log(float x) { return __builtin_amdgcn_logf(x) * 0.69314718055994530942f; }
     static __device__ __forceinline__ float inf() { return __builtin_huge_valf(); }
@@ -100,6 +102,7 @@ struct Mth<double> {
     static __device__ __forceinline__ double rcp_fast(double x) { return 1.0 / x; }
     static __device__ __forceinline__ double recip(double x) { return 1.0 / x; }
     static __device__ __forceinline__ double pow_fast(double x, double e) { return ::pow(x, e); }
+    static __device__ __forceinline__ double exp(double x) { return ::exp(x); }
     static __device__ __forceinline__ double log(double x) { return ::log(x); }
     static __device__ __forceinline__ double inf() { return __builtin_huge_val(); }
     static __device__ __forceinline__ double next(double x, double to) { return nextafter(x, to); }
@@ -297,9 +300,11 @@ __device__ __forceinline__ void store_run(T *p, const T (&v)[CNT], bool vec_ok) 
 // the e/i/r/c values of age a for its SPL strains h*SPL .. h*SPL+SPL-1.  SPL == S is the plain
 // one-lane-per-age mapping; splitting the strains (SPL < S) divides the per-lane state, trading
 // replicated control arithmetic for occupancy and smaller lock-step groups.
-template <typename T, int METHOD, int GA, int ST, bool HAS_E, bool HAS_WANE, bool HAS_C, int W, int ND, int SPL>
+template <typename T, int METHOD, int GA, int ST, bool HAS_E, bool HAS_WANE, bool HAS_C, int W, int ND, int SPL,
+          bool INTRO = false>
 struct Solver {
     static_assert(ST % SPL == 0, "strains per lane must divide the strain count");
+    static_assert(!INTRO || ND == 0, "external introductions have no tangent kernels yet");
     static constexpr int S = SPL;        // strains held by one lane (all per-lane arrays use S)
     static constexpr int GS = ST / SPL;  // strain lanes
     static constexpr int G = GA * GS;    // lanes per trajectory
@@ -321,6 +326,8 @@ struct Solver {
     T beta[S], gamma[S], sigma[S], omega[S];
     T Cx[GA]; // Cx[k] = contact[a][a ^ k] (0 outside the matrix)
     T amp, phase, w_season;
+    // external introductions (INTRO): peak day, 1 / scale, percentage / (scale sqrt(2 pi)) * [age receives it]
+    T itime[INTRO ? S : 1], iinv[INTRO ? S : 1], iamp[INTRO ? S : 1];
     // parameter seeds per direction
     T dbeta[NDA][S], dgamma[NDA][S], dsigma[NDA][S], domega[NDA][S];
     T damp[NDA], dphase[NDA], dw_season[NDA];
@@ -377,6 +384,16 @@ struct Solver {
         T x[S], acc[S], foi[S];
 #pragma unroll
         for (int l = 0; l < S; ++l) x[l] = y0[II + l] * invN;
+        if constexpr (INTRO) {
+            // infectious visitors from an untracked population, mixed in around the introduction day:
+            // I_b + Normal(t; time, scale) * percentage * P_b in the force of infection (ode_model.md)
+            const T visitors = normalize ? T(1) : N;
+#pragma unroll
+            for (int l = 0; l < S; ++l) {
+                const T u = (t - itime[l]) * iinv[l];
+                x[l] += (iamp[l] * M::exp(T(-0.5) * u * u)) * visitors;
+            }
+        }
         contract(x, acc);
         T out_s = 0, back_s = 0;
 #pragma unroll
@@ -731,13 +748,24 @@ struct Solver {
         // ---- per-trajectory parameters (broadcast loads inside the lane group)
         {
             const T *p = ka.params + traj * ka.P;
-            constexpr int oS = 2, oW = 2 + (HAS_E ? 1 : 0), oSe = 2 + (HAS_E ? 1 : 0) + (HAS_WANE ? 1 : 0);
+            constexpr int oS = 2, oW = 2 + (HAS_E ? 1 : 0), oI = 2 + (HAS_E ? 1 : 0) + (HAS_WANE ? 1 : 0),
+                          oSe = oI + (INTRO ? 3 : 0);
 #pragma unroll
             for (int l = 0; l < S; ++l) {
                 L.beta[l] = p[s0 + l];
                 L.gamma[l] = p[ST + s0 + l];
                 L.sigma[l] = HAS_E ? p[oS * ST + s0 + l] : T(0);
                 L.omega[l] = HAS_WANE ? p[oW * ST + s0 + l] : T(0);
+            }
+            if constexpr (INTRO) {
+#pragma unroll
+                for (int l = 0; l < S; ++l) {
+                    const T scale = p[(oI + 1) * ST + s0 + l];
+                    const bool here = !L.pad && ((ka.intro_mask[s0 + l] >> aa) & 1ull);
+                    L.itime[l] = p[oI * ST + s0 + l];
+                    L.iinv[l] = T(1) / scale;
+                    L.iamp[l] = here ? p[(oI + 2) * ST + s0 + l] / (scale * T(2.5066282746310002)) : T(0);
+                }
             }
             L.amp = T(0);
             L.phase = T(0);
@@ -1158,14 +1186,16 @@ struct Solver {
     }
 };
 
-template <typename T, int METHOD, int GA, int ST, bool HAS_E, bool HAS_WANE, bool HAS_C, int W, int ND, int SPL>
+template <typename T, int METHOD, int GA, int ST, bool HAS_E, bool HAS_WANE, bool HAS_C, int W, int ND, int SPL,
+          bool INTRO = false>
 __global__ void __launch_bounds__(64)
 solve_kernel(const KArgs<T> ka) {
-    Solver<T, METHOD, GA, ST, HAS_E, HAS_WANE, HAS_C, W, ND, SPL>::run(ka);
+    Solver<T, METHOD, GA, ST, HAS_E, HAS_WANE, HAS_C, W, ND, SPL, INTRO>::run(ka);
 }
 
 // host-side launcher, one explicit instantiation per compiled shape (instances.def)
-template <typename T, int METHOD, int GA, int ST, bool HAS_E, bool HAS_WANE, bool HAS_C, int W, int ND, int SPL>
+template <typename T, int METHOD, int GA, int ST, bool HAS_E, bool HAS_WANE, bool HAS_C, int W, int ND, int SPL,
+          bool INTRO = false>
 hipError_t launch(const KArgs<T> &ka, hipStream_t stream) {
     constexpr int TPW = 64 / (GA * (ST / SPL));
     const int64_t blocks = ((ka.B << ka.rep_log2) + TPW - 1) / TPW;
@@ -1173,7 +1203,7 @@ hipError_t launch(const KArgs<T> &ka, hipStream_t stream) {
     size_t lds = ((size_t)ka.n_save + (ka.n_jump > 0 ? kMaxJumps : 0)) * sizeof(T); // LDS tables
     if (ND > 0 && ka.obs != nullptr && ka.rep_log2 > 0) // likelihood table of the replicated trajectories of a wave
         lds += (size_t)(64 >> ka.rep_log2) * ka.n_save * (SPL * W) * (1 + ND) * sizeof(T);
-    hipLaunchKernelGGL((solve_kernel<T, METHOD, GA, ST, HAS_E, HAS_WANE, HAS_C, W, ND, SPL>),
+    hipLaunchKernelGGL((solve_kernel<T, METHOD, GA, ST, HAS_E, HAS_WANE, HAS_C, W, ND, SPL, INTRO>),
                        dim3((unsigned)blocks), dim3(64), lds, stream, ka);
     return hipGetLastError();
 }

@@ -79,8 +79,53 @@ class SEIRS_Seasonal_ODEParams(AbstractODEParams):
 
 
 @dataclass
+class IntroductionParams:
+    """Strains seeded from an untracked external population (``Strain.is_introduced`` and its
+    ``introduction_*`` fields, reference src/dynode/config/strains.py:53-109).  Around day
+    ``time`` infectious visitors worth ``percentage`` of every receiving age bin's population mix
+    with it, spread in time as a normal density of standard deviation ``scale``; in the force of
+    infection I_b becomes I_b + Normal(t; time, scale) * percentage * P_b (ode_model.md).
+    A strain that is not introduced has percentage 0."""
+
+    time: Any            # [S] or [B, S]   introduction_time (simulation days)
+    scale: Any           # [S] or [B, S]   introduction_scale (days)
+    percentage: Any      # [S] or [B, S]   introduction_percentage
+    ages_mask: Any       # [S, A] of 0/1   Strain.introduction_ages_mask_vector per strain
+
+
+def introduction_params(strains, initialize_date=None) -> Optional["IntroductionParams"]:
+    """`IntroductionParams` from the ``Strain`` objects of a validated ``SimulationConfig`` (which has
+    filled ``introduction_ages_mask_vector``); None when no strain is introduced.  A calendar
+    ``introduction_time`` is converted to simulation days with ``initialize_date``."""
+    import datetime
+
+    if not any(s.is_introduced for s in strains):
+        return None
+    n_age = next(len(s.introduction_ages_mask_vector) for s in strains if s.introduction_ages_mask_vector is not None)
+
+    def day(s):
+        t = s.introduction_time
+        if isinstance(t, datetime.date):
+            if initialize_date is None:
+                raise ValueError("a calendar introduction_time needs the model's initialize_date")
+            return float((t - initialize_date).days)
+        return t if s.is_introduced else 0.0
+
+    live = lambda s, value, default: value if (s.is_introduced and value is not None) else default
+    stack = lambda vals: (torch.stack([v if isinstance(v, torch.Tensor) else torch.as_tensor(float(v), dtype=torch.float64) for v in vals], dim=-1)
+                          if any(isinstance(v, torch.Tensor) for v in vals) else np.array([float(v) for v in vals]))
+    return IntroductionParams(
+        time=stack([day(s) for s in strains]),
+        scale=stack([live(s, s.introduction_scale, 1.0) for s in strains]),
+        percentage=stack([live(s, s.introduction_percentage, 0.0) for s in strains]),
+        ages_mask=np.array([s.introduction_ages_mask_vector if (s.is_introduced and s.introduction_ages_mask_vector is not None)
+                            else [0] * n_age for s in strains], dtype=float))
+
+
+@dataclass
 class SEIRS_MultiStrain_ODEParams(AbstractODEParams):
-    """examples/seirs_multi_strain_age_stratified.py:177-184 (+ optional seasonality, cfg 5)."""
+    """examples/seirs_multi_strain_age_stratified.py:177-184 (+ optional seasonality, cfg 5, and
+    optional external introductions)."""
 
     beta: Any            # [S] or [B, S]
     gamma: Any
@@ -89,6 +134,7 @@ class SEIRS_MultiStrain_ODEParams(AbstractODEParams):
     contact_matrix: Any  # [A, A]
     idx: Optional[SimpleNamespace] = None
     seasonality_params: Optional[SeasonalityParams] = None
+    introduction_params: Optional[IntroductionParams] = None
 
 
 @dataclass
@@ -125,13 +171,31 @@ class CompartmentalODE:
         return f"<CompartmentalODE {self.__name__}>"
 
     # ------------------------------------------------------------------ packing
+    def _strain_columns(self, p) -> list:
+        """(name, value) of every per-strain block of the parameter vector, in kernel order:
+        beta gamma (sigma) (omega) (intro_time intro_scale intro_pct)."""
+        names = ["beta", "gamma"] + (["sigma"] if self.has_e else []) + (["omega"] if self.has_wane else [])
+        cols = [(n, getattr(p, n)) for n in names]
+        intro = getattr(p, "introduction_params", None)
+        if intro is not None:
+            cols += [("introduction time", intro.time), ("introduction scale", intro.scale),
+                     ("introduction percentage", intro.percentage)]
+        return cols
+
+    @staticmethod
+    def _intro_masks(p, A: int, S: int) -> tuple:
+        intro = getattr(p, "introduction_params", None)
+        if intro is None:
+            return ()
+        mask = np.asarray(_np(intro.ages_mask)).reshape(S, A)
+        return tuple(int(sum(1 << a for a in range(A) if mask[l, a] != 0)) for l in range(S))
+
     def _param_matrix(self, p) -> Tuple[np.ndarray, Optional[int], bool]:
         cols, batch = [], None
-        names = ["beta", "gamma"] + (["sigma"] if self.has_e else []) + (["omega"] if self.has_wane else [])
         strain_rank = 1 if self.multi_strain else 0
         arrays = []
-        for n in names:
-            a = _np(getattr(p, n))
+        for n, value in self._strain_columns(p):
+            a = _np(value)
             if not self.multi_strain and a.ndim == 1 and a.size == 1 and strain_rank == 0:
                 a = a.reshape(())  # the examples pass shape-(1,) or scalar for single-strain models
             if a.ndim == strain_rank + 1:
@@ -168,7 +232,6 @@ class CompartmentalODE:
     def param_tensor(self, p, device) -> "torch.Tensor":
         """[B, P] parameter matrix built with torch ops, keeping the autograd graph of any field
         that is a tensor requiring grad (used by the differentiable solve under NUTS)."""
-        names = ["beta", "gamma"] + (["sigma"] if self.has_e else []) + (["omega"] if self.has_wane else [])
         strain_rank = 1 if self.multi_strain else 0
         f64 = torch.float64
 
@@ -177,8 +240,8 @@ class CompartmentalODE:
                 np.asarray(v, dtype=np.float64), device=device)
 
         arrays = []
-        for n in names:
-            a = tt(getattr(p, n))
+        for _, value in self._strain_columns(p):
+            a = tt(value)
             if not self.multi_strain and a.dim() == 1 and a.numel() == 1:
                 a = a.reshape(())
             arrays.append(a)
@@ -202,6 +265,9 @@ class CompartmentalODE:
         seas = getattr(p, "seasonality_params", None)
         if seas is not None:
             leaves += [seas.forcing_amp, seas.forcing_phase, seas.forcing_period]
+        intro = getattr(p, "introduction_params", None)
+        if intro is not None:
+            leaves += [intro.time, intro.scale, intro.percentage]
         return any(isinstance(v, torch.Tensor) and v.requires_grad for v in leaves)
 
     def _contact(self, p, A: int, contact_shape: tuple) -> np.ndarray:
@@ -223,11 +289,11 @@ class CompartmentalODE:
 
     def _param_meta(self, p):
         """(P, batch, seasonal) from SHAPES only -- no device-to-host copy of tensor-valued fields."""
-        names = ["beta", "gamma"] + (["sigma"] if self.has_e else []) + (["omega"] if self.has_wane else [])
+        columns = self._strain_columns(p)
         strain_rank = 1 if self.multi_strain else 0
         batch, S = None, 1
-        for n in names:
-            shape = tuple(getattr(getattr(p, n), "shape", ()))
+        for _, value in columns:
+            shape = tuple(getattr(value, "shape", np.shape(value)))
             if not self.multi_strain and len(shape) == 1 and shape[0] == 1:
                 shape = ()
             if len(shape) == strain_rank + 1:
@@ -241,7 +307,7 @@ class CompartmentalODE:
                 shape = tuple(getattr(getattr(seas, n), "shape", ()))
                 if len(shape) == 1 and shape[0] > 1:
                     batch = shape[0]
-        P = S * len(names) + (3 if seasonal else 0)
+        P = S * len(columns) + (3 if seasonal else 0)
         return P, batch, seasonal
 
     def pack(self, initial_state, p, with_params: bool = True) -> Packed:
@@ -265,7 +331,7 @@ class CompartmentalODE:
             raise ValueError(f"compartment s has shape {s.shape}; expected rank {self.contact_ndim}")
         contact_shape = s.shape[1:] if sbatch is not None else s.shape
         A = int(np.prod(contact_shape))
-        per_strain = 2 + int(self.has_e) + int(self.has_wane)       # beta, gamma (, sigma) (, omega)
+        per_strain = len(self._strain_columns(p))       # beta, gamma (, sigma) (, omega) (, 3 introduction blocks)
         S = (params.shape[1] - (3 if seasonal else 0)) // per_strain if self.multi_strain else 1
         batch = pbatch if pbatch is not None else sbatch
         if pbatch is not None and sbatch is not None and pbatch != sbatch:
@@ -294,8 +360,10 @@ class CompartmentalODE:
                 params = np.ascontiguousarray(np.broadcast_to(params, (sbatch, params.shape[1])))
         else:
             y0 = np.concatenate(flat)
+        masks = self._intro_masks(p, A, S)
         model = ModelDesc(n_age=A, n_strain=S, has_e=self.has_e, has_wane=self.has_wane, has_c=self.has_c,
-                          n_wane=self.n_wane, normalize=self.normalize, seasonal=seasonal)
+                          n_wane=self.n_wane, normalize=self.normalize, seasonal=seasonal,
+                          has_intro=bool(masks), intro_age_mask=masks)
         assert y0.shape[-1] == model.state_dim and params.shape[1] == model.param_dim
         return Packed(model, np.ascontiguousarray(y0), params, self._contact(p, A, contact_shape), batch,
                       tuple(shapes))

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define DYN_ABI_VERSION 1
+#define DYN_ABI_VERSION 2
 /* the save grid is staged in LDS: n_save * sizeof(real) must not exceed this */
 #define DYN_MAX_SAVE_BYTES 49152
 
@@ -42,7 +42,8 @@ extern "C" {
  * State layout per trajectory, "compartment-major", each block row-major:
  *     s[A] | e[A,S] (has_e) | i[A,S] | r[A,S,W] | c[A,S] (has_c)
  * Parameter vector per trajectory (length P = dyn_param_dim):
- *     beta[S] gamma[S] sigma[S] (has_e) omega[S] (has_wane) amp phase period (seasonal)
+ *     beta[S] gamma[S] sigma[S] (has_e) omega[S] (has_wane)
+ *     intro_time[S] intro_scale[S] intro_pct[S] (has_intro)  amp phase period (seasonal)
  * RHS (seirs_multi_strain_age_stratified.py:213-243; S=1/no-e/no-wane reduce to
  * sir_age_stratified.py:127-142, seirs.py:88-95, sir.py:78-84):
  *     N_b = s_b + sum_l (e+i+sum_w r)_{b,l};  x_{b,l} = i_{b,l}/N_b (normalize) else i_{b,l}
@@ -50,7 +51,13 @@ extern "C" {
  *     ds = -sum_l flux + sum_l W*omega_l r_{a,l,W-1};  de = flux - sigma e;  di = sigma e - gamma i
  *     dr_0 = gamma i - W omega r_0;  dr_w = W omega (r_{w-1} - r_w);  dc = flux
  *     season(t) = 1 + amp*sin(2*pi*t/period + phase)      (seirs_seasonal_forcing.py:40-55)
+ * has_intro: strains seeded from an untracked external population (Strain.is_introduced,
+ * introduction_time / _scale / _percentage / _ages: src/dynode/config/strains.py:53-109; the term is
+ * the one of ode_model.md, "I_b + N(mu, sigma) * phi * P_b" inside the force of infection):
+ *     x_{b,l} += intro_pct_l * NormalPdf(t; intro_time_l, intro_scale_l)   for ages b in intro_age_mask[l]
+ *     (times N_b when normalize = 0)
  */
+#define DYN_MAX_STRAINS 8
 typedef struct dyn_model_desc {
     int32_t n_age;     /* A: bins on the contact axis (1..64) */
     int32_t n_strain;  /* S */
@@ -60,6 +67,9 @@ typedef struct dyn_model_desc {
     int32_t n_wane;    /* W >= 1 (W > 1 requires has_wane) */
     int32_t normalize;
     int32_t seasonal;
+    int32_t has_intro; /* ABI 2 */
+    int32_t reserved;
+    uint64_t intro_age_mask[DYN_MAX_STRAINS]; /* per strain: bit a = age bin a receives introductions */
 } dyn_model_desc;
 
 enum { DYN_TSIT5 = 0, DYN_DOPRI5 = 1 };

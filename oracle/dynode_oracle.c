@@ -80,7 +80,8 @@ int32_t dyo_state_dim(const dyo_model_desc *m) {
 }
 
 int32_t dyo_param_dim(const dyo_model_desc *m) {
-    return m->n_strain * (2 + (m->has_e ? 1 : 0) + (m->has_wane ? 1 : 0)) + (m->seasonal ? 3 : 0);
+    return m->n_strain * (2 + (m->has_e ? 1 : 0) + (m->has_wane ? 1 : 0) + (m->has_intro ? 3 : 0)) +
+           (m->seasonal ? 3 : 0);
 }
 
 /* tableau accessors so tests can check the order conditions of what is compiled in */
@@ -98,6 +99,7 @@ const double *dyo_tableau_ptr(int32_t method, int32_t which) {
 #define REAL double
 #define SFX f64
 #define SIN sin
+#define EXP exp
 #define SQRT sqrt
 #define POW pow
 #define FABS fabs
@@ -106,6 +108,7 @@ const double *dyo_tableau_ptr(int32_t method, int32_t which) {
 #undef REAL
 #undef SFX
 #undef SIN
+#undef EXP
 #undef SQRT
 #undef POW
 #undef FABS
@@ -114,6 +117,7 @@ const double *dyo_tableau_ptr(int32_t method, int32_t which) {
 #define REAL float
 #define SFX f32
 #define SIN sinf
+#define EXP expf
 #define SQRT sqrtf
 #define POW powf
 #define FABS fabsf
@@ -122,6 +126,7 @@ const double *dyo_tableau_ptr(int32_t method, int32_t which) {
 #undef REAL
 #undef SFX
 #undef SIN
+#undef EXP
 #undef SQRT
 #undef POW
 #undef FABS

@@ -43,6 +43,10 @@ typedef struct dyo_model_desc {
     int32_t n_wane;    /* W: Erlang stages of r (1 = the reference's single R) */
     int32_t normalize; /* 1: force of infection uses i_b/N_b ; 0: raw i_b */
     int32_t seasonal;  /* beta_t = beta*(1 + amp*sin(2*pi*t/period + phase)) */
+    int32_t has_intro; /* externally introduced strains: x_{b,l} += pct_l * NormalPdf(t; time_l, scale_l)
+                          for the ages b of intro_age_mask[l] (ode_model.md; config/strains.py:53-109) */
+    int32_t reserved;
+    uint64_t intro_age_mask[8];
 } dyo_model_desc;
 
 typedef struct dyo_solver_opts {

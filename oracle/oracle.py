@@ -31,6 +31,9 @@ class _ModelDesc(ctypes.Structure):
         ("n_wane", ctypes.c_int32),
         ("normalize", ctypes.c_int32),
         ("seasonal", ctypes.c_int32),
+        ("has_intro", ctypes.c_int32),
+        ("reserved", ctypes.c_int32),
+        ("intro_age_mask", ctypes.c_uint64 * 8),
     ]
 
 
@@ -59,11 +62,15 @@ class Model:
     n_wane: int = 1
     normalize: bool = True
     seasonal: bool = False
+    has_intro: bool = False
+    intro_age_mask: tuple = ()      # per strain: bit a = age bin a receives external introductions
 
     def c(self) -> _ModelDesc:
+        masks = tuple(int(v) for v in self.intro_age_mask) + (0,) * (8 - len(self.intro_age_mask))
         return _ModelDesc(
             self.n_age, self.n_strain, int(self.has_e), int(self.has_wane), int(self.has_c),
-            self.n_wane, int(self.normalize), int(self.seasonal),
+            self.n_wane, int(self.normalize), int(self.seasonal), int(self.has_intro), 0,
+            (ctypes.c_uint64 * 8)(*masks),
         )
 
 

@@ -23,7 +23,8 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 def omodel(m) -> "O.Model":
     """dynode_amd ModelDesc (or anything with the same fields) -> oracle Model."""
     return O.Model(m.n_age, m.n_strain, bool(m.has_e), bool(m.has_wane), bool(m.has_c), m.n_wane,
-                   bool(m.normalize), bool(m.seasonal))
+                   bool(m.normalize), bool(m.seasonal), bool(getattr(m, "has_intro", False)),
+                   tuple(getattr(m, "intro_age_mask", ())))
 
 
 def split_state(m, y):
@@ -50,6 +51,10 @@ def split_params(m, p):
         out["sigma"] = p[pos:pos + S]; pos += S
     if m.has_wane:
         out["omega"] = p[pos:pos + S]; pos += S
+    if getattr(m, "has_intro", False):
+        out["intro_time"] = p[pos:pos + S]; pos += S
+        out["intro_scale"] = p[pos:pos + S]; pos += S
+        out["intro_pct"] = p[pos:pos + S]; pos += S
     if m.seasonal:
         out["amp"], out["phase"], out["period"] = p[pos:pos + 3]; pos += 3
     assert pos == p.size
@@ -69,6 +74,11 @@ def rhs_numpy(m, t, y, p, C):
     W = m.n_wane
     N = s + i.sum(1) + r.sum((1, 2)) + (e.sum(1) if e is not None else 0.0)
     x = i / N[:, None] if m.normalize else i
+    if getattr(m, "has_intro", False):
+        # externally introduced strains (ode_model.md): I_b + Normal(t; time, scale) * pct * P_b for the masked ages
+        mask = np.array([[(int(m.intro_age_mask[l]) >> b) & 1 for l in range(m.n_strain)] for b in range(m.n_age)], dtype=float)
+        pulse = pr["intro_pct"] * np.exp(-0.5 * ((t - pr["intro_time"]) / pr["intro_scale"]) ** 2) / (pr["intro_scale"] * np.sqrt(2 * np.pi))
+        x = x + mask * pulse[None, :] * (1.0 if m.normalize else N[:, None])
     beta = pr["beta"]
     if m.seasonal:
         beta = beta * (1.0 + pr["amp"] * np.sin(2 * np.pi * t / pr["period"] + pr["phase"]))

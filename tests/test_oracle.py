@@ -33,6 +33,10 @@ def solve(m, y0, p, C, t1, ts=None, **kw):
     ModelDesc(n_age=8, n_strain=4, has_e=True, has_wane=True, has_c=True, seasonal=True),
     ModelDesc(n_age=8, n_strain=4, has_e=True, has_wane=True, has_c=True, n_wane=8),
     ModelDesc(n_age=3, n_strain=2, has_wane=True, n_wane=2),
+    ModelDesc(n_age=3, n_strain=2, has_e=True, has_wane=True, has_c=True, has_intro=True, intro_age_mask=(0b000, 0b110)),
+    ModelDesc(n_age=8, n_strain=4, has_e=True, has_wane=True, has_c=True, seasonal=True, has_intro=True,
+              intro_age_mask=(0, 0xff, 0x0f, 0x81)),
+    ModelDesc(n_age=2, normalize=False, has_intro=True, intro_age_mask=(0b01,)),
 ])
 def test_rhs_matches_numpy_twin(m):
     rng = np.random.default_rng(3)
@@ -41,6 +45,11 @@ def test_rhs_matches_numpy_twin(m):
         p = rng.uniform(0.05, 0.5, m.param_dim)
         if m.seasonal:
             p[-3:] = [0.3, 1.1, 365.0]
+        if m.has_intro:                      # introduction day near the evaluation time, scale in days, a few per cent
+            S, at = m.n_strain, m.param_dim - (3 if m.seasonal else 0) - 3 * m.n_strain
+            p[at:at + S] = rng.uniform(10.0, 25.0, S)
+            p[at + S:at + 2 * S] = rng.uniform(2.0, 8.0, S)
+            p[at + 2 * S:at + 3 * S] = rng.uniform(0.0, 0.05, S)
         C = rng.uniform(0.1, 1.0, (m.n_age, m.n_age))  # asymmetric: catches a transposed C
         got = O.rhs(H.omodel(m), 17.5, y, p, C)
         want = H.rhs_numpy(m, 17.5, y, p, C)
@@ -177,6 +186,35 @@ def test_oracle_vs_scipy_ground_truth(name, method):
         ys, st, na, nr = solve(m, y0, p, C, t1, ts=ts, dtype=dt, method=method)
         assert st[0] == 0
         assert np.abs(ys[0] - want).max() / scale < bound, (name, method, dt)
+
+
+def test_introduced_strain_vs_scipy_ground_truth_and_limits():
+    """External introductions (ode_model.md term; Strain.is_introduced): the oracle against SciPy on
+    the independent NumPy RHS, and the two limits -- zero percentage is the plain model, and a strain
+    that starts at zero only appears once its visitors arrive."""
+    plain = ModelDesc(n_age=3, n_strain=2, has_e=True, has_wane=True, has_c=True)
+    m = ModelDesc(n_age=3, n_strain=2, has_e=True, has_wane=True, has_c=True, has_intro=True, intro_age_mask=(0, 0b010))
+    rng = np.random.default_rng(5)
+    C = synthetic.contact_matrix(rng, 3)
+    y0 = np.zeros(m.state_dim)
+    y0[:3] = [21780.0, 60390.0, 16830.0]
+    y0[3 + 6:3 + 12:2] = [220.0, 610.0, 170.0]                  # resident strain infectious, newcomer absent
+    base = np.array([1.8 / 7, 2.6 / 6, 1 / 7, 1 / 6, 1 / 3, 1 / 2.5, 1 / 120, 1 / 120])
+    p = np.concatenate([base, [0.0, 60.0], [1.0, 5.0], [0.0, 0.005]])
+    ts = synthetic.save_grid(200.0)
+    want = H.ground_truth(m, y0, p, C, 200.0, ts)
+    scale = np.abs(want).max()
+    for method in ("tsit5", "dopri5"):
+        ys, st, _, _ = solve(m, y0, p, C, 200.0, ts=ts, dtype=np.float64, rtol=1e-10, atol=1e-10 * scale, method=method)
+        assert st[0] == 0 and np.abs(ys[0] - want).max() / scale < 2e-8
+        ys32, st, _, _ = solve(m, y0, p, C, 200.0, ts=ts, method=method)
+        assert st[0] == 0 and np.abs(ys32[0] - want).max() / scale < 2e-4
+    newcomer_i = want[:, 3 + 6 + 1:3 + 12:2].sum(1)
+    assert newcomer_i[:40].max() < 1e-6 * scale and newcomer_i[80] > 5.0 and newcomer_i.max() > 5e2
+    p0 = p.copy(); p0[-2:] = 0.0                                # nobody arrives: identical to the plain model
+    a, _, _, _ = solve(m, y0, p0, C, 200.0, ts=ts, dtype=np.float64)
+    b, _, na, nr = solve(plain, y0, base, C, 200.0, ts=ts, dtype=np.float64)
+    assert np.array_equal(a, b)
 
 
 def test_linear_decay_closed_form():
