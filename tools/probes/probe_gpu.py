@@ -1,6 +1,6 @@
 # first GPU parity probe: HIP vs oracle
 import sys, time, numpy as np, torch
-import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import oracle as O
 from dynode_amd import ModelDesc
 from dynode_amd.engine import solve_batch

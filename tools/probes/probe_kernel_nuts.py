@@ -1,6 +1,6 @@
 """dev probe: KernelNUTS vs GraphNUTS on a Gaussian and on cfg4: iterations, step sizes, divergences."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from dynode_amd.infer.nuts import KernelNUTS, GraphNUTS
 

@@ -1,6 +1,6 @@
 """dev probe: where does the per-chain tail of leapfrog counts come from (cfg4, KernelNUTS)?"""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from dynode_amd.infer.nuts import KernelNUTS
 from dynode_amd.infer.inference import Potential, init_to_median

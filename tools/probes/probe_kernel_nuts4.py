@@ -1,6 +1,6 @@
 """dev probe: at which iteration does each chain pass 100/250/450/950/1000/2000 transitions (cfg4, pooled)?"""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from dynode_amd.infer.nuts import KernelNUTS
 from dynode_amd.infer.inference import Potential, init_to_median

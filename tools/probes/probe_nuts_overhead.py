@@ -1,6 +1,6 @@
 """Dev probe: where does a NUTS iteration spend its time on cfg 4?"""
 import os, sys, time, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from dynode_amd.infer.inference import Potential
 from examples import sir_infer_parameters as ex
 data = ex.synthetic_incidence(100)

@@ -1,6 +1,6 @@
 """Dev probe: PCIe-inclusive rate if a consumer wants the whole cfg-3 ensemble on the host."""
 import os, sys, time, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from dynode_amd import synthetic, sharding
 from dynode_amd.engine import solve_batch
 wl = synthetic.seirs_multi_strain(16384, seed=1)

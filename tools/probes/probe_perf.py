@@ -1,6 +1,6 @@
 """Perf probe (dev tool): kernel time vs batch size / save density on the current GPU."""
 import os, sys, numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from dynode_amd import synthetic
 from dynode_amd.engine import solve_batch
 

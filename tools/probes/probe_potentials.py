@@ -1,6 +1,6 @@
 """dev probe: potentials of model vs model_fused vs float64 over a wide grid of unconstrained points."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from dynode_amd.infer.inference import Potential
 from dynode_amd.simulation import odes

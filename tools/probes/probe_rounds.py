@@ -1,5 +1,5 @@
 import os, sys, numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from dynode_amd import synthetic
 from dynode_amd.engine import solve_batch
 wl = synthetic.WORKLOADS[sys.argv[1] if len(sys.argv) > 1 else "cfg3"]()

@@ -1,6 +1,6 @@
 """Dev probe: does sorting the batch by a cheap dynamics proxy reduce lock-step imbalance?"""
 import os, sys, numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from dynode_amd import synthetic
 from probe_perf import timeit

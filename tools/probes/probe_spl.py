@@ -1,7 +1,7 @@
 """Dev probe: parity + speed of the strain-split kernel variants (DYNODE_HIP_SPL) on cfg3."""
 import os, sys, numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))  # helpers.py
 import helpers as H
 from dynode_amd import synthetic
 from dynode_amd.engine import solve_batch

@@ -1,6 +1,6 @@
 """dev probe: tail masses of KernelNUTS draws on analytic targets (1024 chains x 1000 draws)."""
 import sys, os, math
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from scipy import stats
 from dynode_amd.infer.nuts import KernelNUTS, GraphNUTS

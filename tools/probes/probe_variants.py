@@ -1,6 +1,6 @@
 """dev probe: cfg2/cfg3 at the four (dtype, method) combinations, ms per launch and trajectories/s."""
 import os, sys, numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from dynode_amd import synthetic
 from dynode_amd.engine import solve_batch
 
