@@ -304,7 +304,6 @@ template <typename T, int METHOD, int GA, int ST, bool HAS_E, bool HAS_WANE, boo
           bool INTRO = false>
 struct Solver {
     static_assert(ST % SPL == 0, "strains per lane must divide the strain count");
-    static_assert(!INTRO || ND == 0, "external introductions have no tangent kernels yet");
     static constexpr int S = SPL;        // strains held by one lane (all per-lane arrays use S)
     static constexpr int GS = ST / SPL;  // strain lanes
     static constexpr int G = GA * GS;    // lanes per trajectory
@@ -328,7 +327,9 @@ struct Solver {
     T amp, phase, w_season;
     // external introductions (INTRO): peak day, 1 / scale, percentage / (scale sqrt(2 pi)) * [age receives it]
     T itime[INTRO ? S : 1], iinv[INTRO ? S : 1], iamp[INTRO ? S : 1];
+    T ibase[INTRO ? S : 1];  // iamp / percentage (tangents only)
     // parameter seeds per direction
+    T ditime[INTRO ? NDA : 1][INTRO ? S : 1], discale[INTRO ? NDA : 1][INTRO ? S : 1], dipct[INTRO ? NDA : 1][INTRO ? S : 1];
     T dbeta[NDA][S], dgamma[NDA][S], dsigma[NDA][S], domega[NDA][S];
     T damp[NDA], dphase[NDA], dw_season[NDA];
     bool pad, normalize, seasonal;
@@ -384,14 +385,16 @@ struct Solver {
         T x[S], acc[S], foi[S];
 #pragma unroll
         for (int l = 0; l < S; ++l) x[l] = y0[II + l] * invN;
+        T iu[INTRO ? S : 1], ibell[INTRO ? S : 1]; // (t - time) / scale and exp(-u^2 / 2), reused by the tangents
         if constexpr (INTRO) {
             // infectious visitors from an untracked population, mixed in around the introduction day:
             // I_b + Normal(t; time, scale) * percentage * P_b in the force of infection (ode_model.md)
             const T visitors = normalize ? T(1) : N;
 #pragma unroll
             for (int l = 0; l < S; ++l) {
-                const T u = (t - itime[l]) * iinv[l];
-                x[l] += (iamp[l] * M::exp(T(-0.5) * u * u)) * visitors;
+                iu[l] = (t - itime[l]) * iinv[l];
+                ibell[l] = M::exp(T(-0.5) * iu[l] * iu[l]);
+                x[l] += (iamp[l] * ibell[l]) * visitors;
             }
         }
         contract(x, acc);
@@ -450,6 +453,17 @@ struct Solver {
                 T dx[S], dacc[S];
 #pragma unroll
                 for (int l = 0; l < S; ++l) dx[l] = u[II + l] * invN + y0[II + l] * dinvN;
+                if constexpr (INTRO) {
+                    // pulse = pct * base * bell(u), base = mask / (scale sqrt(2 pi)), u = (t - time) / scale:
+                    // d/dtime = pulse * u / scale, d/dscale = pulse * (u^2 - 1) / scale, d/dpct = base * bell
+#pragma unroll
+                    for (int l = 0; l < S; ++l) {
+                        const T pulse = iamp[l] * ibell[l];
+                        T dp = pulse * iinv[l] * (iu[l] * ditime[j][l] + (iu[l] * iu[l] - T(1)) * discale[j][l]) +
+                               (ibase[l] * ibell[l]) * dipct[j][l];
+                        dx[l] += normalize ? dp : dp * N + pulse * dN;
+                    }
+                }
                 contract(dx, dacc);
                 T dout_s = 0, dback_s = 0;
 #pragma unroll
@@ -764,8 +778,13 @@ struct Solver {
                     const bool here = !L.pad && ((ka.intro_mask[s0 + l] >> aa) & 1ull);
                     L.itime[l] = p[oI * ST + s0 + l];
                     L.iinv[l] = T(1) / scale;
-                    L.iamp[l] = here ? p[(oI + 2) * ST + s0 + l] / (scale * T(2.5066282746310002)) : T(0);
+                    L.ibase[l] = here ? T(1) / (scale * T(2.5066282746310002)) : T(0);
+                    L.iamp[l] = L.ibase[l] * p[(oI + 2) * ST + s0 + l];
                 }
+#pragma unroll
+                for (int j = 0; j < NDA; ++j)
+#pragma unroll
+                    for (int l = 0; l < S; ++l) L.ditime[j][l] = L.discale[j][l] = L.dipct[j][l] = T(0);
             }
             L.amp = T(0);
             L.phase = T(0);
@@ -795,6 +814,11 @@ struct Solver {
                         L.dgamma[j][l] = dp[ST + s0 + l];
                         if constexpr (HAS_E) L.dsigma[j][l] = dp[oS * ST + s0 + l];
                         if constexpr (HAS_WANE) L.domega[j][l] = dp[oW * ST + s0 + l];
+                        if constexpr (INTRO) {
+                            L.ditime[j][l] = dp[oI * ST + s0 + l];
+                            L.discale[j][l] = dp[(oI + 1) * ST + s0 + l];
+                            L.dipct[j][l] = dp[(oI + 2) * ST + s0 + l];
+                        }
                     }
                     if (L.seasonal) {
                         const T *dsp = dp + oSe * ST;

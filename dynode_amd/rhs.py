@@ -112,8 +112,16 @@ def introduction_params(strains, initialize_date=None) -> Optional["Introduction
         return t if s.is_introduced else 0.0
 
     live = lambda s, value, default: value if (s.is_introduced and value is not None) else default
-    stack = lambda vals: (torch.stack([v if isinstance(v, torch.Tensor) else torch.as_tensor(float(v), dtype=torch.float64) for v in vals], dim=-1)
-                          if any(isinstance(v, torch.Tensor) for v in vals) else np.array([float(v) for v in vals]))
+    def stack(vals):
+        """per-strain scalars -> [S] (numpy), or a tensor that keeps autograd graphs and batch axes"""
+        tensors = [v for v in vals if isinstance(v, torch.Tensor)]
+        if not tensors:
+            return np.array([float(v) for v in vals])
+        like = tensors[0]
+        parts = [v.to(like) if isinstance(v, torch.Tensor) else torch.as_tensor(float(v), dtype=like.dtype, device=like.device)
+                 for v in vals]
+        return torch.stack(torch.broadcast_tensors(*parts), dim=-1)
+
     return IntroductionParams(
         time=stack([day(s) for s in strains]),
         scale=stack([live(s, s.introduction_scale, 1.0) for s in strains]),

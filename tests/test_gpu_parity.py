@@ -379,6 +379,3 @@ def test_zero_introduction_is_the_plain_model_and_the_example_runs():
     assert np.abs(total - 100_000).max() < 1.0                   # visitors infect, they do not join the population
     later = ex_intro.run_simulation(ex_intro.get_config(introduction_time=120.0), tf=300)
     assert np.argmax(later.ys[cfg.idx.i].cpu().numpy()[:, :, 1].sum(1) > 1.0) > np.argmax(newcomer > 1.0) + 40
-    # no tangent kernels for introduced strains yet: the differentiable path says so
-    with pytest.raises(Exception):
-        solve_batch(m, y0, p, C, t1, ts, dtype=F64, dparams=np.zeros((9, 1, m.param_dim)))
