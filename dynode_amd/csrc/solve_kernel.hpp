@@ -865,6 +865,14 @@ struct Solver {
         const bool constant = ka.constant_dt > T(0);
         T tprev = ka.t0, tnext;
         L.rhs(tprev, y, k[0]);
+        // NaN / inf in the initial state or its derivative (e.g. NaN parameters): fail at once
+        bool lane_ok = true; // comparisons, not x - x: under -ffp-contract an expression minus itself need not be 0
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+            lane_ok = lane_ok && (M::abs(y[0][v]) < M::inf()) && (M::abs(k[0][0][v]) < M::inf());
+        const unsigned long long bad_lanes = __ballot(!lane_ok);
+        const unsigned long long group_mask = (G == 64 ? ~0ull : ((1ull << G) - 1ull)) << (grp * G);
+        const bool start_ok = (bad_lanes & group_mask) == 0ull;
 
         if (constant) {
             tnext = tprev + ka.constant_dt;
@@ -946,8 +954,8 @@ struct Solver {
         T ts_next = save_idx < n_save ? ts_tab[save_idx] : M::inf();
         T ts_next2 = save_idx + R < n_save ? ts_tab[save_idx + R] : M::inf();
         int64_t steps = 0;
-        int32_t n_acc = 0, n_rej = 0, st = ST_OK;
-        bool done = !(tprev < t_end);
+        int32_t n_acc = 0, n_rej = 0, st = start_ok ? ST_OK : ST_NONFINITE;
+        bool done = !(tprev < t_end) || !start_ok;
         T *const out_traj = ka.out + traj * (int64_t)n_save * ka.d_saved;
         T *const dout_traj = ND > 0 ? ka.dout + traj * (int64_t)n_save * ND * ka.d_saved : nullptr;
         const bool vec_ok = ka.vec_ok != 0;
@@ -1006,9 +1014,13 @@ struct Solver {
                     else
                         ss += r * r;
                 }
-                const T err = M::sqrt(group_sum<G>(ss) / Dn);
+                T err = M::sqrt(group_sum<G>(ss) / Dn);
+                // a trial step that blows up (NaN / inf estimate) is a rejected step with infinite
+                // error -- diffeqsolve turns NaN error estimates into inf before the controller --
+                // and only fails the solve when the step cannot shrink any further
+                if (!(err == err)) err = M::inf();
                 keep = err < T(1);
-                finite = (err == err) && (err < M::inf());
+                finite = !(err == M::inf() && !(tprev + T(0.2) * dt > tprev));
                 // factor = clip(safety * err^(-1/order), keep ? 1 : factormin, factormax)
                 // err == 0 -> +inf -> clipped to factormax
                 T f = T(0.9) * M::pow_fast(err, T(-0.2));

@@ -217,6 +217,21 @@ def test_introduced_strain_vs_scipy_ground_truth_and_limits():
     assert np.array_equal(a, b)
 
 
+def test_blown_up_trial_steps_are_rejected_and_nan_inputs_fail_at_once():
+    """diffeqsolve turns a NaN error estimate into an infinite one, i.e. a rejected step shrunk by
+    factormin; only a non-finite starting state / derivative (e.g. NaN parameters) fails the solve."""
+    from test_gpu_parity import fuzz_case      # the randomized sweep's generator (pure NumPy)
+
+    m, y0, p, C, t1, ts, kw = fuzz_case(22857)  # Dopri5 proposes ~120 days right after a discontinuity point
+    ys, st, na, nr = O.solve(H.omodel(m), y0, p, C, t1, ts, dtype=np.float64, **kw)
+    assert st.max() == 0 and np.isfinite(ys).all() and (na[9], nr[9]) == (35, 5)
+    bad = p.copy()
+    bad[3, 0] = np.nan
+    ys, st, na, nr = O.solve(H.omodel(m), y0, bad, C, t1, ts, dtype=np.float64, **kw)
+    assert st[3] == 2 and na[3] == 0 and nr[3] == 0 and np.isinf(ys[3]).all()
+    assert (np.delete(st, 3) == 0).all() and np.isfinite(np.delete(ys, 3, axis=0)).all()
+
+
 def test_linear_decay_closed_form():
     """beta = 0: i(t) = i0 exp(-gamma t), r = r0 + i0 (1 - exp(-gamma t)) -- pins stepper + interpolant."""
     g = 0.2
