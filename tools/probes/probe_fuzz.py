@@ -1,12 +1,16 @@
 """dev probe: the randomized parity sweep of tests/test_gpu_parity.py (fuzz_case / fuzz_compare) at scale.
-    python tools/probes/probe_fuzz.py [n_cases] [first_seed]"""
+    python tools/probes/probe_fuzz.py [n_cases] [first_seed] [f32]"""
 import os, sys
+
+import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from test_gpu_parity import fuzz_case, fuzz_compare
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+dtype = torch.float32 if len(sys.argv) > 3 and sys.argv[3] == "f32" else torch.float64
+bound = 1e-10 if dtype == torch.float64 else 2e-5
 bad = ran = 0
 worst = 0.0
 for seed in range(seed0, seed0 + N):
@@ -15,10 +19,10 @@ for seed in range(seed0, seed0 + N):
         continue
     ran += 1
     try:
-        err, same = fuzz_compare(case)
+        err, same = fuzz_compare(case, dtype)
     except Exception as e:  # noqa: BLE001
         err, same = repr(e)[:200], False
-    if not same or err >= 1e-10:
+    if not same or err >= bound:
         bad += 1
         print("MISMATCH seed", seed, case[0], "t1", case[4], "n_save", len(case[5]), case[6], "err", err, flush=True)
     elif isinstance(err, float):
