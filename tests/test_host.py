@@ -269,3 +269,28 @@ def test_distribution_log_probs_against_scipy():
     np.testing.assert_allclose(dist.Poisson([2.0, 30.0]).log_prob([3.0, 25.0]), stats.poisson([2.0, 30.0]).logpmf([3, 25]),
                                rtol=1e-10)
     assert float(t.median) == pytest.approx(stats.truncnorm(-3, 3.5, loc=8, scale=2).median(), rel=1e-9)
+
+
+def test_reference_sample_tests_object_arrays_objects_and_prefixes():
+    """The remaining cases of reference tests/test_infer/test_sample.py: distributions inside NumPy
+    object arrays and pydantic objects, sample_then_resolve with a prefix, resolved value identity."""
+    from pydantic import BaseModel, ConfigDict
+
+    from dynode_amd.infer import sample_then_resolve
+
+    params = {"a": dist.Normal(), "b": [1, dist.Normal()], "c": np.array([dist.Normal(), 1]),
+              "d": {"nested_dict": dist.Normal()}, "e": DeterministicParameter("a")}
+    with handlers.trace() as tr:
+        out = sample_then_resolve(params, rng_key=0, _prefix="test_")
+    assert list(tr.sites) == ["test_a", "test_b_1", "test_c_0", "test_d_nested_dict", "test_e"]
+    assert isinstance(out["b"][1], torch.Tensor) and isinstance(out["c"][0], torch.Tensor) and out["c"][1] == 1
+    assert float(out["e"]) == float(out["a"])
+
+    class Holder(BaseModel):
+        model_config = ConfigDict(arbitrary_types_allowed=True)
+        x: object
+
+    held = sample_distributions(Holder(x=dist.Normal()), rng_key=0)
+    assert isinstance(held.x, torch.Tensor)
+    both = sample_then_resolve({"a": dist.Normal(), "b": DeterministicParameter("a")}, rng_key=0)
+    assert isinstance(both["a"], torch.Tensor) and both["a"] == both["b"]
