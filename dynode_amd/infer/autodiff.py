@@ -54,6 +54,112 @@ def _identity_seeds(B: int, P: int, start: int, n: int, dtype, device) -> torch.
     return t
 
 
+# ------------------------------------------------------------------ seeding along the latent coordinates
+_BASIS: dict = {}
+
+
+def _rowwise_leaf(params: torch.Tensor):
+    """The sampler's unconstrained coordinates z [B, D] if ``params`` [B, P] is computed from them row
+    by row (`Potential.potential_and_grad` marks its leaf with ``_dynode_rowwise``) and D < P; else None."""
+    if params.grad_fn is None:
+        return None
+    seen, leaves, stack = set(), {}, [params.grad_fn]
+    while stack:
+        fn = stack.pop()
+        if fn is None or fn in seen:
+            continue
+        seen.add(fn)
+        var = getattr(fn, "variable", None)
+        if var is not None:
+            leaves[id(var)] = var
+        stack.extend(f for f, _ in fn.next_functions)
+    if len(leaves) != 1:
+        return None
+    (leaf,) = leaves.values()
+    if not getattr(leaf, "_dynode_rowwise", False) or leaf.dim() != 2 or leaf.shape[0] != params.shape[0]:
+        return None
+    return leaf if leaf.shape[1] < params.shape[1] else None
+
+
+def _latent_seeds(params: torch.Tensor, leaf: torch.Tensor, dtype) -> torch.Tensor:
+    """[B, D, P]: d params[b, :] / d z[b, k] -- one batched backward through the (small) graph from z to
+    the parameter matrix, so that the tangent solve runs D directions instead of P."""
+    B, P = params.shape
+    key = (B, P, params.dtype, str(params.device))
+    basis = _BASIS.get(key)
+    if basis is None:
+        if len(_BASIS) > 16:
+            _BASIS.clear()
+        basis = torch.eye(P, dtype=params.dtype, device=params.device)[:, None, :].expand(P, B, P).contiguous()
+        _BASIS[key] = basis
+    (rows,) = torch.autograd.grad(params, leaf, grad_outputs=basis, is_grads_batched=True, retain_graph=True)
+    return rows.permute(1, 2, 0).to(dtype).contiguous()          # [P, B, D] -> [B, D, P]
+
+
+class _DiffSolveLatent(torch.autograd.Function):
+    """`_DiffSolve` differentiated along the sampler's D latent coordinates instead of the P ODE
+    parameters: ``seeds`` [B, D, P] = d params / d z; the gradient is returned to ``leaf`` directly."""
+
+    @staticmethod
+    def forward(ctx, leaf, params, seeds, model, y0, contact, t1, save_ts, kw):
+        dtype = kw.get("dtype", torch.float32)
+        method = kw.get("method", "tsit5")
+        D = seeds.shape[1]
+        pk = params.to(dtype)
+        ctx.set_materialize_grads(False)
+        jac, res, start = [], None, 0
+        for n in direction_chunks(model, method, dtype, D):
+            res = solve_batch(model, y0, pk, contact, t1, save_ts, dparams=seeds[:, start:start + n].contiguous(), **kw)
+            jac.append(res.dys)
+            start += n
+        J = jac[0] if len(jac) == 1 else torch.cat(jac, dim=2)     # [B, n_save, D, D_saved]
+        ctx.save_for_backward(J)
+        ctx.in_dtype = leaf.dtype
+        ctx.mark_non_differentiable(res.status, res.n_accept, res.n_reject)
+        return res.ys, res.status, res.n_accept, res.n_reject
+
+    @staticmethod
+    def backward(ctx, g_ys, *_unused):
+        (J,) = ctx.saved_tensors
+        if g_ys is None:
+            return (None,) * 9
+        g = torch.einsum("btd,btkd->bk", g_ys.to(J.dtype), J)
+        return (g.to(ctx.in_dtype),) + (None,) * 8
+
+
+class _DiffLogLikLatent(torch.autograd.Function):
+    """`_DiffLogLik` along the latent coordinates (see `_DiffSolveLatent`)."""
+
+    @staticmethod
+    def forward(ctx, leaf, params, seeds, model, y0, contact, t1, save_ts, obs, comp, increments, floor, kw):
+        dtype = kw.get("dtype", torch.float32)
+        method = kw.get("method", "tsit5")
+        D = seeds.shape[1]
+        pk = params.to(dtype)
+        ctx.set_materialize_grads(False)
+        grads, logp, stats, start = [], None, None, 0
+        for n in direction_chunks(model, method, dtype, D):
+            lp, dlp, st, na, nr = solve_batch_loglik(model, y0, pk, contact, t1, save_ts, obs, comp,
+                                                     dparams=seeds[:, start:start + n].contiguous(),
+                                                     increments=increments, floor=floor, **kw)
+            logp = lp if logp is None else logp
+            stats = (st, na, nr)
+            grads.append(dlp)
+            start += n
+        G = grads[0] if len(grads) == 1 else torch.cat(grads, dim=1)      # [B, D]
+        ctx.save_for_backward(G)
+        ctx.in_dtype = leaf.dtype
+        ctx.mark_non_differentiable(*stats)
+        return (logp,) + stats
+
+    @staticmethod
+    def backward(ctx, g, *_unused):
+        (G,) = ctx.saved_tensors
+        if g is None:
+            return (None,) * 13
+        return ((g.unsqueeze(-1) * G).to(ctx.in_dtype),) + (None,) * 12
+
+
 class _DiffSolve(torch.autograd.Function):
     @staticmethod
     def forward(ctx, params, model, y0, contact, t1, save_ts, kw):
@@ -88,7 +194,12 @@ def solve_batch_diff(model, y0, params: torch.Tensor, contact, t1, save_ts, **kw
     """Like ``engine.solve_batch`` but differentiable with respect to ``params`` ([B, P] tensor)."""
     from ..engine import BatchResult, save_mask_bytes
 
-    ys, status, n_acc, n_rej = _DiffSolve.apply(params, model, y0, contact, t1, save_ts, kw)
+    leaf = _rowwise_leaf(params)
+    if leaf is not None:      # D latent coordinates < P parameters: D tangent directions are enough
+        seeds = _latent_seeds(params, leaf, kw.get("dtype", torch.float32))
+        ys, status, n_acc, n_rej = _DiffSolveLatent.apply(leaf, params.detach(), seeds, model, y0, contact, t1, save_ts, kw)
+    else:
+        ys, status, n_acc, n_rej = _DiffSolve.apply(params, model, y0, contact, t1, save_ts, kw)
     _, saved, sizes = save_mask_bytes(model, kw.get("save_mask"))
     return BatchResult(ys, status, n_acc, n_rej, saved, sizes)
 
@@ -130,5 +241,10 @@ class _DiffLogLik(torch.autograd.Function):
 def solve_loglik_diff(model, y0, params: torch.Tensor, contact, t1, save_ts, obs, obs_compartment: int, *,
                       increments: bool = True, floor: float = 1e-6, **kw):
     """``(logp [B], status, n_accept, n_reject)``, differentiable with respect to ``params``."""
+    leaf = _rowwise_leaf(params)
+    if leaf is not None:
+        seeds = _latent_seeds(params, leaf, kw.get("dtype", torch.float32))
+        return _DiffLogLikLatent.apply(leaf, params.detach(), seeds, model, y0, contact, t1, save_ts, obs,
+                                       int(obs_compartment), bool(increments), float(floor), kw)
     return _DiffLogLik.apply(params, model, y0, contact, t1, save_ts, obs, int(obs_compartment), bool(increments),
                              float(floor), kw)

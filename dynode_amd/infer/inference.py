@@ -108,6 +108,9 @@ class Potential:
 
     def potential_and_grad(self, z: torch.Tensor):
         z = z.detach().requires_grad_(True)
+        # every chain's parameters depend on its own row of z only: lets the differentiable solve seed
+        # its tangents along the D latent coordinates instead of the P ODE parameters (autodiff.py)
+        z._dynode_rowwise = True
         lj, _ = self.log_joint(z)
         minus = self._ones.get(lj.shape[0])
         if minus is None or minus.device != lj.device:

@@ -118,8 +118,7 @@ def introduction_params(strains, initialize_date=None) -> Optional["Introduction
         if not tensors:
             return np.array([float(v) for v in vals])
         like = tensors[0]
-        parts = [v.to(like) if isinstance(v, torch.Tensor) else torch.as_tensor(float(v), dtype=like.dtype, device=like.device)
-                 for v in vals]
+        parts = [v.to(like) if isinstance(v, torch.Tensor) else torch.full_like(like, float(v)) for v in vals]
         return torch.stack(torch.broadcast_tensors(*parts), dim=-1)
 
     return IntroductionParams(
@@ -244,8 +243,11 @@ class CompartmentalODE:
         f64 = torch.float64
 
         def tt(v):
-            return v.to(device=device, dtype=f64) if isinstance(v, torch.Tensor) else torch.as_tensor(
-                np.asarray(v, dtype=np.float64), device=device)
+            if isinstance(v, torch.Tensor):
+                return v.to(device=device, dtype=f64)
+            from .engine import _dev      # constants: cached device copies (no host-to-device copy per gradient)
+
+            return _dev(np.asarray(v, dtype=np.float64), f64, device)
 
         arrays = []
         for _, value in self._strain_columns(p):

@@ -338,3 +338,54 @@ def test_nuts_with_fused_likelihood_matches_grid_quadrature(data):
     for name, grid, cdf in (("strains_0_r0", g_r0, cdf_r0), ("strains_0_infectious_period", g_ti, cdf_ti)):
         thin = post[name][:, ::10].reshape(-1).cpu().numpy()
         assert stats.kstest(thin, lambda x: np.interp(x, grid, cdf)).pvalue > 1e-3
+
+
+def test_tangents_are_seeded_along_the_latent_coordinates():
+    """14 ODE parameters, 2 sampled: the gradient-solve runs 2 tangent directions (one launch), not 14
+    (seven launches), and gives the same potential and gradient (examples/infer_introduction_time.py)."""
+    from dynode_amd import engine
+    from dynode_amd.infer import autodiff
+    from examples import infer_introduction_time as ex_t
+
+    obs = ex_t.synthetic_incidence(150)
+    pot = Potential(ex_t.model, dict(config=ex_t.get_config(), tf=150, obs_data=obs), 0, torch.device("cuda"))
+    assert list(pot.latent) == ["strains_1_introduction_time", "strains_1_introduction_percentage"]
+    z = pot.initial(24, init_to_median, 0) + 0.3 * torch.randn(24, 2, dtype=torch.float64, generator=torch.Generator().manual_seed(3)).cuda()
+    calls = []
+    real = engine.solve_batch_loglik
+
+    def counting(*a, **k):
+        calls.append(int(k["dparams"].shape[1]))
+        return real(*a, **k)
+
+    autodiff.solve_batch_loglik = counting
+    try:
+        u1, g1 = pot.potential_and_grad(z)
+        latent_calls, calls[:] = list(calls), []
+        keep, autodiff._rowwise_leaf = autodiff._rowwise_leaf, lambda params: None      # the P-direction path
+        try:
+            u2, g2 = pot.potential_and_grad(z)
+        finally:
+            autodiff._rowwise_leaf = keep
+        full_calls = list(calls)
+    finally:
+        autodiff.solve_batch_loglik = real
+    assert latent_calls == [2] and sum(full_calls) == 14 and len(full_calls) == 7
+    assert torch.allclose(u1, u2, rtol=1e-12, atol=1e-9)
+    assert torch.allclose(g1, g2, rtol=1e-4, atol=1e-4 * float(g2.abs().max())), float((g1 - g2).abs().max())
+
+
+def test_nuts_recovers_the_introduction_time():
+    from examples import infer_introduction_time as ex_t
+
+    obs = ex_t.synthetic_incidence(150)
+    process = MCMCProcess(numpyro_model=ex_t.model, num_warmup=200, num_samples=200, num_chains=24, nuts_max_tree_depth=8,
+                          progress_bar=False)
+    mcmc = process.infer(config=ex_t.get_config(), tf=150, obs_data=obs)
+    post = process.get_samples()
+    t, pct = post["strains_1_introduction_time"].cpu().numpy(), post["strains_1_introduction_percentage"].cpu().numpy()
+    print("introduction time %.2f +- %.2f, percentage %.5f +- %.5f, leapfrogs/transition %.1f" % (
+        t.mean(), t.std(), pct.mean(), pct.std(), float(mcmc.nuts.num_steps.double().mean())))
+    # noiseless data: the posterior sits on the truth (time and size trade off along a ridge)
+    assert abs(t.mean() - 60.0) < max(3 * t.std(), 1.0) and abs(pct.mean() - 0.005) < max(3 * pct.std(), 5e-4)
+    assert t.std() < 5.0 and int(mcmc.nuts.diverging.sum()) <= 10
