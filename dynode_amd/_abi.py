@@ -29,7 +29,7 @@ EXPORTED_SYMBOLS = (
     "dyn_compartment_offsets", "dyn_is_supported", "dyn_trajectories_per_wave",
     "dyn_last_error", "dyn_solve_batch", "dyn_solve_batch_jvp", "dyn_is_supported_jvp",
     "dyn_nuts_advance", "dyn_nuts_state_size", "dyn_philox4x32_10", "dyn_latent_sites",
-    "dyn_solve_batch_loglik",
+    "dyn_solve_batch_loglik", "dyn_register_instance",
 )
 
 MAX_SITES = 8
@@ -177,6 +177,8 @@ def lib() -> ctypes.CDLL:
             ctypes.c_double, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32,
             ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
         ]
+        L.dyn_register_instance.restype = ctypes.c_int
+        L.dyn_register_instance.argtypes = [ctypes.c_int32] * 11 + [ctypes.c_void_p]
         L.dyn_nuts_advance.restype = ctypes.c_int
         L.dyn_nuts_advance.argtypes = [ctypes.POINTER(NutsStateC), ctypes.c_void_p]
         L.dyn_nuts_state_size.restype = ctypes.c_int32

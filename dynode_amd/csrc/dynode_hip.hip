@@ -8,6 +8,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
+#include <mutex>
+
 namespace dyn {
 
 #define X(T, METHOD, G, S, E, WN, C, W, ND, SPL) \
@@ -55,6 +58,18 @@ static int group_width(int A) {
     return g;
 }
 
+// shapes added at run time (dyn_register_instance): a fixed table, appended under a mutex, entries
+// never move or disappear, so readers need no lock beyond the count's acquire load
+static Entry g_extra[256];
+static std::atomic<int> g_n_extra{0};
+static std::mutex g_extra_mutex;
+
+static bool matches(const Entry &e, const dyn_model_desc *m, int G, int dtype, int method, int nd) {
+    return e.dtype == dtype && e.method == method && e.G == G && e.S == m->n_strain &&
+           e.E == (m->has_e != 0) && e.WN == (m->has_wane != 0) && e.C == (m->has_c != 0) &&
+           e.W == m->n_wane && e.ND == nd && e.INTRO == (m->has_intro != 0);
+}
+
 static const Entry *find_entry(const dyn_model_desc *m, int dtype, int method, int nd = 0) {
     const int G = group_width(m->n_age);
     // DYNODE_HIP_SPL=<n> (tuning aid): prefer the variant with n strains per lane
@@ -63,9 +78,15 @@ static const Entry *find_entry(const dyn_model_desc *m, int dtype, int method, i
     const Entry *first = nullptr;
     for (int i = 0; i < kNumEntries; ++i) {
         const Entry &e = kEntries[i];
-        if (e.dtype == dtype && e.method == method && e.G == G && e.S == m->n_strain &&
-            e.E == (m->has_e != 0) && e.WN == (m->has_wane != 0) && e.C == (m->has_c != 0) &&
-            e.W == m->n_wane && e.ND == nd && e.INTRO == (m->has_intro != 0)) {
+        if (matches(e, m, G, dtype, method, nd)) {
+            if (!first) first = &e;
+            if (want_spl > 0 && e.SPL == want_spl) return &e;
+        }
+    }
+    const int n_extra = g_n_extra.load(std::memory_order_acquire);
+    for (int i = 0; i < n_extra; ++i) {
+        const Entry &e = g_extra[i];
+        if (matches(e, m, G, dtype, method, nd)) {
             if (!first) first = &e;
             if (want_spl > 0 && e.SPL == want_spl) return &e;
         }
@@ -73,7 +94,7 @@ static const Entry *find_entry(const dyn_model_desc *m, int dtype, int method, i
     return first;
 }
 
-static thread_local char tl_error[256] = "";
+static thread_local char tl_error[512] = "";
 
 static int check_model(const dyn_model_desc *m) {
     if (!m) return DYN_ERR_NULL;
@@ -295,11 +316,15 @@ static int solve_impl(const dyn_model_desc *m, const dyn_solver_opts *o, const v
         if (!(o->jump_ts[j] > o->jump_ts[j - 1])) return DYN_ERR_JUMP; /* must be strictly increasing */
     const dyn::Entry *e = dyn::find_entry(m, o->dtype, o->method, n_dir);
     if (!e) {
+        const int ga = dyn::group_width(m->n_age);
         snprintf(dyn::tl_error, sizeof(dyn::tl_error),
-                 "no kernel compiled for A=%d S=%d e=%d wane=%d c=%d W=%d intro=%d dtype=%d method=%d "
-                 "tangent directions=%d",
+                 "no kernel compiled for A=%d S=%d e=%d wane=%d c=%d W=%d intro=%d dtype=%d method=%d tangent "
+                 "directions=%d; to add it put  %s(%s, %d, %d, %d, %s, %s, %s, %d, %d, %d)  into "
+                 "dynode_amd/csrc/instances.def and rebuild (make -C dynode_amd/csrc)",
                  m->n_age, m->n_strain, m->has_e, m->has_wane, m->has_c, m->n_wane, m->has_intro, o->dtype,
-                 o->method, n_dir);
+                 o->method, n_dir, m->has_intro ? "XI" : "X", o->dtype == DYN_F64 ? "double" : "float", o->method,
+                 ga, m->n_strain, m->has_e ? "true" : "false", m->has_wane ? "true" : "false",
+                 m->has_c ? "true" : "false", m->n_wane, n_dir, m->n_strain);
         return DYN_ERR_UNSUPPORTED;
     }
     if (B == 0) return 0;
@@ -368,6 +393,23 @@ int dyn_solve_batch_loglik(const dyn_model_desc *m, const dyn_solver_opts *o, co
     return solve_impl(m, o, y0, y0_is_batched, params, contact, B, t0, t1, save_ts, n_save, nullptr,
                       nullptr, status, n_accept, n_reject, stream, n_dir, dparams, dy0, dy0_is_batched,
                       nullptr, &ll);
+}
+
+int dyn_register_instance(int32_t dtype, int32_t method, int32_t ga, int32_t n_strain, int32_t has_e,
+                          int32_t has_wane, int32_t has_c, int32_t n_wane, int32_t n_dir, int32_t spl,
+                          int32_t has_intro, void *launch_fn) {
+    if (!launch_fn) return DYN_ERR_NULL;
+    if ((dtype != DYN_F32 && dtype != DYN_F64) || (method != DYN_TSIT5 && method != DYN_DOPRI5)) return DYN_ERR_OPTS;
+    if (ga < 1 || ga > 64 || (ga & (ga - 1)) || n_strain < 1 || n_strain > 64 || spl < 1 || n_strain % spl ||
+        n_wane < 1 || n_dir < 0 || ga * (n_strain / spl) > 64)
+        return DYN_ERR_MODEL;
+    std::lock_guard<std::mutex> lock(dyn::g_extra_mutex);
+    const int n = dyn::g_n_extra.load(std::memory_order_relaxed);
+    if (n >= (int)(sizeof(dyn::g_extra) / sizeof(dyn::g_extra[0]))) return DYN_ERR_SIZE;
+    dyn::g_extra[n] = dyn::Entry{dtype, method, ga, n_strain, has_e != 0, has_wane != 0, has_c != 0, n_wane, n_dir,
+                                 spl, has_intro != 0, launch_fn};
+    dyn::g_n_extra.store(n + 1, std::memory_order_release);
+    return 0;
 }
 
 int32_t dyn_is_supported_jvp(const dyn_model_desc *m, const dyn_solver_opts *o, int32_t n_dir) {

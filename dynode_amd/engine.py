@@ -30,6 +30,18 @@ class SolveError(RuntimeError):
         super().__init__(f"dyn_solve_batch failed: {name}" + (f" ({detail})" if detail else ""))
 
 
+def _call_with_jit(call, L, model, dtype, method, n_dir) -> int:
+    """Run the library call; if the only problem is a kernel shape that is not compiled in, build and
+    register it (dynode_amd/jit.py) and call again."""
+    rc = call()
+    if rc == -7 and L.dyn_last_error().decode().startswith("no kernel compiled"):
+        from . import jit
+
+        if jit.enabled() and jit.ensure_kernel(model, dtype, method, n_dir):
+            rc = call()
+    return rc
+
+
 @dataclass
 class BatchResult:
     """Outputs of one batched solve, all resident on the device."""
@@ -152,20 +164,22 @@ def solve_batch(model: ModelDesc, y0, params, contact, t1: float, save_ts, *, t0
         float(constant_dt),
         jt.ctypes.data_as(ctypes.POINTER(ctypes.c_double)) if jt.size else None, int(jt.size))
     s = stream if stream is not None else torch.cuda.current_stream(device)
-    if n_dir == 0:
-        rc = L.dyn_solve_batch(
-            ctypes.byref(model.c()), ctypes.byref(opts), y0_t.data_ptr(), int(batched),
-            params_t.data_ptr(), contact_t.data_ptr(), B, float(t0), float(t1), ts_t.data_ptr(),
-            n_save, mask_c, out.data_ptr(), status.data_ptr(), n_acc.data_ptr(), n_rej.data_ptr(),
-            ctypes.c_void_p(s.cuda_stream))
-    else:
-        rc = L.dyn_solve_batch_jvp(
+    def call():
+        if n_dir == 0:
+            return L.dyn_solve_batch(
+                ctypes.byref(model.c()), ctypes.byref(opts), y0_t.data_ptr(), int(batched),
+                params_t.data_ptr(), contact_t.data_ptr(), B, float(t0), float(t1), ts_t.data_ptr(),
+                n_save, mask_c, out.data_ptr(), status.data_ptr(), n_acc.data_ptr(), n_rej.data_ptr(),
+                ctypes.c_void_p(s.cuda_stream))
+        return L.dyn_solve_batch_jvp(
             ctypes.byref(model.c()), ctypes.byref(opts), y0_t.data_ptr(), int(batched),
             params_t.data_ptr(), contact_t.data_ptr(), B, float(t0), float(t1), ts_t.data_ptr(),
             n_save, mask_c, n_dir, dparams_t.data_ptr(),
             dy0_t.data_ptr() if dy0_t is not None else None,
             int(dy0_t is not None and dy0_t.dim() == 3), out.data_ptr(), dout.data_ptr(),
             status.data_ptr(), n_acc.data_ptr(), n_rej.data_ptr(), ctypes.c_void_p(s.cuda_stream))
+
+    rc = _call_with_jit(call, L, model, dtype, method, n_dir)
     if rc != 0:
         raise SolveError(rc, L.dyn_last_error().decode())
     # keep inputs alive until the stream has consumed them
@@ -229,13 +243,16 @@ def solve_batch_loglik(model: ModelDesc, y0, params, contact, t1: float, save_ts
         _METHODS[method], _DTYPES[dtype], float(rtol), float(atol), int(max_steps), float(constant_dt),
         jt.ctypes.data_as(ctypes.POINTER(ctypes.c_double)) if jt.size else None, int(jt.size))
     s = stream if stream is not None else torch.cuda.current_stream(device)
-    rc = L.dyn_solve_batch_loglik(
-        ctypes.byref(model.c()), ctypes.byref(opts), y0_t.data_ptr(), int(batched), params_t.data_ptr(),
-        contact_t.data_ptr(), B, float(t0), float(t1), ts_t.data_ptr(), n_save, int(obs_compartment),
-        int(bool(increments)), float(floor), obs_t.data_ptr(), n_dir, dparams_t.data_ptr(),
-        dy0_t.data_ptr() if dy0_t is not None else None, int(dy0_t is not None and dy0_t.dim() == 3),
-        logp.data_ptr(), dlogp.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(),
-        ctypes.c_void_p(s.cuda_stream))
+    def call():
+        return L.dyn_solve_batch_loglik(
+            ctypes.byref(model.c()), ctypes.byref(opts), y0_t.data_ptr(), int(batched), params_t.data_ptr(),
+            contact_t.data_ptr(), B, float(t0), float(t1), ts_t.data_ptr(), n_save, int(obs_compartment),
+            int(bool(increments)), float(floor), obs_t.data_ptr(), n_dir, dparams_t.data_ptr(),
+            dy0_t.data_ptr() if dy0_t is not None else None, int(dy0_t is not None and dy0_t.dim() == 3),
+            logp.data_ptr(), dlogp.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(),
+            ctypes.c_void_p(s.cuda_stream))
+
+    rc = _call_with_jit(call, L, model, dtype, method, n_dir)
     if rc != 0:
         raise SolveError(rc, L.dyn_last_error().decode())
     for t in (y0_t, params_t, contact_t, ts_t, obs_t, dparams_t, dy0_t):

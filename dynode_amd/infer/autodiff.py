@@ -28,6 +28,12 @@ def direction_chunks(model, method: str, dtype, P: int) -> list:
     """Split P seed directions into chunks the library has kernels for (largest first)."""
     sizes = [n for n in range(P, 0, -1) if _supported_nd(model, method, dtype, n)]
     if not sizes:
+        from .. import jit
+
+        if jit.enabled():          # no tangent kernel for this shape yet: build the 2-direction one (1 if P == 1)
+            jit.ensure_kernel(model, dtype, method, min(P, 2))
+            sizes = [n for n in range(P, 0, -1) if _supported_nd(model, method, dtype, n)]
+    if not sizes:
         raise RuntimeError(f"no tangent kernel compiled for {model} (method={method}, dtype={dtype})")
     chunks, left = [], P
     while left:

@@ -1,0 +1,122 @@
+"""Kernel shapes on demand: compile one explicit instantiation of the solver template with hipcc and
+register it with the library (``dyn_register_instance``).
+
+``libdynode_hip.so`` ships the shapes of ``csrc/instances.def`` (the reference's examples, the
+BASELINE configurations, their tangent kernels).  Any other member of the RHS family -- 5 ages x 2
+strains, an SEIR without waning, a 12-stage waning chain, ... -- is the same template with different
+constants; the first call with such a model builds ``dynode_amd/lib/jit/<shape>.so`` (10-20 s, kept
+on disk) and later calls and processes load it directly.  This is template instantiation, not
+tracing: the kernel source is csrc/solve_kernel.hpp, unchanged.
+
+Disable with ``DYNODE_HIP_JIT=0`` (the call then fails with the library's "no kernel compiled for
+..." message, which also names the line to add to instances.def for a permanent build).
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+import threading
+
+import torch
+
+from . import _abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_HERE, "csrc")
+_OUT = os.path.join(_HERE, "lib", "jit")
+_LOCK = threading.Lock()
+_LOADED: dict = {}
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+def enabled() -> bool:
+    return os.environ.get("DYNODE_HIP_JIT", "1") != "0"
+
+
+def _group_width(n_age: int) -> int:
+    g = 1
+    while g < n_age:
+        g <<= 1
+    return g
+
+
+def choose_spl(model: _abi.ModelDesc, n_dir: int) -> int:
+    """Strains per lane: all of them on one lane per age while the register file holds it (y, 7 stage
+    derivatives and the stage state of every plane: 9 * values * planes VGPRs), otherwise split the
+    strains over a power-of-two number of lanes (csrc/solve_kernel.hpp, "Strain lanes")."""
+    ga, S = _group_width(model.n_age), model.n_strain
+    per_strain = int(model.has_e) + 1 + model.n_wane + int(model.has_c)
+    best = None
+    for spl in range(S, 0, -1):
+        gs = S // spl
+        if S % spl or gs & (gs - 1) or ga * gs > 64:
+            continue
+        best = spl
+        if 9 * (1 + spl * per_strain) * (1 + n_dir) <= 230:
+            return spl
+    if best is None:
+        raise RuntimeError(f"no lane mapping for {model}: {S} strains cannot be split over a power-of-two number of lanes")
+    if 9 * (1 + best * per_strain) * (1 + n_dir) > 480:
+        raise RuntimeError(f"{model} with {n_dir} tangent directions needs about {9 * (1 + best * per_strain) * (1 + n_dir)} "
+                           "vector registers per lane: too large for the register-resident kernel (512 per lane)")
+    return best
+
+
+def _name(model, dtype, method, n_dir, spl) -> str:
+    return (f"{'f64' if dtype == torch.float64 else 'f32'}_m{method}_g{_group_width(model.n_age)}_s{model.n_strain}"
+            f"_e{int(model.has_e)}w{int(model.has_wane)}c{int(model.has_c)}_W{model.n_wane}_nd{n_dir}_spl{spl}"
+            f"_i{int(model.has_intro)}")
+
+
+def _source(model, dtype, method, n_dir, spl) -> str:
+    t = "double" if dtype == torch.float64 else "float"
+    b = lambda v: "true" if v else "false"
+    args = (f"{t}, {method}, {_group_width(model.n_age)}, {model.n_strain}, {b(model.has_e)}, {b(model.has_wane)}, "
+            f"{b(model.has_c)}, {model.n_wane}, {n_dir}, {spl}, {b(model.has_intro)}")
+    return (f'#include "{os.path.join(_CSRC, "solve_kernel.hpp")}"\n'
+            f"namespace dyn {{ template hipError_t launch<{args}>(const KArgs<{t}> &, hipStream_t); }}\n"
+            f'extern "C" void *dyn_extra_launch(void) {{\n'
+            f"    return (void *)(hipError_t(*)(const dyn::KArgs<{t}> &, hipStream_t)) & dyn::launch<{args}>;\n}}\n")
+
+
+def ensure_kernel(model: _abi.ModelDesc, dtype=torch.float32, method: str = "tsit5", n_dir: int = 0) -> bool:
+    """Make sure a kernel for (model shape, dtype, method, n_dir) exists; returns True if one had to be
+    built or loaded.  Raises if hipcc is missing or the shape cannot be mapped to lanes."""
+    mid = {"tsit5": _abi.DYN_TSIT5, "dopri5": _abi.DYN_DOPRI5}[method]
+    L = _abi.lib()
+    opts = _abi.SolverOptsC(mid, _abi.DYN_F64 if dtype == torch.float64 else _abi.DYN_F32, 1e-5, 1e-6, 10**6, 0.0, None, 0)
+    mc = model.c()
+    have = (L.dyn_is_supported_jvp(ctypes.byref(mc), ctypes.byref(opts), n_dir) if n_dir
+            else L.dyn_is_supported(ctypes.byref(mc), ctypes.byref(opts)))
+    if have:
+        return False
+    spl = choose_spl(model, n_dir)
+    name = _name(model, dtype, mid, n_dir, spl)
+    with _LOCK:
+        if name in _LOADED:
+            return False
+        os.makedirs(_OUT, exist_ok=True)
+        so = os.path.join(_OUT, name + ".so")
+        if not os.path.exists(so):
+            if not os.path.exists(HIPCC):
+                raise RuntimeError(f"{HIPCC} not found: cannot build the kernel for {model}; add it to csrc/instances.def "
+                                   "on a machine with ROCm and rebuild")
+            src = os.path.join(_OUT, name + ".hip")
+            with open(src, "w") as f:
+                f.write(_source(model, dtype, mid, n_dir, spl))
+            tmp = so + f".{os.getpid()}.tmp"
+            print(f"[dynode_amd] building the kernel for {name} (one-off, ~15 s) ...", flush=True)
+            subprocess.run([HIPCC, "-O3", "-std=c++17", "-fPIC", "-shared", "--offload-arch=gfx950", src, "-o", tmp],
+                           check=True)
+            os.replace(tmp, so)            # atomic: concurrent ranks never load a half-written file
+        extra = ctypes.CDLL(so)
+        extra.dyn_extra_launch.restype = ctypes.c_void_p
+        rc = L.dyn_register_instance(opts.dtype, mid, _group_width(model.n_age), model.n_strain, int(model.has_e),
+                                     int(model.has_wane), int(model.has_c), model.n_wane, n_dir, spl,
+                                     int(model.has_intro), ctypes.c_void_p(extra.dyn_extra_launch()))
+        if rc:
+            raise RuntimeError(f"dyn_register_instance: {_abi.ERR_NAMES.get(rc, rc)}")
+        _LOADED[name] = extra
+    return True

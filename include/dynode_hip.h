@@ -175,6 +175,17 @@ int dyn_solve_batch_loglik(const dyn_model_desc *m, const dyn_solver_opts *opts,
                            int32_t n_dir, const void *dparams, const void *dy0, int32_t dy0_is_batched,
                            double *logp_out, double *dlogp_out, int32_t *status, int32_t *n_accept,
                            int32_t *n_reject, void *stream);
+/*
+ * Add a kernel shape at run time.  The library ships the shapes of dynode_amd/csrc/instances.def;
+ * any other member of the family is one explicit instantiation of the same template
+ * (dyn::launch<T, METHOD, GA, S, E, WANE, C, W, ND, SPL[, INTRO]> in csrc/solve_kernel.hpp) compiled
+ * into a separate shared object -- dynode_amd/jit.py does that with hipcc on first use -- whose
+ * launcher is registered here.  ga = lanes on the age axis (power of two >= n_age), spl = strains
+ * per lane.  Registered entries are consulted after the built-in ones.
+ */
+int dyn_register_instance(int32_t dtype, int32_t method, int32_t ga, int32_t n_strain, int32_t has_e,
+                          int32_t has_wane, int32_t has_c, int32_t n_wane, int32_t n_dir, int32_t spl,
+                          int32_t has_intro, void *launch_fn);
 /* 1 if a tangent kernel for (model shape, method, dtype, n_dir) is compiled in */
 int32_t dyn_is_supported_jvp(const dyn_model_desc *m, const dyn_solver_opts *o, int32_t n_dir);
 

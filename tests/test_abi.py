@@ -142,3 +142,26 @@ def test_sampler_entry_validates_before_launching():
     assert lib.dyn_nuts_advance(ctypes.byref(st), None) == -3
     st.max_depth, st.n_chains = 5, 0                      # no chains: nothing to do, no launch
     assert lib.dyn_nuts_advance(ctypes.byref(st), None) == 0
+
+
+def test_on_demand_kernel_build_and_registration():
+    """dynode_amd/jit.py without a GPU: lane mapping choices, and a full build + dyn_register_instance
+    round trip for a shape instances.def does not list (hipcc cross-compiles here)."""
+    import torch
+
+    from dynode_amd import jit
+
+    assert jit.choose_spl(ModelDesc(n_age=8, n_strain=4, has_e=True, has_wane=True, has_c=True), 0) == 4
+    assert jit.choose_spl(ModelDesc(n_age=8, n_strain=4, has_e=True, has_wane=True, has_c=True, n_wane=8), 0) in (1, 2)
+    assert jit.choose_spl(ModelDesc(n_age=8, n_strain=4, has_e=True, has_wane=True, has_c=True), 2) < 4
+    assert jit.choose_spl(ModelDesc(n_age=3, n_strain=5), 0) == 5
+    with pytest.raises(RuntimeError):
+        jit.choose_spl(ModelDesc(n_age=64, n_strain=30, has_wane=True, n_wane=12), 2)       # cannot be mapped to 64 lanes
+    lib = _abi.lib()
+    m = ModelDesc(n_age=3, n_strain=2, has_e=True, has_wane=False, has_c=False)
+    assert lib.dyn_is_supported(ctypes.byref(m.c()), ctypes.byref(_opts())) == 0
+    assert jit.ensure_kernel(m, torch.float32, "tsit5", 0) is True
+    assert lib.dyn_is_supported(ctypes.byref(m.c()), ctypes.byref(_opts())) == 1
+    assert jit.ensure_kernel(m, torch.float32, "tsit5", 0) is False                         # already there
+    assert lib.dyn_register_instance(0, 0, 3, 1, 0, 0, 0, 1, 0, 1, 0, ctypes.c_void_p(1)) == -2   # ga must be a power of two
+    assert lib.dyn_register_instance(0, 0, 4, 1, 0, 0, 0, 1, 0, 1, 0, None) == -1

@@ -275,8 +275,9 @@ def test_final_size_on_gpu(s0, i0):
     assert got[0, -1, 2] == pytest.approx(1 - s_inf, abs=2e-2)
 
 
-def test_unsupported_shape_fails_loudly():
-    with pytest.raises(SolveError, match="UNSUPPORTED"):
+def test_unsupported_shape_fails_loudly(monkeypatch):
+    monkeypatch.setenv("DYNODE_HIP_JIT", "0")                   # without on-demand builds: a clear error, never a fallback
+    with pytest.raises(SolveError, match=r"UNSUPPORTED.*X\(float, 0, 8, 7, false, false, false, 1, 0, 7\)"):
         solve_batch(ModelDesc(n_age=8, n_strain=7), np.zeros(8 * 15), np.zeros((1, 14)), np.eye(8), 10.0, [0.0, 10.0])
     with pytest.raises(SolveError, match="UNSUPPORTED"):       # more jump points than the LDS table holds
         solve_batch(SIR1, [0.9, 0.1, 0], [[0.3, 0.1]], [[1.0]], 100.0, [0.0, 100.0], jump_ts=list(np.arange(1.0, 40.0, 2.0)))
@@ -457,3 +458,26 @@ def test_randomized_parity_sweep():
         assert same and err < 1e-10, (seed, case[0], case[6], err)
         ran += 1
     assert ran >= 60
+
+
+def test_kernel_shapes_are_built_on_demand():
+    """A member of the RHS family that instances.def does not list (5 ages x 2 strains, SEIR with
+    cumulative incidence, no waning) is compiled with hipcc on first use, registered with the library
+    (dyn_register_instance) and then behaves like a built-in shape: float64 parity with the oracle."""
+    import glob
+    import os
+
+    from dynode_amd import jit
+
+    m = ModelDesc(n_age=5, n_strain=2, has_e=True, has_wane=False, has_c=True)
+    assert not _supported(m, F64, "tsit5") or jit._LOADED                # not a built-in shape
+    for stale in glob.glob(os.path.join(jit._OUT, "f64_m0_g8_s2_e1w0c1_*")):
+        if not jit._LOADED:
+            os.remove(stale)                                             # force a real build in a fresh process
+    y0, p, C, t1, ts = random_workload(m, 19, seed=6, t1=120.0)
+    got, st, na, nr = hip(m, y0, p, C, t1, ts, dtype=F64)
+    want, st_o, na_o, nr_o = O.solve(H.omodel(m), y0, p, C, t1, ts, dtype=np.float64, n_threads=8)
+    assert st.max() == 0 and np.abs(got - want).max() / 1000.0 < 1e-11
+    assert np.array_equal(na, na_o) and np.array_equal(nr, nr_o)
+    assert _supported(m, F64, "tsit5")                                    # now part of the dispatch table
+    assert any(f.endswith(".so") for f in os.listdir(jit._OUT))
