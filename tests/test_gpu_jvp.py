@@ -237,3 +237,92 @@ def test_gradient_with_respect_to_the_introduction_time_through_simulate():
         odes.enable_x64(False)
     assert float(g_time) < 0 < float(g_pct)                      # arriving later means fewer cases by day 150
     assert abs(float(g_time) / float(fd_time) - 1) < 1e-4 and abs(float(g_pct) / float(fd_pct) - 1) < 1e-4
+
+
+def test_tangent_kernels_agree_across_direction_counts_on_random_calls():
+    """Randomized consistency sweep (the generator of tests/test_gpu_parity.py: irregular save grids,
+    discontinuity points, sub-save masks, both methods): in float64 the primal of a tangent solve equals
+    the plain solve, and a direction gives the same tangent whether it runs alone (1-direction kernel)
+    or as either slot of the 2-direction kernel."""
+    import ctypes
+
+    from dynode_amd import _abi
+    from test_gpu_parity import fuzz_case
+
+    def has(m, method, nd):
+        o = _abi.SolverOptsC(method={"tsit5": 0, "dopri5": 1}[method], dtype=1, rtol=1e-5, atol=1e-6, max_steps=10**6,
+                             constant_dt=0.0, jump_ts=None, n_jump=0)
+        return bool(_abi.lib().dyn_is_supported_jvp(ctypes.byref(m.c()), ctypes.byref(o), nd))
+
+    ran = 0
+    for seed in range(400):
+        case = fuzz_case(3000 + seed)
+        if case is None:
+            continue
+        m, y0, p, C, t1, ts, kw = case
+        if not (has(m, kw["method"], 1) and has(m, kw["method"], 2)):
+            continue
+        rng = np.random.default_rng(seed)
+        B = p.shape[0]
+        dp = rng.normal(size=(B, 2, m.param_dim)) * 0.1 * np.abs(p)[:, None, :]
+        dy0 = rng.normal(size=(B, 2, m.state_dim)) * (np.abs(np.broadcast_to(y0, (B, m.state_dim)))[:, None, :] > 0)
+        plain = solve_batch(m, y0, p, C, t1, ts, dtype=torch.float64, **kw)
+        both = solve_batch(m, y0, p, C, t1, ts, dtype=torch.float64, dparams=dp, dy0=dy0, **kw)
+        one = [solve_batch(m, y0, p, C, t1, ts, dtype=torch.float64, dparams=dp[:, j:j + 1], dy0=dy0[:, j:j + 1], **kw) for j in (0, 1)]
+        fin = torch.isfinite(plain.ys)
+        scale = float(plain.ys[fin].abs().max()) if bool(fin.any()) else 1.0
+        assert torch.equal(both.status, plain.status) and torch.equal(both.n_accept, plain.n_accept)
+        assert float((both.ys[fin] - plain.ys[fin]).abs().max()) <= 1e-12 * scale if bool(fin.any()) else True
+        for j in (0, 1):
+            a, b = both.dys[:, :, j], one[j].dys[:, :, 0]
+            ok = torch.isfinite(a) & torch.isfinite(b)
+            assert torch.equal(torch.isfinite(a), torch.isfinite(b))
+            if bool(ok.any()):
+                tscale = float(b[ok].abs().max()) + 1e-30
+                assert float((a[ok] - b[ok]).abs().max()) <= 1e-10 * tscale, (seed, m, kw, j)
+        ran += 1
+    assert ran >= 40
+
+
+def test_fused_likelihood_on_random_calls():
+    """The fused Poisson likelihood against scoring the saved tangent solve, on the randomized calls of
+    the parity sweep (irregular save grids, discontinuity points, constant steps, both methods)."""
+    import ctypes
+
+    from dynode_amd import _abi
+    from dynode_amd.engine import solve_batch_loglik
+    from test_gpu_parity import fuzz_case
+
+    ran = 0
+    for seed in range(500):
+        case = fuzz_case(9000 + seed)
+        if case is None:
+            continue
+        m, y0, p, C, t1, ts, kw = case
+        kw = {k: v for k, v in kw.items() if k != "save_mask"}
+        o = _abi.SolverOptsC(method={"tsit5": 0, "dopri5": 1}[kw["method"]], dtype=1, rtol=1e-5, atol=1e-6, max_steps=10**6,
+                             constant_dt=0.0, jump_ts=None, n_jump=0)
+        if len(ts) < 3 or not _abi.lib().dyn_is_supported_jvp(ctypes.byref(m.c()), ctypes.byref(o), 1):
+            continue
+        rng = np.random.default_rng(seed)
+        B = p.shape[0]
+        dp = rng.normal(size=(B, 1, m.param_dim)) * 0.1 * np.abs(p)[:, None, :]
+        comp = int(rng.integers(len(m.compartment_names)))
+        inc = bool(rng.integers(2))
+        ref = solve_batch(m, y0, p, C, t1, ts, dtype=torch.float64, dparams=dp, **kw)
+        off = np.concatenate([[0], np.cumsum(m.compartment_sizes)])
+        v, dv = ref.ys[:, :, off[comp]:off[comp + 1]], ref.dys[:, :, 0, off[comp]:off[comp + 1]]
+        if inc:
+            v, dv = v[:, 1:] - v[:, :-1], dv[:, 1:] - dv[:, :-1]
+        floor = max(float(torch.quantile(v.flatten()[:200000], 0.1)), 1e-3)
+        obs = torch.as_tensor(rng.uniform(0.0, 30.0, tuple(v.shape[1:])), device="cuda")
+        rate = torch.clamp(v, min=floor)
+        want = (obs * torch.log(rate) - rate).sum((1, 2))
+        dwant = (torch.where(v >= floor, obs / rate - 1.0, torch.zeros_like(rate)) * dv).sum((1, 2))
+        lp, dlp, st, _, _ = solve_batch_loglik(m, y0, p, C, t1, ts, obs, comp, dparams=dp, increments=inc, floor=floor,
+                                               dtype=torch.float64, **kw)
+        assert torch.equal(st, ref.status) and int(st.max()) == 0
+        assert torch.allclose(lp, want, rtol=1e-11, atol=1e-8), (seed, m, kw, comp, inc, float((lp - want).abs().max()))
+        assert torch.allclose(dlp[:, 0], dwant, rtol=1e-9, atol=1e-7 * (1.0 + float(dwant.abs().max()))), (seed, m, kw, comp, inc)
+        ran += 1
+    assert ran >= 40
