@@ -16,6 +16,7 @@ time under vmap/pmap.
 from __future__ import annotations
 
 import math
+import sys
 from collections import OrderedDict
 from typing import Any, Callable, Optional
 
@@ -141,7 +142,7 @@ class Potential:
                 out_u, out_g = self.potential_and_grad(static_z)
         except Exception as err:  # pragma: no cover - depends on the user's model
             torch.cuda.synchronize()
-            print(f"[dynode_amd] potential not graph-capturable ({type(err).__name__}); running eagerly")
+            print(f"[dynode_amd] potential not graph-capturable ({type(err).__name__}); running eagerly", file=sys.stderr, flush=True)
             return self.potential_and_grad
 
         def replay(z):

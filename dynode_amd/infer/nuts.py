@@ -16,6 +16,7 @@ communicates.
 from __future__ import annotations
 
 import math
+import sys
 from dataclasses import dataclass
 from typing import Callable, Optional
 
@@ -751,7 +752,7 @@ class GraphNUTS(LockstepNUTS):
                     kidx.zero_()                          # capture does not execute
                 except Exception as err:  # pragma: no cover - depends on the model
                     torch.cuda.synchronize()
-                    print(f"[dynode_amd] NUTS iteration not graph-capturable ({type(err).__name__}: {str(err)[:120]}); eager")
+                    print(f"[dynode_amd] NUTS iteration not graph-capturable ({type(err).__name__}: {str(err)[:120]}); eager", file=sys.stderr, flush=True)
                     graph, self.use_graph = None, False
                     kidx.zero_()
             for _ in range(Kb):
@@ -871,7 +872,7 @@ class KernelNUTS(LockstepNUTS):
                         iteration()
                 except Exception as err:  # pragma: no cover - depends on the model
                     torch.cuda.synchronize()
-                    print(f"[dynode_amd] NUTS iteration not graph-capturable ({type(err).__name__}: {str(err)[:120]}); eager")
+                    print(f"[dynode_amd] NUTS iteration not graph-capturable ({type(err).__name__}: {str(err)[:120]}); eager", file=sys.stderr, flush=True)
                     graph, self.use_graph = None, False
             for _ in range(self.block):
                 if graph is not None:

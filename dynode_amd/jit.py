@@ -16,6 +16,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import sys
 import subprocess
 import threading
 
@@ -107,7 +108,7 @@ def ensure_kernel(model: _abi.ModelDesc, dtype=torch.float32, method: str = "tsi
             with open(src, "w") as f:
                 f.write(_source(model, dtype, mid, n_dir, spl))
             tmp = so + f".{os.getpid()}.tmp"
-            print(f"[dynode_amd] building the kernel for {name} (one-off, ~15 s) ...", flush=True)
+            print(f"[dynode_amd] building the kernel for {name} (one-off, ~15 s) ...", file=sys.stderr, flush=True)
             subprocess.run([HIPCC, "-O3", "-std=c++17", "-fPIC", "-shared", "--offload-arch=gfx950", src, "-o", tmp],
                            check=True)
             os.replace(tmp, so)            # atomic: concurrent ranks never load a half-written file
