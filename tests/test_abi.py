@@ -165,3 +165,13 @@ def test_on_demand_kernel_build_and_registration():
     assert jit.ensure_kernel(m, torch.float32, "tsit5", 0) is False                         # already there
     assert lib.dyn_register_instance(0, 0, 3, 1, 0, 0, 0, 1, 0, 1, 0, ctypes.c_void_p(1)) == -2   # ga must be a power of two
     assert lib.dyn_register_instance(0, 0, 4, 1, 0, 0, 0, 1, 0, 1, 0, None) == -1
+
+
+def test_library_links_only_the_hip_runtime():
+    """The boundary is a plain C-ABI shared object: no torch, no Python in its dependencies."""
+    import subprocess
+
+    deps = subprocess.run(["ldd", _abi.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    names = [line.split()[0] for line in deps.splitlines() if line.strip()]
+    assert any("amdhip64" in n for n in names)
+    assert not any(bad in n for n in names for bad in ("torch", "c10", "python", "numpy"))

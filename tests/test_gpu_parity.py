@@ -481,3 +481,37 @@ def test_kernel_shapes_are_built_on_demand():
     assert np.array_equal(na, na_o) and np.array_equal(nr, nr_o)
     assert _supported(m, F64, "tsit5")                                    # now part of the dispatch table
     assert any(f.endswith(".so") for f in os.listdir(jit._OUT))
+
+
+def test_c_consumer_of_the_abi(tmp_path):
+    """tests/c_abi/consumer.c: a C program (HIP runtime only, no Python / torch) calls dyn_solve_batch
+    and prints what it got; the numbers must be the oracle's."""
+    import os
+    import subprocess
+
+    from dynode_amd import _abi
+
+    exe = str(tmp_path / "consumer")
+    src = os.path.join(H.ROOT, "tests", "c_abi", "consumer.c")
+    libdir = os.path.dirname(_abi.LIB_PATH)
+    subprocess.run(["gcc", "-std=c11", "-O2", "-D__HIP_PLATFORM_AMD__", src, "-I/opt/rocm/include",
+                    "-I", os.path.join(H.ROOT, "include"), "-L", libdir, "-ldynode_hip", "-L/opt/rocm/lib", "-lamdhip64",
+                    f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib", "-o", exe], check=True)
+    run = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0, run.stderr
+    lines = run.stdout.strip().splitlines()
+    assert lines[-1] == "unsupported rc -7"
+    B, ts = 5, np.arange(51.0)
+    p = np.array([[(2.0 + 0.1 * b) / 7.0, 1.0 / 7.0] for b in range(B)])
+    want, st, na, nr = O.solve(H.omodel(ModelDesc(n_age=1)), np.array([0.9, 0.1, 0.0]), p, np.ones((1, 1)), 50.0, ts, dtype=np.float64)
+    seen = 0
+    for line in lines[:-1]:
+        f = line.split()
+        if f[0] == "traj":
+            b = int(f[1])
+            assert (int(f[3]), int(f[5]), int(f[7])) == (st[b], na[b], nr[b])
+        else:
+            b, j = int(f[0]), int(f[1])
+            assert np.abs(np.array([float(v) for v in f[2:]]) - want[b, j]).max() < 1e-13
+            seen += 1
+    assert seen == B * 6
