@@ -84,11 +84,11 @@ class _Welford:
         return scaled + 1e-3 * (5.0 / (self.n + 5.0)) * eye
 
 
-def _adaptation_windows(num_warmup: int):
+def _adaptation_windows(num_warmup: int, init_buffer: int = 75):
     """Stan's schedule: 75-step initial buffer, doubling 25-step windows, 50-step final buffer."""
     if num_warmup < 20:
         return []
-    init, term, base = 75, 50, 25
+    init, term, base = init_buffer, 50, 25
     if init + base + term > num_warmup:
         init, term = int(0.15 * num_warmup), int(0.1 * num_warmup)
         base = num_warmup - init - term
@@ -806,7 +806,10 @@ class KernelNUTS(LockstepNUTS):
         dev, dt, Dm = z0.device, torch.float64, self.max_depth
         if dev.type != "cuda":
             raise RuntimeError("KernelNUTS runs on the GPU only (dyn_nuts_advance); use BatchedNUTS on CPU tensors")
-        windows = _adaptation_windows(num_warmup)
+        # pooled windows see (chains x window) draws: the first one can open after 25 transitions instead
+        # of Stan's single-chain 75 (the identity-metric phase is the most expensive part of warm-up)
+        early = self.adaptation == "pooled" and C >= 16 and num_warmup >= 150
+        windows = _adaptation_windows(num_warmup, 25 if early else 75)
         if D > _abi.NUTS_MAX_DIM or Dm > _abi.NUTS_MAX_DEPTH or len(windows) > _abi.NUTS_MAX_WINDOWS:
             raise ValueError(f"KernelNUTS supports dim <= {_abi.NUTS_MAX_DIM}, max_tree_depth <= {_abi.NUTS_MAX_DEPTH}")
         L = _abi.lib()
