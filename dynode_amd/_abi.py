@@ -54,7 +54,8 @@ MAX_STRAINS = 8
 class ModelDescC(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in (
         "n_age", "n_strain", "has_e", "has_wane", "has_c", "n_wane", "normalize", "seasonal", "has_intro",
-        "reserved")] + [("intro_age_mask", ctypes.c_uint64 * MAX_STRAINS)]
+        "n_vax_tiers")] + [("intro_age_mask", ctypes.c_uint64 * MAX_STRAINS), ("n_vax_knots", ctypes.c_int32),
+                           ("reserved", ctypes.c_int32)]
 
 
 class SolverOptsC(ctypes.Structure):
@@ -97,12 +98,15 @@ class ModelDesc:
     seasonal: bool = False
     has_intro: bool = False          # externally introduced strains (Strain.is_introduced)
     intro_age_mask: tuple = ()       # per strain: bit a set = age bin a receives the introductions
+    n_vax_tiers: int = 0             # > 1: n_age enumerates (age, vaccination tier) groups, 2 or 4 slots per age
+    n_vax_knots: int = 0             # knots of the vaccination-rate splines (0..4)
 
     def c(self) -> ModelDescC:
         masks = tuple(int(v) for v in self.intro_age_mask) + (0,) * (MAX_STRAINS - len(self.intro_age_mask))
         return ModelDescC(self.n_age, self.n_strain, int(self.has_e), int(self.has_wane),
                           int(self.has_c), self.n_wane, int(self.normalize), int(self.seasonal),
-                          int(self.has_intro), 0, (ctypes.c_uint64 * MAX_STRAINS)(*masks))
+                          int(self.has_intro), int(self.n_vax_tiers), (ctypes.c_uint64 * MAX_STRAINS)(*masks),
+                          int(self.n_vax_knots), 0)
 
     # pure-Python mirrors of dyn_state_dim & co (host logic must not need the .so)
     @property
@@ -121,8 +125,14 @@ class ModelDesc:
 
     @property
     def param_dim(self) -> int:
+        vax = self.n_age * (self.n_strain + 4 + 2 * self.n_vax_knots) if self.n_vax_tiers > 1 else 0
         return self.n_strain * (2 + int(self.has_e) + int(self.has_wane) + (3 if self.has_intro else 0)) + (
-            3 if self.seasonal else 0)
+            3 if self.seasonal else 0) + vax
+
+    @property
+    def vax_lanes(self) -> int:
+        """Tier slots per age on the contact axis: 0 (no vaccination axis), 2 or 4."""
+        return 0 if self.n_vax_tiers <= 1 else (2 if self.n_vax_tiers <= 2 else 4)
 
 
 class HipLibraryMissing(RuntimeError):

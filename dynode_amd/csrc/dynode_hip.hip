@@ -16,8 +16,11 @@ namespace dyn {
 #define X(T, METHOD, G, S, E, WN, C, W, ND, SPL) \
     extern template hipError_t launch<T, METHOD, G, S, E, WN, C, W, ND, SPL>(const KArgs<T> &, hipStream_t);
 #define XI(T, METHOD, G, S, E, WN, C, W, ND, SPL) \
-    extern template hipError_t launch<T, METHOD, G, S, E, WN, C, W, ND, SPL, true>(const KArgs<T> &, hipStream_t);
+    extern template hipError_t launch<T, METHOD, G, S, E, WN, C, W, ND, SPL, 1>(const KArgs<T> &, hipStream_t);
+#define XF(T, METHOD, G, S, E, WN, C, W, ND, SPL, FEAT) \
+    extern template hipError_t launch<T, METHOD, G, S, E, WN, C, W, ND, SPL, FEAT>(const KArgs<T> &, hipStream_t);
 #include "instances.def"
+#undef XF
 #undef XI
 #undef X
 
@@ -33,7 +36,7 @@ struct DType<double> {
 };
 
 struct Entry {
-    int dtype, method, G, S, E, WN, C, W, ND, SPL, INTRO;
+    int dtype, method, G, S, E, WN, C, W, ND, SPL, FEAT; // FEAT: bit 0 introductions, bits 1.. vaccination-tier lanes
     void *fn; // hipError_t (*)(const KArgs<T>&, hipStream_t)
 };
 
@@ -45,8 +48,13 @@ static const Entry kEntries[] = {
 #define XI(T, METHOD, G, S, E, WN, C, W, ND, SPL)             \
     {DType<T>::id, METHOD, G, S, E, WN, C, W, ND, SPL, 1,     \
      (void *)(hipError_t(*)(const KArgs<T> &, hipStream_t)) & \
-         launch<T, METHOD, G, S, E, WN, C, W, ND, SPL, true>},
+         launch<T, METHOD, G, S, E, WN, C, W, ND, SPL, 1>},
+#define XF(T, METHOD, G, S, E, WN, C, W, ND, SPL, FEAT)       \
+    {DType<T>::id, METHOD, G, S, E, WN, C, W, ND, SPL, FEAT,  \
+     (void *)(hipError_t(*)(const KArgs<T> &, hipStream_t)) & \
+         launch<T, METHOD, G, S, E, WN, C, W, ND, SPL, FEAT>},
 #include "instances.def"
+#undef XF
 #undef XI
 #undef X
 };
@@ -64,10 +72,16 @@ static Entry g_extra[256];
 static std::atomic<int> g_n_extra{0};
 static std::mutex g_extra_mutex;
 
+// vaccination tiers occupy 2 or 4 lanes per age (0 = the model has no tier axis, -1 = too many)
+static int vax_lanes(const dyn_model_desc *m) {
+    return m->n_vax_tiers <= 1 ? 0 : (m->n_vax_tiers <= 2 ? 2 : (m->n_vax_tiers <= 4 ? 4 : -1));
+}
+static int model_features(const dyn_model_desc *m) { return (m->has_intro ? 1 : 0) | (vax_lanes(m) << 1); }
+
 static bool matches(const Entry &e, const dyn_model_desc *m, int G, int dtype, int method, int nd) {
     return e.dtype == dtype && e.method == method && e.G == G && e.S == m->n_strain &&
            e.E == (m->has_e != 0) && e.WN == (m->has_wane != 0) && e.C == (m->has_c != 0) &&
-           e.W == m->n_wane && e.ND == nd && e.INTRO == (m->has_intro != 0);
+           e.W == m->n_wane && e.ND == nd && e.FEAT == model_features(m);
 }
 
 static const Entry *find_entry(const dyn_model_desc *m, int dtype, int method, int nd = 0) {
@@ -101,6 +115,8 @@ static int check_model(const dyn_model_desc *m) {
     if (m->n_age < 1 || m->n_age > 64 || m->n_strain < 1 || m->n_wane < 1) return DYN_ERR_MODEL;
     if (m->n_wane > 1 && !m->has_wane) return DYN_ERR_MODEL;
     if (m->has_intro && m->n_strain > DYN_MAX_STRAINS) return DYN_ERR_MODEL;
+    if (m->n_vax_tiers < 0 || vax_lanes(m) < 0 || m->n_vax_knots < 0 || m->n_vax_knots > 4) return DYN_ERR_MODEL;
+    if (vax_lanes(m) > 0 && m->n_age % vax_lanes(m) != 0) return DYN_ERR_MODEL; /* groups = ages x tier lanes */
     return 0;
 }
 
@@ -154,6 +170,8 @@ static int enqueue(const Entry *e, const dyn_model_desc *m, const dyn_solver_opt
     ka.normalize = m->normalize ? 1 : 0;
     ka.seasonal = m->seasonal ? 1 : 0;
     for (int l = 0; l < DYN_MAX_STRAINS; ++l) ka.intro_mask[l] = m->has_intro ? m->intro_age_mask[l] : 0;
+    ka.n_vax_tiers = m->n_vax_tiers;
+    ka.n_vax_knots = m->n_vax_knots;
 
     // saved-row layout: saved compartments concatenated in state order
     int32_t off[8];
@@ -265,7 +283,8 @@ int32_t dyn_state_dim(const dyn_model_desc *m) {
 
 int32_t dyn_param_dim(const dyn_model_desc *m) {
     return m->n_strain * (2 + (m->has_e ? 1 : 0) + (m->has_wane ? 1 : 0) + (m->has_intro ? 3 : 0)) +
-           (m->seasonal ? 3 : 0);
+           (m->seasonal ? 3 : 0) +
+           (m->n_vax_tiers > 1 ? m->n_age * (m->n_strain + 4 + 2 * m->n_vax_knots) : 0);
 }
 
 int32_t dyn_trajectories_per_wave(const dyn_model_desc *m) {
@@ -322,7 +341,8 @@ static int solve_impl(const dyn_model_desc *m, const dyn_solver_opts *o, const v
                  "directions=%d; to add it put  %s(%s, %d, %d, %d, %s, %s, %s, %d, %d, %d)  into "
                  "dynode_amd/csrc/instances.def and rebuild (make -C dynode_amd/csrc)",
                  m->n_age, m->n_strain, m->has_e, m->has_wane, m->has_c, m->n_wane, m->has_intro, o->dtype,
-                 o->method, n_dir, m->has_intro ? "XI" : "X", o->dtype == DYN_F64 ? "double" : "float", o->method,
+                 o->method, n_dir, dyn::model_features(m) > 1 ? "XF" : (m->has_intro ? "XI" : "X"),
+                 o->dtype == DYN_F64 ? "double" : "float", o->method,
                  ga, m->n_strain, m->has_e ? "true" : "false", m->has_wane ? "true" : "false",
                  m->has_c ? "true" : "false", m->n_wane, n_dir, m->n_strain);
         return DYN_ERR_UNSUPPORTED;
@@ -397,7 +417,7 @@ int dyn_solve_batch_loglik(const dyn_model_desc *m, const dyn_solver_opts *o, co
 
 int dyn_register_instance(int32_t dtype, int32_t method, int32_t ga, int32_t n_strain, int32_t has_e,
                           int32_t has_wane, int32_t has_c, int32_t n_wane, int32_t n_dir, int32_t spl,
-                          int32_t has_intro, void *launch_fn) {
+                          int32_t features, void *launch_fn) {
     if (!launch_fn) return DYN_ERR_NULL;
     if ((dtype != DYN_F32 && dtype != DYN_F64) || (method != DYN_TSIT5 && method != DYN_DOPRI5)) return DYN_ERR_OPTS;
     if (ga < 1 || ga > 64 || (ga & (ga - 1)) || n_strain < 1 || n_strain > 64 || spl < 1 || n_strain % spl ||
@@ -407,7 +427,7 @@ int dyn_register_instance(int32_t dtype, int32_t method, int32_t ga, int32_t n_s
     const int n = dyn::g_n_extra.load(std::memory_order_relaxed);
     if (n >= (int)(sizeof(dyn::g_extra) / sizeof(dyn::g_extra[0]))) return DYN_ERR_SIZE;
     dyn::g_extra[n] = dyn::Entry{dtype, method, ga, n_strain, has_e != 0, has_wane != 0, has_c != 0, n_wane, n_dir,
-                                 spl, has_intro != 0, launch_fn};
+                                 spl, features, launch_fn};
     dyn::g_n_extra.store(n + 1, std::memory_order_release);
     return 0;
 }

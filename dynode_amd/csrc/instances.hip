@@ -10,8 +10,11 @@ namespace dyn {
 #define X(T, METHOD, G, S, E, WN, C, W, ND, SPL) \
     template hipError_t launch<T, METHOD, G, S, E, WN, C, W, ND, SPL>(const KArgs<T> &, hipStream_t);
 #define XI(T, METHOD, G, S, E, WN, C, W, ND, SPL) \
-    template hipError_t launch<T, METHOD, G, S, E, WN, C, W, ND, SPL, true>(const KArgs<T> &, hipStream_t);
+    template hipError_t launch<T, METHOD, G, S, E, WN, C, W, ND, SPL, 1>(const KArgs<T> &, hipStream_t);
+#define XF(T, METHOD, G, S, E, WN, C, W, ND, SPL, FEAT) \
+    template hipError_t launch<T, METHOD, G, S, E, WN, C, W, ND, SPL, FEAT>(const KArgs<T> &, hipStream_t);
 #include "instances.def"
+#undef XF
 #undef XI
 #undef X
 } // namespace dyn

@@ -39,6 +39,7 @@ struct KArgs {
     int32_t y0_batched, n_save, A, P, normalize, seasonal, d_saved, vec_ok;
     int32_t save_off[5]; // offset of s,e,i,r,c inside a saved row; -1 = not saved
     uint64_t intro_mask[8]; // per strain: bit a set = age bin a receives external introductions
+    int32_t n_vax_tiers, n_vax_knots; // vaccination tiers actually used (<= KV) and spline knots (<= 4)
     // fused observation likelihood (tangent kernels only; obs == nullptr: off)
     const T *obs;        // [n_obs][ll_row] observed counts, shared by the batch
     double *ll_out;      // [B] sum of obs * log(rate) - rate
@@ -300,9 +301,16 @@ __device__ __forceinline__ void store_run(T *p, const T (&v)[CNT], bool vec_ok) 
 // the e/i/r/c values of age a for its SPL strains h*SPL .. h*SPL+SPL-1.  SPL == S is the plain
 // one-lane-per-age mapping; splitting the strains (SPL < S) divides the per-lane state, trading
 // replicated control arithmetic for occupancy and smaller lock-step groups.
+// FEAT (optional model features): bit 0 = externally introduced strains; bits 1.. = KV, the lane width
+// of the vaccination-tier axis (0 = none, 2 or 4): the contact axis then enumerates (age, tier) groups,
+// tier in the low bits, and susceptibles flow from tier k to k + 1 at a spline-in-time rate.
 template <typename T, int METHOD, int GA, int ST, bool HAS_E, bool HAS_WANE, bool HAS_C, int W, int ND, int SPL,
-          bool INTRO = false>
+          int FEAT = 0>
 struct Solver {
+    static constexpr bool INTRO = (FEAT & 1) != 0;
+    static constexpr int KV = FEAT >> 1;
+    static_assert(KV == 0 || ((KV == 2 || KV == 4) && GA % KV == 0 && ND == 0),
+                  "vaccination tiers: 2 or 4 lanes per age, no tangent kernels yet");
     static_assert(ST % SPL == 0, "strains per lane must divide the strain count");
     static constexpr int S = SPL;        // strains held by one lane (all per-lane arrays use S)
     static constexpr int GS = ST / SPL;  // strain lanes
@@ -332,6 +340,11 @@ struct Solver {
     T ditime[INTRO ? NDA : 1][INTRO ? S : 1], discale[INTRO ? NDA : 1][INTRO ? S : 1], dipct[INTRO ? NDA : 1][INTRO ? S : 1];
     T dbeta[NDA][S], dgamma[NDA][S], dsigma[NDA][S], domega[NDA][S];
     T damp[NDA], dphase[NDA], dw_season[NDA];
+    // vaccination tiers (KV): susceptibility 1 - efficacy of this group's tier per strain; this group's
+    // vaccination-rate spline a + b t + c t^2 + d t^3 + sum_i coef_i (t - knot_i)^3 [t > knot_i]
+    T sus[KV ? S : 1], vbase[KV ? 4 : 1], vknot[KV ? 4 : 1], vcoef[KV ? 4 : 1];
+    int vnk;
+    bool vax_top, vax_first;  // last tracked tier (nobody leaves) / tier 0 (nobody arrives)
     bool pad, normalize, seasonal;
     bool lead; // strain lane 0: owns the replicated s for norms and stores
 
@@ -402,6 +415,7 @@ struct Solver {
 #pragma unroll
         for (int l = 0; l < S; ++l) {
             foi[l] = (beta[l] * season) * acc[l];
+            if constexpr (KV > 0) foi[l] *= sus[l];
             const T flux = foi[l] * y0[0];
             const T g_i = gamma[l] * y0[II + l];
             out_s += flux;
@@ -430,6 +444,23 @@ struct Solver {
             if constexpr (HAS_C) dy[0][IC + l] = flux;
         }
         dy[0][0] = strain_sum(back_s - out_s);
+        if constexpr (KV > 0) {
+            // vaccination (ode_model.md): per day nu_{age,tier}(t) * (population of the age) doses go to
+            // the susceptibles of the tier, at most as many as there are; they move up one tier
+            T nu = vbase[0] + t * (vbase[1] + t * (vbase[2] + t * vbase[3]));
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const T lag = t - vknot[q];
+                if (q < vnk && lag > T(0)) nu += vcoef[q] * (lag * lag * lag);
+            }
+            T n_age = N + xchg_xor<1>(N);
+            if constexpr (KV == 4) n_age += xchg_xor<2>(n_age);
+            const T doses = M::max(nu, T(0)) * n_age;
+            const T leave = vax_top ? T(0) : M::min(doses, M::max(y0[0], T(0)));
+            // lane of tier k receives what tier k - 1 of the same age gives up
+            const T from_below = KV == 2 ? xchg_xor<1>(leave) : dpp_mov<0x90>(leave); // quad_perm [0,0,1,2]
+            dy[0][0] += (vax_first ? T(0) : from_below) - leave;
+        }
 
         // ---- JVP planes: the same expression tree, linearised
         if constexpr (ND > 0) {
@@ -785,6 +816,25 @@ struct Solver {
                 for (int j = 0; j < NDA; ++j)
 #pragma unroll
                     for (int l = 0; l < S; ++l) L.ditime[j][l] = L.discale[j][l] = L.dipct[j][l] = T(0);
+            }
+            if constexpr (KV > 0) {
+                // per-trajectory vaccination block after the seasonal numbers:
+                //   susceptibility [groups][ST], then per group: base[4], knot[n_knots], coef[n_knots]
+                const int nk = ka.n_vax_knots;
+                const T *vp = p + oSe * ST + (ka.seasonal ? 3 : 0);
+                const T *sp_ = vp + A * ST + aa * (4 + 2 * nk);
+                L.vnk = nk;
+#pragma unroll
+                for (int l = 0; l < S; ++l) L.sus[l] = L.pad ? T(0) : vp[aa * ST + s0 + l];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    L.vbase[q] = L.pad ? T(0) : sp_[q];
+                    L.vknot[q] = (!L.pad && q < nk) ? sp_[4 + q] : T(0);
+                    L.vcoef[q] = (!L.pad && q < nk) ? sp_[4 + nk + q] : T(0);
+                }
+                const int tier = a % KV;
+                L.vax_first = tier == 0;
+                L.vax_top = tier >= ka.n_vax_tiers - 1;
             }
             L.amp = T(0);
             L.phase = T(0);
@@ -1223,15 +1273,15 @@ struct Solver {
 };
 
 template <typename T, int METHOD, int GA, int ST, bool HAS_E, bool HAS_WANE, bool HAS_C, int W, int ND, int SPL,
-          bool INTRO = false>
+          int FEAT = 0>
 __global__ void __launch_bounds__(64)
 solve_kernel(const KArgs<T> ka) {
-    Solver<T, METHOD, GA, ST, HAS_E, HAS_WANE, HAS_C, W, ND, SPL, INTRO>::run(ka);
+    Solver<T, METHOD, GA, ST, HAS_E, HAS_WANE, HAS_C, W, ND, SPL, FEAT>::run(ka);
 }
 
 // host-side launcher, one explicit instantiation per compiled shape (instances.def)
 template <typename T, int METHOD, int GA, int ST, bool HAS_E, bool HAS_WANE, bool HAS_C, int W, int ND, int SPL,
-          bool INTRO = false>
+          int FEAT = 0>
 hipError_t launch(const KArgs<T> &ka, hipStream_t stream) {
     constexpr int TPW = 64 / (GA * (ST / SPL));
     const int64_t blocks = ((ka.B << ka.rep_log2) + TPW - 1) / TPW;
@@ -1239,7 +1289,7 @@ hipError_t launch(const KArgs<T> &ka, hipStream_t stream) {
     size_t lds = ((size_t)ka.n_save + (ka.n_jump > 0 ? kMaxJumps : 0)) * sizeof(T); // LDS tables
     if (ND > 0 && ka.obs != nullptr && ka.rep_log2 > 0) // likelihood table of the replicated trajectories of a wave
         lds += (size_t)(64 >> ka.rep_log2) * ka.n_save * (SPL * W) * (1 + ND) * sizeof(T);
-    hipLaunchKernelGGL((solve_kernel<T, METHOD, GA, ST, HAS_E, HAS_WANE, HAS_C, W, ND, SPL, INTRO>),
+    hipLaunchKernelGGL((solve_kernel<T, METHOD, GA, ST, HAS_E, HAS_WANE, HAS_C, W, ND, SPL, FEAT>),
                        dim3((unsigned)blocks), dim3(64), lds, stream, ka);
     return hipGetLastError();
 }

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define DYN_ABI_VERSION 2
+#define DYN_ABI_VERSION 3
 /* the save grid is staged in LDS: n_save * sizeof(real) must not exceed this */
 #define DYN_MAX_SAVE_BYTES 49152
 
@@ -44,6 +44,7 @@ extern "C" {
  * Parameter vector per trajectory (length P = dyn_param_dim):
  *     beta[S] gamma[S] sigma[S] (has_e) omega[S] (has_wane)
  *     intro_time[S] intro_scale[S] intro_pct[S] (has_intro)  amp phase period (seasonal)
+ *     vaccination block (n_vax_tiers > 1, see below)
  * RHS (seirs_multi_strain_age_stratified.py:213-243; S=1/no-e/no-wane reduce to
  * sir_age_stratified.py:127-142, seirs.py:88-95, sir.py:78-84):
  *     N_b = s_b + sum_l (e+i+sum_w r)_{b,l};  x_{b,l} = i_{b,l}/N_b (normalize) else i_{b,l}
@@ -56,6 +57,17 @@ extern "C" {
  * the one of ode_model.md, "I_b + N(mu, sigma) * phi * P_b" inside the force of infection):
  *     x_{b,l} += intro_pct_l * NormalPdf(t; intro_time_l, intro_scale_l)   for ages b in intro_age_mask[l]
  *     (times N_b when normalize = 0)
+ * n_vax_tiers > 1: vaccination fluxes (ode_model.md; VaccinationDimension, Strain.vaccine_efficacy,
+ * utils/splines.py).  The contact axis then enumerates (age, tier) GROUPS, g = age * KV + tier with
+ * KV = 2 (two tiers) or 4 (three or four; unused tiers stay empty), n_age = ages * KV, normalize = 0 and
+ * a group contact matrix C[(a,k)][(b,j)] = C_age[a][b] / P_b supplied by the caller, so that
+ * foi_{(a,k),l} = sus_{(a,k),l} * beta_l * sum_b C_age[a][b] * (sum_j i_{(b,j),l}) / P_b.
+ * Susceptibles of tier k < n_vax_tiers - 1 move to tier k + 1:
+ *     flow_{a,k} = min( max(nu_{a,k}(t), 0) * P_a , s_{a,k} ),   P_a = current population of age a,
+ *     nu(t) = base0 + base1 t + base2 t^2 + base3 t^3 + sum_q coef_q (t - knot_q)^3 [t > knot_q]
+ * (the cubic-spline form of utils/splines.py:evaluate_cubic_spline).  Everyone else keeps their tier.
+ * Parameter block, after the seasonal numbers:  sus[groups][S] (= 1 - vaccine efficacy of the group's
+ * tier against each strain), then per group base[4] knot[n_vax_knots] coef[n_vax_knots].
  */
 #define DYN_MAX_STRAINS 8
 typedef struct dyn_model_desc {
@@ -68,8 +80,10 @@ typedef struct dyn_model_desc {
     int32_t normalize;
     int32_t seasonal;
     int32_t has_intro; /* ABI 2 */
-    int32_t reserved;
+    int32_t n_vax_tiers; /* ABI 3: 0/1 = no vaccination axis; 2..4 = tracked dose counts (see above) */
     uint64_t intro_age_mask[DYN_MAX_STRAINS]; /* per strain: bit a = age bin a receives introductions */
+    int32_t n_vax_knots; /* knots of the vaccination-rate splines, 0..4 */
+    int32_t reserved;
 } dyn_model_desc;
 
 enum { DYN_TSIT5 = 0, DYN_DOPRI5 = 1 };
@@ -181,11 +195,11 @@ int dyn_solve_batch_loglik(const dyn_model_desc *m, const dyn_solver_opts *opts,
  * (dyn::launch<T, METHOD, GA, S, E, WANE, C, W, ND, SPL[, INTRO]> in csrc/solve_kernel.hpp) compiled
  * into a separate shared object -- dynode_amd/jit.py does that with hipcc on first use -- whose
  * launcher is registered here.  ga = lanes on the age axis (power of two >= n_age), spl = strains
- * per lane.  Registered entries are consulted after the built-in ones.
+ * per lane, features = the template's FEAT (bit 0: introduced strains; bits 1..: vaccination-tier lanes).  Registered entries are consulted after the built-in ones.
  */
 int dyn_register_instance(int32_t dtype, int32_t method, int32_t ga, int32_t n_strain, int32_t has_e,
                           int32_t has_wane, int32_t has_c, int32_t n_wane, int32_t n_dir, int32_t spl,
-                          int32_t has_intro, void *launch_fn);
+                          int32_t features, void *launch_fn);
 /* 1 if a tangent kernel for (model shape, method, dtype, n_dir) is compiled in */
 int32_t dyn_is_supported_jvp(const dyn_model_desc *m, const dyn_solver_opts *o, int32_t n_dir);
 

@@ -81,7 +81,8 @@ int32_t dyo_state_dim(const dyo_model_desc *m) {
 
 int32_t dyo_param_dim(const dyo_model_desc *m) {
     return m->n_strain * (2 + (m->has_e ? 1 : 0) + (m->has_wane ? 1 : 0) + (m->has_intro ? 3 : 0)) +
-           (m->seasonal ? 3 : 0);
+           (m->seasonal ? 3 : 0) +
+           (m->n_vax_tiers > 1 ? m->n_age * (m->n_strain + 4 + 2 * m->n_vax_knots) : 0);
 }
 
 /* tableau accessors so tests can check the order conditions of what is compiled in */

@@ -45,8 +45,12 @@ typedef struct dyo_model_desc {
     int32_t seasonal;  /* beta_t = beta*(1 + amp*sin(2*pi*t/period + phase)) */
     int32_t has_intro; /* externally introduced strains: x_{b,l} += pct_l * NormalPdf(t; time_l, scale_l)
                           for the ages b of intro_age_mask[l] (ode_model.md; config/strains.py:53-109) */
-    int32_t reserved;
+    int32_t n_vax_tiers; /* > 1: the contact axis enumerates (age, tier) groups, tier in the low bits of the
+                            group index over KV = 2 or 4 slots; susceptibles move up one tier at the
+                            spline rate nu_{group}(t) (include/dynode_hip.h has the full statement) */
     uint64_t intro_age_mask[8];
+    int32_t n_vax_knots;
+    int32_t reserved;
 } dyo_model_desc;
 
 typedef struct dyo_solver_opts {

@@ -32,8 +32,10 @@ class _ModelDesc(ctypes.Structure):
         ("normalize", ctypes.c_int32),
         ("seasonal", ctypes.c_int32),
         ("has_intro", ctypes.c_int32),
-        ("reserved", ctypes.c_int32),
+        ("n_vax_tiers", ctypes.c_int32),
         ("intro_age_mask", ctypes.c_uint64 * 8),
+        ("n_vax_knots", ctypes.c_int32),
+        ("reserved", ctypes.c_int32),
     ]
 
 
@@ -64,13 +66,15 @@ class Model:
     seasonal: bool = False
     has_intro: bool = False
     intro_age_mask: tuple = ()      # per strain: bit a = age bin a receives external introductions
+    n_vax_tiers: int = 0            # > 1: n_age enumerates (age, tier) groups (see include/dynode_hip.h)
+    n_vax_knots: int = 0
 
     def c(self) -> _ModelDesc:
         masks = tuple(int(v) for v in self.intro_age_mask) + (0,) * (8 - len(self.intro_age_mask))
         return _ModelDesc(
             self.n_age, self.n_strain, int(self.has_e), int(self.has_wane), int(self.has_c),
-            self.n_wane, int(self.normalize), int(self.seasonal), int(self.has_intro), 0,
-            (ctypes.c_uint64 * 8)(*masks),
+            self.n_wane, int(self.normalize), int(self.seasonal), int(self.has_intro), int(self.n_vax_tiers),
+            (ctypes.c_uint64 * 8)(*masks), int(self.n_vax_knots), 0,
         )
 
 

@@ -24,7 +24,8 @@ def omodel(m) -> "O.Model":
     """dynode_amd ModelDesc (or anything with the same fields) -> oracle Model."""
     return O.Model(m.n_age, m.n_strain, bool(m.has_e), bool(m.has_wane), bool(m.has_c), m.n_wane,
                    bool(m.normalize), bool(m.seasonal), bool(getattr(m, "has_intro", False)),
-                   tuple(getattr(m, "intro_age_mask", ())))
+                   tuple(getattr(m, "intro_age_mask", ())), int(getattr(m, "n_vax_tiers", 0)),
+                   int(getattr(m, "n_vax_knots", 0)))
 
 
 def split_state(m, y):
@@ -57,6 +58,10 @@ def split_params(m, p):
         out["intro_pct"] = p[pos:pos + S]; pos += S
     if m.seasonal:
         out["amp"], out["phase"], out["period"] = p[pos:pos + 3]; pos += 3
+    if getattr(m, "n_vax_tiers", 0) > 1:
+        A, nk = m.n_age, m.n_vax_knots
+        out["sus"] = p[pos:pos + A * S].reshape(A, S); pos += A * S
+        out["spline"] = p[pos:pos + A * (4 + 2 * nk)].reshape(A, 4 + 2 * nk); pos += A * (4 + 2 * nk)
     assert pos == p.size
     return out
 
@@ -83,6 +88,8 @@ def rhs_numpy(m, t, y, p, C):
     if m.seasonal:
         beta = beta * (1.0 + pr["amp"] * np.sin(2 * np.pi * t / pr["period"] + pr["phase"]))
     foi = beta[None, :] * np.einsum("ab,bl->al", np.asarray(C, dtype=np.float64), x)
+    if "sus" in pr:
+        foi = foi * pr["sus"]
     flux = foi * s[:, None]
     g_i = pr["gamma"][None, :] * i
     ds = -flux.sum(1)
@@ -99,6 +106,18 @@ def rhs_numpy(m, t, y, p, C):
         ds = ds + rate[:, :, -1].sum(1)
     else:
         dr[:, :, 0] = g_i
+    if "spline" in pr:                 # vaccination: tier k -> k + 1 within each age (groups = age * KV + tier)
+        nk, KV = m.n_vax_knots, (2 if m.n_vax_tiers <= 2 else 4)
+        c = pr["spline"]
+        nu = c[:, 0] + c[:, 1] * t + c[:, 2] * t**2 + c[:, 3] * t**3
+        if nk:
+            lag = np.maximum(t - c[:, 4:4 + nk], 0.0)
+            nu = nu + (c[:, 4 + nk:4 + 2 * nk] * lag**3).sum(1)
+        n_age = np.repeat(N.reshape(-1, KV).sum(1), KV)
+        tier = np.arange(m.n_age) % KV
+        leave = np.where(tier >= m.n_vax_tiers - 1, 0.0, np.minimum(np.maximum(nu, 0.0) * n_age, np.maximum(s, 0.0)))
+        arrive = np.where(tier == 0, 0.0, np.roll(leave, 1))
+        ds = ds + arrive - leave
     parts = [ds]
     if de is not None:
         parts.append(de.ravel())

@@ -515,3 +515,86 @@ def test_c_consumer_of_the_abi(tmp_path):
             assert np.abs(np.array([float(v) for v in f[2:]]) - want[b, j]).max() < 1e-13
             seen += 1
     assert seen == B * 6
+
+
+# ------------------------------------------------------------------ vaccination tiers
+VAX = [
+    # (ages, model of the (age, tier) groups)
+    (2, ModelDesc(n_age=4, normalize=False, n_vax_tiers=2, n_vax_knots=2)),
+    (2, ModelDesc(n_age=8, normalize=False, n_vax_tiers=3, n_vax_knots=1)),
+    (2, ModelDesc(n_age=8, normalize=False, n_vax_tiers=4, n_vax_knots=0)),
+    (4, ModelDesc(n_age=8, n_strain=2, has_e=True, has_wane=True, has_c=True, normalize=False, n_vax_tiers=2, n_vax_knots=3)),
+    (3, ModelDesc(n_age=12, n_strain=2, has_e=True, has_wane=True, has_c=True, normalize=False, n_vax_tiers=3, n_vax_knots=2)),
+    (8, ModelDesc(n_age=32, n_strain=4, has_e=True, has_wane=True, has_c=True, normalize=False, n_vax_tiers=4, n_vax_knots=4)),
+]
+
+
+def vax_workload(ages, m, B, seed, t1=200.0):
+    """Random vaccination ensemble on the flattened (age, tier) axis: everyone starts in tier 0, doses are
+    given at spline rates of a few per mille of the age group per day, higher tiers are less susceptible."""
+    rng = np.random.default_rng(seed)
+    KV, S, G = m.vax_lanes, m.n_strain, m.n_age
+    C_age = synthetic.contact_matrix(rng, ages) if ages > 1 else np.array([[1.0]])
+    pop = 1000.0 * rng.dirichlet(5 * np.ones(ages))
+    Cg = np.repeat(np.repeat(C_age / pop[None, :], KV, axis=0), KV, axis=1)        # C[(a,k)][(b,j)] = C_age[a][b] / P_b
+    r0 = rng.uniform(1.5, 3.0, (B, S)); ti = rng.uniform(4, 9, (B, S))
+    cols = [r0 / ti, 1 / ti]
+    if m.has_e:
+        cols.append(1 / rng.uniform(2, 4, (B, S)))
+    if m.has_wane:
+        cols.append(1 / rng.uniform(40, 90, (B, S)))
+    tier = np.arange(G) % KV
+    sus = np.clip(1.0 - 0.25 * tier[None, :, None] * rng.uniform(0.5, 1.5, (B, 1, S)), 0.05, 1.0) * np.ones((B, G, S))
+    nk = m.n_vax_knots
+    spline = np.zeros((B, G, 4 + 2 * nk))
+    spline[:, :, 0] = rng.uniform(0.0, 0.004, (B, G))                               # doses per person per day at t = 0
+    spline[:, :, 1] = rng.uniform(-1e-5, 2e-5, (B, G))
+    if nk:
+        spline[:, :, 4:4 + nk] = np.sort(rng.uniform(10.0, 0.8 * t1, (B, G, nk)), axis=2)
+        spline[:, :, 4 + nk:] = rng.uniform(-2e-9, 2e-9, (B, G, nk))
+    params = np.concatenate(cols + [sus.reshape(B, -1), spline.reshape(B, -1)], 1)
+    assert params.shape[1] == m.param_dim
+    y0 = np.zeros((B, m.state_dim))
+    first = np.arange(ages) * KV                                                    # tier 0 of every age
+    y0[:, first] = 0.99 * pop
+    off_i = G + (G * S if m.has_e else 0)
+    seed_i = 0.01 * pop[None, :, None] * rng.dirichlet(np.ones(S), B)[:, None, :]
+    for l in range(S):
+        y0[:, off_i + first * S + l] = seed_i[:, :, l]
+    return y0, params, Cg, t1, synthetic.save_grid(t1), pop
+
+
+@pytest.mark.parametrize("dtype", [F64, F32])
+@pytest.mark.parametrize("ages,m", VAX, ids=lambda v: str(v) if isinstance(v, int) else f"G{v.n_age}S{v.n_strain}K{v.n_vax_tiers}k{v.n_vax_knots}")
+def test_vaccination_tiers_match_oracle_and_move_people_up(ages, m, dtype):
+    if not _supported(m, dtype, "tsit5"):
+        pytest.skip("shape not compiled for this dtype")
+    B = 13
+    y0, p, C, t1, ts, pop = vax_workload(ages, m, B, seed=2)
+    # the same right-hand side: with a constant step the two implementations agree to rounding
+    rc = solve_batch(m, y0, p, C, t1, ts, dtype=dtype, constant_dt=0.5)
+    wc, stc, _, _ = O.solve(H.omodel(m), y0, p, C, t1, ts, dtype=NP[dtype], n_threads=8, constant_dt=0.5)
+    assert int(rc.status.max()) == 0 and np.abs(rc.ys.cpu().numpy() - wc).max() / 1000.0 < (1e-11 if dtype == F64 else 1e-5)
+    # adaptive: min(doses, susceptibles) has a kink where a tier runs empty; around it the error estimate
+    # sits at the tolerance and rounding decides single accept/reject calls, so the two runs agree to the
+    # solver tolerance (1e-5), not to rounding as the smooth models do
+    r = solve_batch(m, y0, p, C, t1, ts, dtype=dtype)
+    want, st, na, nr = O.solve(H.omodel(m), y0, p, C, t1, ts, dtype=NP[dtype], n_threads=8)
+    got = r.ys.cpu().numpy()
+    assert int(r.status.max()) == 0 and int(st.max()) == 0
+    assert np.abs(got - want).max() / 1000.0 < 5e-5
+    assert np.abs((r.n_accept + r.n_reject).cpu().numpy() - (na + nr)).max() <= max(12, 0.25 * (na + nr).max())
+    KV, G, S = m.vax_lanes, m.n_age, m.n_strain
+    n_pop = m.state_dim - (G * S if m.has_c else 0)
+    people = got[:, :, :n_pop]
+    per_group = people[:, :, :G].copy()                                              # s
+    pos = G
+    for width in ([S] if m.has_e else []) + [S, S * m.n_wane]:
+        per_group += people[:, :, pos:pos + G * width].reshape(B, len(ts), G, width).sum(-1)
+        pos += G * width
+    by_age = per_group.reshape(B, len(ts), ages, KV).sum(-1)
+    assert np.abs(by_age - pop).max() < (1e-8 if dtype == F64 else 2e-2)             # nobody changes age, nobody is lost
+    tiers = per_group.reshape(B, len(ts), ages, KV).sum(2)
+    assert np.all(tiers[:, 0, 1:] == 0) and np.all(tiers[:, -1, 1:m.n_vax_tiers] > 0)    # doses move people up ...
+    assert np.all(tiers[:, :, m.n_vax_tiers:] == 0)                                        # ... never beyond the last tracked tier
+    assert np.all(np.diff(tiers[:, :, 0], axis=1) <= 2e-3)                                 # tier 0 only loses people (up to interpolation ripple at the kink)
