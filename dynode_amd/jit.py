@@ -43,6 +43,11 @@ def _group_width(n_age: int) -> int:
     return g
 
 
+def _features(model: _abi.ModelDesc) -> int:
+    """The kernel template's FEAT word: bit 0 = externally introduced strains, the rest = vaccination-tier lanes."""
+    return int(model.has_intro) | (model.vax_lanes << 1)
+
+
 def choose_spl(model: _abi.ModelDesc, n_dir: int) -> int:
     """Strains per lane: all of them on one lane per age while the register file holds it (y, 7 stage
     derivatives and the stage state of every plane: 9 * values * planes VGPRs), otherwise split the
@@ -68,14 +73,14 @@ def choose_spl(model: _abi.ModelDesc, n_dir: int) -> int:
 def _name(model, dtype, method, n_dir, spl) -> str:
     return (f"{'f64' if dtype == torch.float64 else 'f32'}_m{method}_g{_group_width(model.n_age)}_s{model.n_strain}"
             f"_e{int(model.has_e)}w{int(model.has_wane)}c{int(model.has_c)}_W{model.n_wane}_nd{n_dir}_spl{spl}"
-            f"_i{int(model.has_intro)}")
+            f"_f{_features(model)}")
 
 
 def _source(model, dtype, method, n_dir, spl) -> str:
     t = "double" if dtype == torch.float64 else "float"
     b = lambda v: "true" if v else "false"
     args = (f"{t}, {method}, {_group_width(model.n_age)}, {model.n_strain}, {b(model.has_e)}, {b(model.has_wane)}, "
-            f"{b(model.has_c)}, {model.n_wane}, {n_dir}, {spl}, {b(model.has_intro)}")
+            f"{b(model.has_c)}, {model.n_wane}, {n_dir}, {spl}, {_features(model)}")
     return (f'#include "{os.path.join(_CSRC, "solve_kernel.hpp")}"\n'
             f"namespace dyn {{ template hipError_t launch<{args}>(const KArgs<{t}> &, hipStream_t); }}\n"
             f'extern "C" void *dyn_extra_launch(void) {{\n'
@@ -116,7 +121,7 @@ def ensure_kernel(model: _abi.ModelDesc, dtype=torch.float32, method: str = "tsi
         extra.dyn_extra_launch.restype = ctypes.c_void_p
         rc = L.dyn_register_instance(opts.dtype, mid, _group_width(model.n_age), model.n_strain, int(model.has_e),
                                      int(model.has_wane), int(model.has_c), model.n_wane, n_dir, spl,
-                                     int(model.has_intro), ctypes.c_void_p(extra.dyn_extra_launch()))
+                                     _features(model), ctypes.c_void_p(extra.dyn_extra_launch()))
         if rc:
             raise RuntimeError(f"dyn_register_instance: {_abi.ERR_NAMES.get(rc, rc)}")
         _LOADED[name] = extra

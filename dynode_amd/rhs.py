@@ -130,6 +130,23 @@ def introduction_params(strains, initialize_date=None) -> Optional["Introduction
 
 
 @dataclass
+class VaccinationParams:
+    """Vaccination fluxes (ode_model.md; ``VaccinationDimension``, ``Strain.vaccine_efficacy``, the spline
+    arguments of ``utils.evaluate_cubic_spline`` -- reference src/dynode/utils/splines.py:66-109).
+
+    Compartments gain a tier axis after age: ``s[A, K]``, ``e/i/r/c[A, K, S]``.  Per day
+    ``nu_{a,k}(t) * (population of age a)`` doses reach the susceptibles of tier ``k`` (at most as many
+    as there are) and move them to tier ``k + 1``; ``nu`` is the cubic spline given here per (age, tier);
+    the last tier keeps its people.  A tier's susceptibility to strain ``l`` is
+    ``1 - vaccine_efficacy[l, k]``."""
+
+    knot_locations: Any      # [A, K, n_knots]   n_knots <= 4
+    base_equations: Any      # [A, K, 4]         a + b t + c t^2 + d t^3
+    knot_coefficients: Any   # [A, K, n_knots]
+    vaccine_efficacy: Any    # [S, K]            0 = no protection .. 1 = full protection
+
+
+@dataclass
 class SEIRS_MultiStrain_ODEParams(AbstractODEParams):
     """examples/seirs_multi_strain_age_stratified.py:177-184 (+ optional seasonality, cfg 5, and
     optional external introductions)."""
@@ -142,6 +159,7 @@ class SEIRS_MultiStrain_ODEParams(AbstractODEParams):
     idx: Optional[SimpleNamespace] = None
     seasonality_params: Optional[SeasonalityParams] = None
     introduction_params: Optional[IntroductionParams] = None
+    vaccination_params: Optional[VaccinationParams] = None
 
 
 @dataclass
@@ -154,6 +172,7 @@ class Packed:
     contact: np.ndarray     # [A, A]
     batch: Optional[int]    # None = unbatched call
     shapes: Tuple[tuple, ...]  # per-compartment shapes without time/batch axes
+    tiers: Optional[int] = None  # vaccination: tracked tiers K; the tier axis (axis 1) is padded to 2 or 4
 
 
 class CompartmentalODE:
@@ -272,6 +291,8 @@ class CompartmentalODE:
 
     def wants_grad(self, p) -> bool:
         leaves = [getattr(p, f.name) for f in fields(p)]
+        if getattr(p, "vaccination_params", None) is not None:
+            return False      # no tangent kernels for vaccination tiers yet: the solve is not differentiable
         seas = getattr(p, "seasonality_params", None)
         if seas is not None:
             leaves += [seas.forcing_amp, seas.forcing_phase, seas.forcing_period]
@@ -327,6 +348,8 @@ class CompartmentalODE:
         if len(initial_state) != len(self.compartments):
             raise ValueError(f"{self.__name__} expects compartments {self.compartments}, got "
                              f"{len(initial_state)} arrays")
+        if getattr(p, "vaccination_params", None) is not None:
+            return self._pack_vaccination(initial_state, p)
         if with_params:
             params, pbatch, seasonal = self._param_matrix(p)
         else:
@@ -378,6 +401,58 @@ class CompartmentalODE:
         return Packed(model, np.ascontiguousarray(y0), params, self._contact(p, A, contact_shape), batch,
                       tuple(shapes))
 
+    def _pack_vaccination(self, initial_state, p) -> Packed:
+        """Vaccination tiers: the (age, tier) pairs become the groups of the kernel's contact axis
+        (include/dynode_hip.h, "n_vax_tiers"), tier padded to 2 or 4 slots; the caller's age contact
+        matrix is turned into the group matrix C[a][b] / P_b (P_b = population of age b in the initial
+        state) and the model runs with normalize = 0."""
+        if not self.multi_strain or self.contact_ndim != 1:
+            raise ValueError(f"{self.__name__}: vaccination tiers are available for the multi-strain family")
+        vp = p.vaccination_params
+        base, knots, coefs, ve = (_np(vp.base_equations), _np(vp.knot_locations), _np(vp.knot_coefficients),
+                                  _np(vp.vaccine_efficacy))
+        A, K = base.shape[:2]
+        nk = knots.shape[-1] if knots.ndim == 3 else 0
+        if base.shape != (A, K, 4) or knots.shape != (A, K, nk) or coefs.shape != (A, K, nk) or not 2 <= K <= 4 or nk > 4:
+            raise ValueError("vaccination splines must be base_equations [A, K, 4], knot_locations / knot_coefficients "
+                             "[A, K, n_knots] with 2 <= K <= 4 tiers and n_knots <= 4")
+        KV = 2 if K == 2 else 4
+        rates, pbatch, seasonal = self._param_matrix(p)
+        S = (rates.shape[1] - (3 if seasonal else 0)) // len(self._strain_columns(p))
+        if ve.shape != (S, K) or ve.min() < 0 or ve.max() > 1:
+            raise ValueError(f"vaccine_efficacy must have shape (strains, tiers) = {(S, K)} with values in [0, 1]")
+        arrs = [_np(a).astype(np.float64) for a in initial_state]
+        flat, shapes, pop = [], [], np.zeros(A)
+        for name, a in zip(self.compartments, arrs):
+            tail = () if name == "s" else ((S,) + ((self.n_wane,) if (name == "r" and self.n_wane > 1) else ()))
+            if a.shape != (A, K) + tail:
+                raise ValueError(f"compartment {name} has shape {a.shape}; expected {(A, K) + tail} (age, tier, ...)")
+            padded = np.zeros((A, KV) + tail)
+            padded[:, :K] = a
+            flat.append(padded.reshape(-1))
+            shapes.append((A, KV) + tail)
+            if name != "c":
+                pop += a.reshape(A, -1).sum(1)
+        C = _np(p.contact_matrix)
+        if C.shape != (A, A):
+            raise ValueError(f"contact_matrix has shape {C.shape}, expected {(A, A)}")
+        Cg = np.repeat(np.repeat(C / pop[None, :], KV, axis=0), KV, axis=1)
+        sus = np.ones((A, KV, S))
+        sus[:, :K, :] = 1.0 - ve.T[None, :, :]
+        spl = np.zeros((A, KV, 4 + 2 * nk))
+        spl[:, :K, :4], spl[:, :K, 4:4 + nk], spl[:, :K, 4 + nk:] = base, knots, coefs
+        B = rates.shape[0]
+        params = np.concatenate([rates, np.broadcast_to(sus.reshape(1, -1), (B, sus.size)),
+                                 np.broadcast_to(spl.reshape(1, -1), (B, spl.size))], axis=1)
+        masks = self._intro_masks(p, A, S)
+        if masks:
+            raise ValueError("introduced strains and vaccination tiers cannot be combined yet")
+        model = ModelDesc(n_age=A * KV, n_strain=S, has_e=self.has_e, has_wane=self.has_wane, has_c=self.has_c,
+                          n_wane=self.n_wane, normalize=False, seasonal=seasonal, n_vax_tiers=K, n_vax_knots=nk)
+        assert params.shape[1] == model.param_dim
+        return Packed(model, np.concatenate(flat), np.ascontiguousarray(params), np.ascontiguousarray(Cg), pbatch,
+                      tuple(shapes), tiers=K)
+
     # ------------------------------------------------------------------ host evaluation
     def __call__(self, t, state, p):
         """f(t, state, p) with NumPy, unbatched -- for inspection/tests, never used by simulate."""
@@ -399,12 +474,32 @@ class CompartmentalODE:
         k += int(m.has_e)
         omega = q[k * S:(k + 1) * S] if m.has_wane else None
         k += int(m.has_wane)
+        pos = k * S
+        intro = None
+        if m.has_intro:
+            intro = q[pos:pos + 3 * S].reshape(3, S); pos += 3 * S
         if m.seasonal:
-            amp, phase, period = q[k * S:k * S + 3]
+            amp, phase, period = q[pos:pos + 3]; pos += 3
             beta = beta * (1.0 + amp * np.sin(2 * np.pi * t / period + phase))
         N = s + i.sum(1) + r.sum((1, 2)) + (e.sum(1) if e is not None else 0.0)
         x = i / N[:, None] if m.normalize else i
-        flux = (beta[None, :] * (C @ x)) * s[:, None]
+        if intro is not None:               # external introductions: a Gaussian pulse of infectious contacts
+            when, scale, pct = intro
+            mask = np.array([[(int(m.intro_age_mask[l]) >> b) & 1 for l in range(S)] for b in range(A)], dtype=float)
+            pulse = pct * np.exp(-0.5 * ((t - when) / scale) ** 2) / (scale * np.sqrt(2 * np.pi))
+            x = x + mask * pulse[None, :] * (1.0 if m.normalize else N[:, None])
+        foi = beta[None, :] * (C @ x)
+        doses = None
+        if m.n_vax_tiers > 1:               # groups = (age, tier): susceptibility per group, doses move s up a tier
+            KV, nk = m.vax_lanes, m.n_vax_knots
+            foi = foi * q[pos:pos + A * S].reshape(A, S); pos += A * S
+            c = q[pos:pos + A * (4 + 2 * nk)].reshape(A, 4 + 2 * nk)
+            nu = c[:, 0] + t * (c[:, 1] + t * (c[:, 2] + t * c[:, 3]))
+            nu = nu + (c[:, 4 + nk:] * np.maximum(t - c[:, 4:4 + nk], 0.0) ** 3).sum(1)
+            tier = np.arange(A) % KV
+            people = np.repeat(N.reshape(-1, KV).sum(1), KV)
+            doses = np.where(tier >= m.n_vax_tiers - 1, 0.0, np.minimum(np.maximum(nu, 0.0) * people, np.maximum(s, 0.0)))
+        flux = foi * s[:, None]
         g_i = gamma[None, :] * i
         ds = -flux.sum(1)
         out = []
@@ -421,9 +516,12 @@ class CompartmentalODE:
             ds = ds + rate[:, :, -1].sum(1)
         else:
             dr[:, :, 0] = g_i
+        if doses is not None:
+            ds = ds - doses + np.where(tier == 0, 0.0, np.roll(doses, 1))
         parts = [ds] + ([de] if de is not None else []) + [di, dr] + ([flux] if m.has_c else [])
         for arr, shape in zip(parts, pk.shapes):
-            out.append(np.asarray(arr).reshape(shape))
+            arr = np.asarray(arr).reshape(shape)
+            out.append(arr[:, :pk.tiers] if pk.tiers is not None else arr)
         return tuple(out)
 
 

@@ -228,6 +228,8 @@ def simulate(ode, duration_days, initial_state: CompartmentState, ode_parameters
             continue
         size = int(np.prod(shape))
         block = res.ys[:, :, pos:pos + size].reshape((res.ys.shape[0], n_save) + tuple(shape))
+        if packed.tiers is not None:                      # vaccination: drop the padded tier slots (axis after age)
+            block = block[:, :, :, :packed.tiers]
         ys.append(block if batched else block[0])
         pos += size
     unb = (lambda t: t) if batched else (lambda t: t[0])

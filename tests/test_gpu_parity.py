@@ -598,3 +598,17 @@ def test_vaccination_tiers_match_oracle_and_move_people_up(ages, m, dtype):
     assert np.all(tiers[:, 0, 1:] == 0) and np.all(tiers[:, -1, 1:m.n_vax_tiers] > 0)    # doses move people up ...
     assert np.all(tiers[:, :, m.n_vax_tiers:] == 0)                                        # ... never beyond the last tracked tier
     assert np.all(np.diff(tiers[:, :, 0], axis=1) <= 2e-3)                                 # tier 0 only loses people (up to interpolation ripple at the kink)
+
+
+def test_vaccination_shape_built_on_demand():
+    """A vaccinated member of the family that instances.def does not list (5 ages x 2 tiers, one strain,
+    SEIRS): the on-demand build passes the vaccination lanes in the template's feature word."""
+    from dynode_amd import jit
+
+    m = ModelDesc(n_age=10, n_strain=1, has_e=True, has_wane=True, has_c=True, normalize=False, n_vax_tiers=2, n_vax_knots=2)
+    assert jit._features(m) == 4
+    y0, p, C, t1, ts, pop = vax_workload(5, m, 7, seed=4)
+    r = solve_batch(m, y0, p, C, t1, ts, dtype=F64, constant_dt=0.5)
+    want, st, _, _ = O.solve(H.omodel(m), y0, p, C, t1, ts, dtype=np.float64, n_threads=8, constant_dt=0.5)
+    assert int(r.status.max()) == 0 and np.abs(r.ys.cpu().numpy() - want).max() / 1000.0 < 1e-11
+    assert _supported(m, F64, "tsit5")
