@@ -253,7 +253,7 @@ def main():
         if world == 1 and not args.no_extra and args.workload == "cfg3":
             # the other single-GPU configs of BASELINE.json, 20 launches each (not the headline value)
             line["other_workloads"] = {}
-            for name in ("cfg2", "cfg5", "cfg3w8"):
+            for name in ("cfg2", "cfg5", "cfg3w8", "seip"):
                 w2 = synthetic.WORKLOADS[name]()
                 a = [torch.as_tensor(x, dtype=f32, device=dev) for x in (w2.y0, w2.params, w2.contact, w2.save_ts)]
                 o2 = torch.empty((w2.B, w2.n_save, w2.model.state_dim), dtype=f32, device=dev)
@@ -272,7 +272,10 @@ def main():
                 ms = e0.elapsed_time(e1) / 20
                 gbs = w2.bytes_per_trajectory(4) * w2.B / (ms * 1e-3) / 1e9
                 line["other_workloads"][name] = {
-                    "workload": f"{w2.name}: A={w2.model.n_age} S={w2.model.n_strain} W={w2.model.n_wane} D={w2.model.state_dim}, B={w2.B}",
+                    "workload": (f"{w2.name}: A={w2.model.n_age} S={w2.model.n_strain} W={w2.model.n_wane} D={w2.model.state_dim}, B={w2.B}"
+                                 if w2.model.family == 0 else
+                                 "seip (ode_model.md): {0} ages x {2} immune histories x {3} vaccination tiers x {4} waning states, "
+                                 "{1} strains, D={5}, B={6}".format(*w2.model.seip_dims[:5], w2.model.state_dim, w2.B)),
                     "trajectories_per_s": w2.B / (ms * 1e-3), "ms_per_launch": ms, "hbm_frac": gbs / HBM_PEAK_GBS,
                     "all_status_ok": int(st2[0].max()) == 0}
                 del o2

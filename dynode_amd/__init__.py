@@ -5,7 +5,7 @@ Drop-in for the simulate path of CDCgov/DynODE: ``SimulationConfig`` / ``Initial
 Tsit5/Dopri5 solve and the compartmental RHS fused into one hand-written HIP kernel for gfx950.
 """
 
-from . import config, infer, simulation, typing, utils  # noqa: F401
+from . import config, infer, seip, simulation, typing, utils  # noqa: F401
 from ._abi import ModelDesc  # noqa: F401
 from .config import *  # noqa: F401,F403  (every name of dynode.config, see config/__init__.py)
 from .infer import (InferenceProcess, MCMCProcess, SVIProcess, checkpoint_compartment_sizes,  # noqa: F401

@@ -55,7 +55,7 @@ class ModelDescC(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in (
         "n_age", "n_strain", "has_e", "has_wane", "has_c", "n_wane", "normalize", "seasonal", "has_intro",
         "n_vax_tiers")] + [("intro_age_mask", ctypes.c_uint64 * MAX_STRAINS), ("n_vax_knots", ctypes.c_int32),
-                           ("reserved", ctypes.c_int32)]
+                           ("family", ctypes.c_int32), ("seasonal_vax", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
 class SolverOptsC(ctypes.Structure):
@@ -100,21 +100,33 @@ class ModelDesc:
     intro_age_mask: tuple = ()       # per strain: bit a set = age bin a receives the introductions
     n_vax_tiers: int = 0             # > 1: n_age enumerates (age, vaccination tier) groups, 2 or 4 slots per age
     n_vax_knots: int = 0             # knots of the vaccination-rate splines (0..4)
+    family: int = 0                  # 1 = SEIP with immune histories (include/dynode_hip.h, "SEIP")
+    seasonal_vax: bool = False       # SEIP: yearly reset of the top vaccination tier
 
     def c(self) -> ModelDescC:
         masks = tuple(int(v) for v in self.intro_age_mask) + (0,) * (MAX_STRAINS - len(self.intro_age_mask))
         return ModelDescC(self.n_age, self.n_strain, int(self.has_e), int(self.has_wane),
                           int(self.has_c), self.n_wane, int(self.normalize), int(self.seasonal),
                           int(self.has_intro), int(self.n_vax_tiers), (ctypes.c_uint64 * MAX_STRAINS)(*masks),
-                          int(self.n_vax_knots), 0)
+                          int(self.n_vax_knots), int(self.family), int(self.seasonal_vax), 0)
 
     # pure-Python mirrors of dyn_state_dim & co (host logic must not need the .so)
     @property
+    def seip_dims(self) -> tuple:
+        """(A, L, H, K1, M1, n_knots) of a family-1 model."""
+        return self.n_age, self.n_strain, 1 << self.n_strain, max(int(self.n_vax_tiers), 1), self.n_wane, self.n_vax_knots
+
+    @property
     def compartment_names(self) -> tuple:
+        if self.family == 1:
+            return ("s", "e", "i", "c")
         return ("s",) + (("e",) if self.has_e else ()) + ("i", "r") + (("c",) if self.has_c else ())
 
     @property
     def compartment_sizes(self) -> tuple:
+        if self.family == 1:
+            A, L, H, K1, M1, _ = self.seip_dims
+            return (A * H * K1 * M1,) + (A * H * K1 * L,) * 3
         A, AS = self.n_age, self.n_age * self.n_strain
         return (A,) + ((AS,) if self.has_e else ()) + (AS, AS * self.n_wane) + (
             (AS,) if self.has_c else ())
@@ -125,6 +137,9 @@ class ModelDesc:
 
     @property
     def param_dim(self) -> int:
+        if self.family == 1:
+            A, L, H, K1, M1, nk = self.seip_dims
+            return 3 * L + M1 + (3 if self.seasonal else 0) + int(self.seasonal_vax) + A + H * K1 * M1 * L + A * K1 * (4 + 2 * nk)
         vax = self.n_age * (self.n_strain + 4 + 2 * self.n_vax_knots) if self.n_vax_tiers > 1 else 0
         return self.n_strain * (2 + int(self.has_e) + int(self.has_wane) + (3 if self.has_intro else 0)) + (
             3 if self.seasonal else 0) + vax
@@ -132,7 +147,7 @@ class ModelDesc:
     @property
     def vax_lanes(self) -> int:
         """Tier slots per age on the contact axis: 0 (no vaccination axis), 2 or 4."""
-        return 0 if self.n_vax_tiers <= 1 else (2 if self.n_vax_tiers <= 2 else 4)
+        return 0 if (self.n_vax_tiers <= 1 or self.family == 1) else (2 if self.n_vax_tiers <= 2 else 4)
 
 
 class HipLibraryMissing(RuntimeError):

@@ -3,6 +3,7 @@
 // no global mutable state (the last-error text is thread-local).
 #include "../../include/dynode_hip.h"
 #include "solve_kernel.hpp"
+#include "seip_kernel.hpp"
 
 #include <stdio.h>
 #include <stdlib.h>
@@ -23,6 +24,10 @@ namespace dyn {
 #undef XF
 #undef XI
 #undef X
+#define Y(T, METHOD, GA, L, K1, M1) \
+    extern template hipError_t launch_seip<T, METHOD, GA, L, K1, M1>(const KArgs<T> &, hipStream_t);
+#include "seip_instances.def"
+#undef Y
 
 template <typename T>
 struct DType;
@@ -39,6 +44,9 @@ struct Entry {
     int dtype, method, G, S, E, WN, C, W, ND, SPL, FEAT; // FEAT: bit 0 introductions, bits 1.. vaccination-tier lanes
     void *fn; // hipError_t (*)(const KArgs<T>&, hipStream_t)
 };
+// SEIP shapes (seip_kernel.hpp) share the table: G = age lanes, S = strains, W = waning states,
+// FEAT = kSeip | tiers; the lane group is G * 2^S
+constexpr int kSeip = 0x100;
 
 static const Entry kEntries[] = {
 #define X(T, METHOD, G, S, E, WN, C, W, ND, SPL)              \
@@ -57,6 +65,11 @@ static const Entry kEntries[] = {
 #undef XF
 #undef XI
 #undef X
+#define Y(T, METHOD, GA, L, K1, M1)                                          \
+    {DType<T>::id, METHOD, GA, L, 1, 1, 1, M1, 0, 1, kSeip | K1,             \
+     (void *)(hipError_t(*)(const KArgs<T> &, hipStream_t)) & launch_seip<T, METHOD, GA, L, K1, M1>},
+#include "seip_instances.def"
+#undef Y
 };
 static constexpr int kNumEntries = sizeof(kEntries) / sizeof(kEntries[0]);
 
@@ -76,7 +89,13 @@ static std::mutex g_extra_mutex;
 static int vax_lanes(const dyn_model_desc *m) {
     return m->n_vax_tiers <= 1 ? 0 : (m->n_vax_tiers <= 2 ? 2 : (m->n_vax_tiers <= 4 ? 4 : -1));
 }
-static int model_features(const dyn_model_desc *m) { return (m->has_intro ? 1 : 0) | (vax_lanes(m) << 1); }
+static int seip_tiers(const dyn_model_desc *m) { return m->n_vax_tiers > 1 ? m->n_vax_tiers : 1; }
+static int model_features(const dyn_model_desc *m) {
+    if (m->family == 1) return kSeip | seip_tiers(m);
+    return (m->has_intro ? 1 : 0) | (vax_lanes(m) << 1);
+}
+// lanes one trajectory occupies in a wave
+static int entry_lanes(const Entry *e) { return (e->FEAT & kSeip) ? (e->G << e->S) : e->G * (e->S / e->SPL); }
 
 static bool matches(const Entry &e, const dyn_model_desc *m, int G, int dtype, int method, int nd) {
     return e.dtype == dtype && e.method == method && e.G == G && e.S == m->n_strain &&
@@ -115,6 +134,15 @@ static int check_model(const dyn_model_desc *m) {
     if (m->n_age < 1 || m->n_age > 64 || m->n_strain < 1 || m->n_wane < 1) return DYN_ERR_MODEL;
     if (m->n_wane > 1 && !m->has_wane) return DYN_ERR_MODEL;
     if (m->has_intro && m->n_strain > DYN_MAX_STRAINS) return DYN_ERR_MODEL;
+    if (m->family != 0 && m->family != 1) return DYN_ERR_MODEL;
+    if (m->family == 1) { /* SEIP: groups = age x 2^strains lanes */
+        if (m->n_strain > 4 || (group_width(m->n_age) << m->n_strain) > 64 || m->n_vax_tiers < 0 || m->n_vax_tiers > 4 ||
+            m->n_vax_knots < 0 || m->n_vax_knots > 4 || !m->has_e || !m->has_c || !m->has_wane || m->normalize ||
+            m->has_intro)
+            return DYN_ERR_MODEL;
+        return 0;
+    }
+    if (m->seasonal_vax) return DYN_ERR_MODEL;
     if (m->n_vax_tiers < 0 || vax_lanes(m) < 0 || m->n_vax_knots < 0 || m->n_vax_knots > 4) return DYN_ERR_MODEL;
     if (vax_lanes(m) > 0 && m->n_age % vax_lanes(m) != 0) return DYN_ERR_MODEL; /* groups = ages x tier lanes */
     return 0;
@@ -172,6 +200,7 @@ static int enqueue(const Entry *e, const dyn_model_desc *m, const dyn_solver_opt
     for (int l = 0; l < DYN_MAX_STRAINS; ++l) ka.intro_mask[l] = m->has_intro ? m->intro_age_mask[l] : 0;
     ka.n_vax_tiers = m->n_vax_tiers;
     ka.n_vax_knots = m->n_vax_knots;
+    ka.seasonal_vax = m->seasonal_vax ? 1 : 0;
 
     // saved-row layout: saved compartments concatenated in state order
     int32_t off[8];
@@ -181,7 +210,7 @@ static int enqueue(const Entry *e, const dyn_model_desc *m, const dyn_solver_opt
     slot_of[n++] = 0;
     if (m->has_e) slot_of[n++] = 1;
     slot_of[n++] = 2;
-    slot_of[n++] = 3;
+    if (m->family != 1) slot_of[n++] = 3; /* SEIP has no r: s e i c */
     if (m->has_c) slot_of[n++] = 4;
     for (int s = 0; s < 5; ++s) ka.save_off[s] = -1;
     int pos = 0;
@@ -210,7 +239,7 @@ static int enqueue(const Entry *e, const dyn_model_desc *m, const dyn_solver_opt
     // trajectory's dense output: replicate each trajectory over 2^r lane groups (<= 8) while the
     // grid still fits in one resident round (~2 waves per SIMD on 1024 SIMDs).
     {
-        const int tpw = 64 / (group_width(m->n_age) * (e->S / e->SPL));
+        const int tpw = 64 / entry_lanes(e);
         const int64_t waves = (B + tpw - 1) / tpw;
         int r = 0;
         const char *env = getenv("DYNODE_HIP_REPLICAS_LOG2");
@@ -220,12 +249,12 @@ static int enqueue(const Entry *e, const dyn_model_desc *m, const dyn_solver_opt
             // measured: tiny states (<= 5 values per lane: SIR, SEIRS) gain up to 4 waves per SIMD
             // (cfg 2: 0.37 -> 0.19 ms); register-heavy VALU-bound shapes do not (cfg 5: 0.72 -> 0.89 ms)
             const int nv = 1 + e->SPL * (e->E + 1 + e->W + e->C);
-            if (nv <= 5)
+            if (nv <= 5 && !(e->FEAT & kSeip))
                 while (r < 3 && (waves << (r + 1)) <= 4096) ++r;
         }
         ka.rep_log2 = r < 0 ? 0 : (r > 3 ? 3 : r);
         if (ll) { // the replicas of a trajectory must share a wave (LDS table, lane reductions)
-            const int lanes = group_width(m->n_age) * (e->S / e->SPL);
+            const int lanes = entry_lanes(e);
             while (ka.rep_log2 > 0 && (lanes << ka.rep_log2) > 64) --ka.rep_log2;
         }
         if (ll && ka.rep_log2 > 0) {
@@ -252,10 +281,18 @@ extern "C" {
 int32_t dyn_abi_version(void) { return DYN_ABI_VERSION; }
 
 int32_t dyn_n_compartments(const dyn_model_desc *m) {
+    if (m->family == 1) return 4; /* s e i c */
     return 3 + (m->has_e ? 1 : 0) + (m->has_c ? 1 : 0);
 }
 
 int32_t dyn_compartment_offsets(const dyn_model_desc *m, int32_t *off) {
+    if (m->family == 1) {
+        const int groups = (m->n_age << m->n_strain) * dyn::seip_tiers(m);
+        off[0] = 0;
+        off[1] = groups * m->n_wane;
+        for (int c = 2; c <= 4; ++c) off[c] = off[c - 1] + groups * m->n_strain;
+        return 4;
+    }
     const int A = m->n_age, AS = m->n_age * m->n_strain;
     int n = 0, pos = 0;
     off[n++] = pos;
@@ -277,11 +314,17 @@ int32_t dyn_compartment_offsets(const dyn_model_desc *m, int32_t *off) {
 }
 
 int32_t dyn_state_dim(const dyn_model_desc *m) {
+    if (m->family == 1) return (m->n_age << m->n_strain) * dyn::seip_tiers(m) * (m->n_wane + 3 * m->n_strain);
     return m->n_age *
            (1 + m->n_strain * ((m->has_e ? 1 : 0) + 1 + m->n_wane + (m->has_c ? 1 : 0)));
 }
 
 int32_t dyn_param_dim(const dyn_model_desc *m) {
+    if (m->family == 1) {
+        const int L = m->n_strain, K1 = dyn::seip_tiers(m);
+        return 3 * L + m->n_wane + (m->seasonal ? 3 : 0) + (m->seasonal_vax ? 1 : 0) + m->n_age +
+               (1 << L) * K1 * m->n_wane * L + m->n_age * K1 * (4 + 2 * m->n_vax_knots);
+    }
     return m->n_strain * (2 + (m->has_e ? 1 : 0) + (m->has_wane ? 1 : 0) + (m->has_intro ? 3 : 0)) +
            (m->seasonal ? 3 : 0) +
            (m->n_vax_tiers > 1 ? m->n_age * (m->n_strain + 4 + 2 * m->n_vax_knots) : 0);
@@ -290,6 +333,7 @@ int32_t dyn_param_dim(const dyn_model_desc *m) {
 int32_t dyn_trajectories_per_wave(const dyn_model_desc *m) {
     if (dyn::check_model(m)) return 0;
     const dyn::Entry *e = dyn::find_entry(m, DYN_F32, DYN_TSIT5, 0);
+    if (m->family == 1) return 64 / (dyn::group_width(m->n_age) << m->n_strain);
     const int gs = e ? e->S / e->SPL : 1;
     return 64 / (dyn::group_width(m->n_age) * gs);
 }
@@ -333,7 +377,30 @@ static int solve_impl(const dyn_model_desc *m, const dyn_solver_opts *o, const v
     }
     for (int j = 1; j < o->n_jump; ++j)
         if (!(o->jump_ts[j] > o->jump_ts[j - 1])) return DYN_ERR_JUMP; /* must be strictly increasing */
+    if (m->family == 1 && (n_dir > 0 || o->n_jump > 0)) {
+        snprintf(dyn::tl_error, sizeof(dyn::tl_error), "the SEIP kernels have no %s yet",
+                 n_dir > 0 ? "tangent planes" : "discontinuity_points");
+        return DYN_ERR_UNSUPPORTED;
+    }
     const dyn::Entry *e = dyn::find_entry(m, o->dtype, o->method, n_dir);
+    if (!e && m->family == 1) {
+        snprintf(dyn::tl_error, sizeof(dyn::tl_error),
+                 "no SEIP kernel compiled for A=%d strains=%d tiers=%d waning states=%d dtype=%d method=%d; to add it "
+                 "put  Y(%s, %d, %d, %d, %d, %d)  into dynode_amd/csrc/seip_instances.def and rebuild",
+                 m->n_age, m->n_strain, dyn::seip_tiers(m), m->n_wane, o->dtype, o->method,
+                 o->dtype == DYN_F64 ? "double" : "float", o->method, dyn::group_width(m->n_age), m->n_strain,
+                 dyn::seip_tiers(m), m->n_wane);
+        return DYN_ERR_UNSUPPORTED;
+    }
+    if (e && m->family == 1) { // susceptibility table and splines of every trajectory of a wave sit in LDS
+        const size_t per_traj = (size_t)(1 << m->n_strain) * dyn::seip_tiers(m) * m->n_wane * m->n_strain +
+                                (size_t)m->n_age * dyn::seip_tiers(m) * (4 + 2 * m->n_vax_knots);
+        const size_t bytes = ((size_t)n_save + (64 / dyn::entry_lanes(e)) * per_traj) * (o->dtype == DYN_F64 ? 8 : 4);
+        if (bytes > 64 * 1024) {
+            snprintf(dyn::tl_error, sizeof(dyn::tl_error), "SEIP tables need %zu bytes of LDS per wave (limit 65536)", bytes);
+            return DYN_ERR_UNSUPPORTED;
+        }
+    }
     if (!e) {
         const int ga = dyn::group_width(m->n_age);
         snprintf(dyn::tl_error, sizeof(dyn::tl_error),
@@ -400,7 +467,7 @@ int dyn_solve_batch_loglik(const dyn_model_desc *m, const dyn_solver_opts *o, co
     slot_of[n++] = 0;
     if (m->has_e) slot_of[n++] = 1;
     slot_of[n++] = 2;
-    slot_of[n++] = 3;
+    if (m->family != 1) slot_of[n++] = 3; /* SEIP has no r: s e i c */
     if (m->has_c) slot_of[n++] = 4;
     dyn::LLArgs ll;
     ll.obs = obs;

@@ -1,0 +1,433 @@
+// seip_kernel.hpp -- the SEIP family (include/dynode_hip.h "SEIP"; ode_model.md:15-53, 70-105, 176-211):
+// age x immune history x vaccination tier x waning state, fused with the same adaptive Tsit5 / Dopri5
+// stepper as solve_kernel.hpp (same controller, same dense output, same status codes).
+//
+// Lane mapping: a trajectory owns GA x H lanes, GA = power of two >= n_age in the low lane bits (so the
+// age contraction is the DPP gather of solve_kernel.hpp, unchanged), H = 2^L immune histories above
+// them.  Lane (a, j) keeps in registers everything of age a with history j:
+//     s[K1][M1] | e[K1][L] | i[K1][L] | c[K1][L]        NV = K1 * (M1 + 3 L) values
+// Cross-lane traffic per right-hand side, all xor-shaped:
+//     sum over histories of the infectious and of each tier's susceptibles   (butterfly over the high bits)
+//     age contraction  lambda_a = sum_b C[a][b] x_b                          (DPP, low bits)
+//     recovery  eta(j, l) = j | 2^l: lanes whose bit l is set take gamma_l i from lane j ^ 2^l (and keep their own)
+// Infection, waning, vaccination and the seasonal reset move people inside a lane.  The susceptibility
+// table sus[H][K1][M1][L] and the dose-rate splines of a trajectory are staged in LDS.
+// Primal only (no tangent planes), no discontinuity points, no replication: one group per trajectory.
+#pragma once
+#include "solve_kernel.hpp"
+
+namespace dyn {
+
+template <typename T, int METHOD, int GA, int L, int K1, int M1>
+struct Seip {
+    static constexpr int H = 1 << L, G = GA * H, TPW = 64 / G, K = K1 - 1;
+    static_assert(G <= 64 && L >= 1 && L <= 4 && K1 >= 1 && K1 <= 4 && M1 >= 1, "SEIP lane group");
+    static constexpr int NS = K1 * M1, NE = K1 * L, NV = NS + 3 * NE;
+    static constexpr int IE = NS, II = NS + NE, IC = NS + 2 * NE;
+    using M = Mth<T>;
+    using TB = Tab<METHOD>;
+    // the age contraction and the dense output are the ones of the s/e/i/r/c kernels
+    using Lanes = Solver<T, METHOD, GA, L, true, true, true, 1, 0, L>;
+    using Dense = typename Lanes::Dense;
+
+    T beta[L], gamma[L], sigma[L], omega[M1];
+    Lanes ages;        // only Cx (pre-permuted contact row) is used
+    T amp, phase, w_season, tau;
+    T pop;             // population of this lane's age (doses per day = nu * pop)
+    const T *sus;      // LDS: sus[K1][M1][L] of this lane's history
+    const T *spl;      // LDS: spline[K1][4 + 2 nk] of this lane's age
+    int nk, hist;
+    bool pad, seasonal, seasonal_vax;
+
+    __device__ __forceinline__ static T hist_sum(T v) {
+        if constexpr (H >= 2) v += xchg_xor<GA>(v);
+        if constexpr (H >= 4) v += xchg_xor<2 * GA>(v);
+        if constexpr (H >= 8) v += xchg_xor<4 * GA>(v);
+        if constexpr (H >= 16) v += xchg_xor<8 * GA>(v);
+        return v;
+    }
+
+    // recovery of strain l: gamma_l i_{a,j,k,l} enters s_{a, j | 2^l, k, 0}
+    template <int l>
+    __device__ __forceinline__ void recover(const T (&y)[NV], T (&dy)[NV]) const {
+        if constexpr (l < L) {
+            const bool has = (hist >> l) & 1;
+#pragma unroll
+            for (int k = 0; k < K1; ++k) {
+                const T g_i = gamma[l] * y[II + k * L + l];
+                const T partner = xchg_xor<(GA << l)>(g_i); // every lane takes part in the exchange
+                dy[k * M1] += has ? partner + g_i : T(0);
+            }
+            recover<l + 1>(y, dy);
+        }
+    }
+
+    __device__ __forceinline__ void rhs(T t, const T (&y)[NV], T (&dy)[NV]) const {
+        T x[L], lam[L];
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            T a = y[II + l];
+#pragma unroll
+            for (int k = 1; k < K1; ++k) a += y[II + k * L + l];
+            x[l] = hist_sum(a);
+        }
+        ages.contract(x, lam);
+        T season = T(1), phi = T(0);
+        if (seasonal) season = T(1) + amp * M::sin(w_season * t + phase);
+        if (seasonal_vax) {
+            // sin^1000 by squaring (the oracle multiplies in the same order): 1000 = 2 * (256+128+64+32+16+4)
+            const T sn = M::sin(T(6.283185307179586476925286766559) * (t + tau) / T(730));
+            const T u = sn * sn, u2 = u * u, u4 = u2 * u2, u8 = u4 * u4, u16 = u8 * u8, u32 = u16 * u16,
+                    u64 = u32 * u32, u128 = u64 * u64, u256 = u128 * u128;
+            phi = ((((u256 * u128) * u64) * u32) * u16) * u4;
+        }
+#pragma unroll
+        for (int l = 0; l < L; ++l) lam[l] = (beta[l] * season) * lam[l];
+
+        // share of each tier's susceptibles vaccinated per day
+        T rate[K1];
+#pragma unroll
+        for (int k = 0; k < K1; ++k) {
+            const T *c = spl + k * (4 + 2 * nk);
+            T nu = c[0] + t * (c[1] + t * (c[2] + t * c[3]));
+            for (int n = 0; n < nk; ++n) {
+                const T lag = t - c[4 + n];
+                if (lag > T(0)) nu += c[4 + nk + n] * (lag * lag * lag);
+            }
+            T tot = y[k * M1];
+#pragma unroll
+            for (int m = 1; m < M1; ++m) tot += y[k * M1 + m];
+            tot = hist_sum(tot);
+            const T doses = M::max(nu, T(0)) * pop;
+            rate[k] = tot > T(0) ? (doses < tot ? doses / tot : T(1)) : T(0);
+        }
+
+#pragma unroll
+        for (int v = 0; v < NS; ++v) dy[v] = T(0);
+#pragma unroll
+        for (int k = 0; k < K1; ++k) {
+            T inflow[L];
+#pragma unroll
+            for (int l = 0; l < L; ++l) inflow[l] = T(0);
+#pragma unroll
+            for (int m = 0; m < M1; ++m) {
+                const T S = y[k * M1 + m];
+                const T *su = sus + (k * M1 + m) * L;
+                T out = T(0);
+#pragma unroll
+                for (int l = 0; l < L; ++l) {
+                    const T f = (lam[l] * su[l]) * S;
+                    inflow[l] += f;
+                    out += f;
+                }
+                dy[k * M1 + m] -= out;
+                if (m + 1 < M1) { // waning; the last state keeps its people
+                    const T wn = omega[m] * S;
+                    dy[k * M1 + m] -= wn;
+                    dy[k * M1 + m + 1] += wn;
+                }
+                if (!(k == K && m == 0)) { // vaccination: up one tier, freshest state; top tier: refreshed in place
+                    const T v = rate[k] * S;
+                    dy[k * M1 + m] -= v;
+                    dy[(k < K ? k + 1 : K) * M1] += v;
+                }
+                if (k == K && K > 0) { // seasonal vaccination: the top tier falls back one
+                    const T f = phi * S;
+                    dy[k * M1 + m] -= f;
+                    dy[(K > 0 ? K - 1 : 0) * M1 + m] += f;
+                }
+            }
+#pragma unroll
+            for (int l = 0; l < L; ++l) {
+                const int q = k * L + l;
+                const T s_e = sigma[l] * y[IE + q], g_i = gamma[l] * y[II + q];
+                dy[IE + q] = inflow[l] - s_e;
+                dy[II + q] = s_e - g_i;
+                dy[IC + q] = inflow[l];
+            }
+        }
+        recover<0>(y, dy);
+        if constexpr (K > 0) {
+#pragma unroll
+            for (int l = 0; l < L; ++l) {
+                const T fe = phi * y[IE + K * L + l], fi = phi * y[II + K * L + l];
+                dy[IE + K * L + l] -= fe;
+                dy[II + K * L + l] -= fi;
+                dy[IE + (K - 1) * L + l] += fe;
+                dy[II + (K - 1) * L + l] += fi;
+            }
+        }
+    }
+
+    // stages SG..6 of the step (k[0] is FSAL); compile-time stage index: every k[q][v] is a named register
+    template <int SG>
+    __device__ __forceinline__ void stages(T tprev, T dt, const T (&y)[NV], T (&yt)[NV], T (&k)[7][NV]) const {
+        if constexpr (SG < 7) {
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                T acc = T(TB::a[SG][0]) * k[0][v];
+#pragma unroll
+                for (int r = 1; r < SG; ++r)
+                    if (TB::a[SG][r] != 0.0) acc += T(TB::a[SG][r]) * k[r][v];
+                yt[v] = y[v] + dt * acc;
+            }
+            rhs(tprev + T(TB::c[SG]) * dt, yt, k[SG]);
+            stages<SG + 1>(tprev, dt, y, yt, k);
+        }
+    }
+
+    template <int FIRST, int CNT>
+    __device__ __forceinline__ static void save_block(const Dense &d, T dt, const T (&y)[NV], const T (&y1)[NV],
+                                                      const T (&k)[7][NV], T *dst, bool vec_ok) {
+        T v[CNT];
+#pragma unroll
+        for (int q = 0; q < CNT; ++q) {
+            const int j = FIRST + q;
+            v[q] = Lanes::dense_eval(d, dt, y[j], y1[j], k[0][j], k[1][j], k[2][j], k[3][j], k[4][j], k[5][j], k[6][j]);
+        }
+        store_run<T, CNT>(dst, v, vec_ok);
+    }
+
+    __device__ __forceinline__ static void run(const KArgs<T> &ka) {
+        const int lane = threadIdx.x & 63;
+        const int a = lane % GA, j = (lane / GA) % H, grp = lane / G;
+        int64_t traj = (int64_t)blockIdx.x * TPW + grp;
+        const bool valid_traj = traj < ka.B;
+        if (!valid_traj) traj = ka.B - 1;
+        const int A = ka.A, nk = ka.n_vax_knots;
+        Seip S;
+        S.pad = a >= A;
+        S.hist = j;
+        S.nk = nk;
+        S.seasonal = ka.seasonal != 0;
+        S.seasonal_vax = ka.seasonal_vax != 0;
+        const int aa = S.pad ? 0 : a;
+        const bool writer = valid_traj && !S.pad;
+
+        // ---- LDS: save grid, then per trajectory slot the susceptibility table and the splines
+        extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
+        T *const ts_tab = reinterpret_cast<T *>(dyn_smem);
+        const int n_save = ka.n_save;
+        constexpr int SUSN = H * NS * L;
+        const int spln = A * K1 * (4 + 2 * nk);
+        T *const tab = ts_tab + n_save + grp * (SUSN + spln);
+        const T *p = ka.params + traj * ka.P;
+        const T *q = p + 3 * L + M1;
+        S.amp = S.phase = S.w_season = S.tau = T(0);
+        if (S.seasonal) {
+            S.amp = q[0];
+            S.phase = q[1];
+            S.w_season = T(6.283185307179586476925286766559) / q[2];
+            q += 3;
+        }
+        if (S.seasonal_vax) {
+            S.tau = q[0];
+            q += 1;
+        }
+        S.pop = S.pad ? T(0) : q[aa];
+        q += A;
+        for (int n = lane; n < n_save; n += 64) ts_tab[n] = ka.save_ts[n];
+        for (int n = lane % G; n < SUSN + spln; n += G) tab[n] = q[n];
+        __syncthreads();
+        S.sus = tab + j * (NS * L);
+        S.spl = tab + SUSN + aa * K1 * (4 + 2 * nk);
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            S.beta[l] = p[l];
+            S.gamma[l] = p[L + l];
+            S.sigma[l] = p[2 * L + l];
+        }
+#pragma unroll
+        for (int m = 0; m < M1; ++m) S.omega[m] = p[3 * L + m];
+#pragma unroll
+        for (int k = 0; k < GA; ++k) {
+            const int b = a ^ k;
+            S.ages.Cx[k] = (!S.pad && b < A) ? ka.contact[aa * A + b] : T(0);
+        }
+
+        // ---- state: this lane's chunk of every compartment
+        const int g = aa * H + j; // (age, history) group in memory order
+        const int offE = A * H * NS, nE = A * H * NE;
+        const int D = offE + 3 * nE;
+        T y[NV], yt[NV], k[7][NV];
+        {
+            const T *src = ka.y0 + (ka.y0_batched ? traj * D : 0);
+#pragma unroll
+            for (int v = 0; v < NS; ++v) y[v] = S.pad ? T(0) : src[g * NS + v];
+#pragma unroll
+            for (int v = 0; v < NE; ++v) {
+                y[IE + v] = S.pad ? T(0) : src[offE + g * NE + v];
+                y[II + v] = S.pad ? T(0) : src[offE + nE + g * NE + v];
+                y[IC + v] = S.pad ? T(0) : src[offE + 2 * nE + g * NE + v];
+            }
+        }
+
+        const T rtol = ka.rtol, atol = ka.atol, t_end = ka.t1;
+        const T Dn = T(D);
+        const bool constant = ka.constant_dt > T(0);
+        T tprev = ka.t0, tnext;
+        S.rhs(tprev, y, k[0]);
+        bool lane_ok = true;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) lane_ok = lane_ok && (M::abs(y[v]) < M::inf()) && (M::abs(k[0][v]) < M::inf());
+        const unsigned long long bad_lanes = __ballot(!lane_ok);
+        const unsigned long long group_mask = (G == 64 ? ~0ull : ((1ull << G) - 1ull)) << (grp * G);
+        const bool start_ok = (bad_lanes & group_mask) == 0ull;
+
+        if (constant) {
+            tnext = tprev + ka.constant_dt;
+        } else { // Hairer-Norsett-Wanner II.4 starting step, as in solve_kernel.hpp
+            T n0 = 0, n1 = 0;
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const T sc = atol + M::abs(y[v]) * rtol;
+                const T q0 = y[v] / sc, q1 = k[0][v] / sc;
+                n0 += q0 * q0;
+                n1 += q1 * q1;
+            }
+            const T d0 = M::sqrt(group_sum<G>(n0) / Dn), d1 = M::sqrt(group_sum<G>(n1) / Dn);
+            const bool small = (d0 < T(1e-5)) || (d1 < T(1e-5));
+            const T h0 = small ? T(1e-6) : T(0.01) * (d0 / d1);
+#pragma unroll
+            for (int v = 0; v < NV; ++v) yt[v] = y[v] + h0 * k[0][v];
+            S.rhs(tprev + h0, yt, k[1]);
+            T s2 = 0;
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const T sc = atol + M::abs(y[v]) * rtol;
+                const T q2 = (k[1][v] - k[0][v]) / sc;
+                s2 += q2 * q2;
+            }
+            const T d2 = M::sqrt(group_sum<G>(s2) / Dn) / h0;
+            const T max_d = M::max(d1, d2);
+            const T h1 = (max_d <= T(1e-15)) ? M::max(T(1e-6), h0 * T(1e-3)) : M::pow_fast(T(0.01) / max_d, T(0.2));
+            tnext = tprev + M::min(T(100) * h0, h1);
+        }
+        tnext = M::min(tnext, t_end);
+
+        int save_idx = 0;
+        T ts_next = save_idx < n_save ? ts_tab[save_idx] : M::inf();
+        int64_t steps = 0;
+        int32_t n_acc = 0, n_rej = 0, st = start_ok ? ST_OK : ST_NONFINITE;
+        bool done = !(tprev < t_end) || !start_ok;
+        T *const out_traj = ka.out + traj * (int64_t)n_save * ka.d_saved;
+        const bool vec_ok = ka.vec_ok != 0;
+
+        while (__any(!done)) {
+            const T dt = tnext - tprev;
+            S.template stages<1>(tprev, dt, y, yt, k);
+            bool keep = true, finite = true;
+            T factor = T(1);
+            if (!constant) {
+                T ss = 0;
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    T e = T(TB::berr[0]) * k[0][v];
+#pragma unroll
+                    for (int r = 1; r < 7; ++r)
+                        if (TB::berr[r] != 0.0) e += T(TB::berr[r]) * k[r][v];
+                    const T ym = M::max(M::abs(y[v]), M::abs(yt[v]));
+                    const T r = (dt * e) * M::rcp_fast(atol + ym * rtol);
+                    ss += r * r;
+                }
+                T err = M::sqrt(group_sum<G>(ss) / Dn);
+                if (!(err == err)) err = M::inf();
+                keep = err < T(1);
+                finite = !(err == M::inf() && !(tprev + T(0.2) * dt > tprev));
+                T f = T(0.9) * M::pow_fast(err, T(-0.2));
+                f = M::max(f, keep ? T(1) : T(0.2));
+                factor = M::min(f, T(10));
+            } else {
+                bool ok = true;
+#pragma unroll
+                for (int v = 0; v < NV; ++v) ok = ok && (M::abs(yt[v]) < M::inf());
+                finite = ((__ballot(!ok) & group_mask) == 0ull);
+            }
+            const bool act = !done;
+            steps += act ? 1 : 0;
+            if (act && !finite) {
+                st = ST_NONFINITE;
+                done = true;
+            }
+            const bool accept = act && finite && keep;
+
+            bool pending = accept && (save_idx < n_save) && (ts_next <= tnext);
+            const T inv_dt = M::recip(dt);
+            while (__any(pending)) {
+                if (pending) {
+                    Dense dn;
+                    Lanes::dense_prepare((ts_next - tprev) * inv_dt, dn);
+                    if (writer) {
+                        T *row = out_traj + (int64_t)save_idx * ka.d_saved;
+                        if (ka.save_off[0] >= 0) save_block<0, NS>(dn, dt, y, yt, k, row + ka.save_off[0] + g * NS, vec_ok);
+                        if (ka.save_off[1] >= 0) save_block<IE, NE>(dn, dt, y, yt, k, row + ka.save_off[1] + g * NE, vec_ok);
+                        if (ka.save_off[2] >= 0) save_block<II, NE>(dn, dt, y, yt, k, row + ka.save_off[2] + g * NE, vec_ok);
+                        if (ka.save_off[4] >= 0) save_block<IC, NE>(dn, dt, y, yt, k, row + ka.save_off[4] + g * NE, vec_ok);
+                    }
+                    ++save_idx;
+                    ts_next = save_idx < n_save ? ts_tab[save_idx] : M::inf();
+                }
+                pending = accept && (save_idx < n_save) && (ts_next <= tnext);
+            }
+
+            if (accept) {
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    y[v] = yt[v];
+                    k[0][v] = k[6][v];
+                }
+                ++n_acc;
+            } else if (act && finite) {
+                ++n_rej;
+            }
+            const T next_t0 = accept ? tnext : tprev;
+            T next_t1 = next_t0 + (constant ? ka.constant_dt : dt * factor);
+            const T tp = M::min(next_t0, t_end);
+            if (next_t1 > t_end - M::clip_tol) next_t1 = accept ? t_end : tp + T(0.5) * (t_end - tp);
+            if (!done) {
+                tprev = tp;
+                tnext = next_t1;
+                if (!(tprev < t_end)) {
+                    done = true;
+                } else if (steps >= ka.max_steps) {
+                    st = ST_MAX_STEPS;
+                    done = true;
+                }
+            }
+        }
+
+        if (writer) {
+            for (; save_idx < n_save; ++save_idx) { // rows never reached: +inf, like an unfilled SaveAt buffer
+                T *row = out_traj + (int64_t)save_idx * ka.d_saved;
+                if (ka.save_off[0] >= 0)
+                    for (int v = 0; v < NS; ++v) row[ka.save_off[0] + g * NS + v] = M::inf();
+                for (int c = 1; c <= 4; ++c)
+                    if (c != 3 && ka.save_off[c] >= 0)
+                        for (int v = 0; v < NE; ++v) row[ka.save_off[c] + g * NE + v] = M::inf();
+            }
+            if (a == 0 && j == 0) {
+                ka.status[traj] = st;
+                ka.n_acc[traj] = n_acc;
+                ka.n_rej[traj] = n_rej;
+            }
+        }
+    }
+};
+
+template <typename T, int METHOD, int GA, int L, int K1, int M1>
+__global__ void __launch_bounds__(64) seip_kernel(const KArgs<T> ka) {
+    Seip<T, METHOD, GA, L, K1, M1>::run(ka);
+}
+
+template <typename T, int METHOD, int GA, int L, int K1, int M1>
+hipError_t launch_seip(const KArgs<T> &ka, hipStream_t stream) {
+    constexpr int TPW = 64 / (GA << L);
+    const int64_t blocks = (ka.B + TPW - 1) / TPW;
+    if (blocks <= 0) return hipSuccess;
+    const size_t per_traj = (size_t)(1 << L) * K1 * M1 * L + (size_t)ka.A * K1 * (4 + 2 * ka.n_vax_knots);
+    const size_t lds = ((size_t)ka.n_save + TPW * per_traj) * sizeof(T);
+    hipLaunchKernelGGL((seip_kernel<T, METHOD, GA, L, K1, M1>), dim3((unsigned)blocks), dim3(64), lds, stream, ka);
+    return hipGetLastError();
+}
+
+} // namespace dyn

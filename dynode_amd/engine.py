@@ -34,7 +34,7 @@ def _call_with_jit(call, L, model, dtype, method, n_dir) -> int:
     """Run the library call; if the only problem is a kernel shape that is not compiled in, build and
     register it (dynode_amd/jit.py) and call again."""
     rc = call()
-    if rc == -7 and L.dyn_last_error().decode().startswith("no kernel compiled"):
+    if rc == -7 and L.dyn_last_error().decode().startswith(("no kernel compiled", "no SEIP kernel compiled")):
         from . import jit
 
         if jit.enabled() and jit.ensure_kernel(model, dtype, method, n_dir):

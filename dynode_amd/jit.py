@@ -15,6 +15,7 @@ Disable with ``DYNODE_HIP_JIT=0`` (the call then fails with the library's "no ke
 from __future__ import annotations
 
 import ctypes
+import hashlib
 import os
 import sys
 import subprocess
@@ -45,6 +46,8 @@ def _group_width(n_age: int) -> int:
 
 def _features(model: _abi.ModelDesc) -> int:
     """The kernel template's FEAT word: bit 0 = externally introduced strains, the rest = vaccination-tier lanes."""
+    if model.family == 1:
+        return 0x100 | max(int(model.n_vax_tiers), 1)        # kSeip | tiers (csrc/dynode_hip.hip)
     return int(model.has_intro) | (model.vax_lanes << 1)
 
 
@@ -52,6 +55,8 @@ def choose_spl(model: _abi.ModelDesc, n_dir: int) -> int:
     """Strains per lane: all of them on one lane per age while the register file holds it (y, 7 stage
     derivatives and the stage state of every plane: 9 * values * planes VGPRs), otherwise split the
     strains over a power-of-two number of lanes (csrc/solve_kernel.hpp, "Strain lanes")."""
+    if model.family == 1:
+        return 1                                             # SEIP: lanes are (age, immune history) pairs
     ga, S = _group_width(model.n_age), model.n_strain
     per_strain = int(model.has_e) + 1 + model.n_wane + int(model.has_c)
     best = None
@@ -70,15 +75,39 @@ def choose_spl(model: _abi.ModelDesc, n_dir: int) -> int:
     return best
 
 
+_STAMP = None
+
+
+def _stamp() -> str:
+    """Fingerprint of the kernel sources: a cached build made from other sources (different argument struct,
+    different arithmetic) must never be loaded, so it is part of every cache file's name."""
+    global _STAMP
+    if _STAMP is None:
+        h = hashlib.sha1()
+        for f in sorted(os.listdir(_CSRC)):
+            if f.endswith((".hpp", ".h")):
+                with open(os.path.join(_CSRC, f), "rb") as fh:
+                    h.update(fh.read())
+        _STAMP = h.hexdigest()[:10]
+    return _STAMP
+
+
 def _name(model, dtype, method, n_dir, spl) -> str:
     return (f"{'f64' if dtype == torch.float64 else 'f32'}_m{method}_g{_group_width(model.n_age)}_s{model.n_strain}"
             f"_e{int(model.has_e)}w{int(model.has_wane)}c{int(model.has_c)}_W{model.n_wane}_nd{n_dir}_spl{spl}"
-            f"_f{_features(model)}")
+            f"_f{_features(model)}_{_stamp()}")
 
 
 def _source(model, dtype, method, n_dir, spl) -> str:
     t = "double" if dtype == torch.float64 else "float"
     b = lambda v: "true" if v else "false"
+    if model.family == 1:
+        A, L, _, K1, M1, _ = model.seip_dims
+        args = f"{t}, {method}, {_group_width(A)}, {L}, {K1}, {M1}"
+        return (f'#include "{os.path.join(_CSRC, "seip_kernel.hpp")}"\n'
+                f"namespace dyn {{ template hipError_t launch_seip<{args}>(const KArgs<{t}> &, hipStream_t); }}\n"
+                f'extern "C" void *dyn_extra_launch(void) {{\n'
+                f"    return (void *)(hipError_t(*)(const dyn::KArgs<{t}> &, hipStream_t)) & dyn::launch_seip<{args}>;\n}}\n")
     args = (f"{t}, {method}, {_group_width(model.n_age)}, {model.n_strain}, {b(model.has_e)}, {b(model.has_wane)}, "
             f"{b(model.has_c)}, {model.n_wane}, {n_dir}, {spl}, {_features(model)}")
     return (f'#include "{os.path.join(_CSRC, "solve_kernel.hpp")}"\n'

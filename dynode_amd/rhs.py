@@ -173,6 +173,7 @@ class Packed:
     batch: Optional[int]    # None = unbatched call
     shapes: Tuple[tuple, ...]  # per-compartment shapes without time/batch axes
     tiers: Optional[int] = None  # vaccination: tracked tiers K; the tier axis (axis 1) is padded to 2 or 4
+    history_perm: Optional[np.ndarray] = None  # SEIP: kernel history slot of each reference bin (axis 1)
 
 
 class CompartmentalODE:
@@ -436,7 +437,8 @@ class CompartmentalODE:
         C = _np(p.contact_matrix)
         if C.shape != (A, A):
             raise ValueError(f"contact_matrix has shape {C.shape}, expected {(A, A)}")
-        Cg = np.repeat(np.repeat(C / pop[None, :], KV, axis=0), KV, axis=1)
+        inv_pop = np.where(pop > 0, 1.0 / np.where(pop > 0, pop, 1.0), 0.0)   # an empty age group infects nobody
+        Cg = np.repeat(np.repeat(C * inv_pop[None, :], KV, axis=0), KV, axis=1)
         sus = np.ones((A, KV, S))
         sus[:, :K, :] = 1.0 - ve.T[None, :, :]
         spl = np.zeros((A, KV, 4 + 2 * nk))

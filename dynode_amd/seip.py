@@ -1,0 +1,209 @@
+"""The SEIP model of the reference's ode_model.md behind the ODE-descriptor interface.
+
+The reference documents its production model -- susceptible / exposed / infectious / partially immune,
+stratified by age, immune history, vaccination count and waning state (ode_model.md:15-53, 70-105, 176-211)
+-- and ships the configuration classes for it (``FullStratifiedImmuneHistoryDimension``,
+``VaccinationDimension``, ``WaneDimension``/``WaneBin``, ``Strain.vaccine_efficacy``,
+``TransmissionParams.strain_interactions``), but no right-hand side.  Here it is a member of the kernel
+family (``family = 1``; include/dynode_hip.h "SEIP", csrc/seip_kernel.hpp):
+
+    state        s[A, H, K1, M1]    e, i, c[A, H, K1, L]        H = 2^L immune histories
+    simulate(seip_ode, days, (s, e, i, c), SEIP_ODEParams(...), SolverParams())
+
+The history axis follows the reference's bin order (``none, a, b, c, a_b, a_c, b_c, a_b_c``:
+config/dimension.py:152-171); the kernel indexes histories by bit set and the front-end permutes.
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass
+from itertools import combinations
+from types import SimpleNamespace
+from typing import Any, Optional
+
+import numpy as np
+
+from ._abi import ModelDesc
+from .rhs import AbstractODEParams, CompartmentalODE, Packed, SeasonalityParams, VaccinationParams, _np
+
+
+def history_masks(n_strains: int) -> np.ndarray:
+    """Bit set of every bin of ``FullStratifiedImmuneHistoryDimension`` in the reference's order: subsets
+    by size, then by strain order (strain q = bit q)."""
+    masks = [0] + [sum(1 << q for q in sub) for size in range(1, n_strains + 1) for sub in combinations(range(n_strains), size)]
+    return np.asarray(masks, dtype=np.int64)
+
+
+def protection_table(crossimmunity, vaccine_efficacy, wane_protection, min_homologous_immunity=0.0) -> np.ndarray:
+    """Susceptibility ``1 - WI`` of ode_model.md:185-211, indexed [history bit set, doses, waning state, strain].
+
+    For a susceptible with past strains ``j``, ``k`` doses, in waning state ``m``, challenged by strain ``l``:
+    initial immunity ``II = 1 - (1 - ve[l, k]) * prod_{q in j} (1 - chi[l, q])`` (cross-immunity
+    ``strain_interactions`` and ``Strain.vaccine_efficacy``), waned ``WIB = II * protection[m]``
+    (``WaneBin.base_protection``), homologous floor ``WIM = (1 - WIB) * M_HI`` if ``l`` is in ``j``;
+    ``WI = WIB + WIM``."""
+    chi, ve, prot = (np.asarray(v, dtype=float) for v in (crossimmunity, vaccine_efficacy, wane_protection))
+    L, K1, M1 = chi.shape[0], ve.shape[1], prot.shape[0]
+    sus = np.empty((1 << L, K1, M1, L))
+    for j in range(1 << L):
+        past = [q for q in range(L) if (j >> q) & 1]
+        for l in range(L):
+            escape = float(np.prod([1.0 - chi[l, q] for q in past])) if past else 1.0
+            initial = 1.0 - (1.0 - ve[l, :]) * escape
+            wib = initial[:, None] * prot[None, :]
+            wim = (1.0 - wib) * (min_homologous_immunity if (j >> l) & 1 else 0.0)
+            sus[j, :, :, l] = 1.0 - (wib + wim)
+    return sus
+
+
+@dataclass
+class SEIP_ODEParams(AbstractODEParams):
+    """Parameters of :data:`seip_ode`.  Rates may carry a leading batch axis."""
+
+    beta: Any                   # [L] or [B, L]   transmission rate per strain
+    gamma: Any                  # [L]             recovery rate
+    sigma: Any                  # [L]             exposed -> infectious
+    waning_rates: Any           # [M1]            1 / WaneBin.waiting_time; the last state keeps its people
+    contact_matrix: Any         # [A, A]          lambda_a = beta * sum_b C[a, b] * I_b / P_b
+    susceptibility: Any         # [H, K1, M1, L]  by history BIT SET (protection_table), or [B, ...]
+    vaccination_params: Optional[VaccinationParams] = None   # splines [A, K1, ...]; vaccine_efficacy is unused here
+    seasonality_params: Optional[SeasonalityParams] = None
+    seasonal_vaccination_tau: Optional[float] = None         # tau = 182.5 - days to the season change; None = off
+    population: Any = None      # [A]; default: the initial state's population per age
+    idx: Optional[SimpleNamespace] = None
+
+
+class SEIPODE(CompartmentalODE):
+    """Descriptor of the SEIP right-hand side (compartments s, e, i, c)."""
+
+    def __init__(self):
+        super().__init__("seip_ode", SEIP_ODEParams, ("s", "e", "i", "c"), multi_strain=True, has_e=True, has_wane=True,
+                         has_c=True, seasonal=None, normalize=False,
+                         doc="SEIP with immune histories, vaccination tiers and waning states: ode_model.md:15-53.")
+
+    def wants_grad(self, p) -> bool:
+        return False          # primal kernels only: simulate, do not differentiate
+
+    def pack(self, initial_state, p, with_params: bool = True) -> Packed:
+        if len(initial_state) != 4:
+            raise ValueError(f"seip_ode expects compartments {self.compartments}, got {len(initial_state)} arrays")
+        s, e, i, c = (_np(a) for a in initial_state)
+        if s.ndim != 4 or e.ndim != 4:
+            raise ValueError("seip_ode state: s[age, history, doses, waning state], e / i / c[age, history, doses, strain]")
+        A, H, K1, M1 = s.shape
+        L = e.shape[3]
+        if H != 1 << L or e.shape != (A, H, K1, L) or i.shape != e.shape or c.shape != e.shape:
+            raise ValueError(f"seip_ode state shapes {s.shape}, {e.shape}, {i.shape}, {c.shape}: expected s{(A, 1 << L, K1, M1)} "
+                             f"and e, i, c{(A, 1 << L, K1, L)} with 2^strains immune histories")
+        masks = history_masks(L)                    # reference bin r holds bit set masks[r]
+        inv = np.argsort(masks)                     # kernel slot j holds reference bin inv[j]
+        rates, batch = [], None
+        for name, width in (("beta", L), ("gamma", L), ("sigma", L), ("waning_rates", M1)):
+            a = _np(getattr(p, name))
+            if a.shape[-1:] != (width,) or a.ndim not in (1, 2):
+                raise ValueError(f"{name} must have shape ({width},) or (batch, {width}), got {a.shape}")
+            if a.ndim == 2:
+                if batch not in (None, a.shape[0]):
+                    raise ValueError(f"inconsistent batch sizes in ode parameters ({name})")
+                batch = a.shape[0]
+            rates.append(a)
+        sus = _np(p.susceptibility)
+        if sus.shape[-4:] != (H, K1, M1, L) or sus.ndim not in (4, 5) or sus.min() < 0:
+            raise ValueError(f"susceptibility must have shape {(H, K1, M1, L)} (optionally batched) with values >= 0")
+        if sus.ndim == 5:
+            if batch not in (None, sus.shape[0]):
+                raise ValueError("inconsistent batch sizes in ode parameters (susceptibility)")
+            batch = sus.shape[0]
+        B = batch or 1
+        cols = [np.broadcast_to(a.reshape(-1, a.shape[-1]), (B, a.shape[-1])) for a in rates]
+        seas = p.seasonality_params
+        if seas is not None:
+            cols += [np.full((B, 1), float(_np(getattr(seas, n)).reshape(-1)[0])) for n in ("forcing_amp", "forcing_phase", "forcing_period")]
+        if p.seasonal_vaccination_tau is not None:
+            cols.append(np.full((B, 1), float(p.seasonal_vaccination_tau)))
+        pop = (s.sum((1, 2, 3)) + e.sum((1, 2, 3)) + i.sum((1, 2, 3))) if p.population is None else _np(p.population)
+        if pop.shape != (A,):
+            raise ValueError(f"population must have shape {(A,)}")
+        cols.append(np.broadcast_to(pop, (B, A)))
+        cols.append(np.broadcast_to(sus.reshape(-1, H * K1 * M1 * L), (B, H * K1 * M1 * L)))
+        vp = p.vaccination_params
+        nk = 0
+        if vp is not None:
+            base, knots, coefs = _np(vp.base_equations), _np(vp.knot_locations), _np(vp.knot_coefficients)
+            nk = knots.shape[-1] if knots.ndim == 3 else 0
+            if base.shape != (A, K1, 4) or knots.shape != (A, K1, nk) or coefs.shape != (A, K1, nk) or nk > 4:
+                raise ValueError(f"vaccination splines: base_equations {(A, K1, 4)}, knot_locations / knot_coefficients "
+                                 f"{(A, K1)} + (n_knots <= 4,)")
+            spl = np.concatenate([base, knots, coefs], axis=2)
+        else:
+            spl = np.zeros((A, K1, 4))
+        cols.append(np.broadcast_to(spl.reshape(1, -1), (B, spl.size)))
+        C = _np(p.contact_matrix)
+        if C.shape != (A, A):
+            raise ValueError(f"contact_matrix has shape {C.shape}, expected {(A, A)}")
+        inv_pop = np.where(pop > 0, 1.0 / np.where(pop > 0, pop, 1.0), 0.0)   # an empty age group infects nobody
+        model = ModelDesc(n_age=A, n_strain=L, has_e=True, has_wane=True, has_c=True, n_wane=M1, normalize=False,
+                          seasonal=seas is not None, n_vax_tiers=K1, n_vax_knots=nk, family=1,
+                          seasonal_vax=p.seasonal_vaccination_tau is not None)
+        params = np.ascontiguousarray(np.concatenate(cols, axis=1))
+        assert params.shape[1] == model.param_dim
+        y0 = np.concatenate([a[:, inv].reshape(-1) for a in (s, e, i, c)])
+        return Packed(model, y0, params, np.ascontiguousarray(C * inv_pop[None, :]), batch,
+                      ((A, H, K1, M1),) + ((A, H, K1, L),) * 3, history_perm=masks)
+
+    def __call__(self, t, state, p):
+        """f(t, state, p) with NumPy, unbatched (inspection and tests; simulate never uses it)."""
+        pk = self.pack(state, p)
+        if pk.batch is not None:
+            raise ValueError("the host evaluation of an ODE descriptor is unbatched")
+        m, q, C = pk.model, pk.params[0], pk.contact
+        A, L, H, K1, M1, nk = m.seip_dims
+        K = K1 - 1
+        s, e, i, _ = (pk.y0[a:b].reshape(shape) for (a, b), shape in zip(_bounds(pk.shapes), pk.shapes))
+        beta, gamma, sigma, omega = q[:L], q[L:2 * L], q[2 * L:3 * L], q[3 * L:3 * L + M1]
+        pos = 3 * L + M1
+        season = phi = None
+        if m.seasonal:
+            season = 1.0 + q[pos] * np.sin(2 * np.pi * t / q[pos + 2] + q[pos + 1]); pos += 3
+        if m.seasonal_vax:
+            phi = np.sin(2 * np.pi * (t + q[pos]) / 730.0) ** 1000; pos += 1
+        pop = q[pos:pos + A]; pos += A
+        sus = q[pos:pos + H * K1 * M1 * L].reshape(H, K1, M1, L); pos += H * K1 * M1 * L
+        spl = q[pos:].reshape(A, K1, 4 + 2 * nk)
+        lam = beta * (season if season is not None else 1.0) * (C @ i.sum((1, 2)))
+        infect = lam[:, None, None, None, :] * sus[None] * s[..., None]
+        ds, inflow = -infect.sum(-1), infect.sum(3)
+        wane = omega * s
+        wane[..., -1] = 0.0
+        ds -= wane
+        ds[..., 1:] += wane[..., :-1]
+        nu = spl[..., 0] + t * (spl[..., 1] + t * (spl[..., 2] + t * spl[..., 3]))
+        nu = nu + (spl[..., 4 + nk:] * np.maximum(t - spl[..., 4:4 + nk], 0.0) ** 3).sum(-1)
+        tot = s.sum((1, 3))
+        rate = np.where(tot > 0, np.minimum(np.maximum(nu, 0.0) * pop[:, None] / np.where(tot > 0, tot, 1.0), 1.0), 0.0)
+        vax = rate[:, None, :, None] * s
+        vax[:, :, K, 0] = 0.0
+        ds -= vax
+        ds[:, :, 1:, 0] += vax[:, :, :K].sum(-1)
+        ds[:, :, K, 0] += vax[:, :, K].sum(-1)
+        s_e, g_i = sigma * e, gamma * i
+        de, di, dc = inflow - s_e, s_e - g_i, inflow.copy()
+        for l in range(L):
+            for j in range(H):
+                ds[:, j | (1 << l), :, 0] += g_i[:, j, :, l]
+        if phi is not None and K > 0:
+            for arr, darr in ((s, ds), (e, de), (i, di)):
+                darr[:, :, K] -= phi * arr[:, :, K]
+                darr[:, :, K - 1] += phi * arr[:, :, K]
+        return tuple(d[:, pk.history_perm] for d in (ds, de, di, dc))
+
+
+def _bounds(shapes):
+    pos = 0
+    for shape in shapes:
+        n = int(np.prod(shape))
+        yield pos, pos + n
+        pos += n
+
+
+seip_ode = SEIPODE()

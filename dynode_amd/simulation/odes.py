@@ -230,6 +230,8 @@ def simulate(ode, duration_days, initial_state: CompartmentState, ode_parameters
         block = res.ys[:, :, pos:pos + size].reshape((res.ys.shape[0], n_save) + tuple(shape))
         if packed.tiers is not None:                      # vaccination: drop the padded tier slots (axis after age)
             block = block[:, :, :, :packed.tiers]
+        if packed.history_perm is not None:               # SEIP: back to the reference's immune-history bin order
+            block = block[:, :, :, packed.history_perm]
         ys.append(block if batched else block[0])
         pos += size
     unb = (lambda t: t) if batched else (lambda t: t[0])

@@ -127,9 +127,73 @@ def seirs_multi_strain(B: int = 16384, seed: int = 1, A: int = 8, S: int = 4, W:
     return Workload(name, model, y0, params, C, t1, save_grid(t1), 1000.0)
 
 
+def seip_protection_table(*args, **kwargs) -> np.ndarray:
+    """``dynode_amd.seip.protection_table`` (ode_model.md:185-211)."""
+    from .seip import protection_table
+
+    return protection_table(*args, **kwargs)
+
+
+def seip(B: int = 4096, seed: int = 7, A: int = 8, L: int = 2, K1: int = 3, M1: int = 4, n_knots: int = 2,
+         seasonal: bool = False, seasonal_vax: bool = False, t1: float = 365.0) -> Workload:
+    """SEIP ensemble (ode_model.md; include/dynode_hip.h "SEIP"): A ages x 2^L immune histories x K1 vaccination
+    tiers x M1 waning states, L strains.  Rates as cfg 3; everyone starts unexposed and unvaccinated in the
+    last waning state; doses start between day 20 and 120 at 0.2-1 % of the age group per day; cross-immunity
+    0.4-0.9, vaccine efficacy rising with doses, protection falling over the waning states."""
+    rng = np.random.default_rng(seed)
+    H = 1 << L
+    model = ModelDesc(n_age=A, n_strain=L, has_e=True, has_wane=True, has_c=True, n_wane=M1, normalize=False,
+                      seasonal=seasonal, n_vax_tiers=K1, n_vax_knots=n_knots, family=1, seasonal_vax=seasonal_vax)
+    w = rng.dirichlet(5.0 * np.ones(A))
+    pop = 1000.0 * w
+    C = contact_matrix(rng, A) / pop[None, :]                          # lambda_a = beta sum_b C_ab I_b / P_b
+    r0 = rng.uniform(1.8, 2.8, (B, L))
+    t_inf, t_lat = rng.uniform(5.0, 9.0, (B, L)), rng.uniform(2.0, 4.0, (B, L))
+    omega = 1.0 / rng.uniform(20.0, 60.0, (B, M1))
+    cols = [r0 / t_inf, 1.0 / t_inf, 1.0 / t_lat, omega]
+    if seasonal:
+        cols += [rng.uniform(0.0, 0.4, (B, 1)), rng.uniform(0.0, 2 * np.pi, (B, 1)), np.full((B, 1), 365.0)]
+    if seasonal_vax:
+        cols.append(rng.uniform(100.0, 260.0, (B, 1)))                 # tau = 182.5 - days to the season change
+    cols.append(np.broadcast_to(pop, (B, A)))
+    prot = np.linspace(1.0, 0.0, M1) if M1 > 1 else np.ones(1)
+    sus = np.empty((B, H * K1 * M1 * L))
+    for b in range(B):
+        chi = rng.uniform(0.4, 0.9, (L, L))
+        np.fill_diagonal(chi, 1.0)
+        ve = np.sort(rng.uniform(0.0, 0.7, (L, K1)), axis=1)
+        ve[:, 0] = 0.0
+        sus[b] = seip_protection_table(chi, ve, prot, rng.uniform(0.0, 0.3)).ravel()
+    cols.append(sus)
+    spl = np.zeros((B, A, K1, 4 + 2 * n_knots))
+    if n_knots:
+        start = rng.uniform(20.0, 120.0, (B, A, K1, 1)) + 30.0 * np.arange(K1)[None, None, :, None]
+        ramp = rng.uniform(10.0, 30.0, (B, A, K1, 1))
+        plateau = rng.uniform(0.002, 0.01, (B, A, K1))
+        spl[..., 4:4 + n_knots] = start + ramp * np.arange(n_knots)[None, None, None, :]
+        coef = plateau / (ramp[..., 0] ** 3 * 6.0)
+        spl[..., 4 + n_knots] = coef                                   # cubic rise from the first knot ...
+        if n_knots > 1:
+            spl[..., 4 + n_knots + 1] = -coef                          # ... turned into a quadratic one at the second
+    else:
+        spl[..., 0] = rng.uniform(0.0, 0.004, (B, A, K1))
+    cols.append(spl.reshape(B, -1))
+    params = np.concatenate(cols, axis=1)
+    assert params.shape[1] == model.param_dim
+    s0 = np.zeros((B, A, H, K1, M1))
+    i0 = np.zeros((B, A, H, K1, L))
+    dom = r0 / r0.sum(axis=1, keepdims=True)
+    s0[:, :, 0, 0, M1 - 1] = 0.99 * pop
+    i0[:, :, 0, 0, :] = 0.01 * pop[None, :, None] * dom[:, None, :]
+    zeros = np.zeros_like(i0).reshape(B, -1)
+    y0 = np.concatenate([s0.reshape(B, -1), zeros, i0.reshape(B, -1), zeros], axis=1)
+    return Workload("seip", model, y0, params, C, t1, save_grid(t1), 1000.0)
+
+
 WORKLOADS = {
     "cfg2": lambda B=4096, seed=0: sir_age_stratified(B, seed),
     "cfg3": lambda B=16384, seed=1: seirs_multi_strain(B, seed),
     "cfg3w8": lambda B=16384, seed=1: seirs_multi_strain(B, seed, W=8),
+    "seip": lambda B=4096, seed=7: seip(B, seed),
     "cfg5": lambda B=8192, seed=5: seirs_multi_strain(B, seed, seasonal=True),
 }

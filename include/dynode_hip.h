@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define DYN_ABI_VERSION 3
+#define DYN_ABI_VERSION 4
 /* the save grid is staged in LDS: n_save * sizeof(real) must not exceed this */
 #define DYN_MAX_SAVE_BYTES 49152
 
@@ -68,6 +68,29 @@ extern "C" {
  * (the cubic-spline form of utils/splines.py:evaluate_cubic_spline).  Everyone else keeps their tier.
  * Parameter block, after the seasonal numbers:  sus[groups][S] (= 1 - vaccine efficacy of the group's
  * tier against each strain), then per group base[4] knot[n_vax_knots] coef[n_vax_knots].
+ *
+ * SEIP (family = 1): the production model of ode_model.md:15-53 -- susceptible / exposed / infectious /
+ * partially immune, stratified by age a, immune history j (a bit set over the L strains, H = 2^L), vaccination
+ * tier k = 0..K (K1 = max(n_vax_tiers, 1) tiers) and, for the susceptibles, waning state m = 0..M
+ * (M1 = n_wane states).  The reference describes it in prose only; this is the concrete form built here.
+ * State, compartment-major, row-major blocks:   s[A][H][K1][M1] | e[A][H][K1][L] | i[A][H][K1][L] | c[A][H][K1][L]
+ * Parameters:  beta[L] gamma[L] sigma[L] | omega[M1] (rate of leaving waning state m; the last entry is ignored,
+ *     the last state keeps its people) | amp phase period (seasonal) | tau (seasonal_vax) | pop[A] |
+ *     sus[H][K1][M1][L] | spline[A][K1][4 + 2 n_vax_knots] (base[4] knot[] coef[] as above)
+ * Right-hand side (has_e = has_c = has_wane = 1, normalize = has_intro = 0; `contact` is used as given, the
+ * caller folds 1 / P into it):
+ *     lambda_{a,l} = beta_l season(t) sum_b C[a][b] sum_{j,k} i_{b,j,k,l}           (ode_model.md:176-183)
+ *     infection     f_{a,j,k,m,l} = lambda_{a,l} sus_{j,k,m,l} s_{a,j,k,m}: leaves s, enters e_{a,j,k,l} and c
+ *         (sus = 1 - WI of ode_model.md:185-211: the host evaluates cross-immunity, vaccine efficacy, waning
+ *          protection and minimum homologous immunity into the table)
+ *     progression   de = sum_m f - sigma_l e;   di = sigma_l e - gamma_l i
+ *     recovery      gamma_l i_{a,j,k,l} enters s_{a, j | 2^l, k, 0}                   (eta, ode_model.md:86-105)
+ *     waning        omega_m s_{a,j,k,m}: m -> m + 1 for m < M
+ *     vaccination   r_{a,k} = min( max(nu_{a,k}(t), 0) pop_a / sum_{j,m} s_{a,j,k,m}, 1 )  (0 when the sum is <= 0);
+ *         r_{a,k} s_{a,j,k,m} moves to (k + 1, m = 0); in the top tier K to (K, 0), and (K, 0) itself stays --
+ *         the m' = 0 term of ode_model.md's top-tier gain has no matching loss and is dropped, so people are conserved
+ *     seasonal vaccination (seasonal_vax)   phi(t) = sin(2 pi (t + tau) / 730)^1000 moves s, e, i of tier K to K - 1
+ *         (ode_model.md:70-84; applied at all times -- the power makes it vanish outside the yearly window)
  */
 #define DYN_MAX_STRAINS 8
 typedef struct dyn_model_desc {
@@ -83,6 +106,8 @@ typedef struct dyn_model_desc {
     int32_t n_vax_tiers; /* ABI 3: 0/1 = no vaccination axis; 2..4 = tracked dose counts (see above) */
     uint64_t intro_age_mask[DYN_MAX_STRAINS]; /* per strain: bit a = age bin a receives introductions */
     int32_t n_vax_knots; /* knots of the vaccination-rate splines, 0..4 */
+    int32_t family;       /* ABI 4: 0 = the s/e/i/r/c family, 1 = SEIP (see above; n_strain <= 3, n_age * 2^n_strain <= 64) */
+    int32_t seasonal_vax; /* ABI 4, SEIP only */
     int32_t reserved;
 } dyn_model_desc;
 

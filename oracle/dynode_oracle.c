@@ -53,9 +53,23 @@ static const double DOPRI5_CMID[7] = {6025192743.0 / 30085553152.0 / 2,
                                       -1776094331.0 / 19743644256.0 / 2,
                                       11237099.0 / 235043384.0 / 2};
 
-int32_t dyo_n_compartments(const dyo_model_desc *m) { return 3 + (m->has_e ? 1 : 0) + (m->has_c ? 1 : 0); }
+int32_t dyo_n_compartments(const dyo_model_desc *m) {
+    if (m->family == 1) return 4; /* s e i c */
+    return 3 + (m->has_e ? 1 : 0) + (m->has_c ? 1 : 0);
+}
+
+/* SEIP: groups = (age, immune history) pairs, per group s[K1][M1] and e, i, c[K1][L] */
+static int seip_groups(const dyo_model_desc *m) { return m->n_age << m->n_strain; }
+static int seip_tiers(const dyo_model_desc *m) { return m->n_vax_tiers > 1 ? m->n_vax_tiers : 1; }
 
 void dyo_compartment_offsets(const dyo_model_desc *m, int32_t *off) {
+    if (m->family == 1) {
+        const int G = seip_groups(m), K1 = seip_tiers(m);
+        off[0] = 0;
+        off[1] = G * K1 * m->n_wane;
+        for (int c = 2; c <= 4; ++c) off[c] = off[c - 1] + G * K1 * m->n_strain;
+        return;
+    }
     const int A = m->n_age, AS = m->n_age * m->n_strain;
     int n = 0, pos = 0;
     off[n++] = pos;
@@ -76,10 +90,18 @@ void dyo_compartment_offsets(const dyo_model_desc *m, int32_t *off) {
 }
 
 int32_t dyo_state_dim(const dyo_model_desc *m) {
+    if (m->family == 1) return seip_groups(m) * seip_tiers(m) * (m->n_wane + 3 * m->n_strain);
     return m->n_age * (1 + m->n_strain * ((m->has_e ? 1 : 0) + 1 + m->n_wane + (m->has_c ? 1 : 0)));
 }
 
 int32_t dyo_param_dim(const dyo_model_desc *m) {
+    if (m->family == 1) {
+        /* beta gamma sigma [L] | omega [M1] | (amp phase period) | (tau) | pop [A] | sus [H][K1][M1][L] |
+         * spline [A][K1][4 + 2 nk] */
+        const int L = m->n_strain, K1 = seip_tiers(m);
+        return 3 * L + m->n_wane + (m->seasonal ? 3 : 0) + (m->seasonal_vax ? 1 : 0) + m->n_age +
+               (1 << L) * K1 * m->n_wane * L + m->n_age * K1 * (4 + 2 * m->n_vax_knots);
+    }
     return m->n_strain * (2 + (m->has_e ? 1 : 0) + (m->has_wane ? 1 : 0) + (m->has_intro ? 3 : 0)) +
            (m->seasonal ? 3 : 0) +
            (m->n_vax_tiers > 1 ? m->n_age * (m->n_strain + 4 + 2 * m->n_vax_knots) : 0);
@@ -137,8 +159,8 @@ void dyo_tsit5_dense_weights_f64(double theta, double *b7) { tsit5_bt_f64(theta,
 
 void dyo_rhs_f64(const dyo_model_desc *m, double t, const double *y, const double *params,
                  const double *contact, double *dydt) {
-    double *scratch = (double *)malloc(sizeof(double) * (size_t)m->n_age * (m->n_strain + 1));
-    rhs_f64(m, t, y, params, contact, dydt, scratch);
+    double *scratch = (double *)malloc(sizeof(double) * (size_t)m->n_age * (2 * m->n_strain + 2));
+    rhs_any_f64(m, t, y, params, contact, dydt, scratch);
     free(scratch);
 }
 
@@ -146,6 +168,10 @@ static int check_model(const dyo_model_desc *m) {
     if (!m) return -1;
     if (m->n_age < 1 || m->n_strain < 1 || m->n_wane < 1) return -2;
     if (m->n_wane > 1 && !m->has_wane) return -2;
+    if (m->family != 0 && m->family != 1) return -2;
+    if (m->family == 1 && (m->n_strain > 4 || m->n_vax_tiers > 4 || m->n_vax_knots < 0 || m->n_vax_knots > 4 ||
+                           m->has_intro || m->normalize))
+        return -2;
     return 0;
 }
 

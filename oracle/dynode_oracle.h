@@ -50,6 +50,9 @@ typedef struct dyo_model_desc {
                             spline rate nu_{group}(t) (include/dynode_hip.h has the full statement) */
     uint64_t intro_age_mask[8];
     int32_t n_vax_knots;
+    int32_t family;       /* 0 = the s/e/i/r/c family above; 1 = SEIP with immune histories (ode_model.md), see
+                             rhs_seip in dynode_oracle_impl.inc and "SEIP" in include/dynode_hip.h */
+    int32_t seasonal_vax; /* SEIP: phi(t) = sin(2 pi (t + tau) / 730)^1000 moves the top vaccination tier down one */
     int32_t reserved;
 } dyo_model_desc;
 

@@ -35,6 +35,8 @@ class _ModelDesc(ctypes.Structure):
         ("n_vax_tiers", ctypes.c_int32),
         ("intro_age_mask", ctypes.c_uint64 * 8),
         ("n_vax_knots", ctypes.c_int32),
+        ("family", ctypes.c_int32),
+        ("seasonal_vax", ctypes.c_int32),
         ("reserved", ctypes.c_int32),
     ]
 
@@ -68,13 +70,15 @@ class Model:
     intro_age_mask: tuple = ()      # per strain: bit a = age bin a receives external introductions
     n_vax_tiers: int = 0            # > 1: n_age enumerates (age, tier) groups (see include/dynode_hip.h)
     n_vax_knots: int = 0
+    family: int = 0                 # 1 = SEIP with immune histories (rhs_seip in dynode_oracle_impl.inc)
+    seasonal_vax: bool = False
 
     def c(self) -> _ModelDesc:
         masks = tuple(int(v) for v in self.intro_age_mask) + (0,) * (8 - len(self.intro_age_mask))
         return _ModelDesc(
             self.n_age, self.n_strain, int(self.has_e), int(self.has_wane), int(self.has_c),
             self.n_wane, int(self.normalize), int(self.seasonal), int(self.has_intro), int(self.n_vax_tiers),
-            (ctypes.c_uint64 * 8)(*masks), int(self.n_vax_knots), 0,
+            (ctypes.c_uint64 * 8)(*masks), int(self.n_vax_knots), int(self.family), int(self.seasonal_vax), 0,
         )
 
 

@@ -25,7 +25,7 @@ def omodel(m) -> "O.Model":
     return O.Model(m.n_age, m.n_strain, bool(m.has_e), bool(m.has_wane), bool(m.has_c), m.n_wane,
                    bool(m.normalize), bool(m.seasonal), bool(getattr(m, "has_intro", False)),
                    tuple(getattr(m, "intro_age_mask", ())), int(getattr(m, "n_vax_tiers", 0)),
-                   int(getattr(m, "n_vax_knots", 0)))
+                   int(getattr(m, "n_vax_knots", 0)), int(getattr(m, "family", 0)), bool(getattr(m, "seasonal_vax", False)))
 
 
 def split_state(m, y):
@@ -135,3 +135,91 @@ def ground_truth(m, y0, p, C, t1, save_ts, rtol=1e-12, atol=1e-12):
                     method="DOP853", t_eval=np.asarray(save_ts, float), rtol=rtol, atol=atol)
     assert sol.success
     return sol.y.T  # [n_save, D]
+
+
+# ------------------------------------------------------------------------------------------- SEIP
+def seip_dims(m):
+    """(A, L, H, K1, M1, nk) of a family-1 model."""
+    return m.n_age, m.n_strain, 1 << m.n_strain, max(int(m.n_vax_tiers), 1), m.n_wane, int(m.n_vax_knots)
+
+
+def seip_pack_params(m, beta, gamma, sigma, omega, pop, sus, spline, seasonal=None, tau=None):
+    """Parameter row of the SEIP family: beta gamma sigma [L] | omega [M1] | (amp phase period) | (tau) |
+    pop [A] | sus [H, K1, M1, L] | spline [A, K1, 4 + 2 nk]."""
+    A, L, H, K1, M1, nk = seip_dims(m)
+    parts = [np.asarray(beta, float).reshape(L), np.asarray(gamma, float).reshape(L), np.asarray(sigma, float).reshape(L),
+             np.asarray(omega, float).reshape(M1)]
+    if m.seasonal:
+        parts.append(np.asarray(seasonal, float).reshape(3))
+    if m.seasonal_vax:
+        parts.append(np.asarray([tau], float))
+    parts += [np.asarray(pop, float).reshape(A), np.asarray(sus, float).reshape(H * K1 * M1 * L),
+              np.asarray(spline, float).reshape(A * K1 * (4 + 2 * nk))]
+    return np.concatenate(parts)
+
+
+def seip_split_state(m, y):
+    A, L, H, K1, M1, _ = seip_dims(m)
+    nS, nE = A * H * K1 * M1, A * H * K1 * L
+    y = np.asarray(y)
+    return (y[:nS].reshape(A, H, K1, M1), y[nS:nS + nE].reshape(A, H, K1, L),
+            y[nS + nE:nS + 2 * nE].reshape(A, H, K1, L), y[nS + 2 * nE:].reshape(A, H, K1, L))
+
+
+def rhs_seip_numpy(m, t, y, p, C):
+    """Vectorised statement of ode_model.md's SEIP equations (the build's concrete form, include/dynode_hip.h
+    "SEIP"), written with array operations independently of the oracle's loops."""
+    A, L, H, K1, M1, nk = seip_dims(m)
+    K = K1 - 1
+    p = np.asarray(p, float)
+    beta, gamma, sigma, omega = p[:L], p[L:2 * L], p[2 * L:3 * L], p[3 * L:3 * L + M1]
+    pos = 3 * L + M1
+    season, phi = 1.0, 0.0
+    if m.seasonal:
+        amp, phase, period = p[pos:pos + 3]; pos += 3
+        season = 1.0 + amp * np.sin(2 * np.pi * t / period + phase)
+    if m.seasonal_vax:
+        phi = np.sin(2 * np.pi * (t + p[pos]) / 730.0) ** 1000; pos += 1
+    pop = p[pos:pos + A]; pos += A
+    sus = p[pos:pos + H * K1 * M1 * L].reshape(H, K1, M1, L); pos += H * K1 * M1 * L
+    spl = p[pos:].reshape(A, K1, 4 + 2 * nk)
+    s, e, i, _ = seip_split_state(m, np.asarray(y, float))
+    lam = beta * season * (np.asarray(C, float) @ i.sum((1, 2)))                       # [A, L]
+    infect = lam[:, None, None, None, :] * sus[None] * s[..., None]                     # [A, H, K1, M1, L]
+    ds = -infect.sum(-1)
+    inflow = infect.sum(3)                                                             # [A, H, K1, L]
+    wane = omega[None, None, None, :] * s
+    wane[..., -1] = 0.0
+    ds -= wane
+    ds[..., 1:] += wane[..., :-1]
+    nu = spl[..., 0] + spl[..., 1] * t + spl[..., 2] * t**2 + spl[..., 3] * t**3
+    if nk:
+        nu = nu + (spl[..., 4 + nk:] * np.maximum(t - spl[..., 4:4 + nk], 0.0) ** 3).sum(-1)
+    tot = s.sum((1, 3))                                                                # [A, K1]
+    doses = np.maximum(nu, 0.0) * pop[:, None]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        rate = np.where(tot > 0, np.minimum(doses / np.where(tot > 0, tot, 1.0), 1.0), 0.0)
+    vax = rate[:, None, :, None] * s
+    vax[:, :, K, 0] = 0.0                                                              # freshest state of the top tier stays
+    ds -= vax
+    ds[:, :, 1:, 0] += vax[:, :, :K].sum(-1)
+    ds[:, :, K, 0] += vax[:, :, K].sum(-1)
+    s_e, g_i = sigma * e, gamma * i
+    de, di, dc = inflow - s_e, s_e - g_i, inflow.copy()
+    for l in range(L):
+        for j in range(H):
+            ds[:, j | (1 << l), :, 0] += g_i[:, j, :, l]
+    if K > 0 and phi != 0.0:
+        for arr, darr in ((s, ds), (e, de), (i, di)):
+            darr[:, :, K] -= phi * arr[:, :, K]
+            darr[:, :, K - 1] += phi * arr[:, :, K]
+    return np.concatenate([ds.ravel(), de.ravel(), di.ravel(), dc.ravel()])
+
+
+def ground_truth_seip(m, y0, p, C, t1, save_ts, rtol=1e-11, atol=1e-9):
+    from scipy.integrate import solve_ivp
+
+    sol = solve_ivp(lambda t, y: rhs_seip_numpy(m, t, y, p, C), (0.0, float(t1)), np.asarray(y0, float),
+                    method="DOP853", t_eval=np.asarray(save_ts, float), rtol=rtol, atol=atol)
+    assert sol.success
+    return sol.y.T

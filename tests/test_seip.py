@@ -1,0 +1,300 @@
+"""SEIP family (ode_model.md; include/dynode_hip.h "SEIP"): oracle pins on the CPU, HIP parity on the GPU.
+
+The reference states this model in prose only, so the oracle is pinned by (i) an independent vectorised NumPy
+statement of the same equations, (ii) SciPy DOP853 on that statement, (iii) conservation of people per age,
+(iv) the reduction to the pinned SEIRS family: one strain, two waning states, recovered = history 1 / state 0.
+"""
+
+import numpy as np
+import pytest
+
+import helpers as H
+from helpers import O
+
+from dynode_amd import ModelDesc, synthetic
+
+SHAPES = [
+    dict(A=1, L=1, K1=1, M1=2, n_knots=0),
+    dict(A=2, L=2, K1=2, M1=2, n_knots=1),
+    dict(A=3, L=2, K1=3, M1=4, n_knots=2, seasonal=True),
+    dict(A=8, L=2, K1=3, M1=4, n_knots=2, seasonal_vax=True),
+    dict(A=4, L=3, K1=2, M1=3, n_knots=3, seasonal=True, seasonal_vax=True),
+]
+
+
+def _ids(v):
+    return "-".join(f"{k}{int(x)}" for k, x in v.items())
+
+
+@pytest.mark.parametrize("shape", SHAPES, ids=_ids)
+def test_rhs_oracle_matches_numpy_twin_and_conserves_people(shape):
+    wl = synthetic.seip(B=3, seed=11, **shape)
+    m, rng = wl.model, np.random.default_rng(5)
+    A, L, Hn, K1, M1, _ = m.seip_dims
+    assert m.state_dim == A * Hn * K1 * (M1 + 3 * L) == O.state_dim(H.omodel(m)) and m.param_dim == O.param_dim(H.omodel(m))
+    assert list(O.compartment_offsets(H.omodel(m))) == list(np.cumsum((0,) + m.compartment_sizes))
+    for b in range(3):
+        y = rng.uniform(0.0, 30.0, m.state_dim)                   # every cell populated: all fluxes are exercised
+        for t in (0.0, 47.3, 150.0, 171.0, 300.0):
+            want = H.rhs_seip_numpy(m, t, y, wl.params[b], wl.contact)
+            got = O.rhs(H.omodel(m), t, y, wl.params[b], wl.contact)
+            assert np.abs(got - want).max() < 1e-12 * np.abs(want).max()
+            ds, de, di, dc = H.seip_split_state(m, got)
+            per_age = ds.sum((1, 2, 3)) + (de + di).sum((1, 2, 3))
+            assert np.abs(per_age).max() < 1e-11 * np.abs(got).max()   # nobody is created, lost or changes age
+            assert np.all(dc >= 0)
+
+
+def test_seasonal_vaccination_pulse_moves_the_top_tier_down():
+    wl = synthetic.seip(B=1, seed=3, A=2, L=2, K1=3, M1=2, n_knots=0, seasonal_vax=True)
+    m = wl.model
+    p = wl.params[0].copy()
+    tau = p[3 * 2 + 2]
+    t_peak = 182.5 - tau                                          # sin(2 pi (t + tau) / 730) = 1
+    y = np.random.default_rng(0).uniform(1.0, 2.0, m.state_dim)
+    on = H.seip_split_state(m, O.rhs(H.omodel(m), t_peak, y, p, wl.contact))
+    off = H.seip_split_state(m, O.rhs(H.omodel(m), t_peak + 60.0, y, p, wl.contact))
+    s, e, i, _ = H.seip_split_state(m, y)
+    for arr, d_on, d_off in zip((s, e, i), on, off):
+        assert np.allclose(d_on[:, :, 2] - d_off[:, :, 2], -arr[:, :, 2], rtol=1e-9)      # phi = 1 at the peak, 0 two months on
+        assert np.allclose(d_on[:, :, 1] - d_off[:, :, 1], arr[:, :, 2], rtol=1e-9)
+        assert np.allclose(d_on[:, :, 0], d_off[:, :, 0], rtol=1e-12)
+
+
+@pytest.mark.parametrize("shape", SHAPES[1:4], ids=_ids)
+def test_oracle_solution_vs_scipy(shape):
+    wl = synthetic.seip(B=2, seed=21, t1=120.0, **shape)
+    m, ts = wl.model, np.arange(0.0, 121.0, 20.0)
+    ys, st, na, nr = O.solve(H.omodel(m), wl.y0, wl.params, wl.contact, 120.0, ts, dtype=np.float64, rtol=1e-9, atol=1e-9)
+    assert st.max() == 0
+    for b in range(2):
+        want = H.ground_truth_seip(m, wl.y0[b], wl.params[b], wl.contact, 120.0, ts)
+        assert np.abs(ys[b] - want).max() < 2e-5                   # of 1000 people; the dose cap has kinks
+    s, e, i, c = H.seip_split_state(m, ys[0][-1])
+    A = m.n_age
+    assert np.allclose((s.sum((1, 2, 3)) + (e + i).sum((1, 2, 3))), wl.params[0][3 * m.n_strain + m.n_wane + (3 if m.seasonal else 0) + int(m.seasonal_vax):][:A], rtol=1e-9)
+    assert s[:, 0].sum() < s.sum() and s[:, 1:].sum() > 0           # recovered people carry a history
+    assert s[:, :, 1:].sum() > 0                                    # and doses were given
+
+
+def test_one_strain_two_waning_states_is_the_seirs_family():
+    """L = 1: history 1 / waning state 0 with full protection is R, history 1 / state 1 is susceptible again:
+    s + r + waned = the SEIRS of examples/seirs.py with the same rates (age-stratified, contact C / P)."""
+    A = 3
+    rng = np.random.default_rng(2)
+    pop = 1000.0 * rng.dirichlet(5 * np.ones(A))
+    C = synthetic.contact_matrix(rng, A) / pop[None, :]
+    beta, gamma, sigma, omega = 0.3, 1 / 7.0, 1 / 3.0, 1 / 50.0
+    m = ModelDesc(n_age=A, n_strain=1, has_e=True, has_wane=True, has_c=True, n_wane=2, normalize=False, family=1)
+    sus = np.ones((2, 1, 2, 1)); sus[1, 0, 0, 0] = 0.0
+    p = H.seip_pack_params(m, [beta], [gamma], [sigma], [omega, 0.0], pop, sus, np.zeros((A, 1, 4)))
+    s0 = np.zeros((A, 2, 1, 2)); s0[:, 0, 0, 1] = 0.99 * pop
+    i0 = np.zeros((A, 2, 1, 1)); i0[:, 0, 0, 0] = 0.01 * pop
+    y0 = np.concatenate([s0.ravel(), np.zeros(2 * A), i0.ravel(), np.zeros(2 * A)])
+    ts = np.arange(0.0, 301.0, 50.0)
+    ys, st, _, _ = O.solve(H.omodel(m), y0, p[None], C, 300.0, ts, dtype=np.float64, rtol=1e-10, atol=1e-10)
+    plain = ModelDesc(n_age=A, has_e=True, has_wane=True, has_c=True, normalize=False)
+    y0p = np.concatenate([0.99 * pop, np.zeros(A), 0.01 * pop, np.zeros(A), np.zeros(A)])
+    yp, stp, _, _ = O.solve(H.omodel(plain), y0p, np.array([[beta, gamma, sigma, omega]]), C, 300.0, ts, dtype=np.float64,
+                            rtol=1e-10, atol=1e-10)
+    assert st[0] == 0 and stp[0] == 0
+    for row, rowp in zip(ys[0], yp[0]):
+        s, e, i, c = H.seip_split_state(m, row)
+        assert np.allclose(s[:, 0].sum((1, 2)) + s[:, 1, 0, 1], rowp[:A], atol=1e-6)           # susceptible (never infected + waned)
+        assert np.allclose(e.sum((1, 2, 3)), rowp[A:2 * A], atol=1e-6)
+        assert np.allclose(i.sum((1, 2, 3)), rowp[2 * A:3 * A], atol=1e-6)
+        assert np.allclose(s[:, 1, 0, 0], rowp[3 * A:4 * A], atol=1e-6)                       # recovered, protected
+        assert np.allclose(c.sum((1, 2, 3)), rowp[4 * A:], atol=1e-6)
+
+
+def test_protection_table_follows_ode_model_md():
+    chi = np.array([[1.0, 0.5], [0.25, 1.0]])
+    ve = np.array([[0.0, 0.4], [0.0, 0.2]])
+    sus = synthetic.seip_protection_table(chi, ve, np.array([1.0, 0.5, 0.0]), 0.1)
+    assert sus.shape == (4, 2, 3, 2)
+    assert np.allclose(sus[0, 0], 1.0)                               # no history, no doses: fully susceptible
+    assert np.allclose(sus[0, 1, :, 0], 1.0 - 0.4 * np.array([1.0, 0.5, 0.0]))
+    # history {strain 1} against strain 0: cross-immunity 0.5, fresh: 1 - 0.5; fully waned: no protection (not homologous)
+    assert np.allclose(sus[2, 0, :, 0], [0.5, 0.75, 1.0])
+    # history {strain 0} against strain 0: homologous, full at first, floor 0.1 when waned
+    assert np.allclose(sus[1, 0, :, 0], [0.0, 1.0 - (0.5 + 0.5 * 0.1), 0.9])
+    # both: 1 - (1 - 0.2) * (1 - 0.25) * (1 - 1) = 1 for strain 1 with one dose
+    assert np.allclose(sus[3, 1, 0, 1], 0.0)
+
+
+# ------------------------------------------------------------------------------------------- GPU
+GPU_CASES = [(SHAPES[0], "f64", "tsit5"), (SHAPES[1], "f64", "tsit5"), (SHAPES[1], "f64", "dopri5"), (SHAPES[4], "f64", "tsit5"),
+             (SHAPES[0], "f32", "tsit5"), (SHAPES[1], "f32", "dopri5"), (SHAPES[2], "f32", "tsit5"), (SHAPES[3], "f32", "tsit5"),
+             (SHAPES[3], "f32", "dopri5"), (SHAPES[4], "f32", "tsit5")]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,prec,method", GPU_CASES, ids=lambda v: _ids(v) if isinstance(v, dict) else v)
+def test_hip_matches_oracle(shape, prec, method):
+    import torch
+    from dynode_amd.engine import solve_batch
+
+    dtype, npd = (torch.float64, np.float64) if prec == "f64" else (torch.float32, np.float32)
+    B = 9
+    wl = synthetic.seip(B=B, seed=31, t1=150.0, **shape)
+    m, ts = wl.model, synthetic.save_grid(150.0)
+    # the same right-hand side: under a constant step the two implementations differ by rounding only
+    rc = solve_batch(m, wl.y0, wl.params, wl.contact, 150.0, ts, dtype=dtype, method=method, constant_dt=0.5)
+    wc, stc, _, _ = O.solve(H.omodel(m), wl.y0, wl.params, wl.contact, 150.0, ts, dtype=npd, method=method, n_threads=8, constant_dt=0.5)
+    assert int(rc.status.max()) == 0 and stc.max() == 0
+    assert np.abs(rc.ys.cpu().numpy() - wc).max() / 1000.0 < (1e-11 if prec == "f64" else 2e-5)
+    # adaptive: the dose cap min(nu P / S, 1) has kinks, so step decisions may differ by a few near them
+    r = solve_batch(m, wl.y0, wl.params, wl.contact, 150.0, ts, dtype=dtype, method=method)
+    want, st, na, nr = O.solve(H.omodel(m), wl.y0, wl.params, wl.contact, 150.0, ts, dtype=npd, method=method, n_threads=8)
+    got = r.ys.cpu().numpy()
+    assert int(r.status.max()) == 0 and st.max() == 0
+    assert np.abs(got - want).max() / 1000.0 < (5e-5 if prec == "f64" else 2e-4)   # a few solver tolerances (rtol 1e-5)
+    steps = (r.n_accept + r.n_reject).cpu().numpy()
+    assert np.abs(steps - (na + nr)).max() <= max(8, 0.2 * (na + nr).max())
+    assert np.array_equal(got[:, 0], wl.y0.astype(npd))                     # first row = initial state, exactly
+    s, e, i, c = H.seip_split_state(m, got[0, -1].astype(np.float64))
+    pop = wl.params[0][3 * m.n_strain + m.n_wane + (3 if m.seasonal else 0) + int(m.seasonal_vax):][:m.n_age]
+    assert np.allclose(s.sum((1, 2, 3)) + (e + i).sum((1, 2, 3)), pop, rtol=1e-9 if prec == "f64" else 2e-5)
+
+
+@pytest.mark.gpu
+def test_hip_sub_save_and_batch_invariance():
+    import torch
+    from dynode_amd.engine import solve_batch
+
+    wl = synthetic.seip(B=37, seed=5, t1=100.0, **SHAPES[3])
+    m, ts = wl.model, synthetic.save_grid(100.0, 5)
+    full = solve_batch(m, wl.y0, wl.params, wl.contact, 100.0, ts).ys.cpu().numpy()
+    mask = np.array([0, 0, 0, 1], dtype=np.uint8)                           # cumulative infections only
+    sub = solve_batch(m, wl.y0, wl.params, wl.contact, 100.0, ts, save_mask=mask)
+    nC = m.compartment_sizes[3]
+    assert sub.ys.shape == (37, len(ts), nC) and np.array_equal(sub.ys.cpu().numpy(), full[:, :, -nC:])
+    one = solve_batch(m, wl.y0[20:21], wl.params[20:21], wl.contact, 100.0, ts).ys.cpu().numpy()
+    assert np.array_equal(one[0], full[20])                                # a trajectory does not depend on its neighbours
+
+
+@pytest.mark.gpu
+def test_hip_rejects_what_the_family_does_not_have(monkeypatch):
+    from dynode_amd.engine import SolveError, solve_batch
+
+    wl = synthetic.seip(B=2, seed=5, t1=50.0, **SHAPES[1])
+    with pytest.raises(SolveError, match="discontinuity_points"):
+        solve_batch(wl.model, wl.y0, wl.params, wl.contact, 50.0, synthetic.save_grid(50.0), jump_ts=[10.0])
+    monkeypatch.setenv("DYNODE_HIP_JIT", "0")
+    odd = synthetic.seip(B=2, seed=5, t1=50.0, A=3, L=1, K1=2, M1=5, n_knots=1)
+    with pytest.raises(SolveError, match="seip_instances.def"):
+        solve_batch(odd.model, odd.y0, odd.params, odd.contact, 50.0, synthetic.save_grid(50.0))
+
+
+@pytest.mark.gpu
+def test_seip_shape_built_on_demand():
+    import torch
+    from dynode_amd.engine import solve_batch
+
+    odd = synthetic.seip(B=5, seed=8, t1=80.0, A=3, L=1, K1=2, M1=5, n_knots=1)
+    ts = synthetic.save_grid(80.0)
+    r = solve_batch(odd.model, odd.y0, odd.params, odd.contact, 80.0, ts, dtype=torch.float64, constant_dt=0.25)
+    want, st, _, _ = O.solve(H.omodel(odd.model), odd.y0, odd.params, odd.contact, 80.0, ts, dtype=np.float64, n_threads=8, constant_dt=0.25)
+    assert int(r.status.max()) == 0 and np.abs(r.ys.cpu().numpy() - want).max() / 1000.0 < 1e-11
+
+
+# ------------------------------------------------------------------------------------------- front-end
+def test_history_bins_follow_the_reference_order():
+    from dynode_amd import FullStratifiedImmuneHistoryDimension, Strain
+    from dynode_amd.seip import history_masks
+
+    strains = [Strain(strain_name=n, r0=2.0, infectious_period=7.0) for n in "abc"]
+    names = [b.name for b in FullStratifiedImmuneHistoryDimension(strains).bins]
+    assert names == ["none", "a", "b", "c", "a_b", "a_c", "b_c", "a_b_c"]
+    masks = history_masks(3)
+    for name, mask in zip(names, masks):
+        assert sorted(name.split("_")) == (["none"] if mask == 0 else [n for q, n in enumerate("abc") if (mask >> q) & 1])
+
+
+def _three_strain_case():
+    from dynode_amd.seip import SEIP_ODEParams, protection_table
+
+    rng = np.random.default_rng(9)
+    A, L, K1, M1 = 2, 3, 2, 3
+    chi = rng.uniform(0.3, 0.9, (L, L)); np.fill_diagonal(chi, 1.0)
+    ve = np.array([[0.0, 0.5], [0.0, 0.3], [0.0, 0.1]])
+    p = SEIP_ODEParams(beta=rng.uniform(0.2, 0.4, L), gamma=np.full(L, 1 / 7.0), sigma=np.full(L, 1 / 3.0),
+                       waning_rates=np.array([1 / 30.0, 1 / 60.0, 0.0]), contact_matrix=np.array([[0.7, 0.3], [0.3, 0.7]]),
+                       susceptibility=protection_table(chi, ve, [1.0, 0.5, 0.0], 0.2), seasonal_vaccination_tau=100.0)
+    state = (rng.uniform(1, 50, (A, 8, K1, M1)),) + tuple(rng.uniform(0, 5, (A, 8, K1, L)) for _ in range(3))
+    return p, state
+
+
+def test_pack_permutes_histories_to_bit_sets_and_back():
+    from dynode_amd.seip import history_masks, seip_ode
+
+    p, state = _three_strain_case()
+    pk = seip_ode.pack(state, p)
+    m = pk.model
+    assert (m.family, m.n_age, m.n_strain, m.n_vax_tiers, m.n_wane, m.seasonal_vax) == (1, 2, 3, 2, 3, True)
+    s_k, e_k, i_k, c_k = H.seip_split_state(m, pk.y0)
+    masks = history_masks(3)
+    for r, mask in enumerate(masks):                               # reference bin r sits in kernel slot mask
+        assert np.array_equal(s_k[:, mask], state[0][:, r]) and np.array_equal(i_k[:, mask], state[2][:, r])
+    pop = sum(a.sum((1, 2, 3)) for a in state[:3])
+    assert np.allclose(pk.contact, np.asarray(p.contact_matrix) / pop[None, :], rtol=1e-15)
+    # the host evaluation (reference bin order in and out) equals the NumPy twin on the kernel layout
+    got = seip_ode(140.0, state, p)
+    twin = H.seip_split_state(m, H.rhs_seip_numpy(m, 140.0, pk.y0, pk.params[0], pk.contact))
+    for g, t in zip(got, twin):
+        assert np.allclose(g, t[:, masks], rtol=1e-12, atol=1e-12)
+    # recovery from strain c (bit 2) of people with history "a_b" (bin 4) lands in "a_b_c" (bin 7)
+    only_i = tuple(np.zeros_like(a) for a in state)
+    only_i[2][0, 4, 1, 2] = 10.0
+    ds = seip_ode(0.0, only_i, p)[0]
+    assert ds[0, 7, 1, 0] == pytest.approx(10.0 / 7.0) and np.count_nonzero(ds) == 1
+
+
+def test_pack_rejects_bad_shapes():
+    from dynode_amd.seip import seip_ode
+
+    p, state = _three_strain_case()
+    with pytest.raises(ValueError, match="immune histories"):
+        seip_ode.pack((state[0][:, :4],) + state[1:], p)
+    p.waning_rates = np.ones(2)
+    with pytest.raises(ValueError, match="waning_rates"):
+        seip_ode.pack(state, p)
+
+
+@pytest.mark.gpu
+def test_simulate_example_in_reference_bin_order():
+    import torch
+    from examples import seip_immune_history as ex
+    from dynode_amd.seip import seip_ode
+
+    cfg = ex.get_config()
+    sol = ex.run_simulation(cfg, tf=200)
+    idx = cfg.idx
+    s, e, i, c = (a.cpu().numpy() for a in sol.ys)
+    assert s.shape == (201, 3, 4, 3, 4) and c.shape == (201, 3, 4, 3, 2) and (idx.s, idx.c) == (0, 3)
+    state = cfg.initializer.get_initial_state(cfg)
+    assert np.array_equal(s[0], state[0].astype(np.float32))
+    pk = seip_ode.pack(state, ex.get_odeparams(cfg))
+    want, st, _, _ = O.solve(H.omodel(pk.model), pk.y0, pk.params, pk.contact, 200.0, np.arange(201.0), dtype=np.float32)
+    ws, we, wi, wc = H.seip_split_state(pk.model, want[0][-1])
+    assert st[0] == 0 and np.abs(s[-1] - ws).max() < 2e-4 * 1e5 and np.abs(c[-1] - wc).max() < 2e-4 * 1e5    # 2 strains: same order
+    people = s.sum((2, 3, 4)) + (e + i).sum((2, 3, 4))
+    assert np.abs(people - people[0]).max() < 1.0                                    # fp32, 1e5 people
+    assert s[-1][:, 3].sum() > 0 and c[-1][:, 1:].sum() > 0                          # reinfections: histories fill up
+    assert s[40][:, :, 1:].sum() == 0 and s[-1][:, :, 2].sum() > 0.5 * s[-1].sum()   # doses from day 60
+
+
+@pytest.mark.gpu
+def test_simulate_three_strains_returns_reference_bin_order():
+    import torch
+    from dynode_amd import SolverParams, simulate
+    from dynode_amd.seip import history_masks, seip_ode
+
+    p, state = _three_strain_case()
+    sol = simulate(seip_ode, 60, state, p, SolverParams(), dtype=torch.float64)
+    pk = seip_ode.pack(state, p)
+    want, st, _, _ = O.solve(H.omodel(pk.model), pk.y0, pk.params, pk.contact, 60.0, np.arange(61.0), dtype=np.float64)
+    masks = history_masks(3)
+    for got, ref in zip(sol.ys, H.seip_split_state(pk.model, want[0][-1])):
+        assert np.abs(got[-1].cpu().numpy() - ref[:, masks]).max() < 5e-5 * 500
+    assert np.array_equal(sol.ys[0][0].cpu().numpy(), state[0])
