@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- trajectories/sec of the fused 365-day solve on N MI355X GPUs.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3|cfg2|cfg5|cfg3w8]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3|cfg2|cfg5|cfg3w8|seip]
 
 A "step" is one pass of the hot path over one batch of synthetic parameter samples: ONE launch
 of the fused Tsit5+RHS kernel integrating B trajectories over 365 days with daily dense output
@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="cfg3", choices=["cfg2", "cfg3", "cfg3w8", "cfg5"])
+    ap.add_argument("--workload", default="cfg3", choices=["cfg2", "cfg3", "cfg3w8", "cfg5", "seip"])
     ap.add_argument("--batch", type=int, default=0, help="trajectories per GPU (0 = config default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the short cfg2/cfg5 side measurements (N=1 only)")
@@ -158,7 +158,7 @@ def main():
     gen = synthetic.WORKLOADS[args.workload]
     base = gen()
     B = args.batch or base.B
-    seed = {"cfg2": 0, "cfg3": 1, "cfg3w8": 1, "cfg5": 5}[args.workload] + 1000 * rank
+    seed = {"cfg2": 0, "cfg3": 1, "cfg3w8": 1, "cfg5": 5, "seip": 7}[args.workload] + 1000 * rank
     wl = gen(B, seed)
     m = wl.model
     f32 = torch.float32
@@ -245,7 +245,7 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
-                "kernel": "dyn::solve_kernel",
+                "kernel": "dyn::seip_kernel" if m.family == 1 else "dyn::solve_kernel",
                 "kernel_ms": kern_ms,
                 "algorithmic_bytes_per_trajectory": bytes_traj,
             },

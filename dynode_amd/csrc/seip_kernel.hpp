@@ -90,16 +90,20 @@ struct Seip {
         for (int k = 0; k < K1; ++k) {
             const T *c = spl + k * (4 + 2 * nk);
             T nu = c[0] + t * (c[1] + t * (c[2] + t * c[3]));
-            for (int n = 0; n < nk; ++n) {
-                const T lag = t - c[4 + n];
-                if (lag > T(0)) nu += c[4 + nk + n] * (lag * lag * lag);
+#pragma unroll
+            for (int n = 0; n < 4; ++n) { // branch-free: knots beyond nk (wave-uniform) contribute coef = 0
+                const bool on = n < nk;
+                const T knot = c[on ? 4 + n : 0], coef = on ? c[on ? 4 + nk + n : 0] : T(0);
+                const T lag = M::max(t - knot, T(0));
+                nu += coef * (lag * lag * lag);
             }
             T tot = y[k * M1];
 #pragma unroll
             for (int m = 1; m < M1; ++m) tot += y[k * M1 + m];
             tot = hist_sum(tot);
             const T doses = M::max(nu, T(0)) * pop;
-            rate[k] = tot > T(0) ? (doses < tot ? doses / tot : T(1)) : T(0);
+            const T share = doses * M::recip(tot > T(0) ? tot : T(1));
+            rate[k] = tot > T(0) ? (doses < tot ? share : T(1)) : T(0);
         }
 
 #pragma unroll
