@@ -220,7 +220,8 @@ int dyn_solve_batch_loglik(const dyn_model_desc *m, const dyn_solver_opts *opts,
  * (dyn::launch<T, METHOD, GA, S, E, WANE, C, W, ND, SPL[, INTRO]> in csrc/solve_kernel.hpp) compiled
  * into a separate shared object -- dynode_amd/jit.py does that with hipcc on first use -- whose
  * launcher is registered here.  ga = lanes on the age axis (power of two >= n_age), spl = strains
- * per lane, features = the template's FEAT (bit 0: introduced strains; bits 1..: vaccination-tier lanes).  Registered entries are consulted after the built-in ones.
+ * per lane, features = the template's FEAT (bit 0: introduced strains; bits 1..: vaccination-tier lanes); for a SEIP kernel
+ * (launch_seip of csrc/seip_kernel.hpp) pass n_strain = L, n_wane = M1, spl = 1 and features = 0x100 | tiers.  Registered entries are consulted after the built-in ones.
  */
 int dyn_register_instance(int32_t dtype, int32_t method, int32_t ga, int32_t n_strain, int32_t has_e,
                           int32_t has_wane, int32_t has_c, int32_t n_wane, int32_t n_dir, int32_t spl,

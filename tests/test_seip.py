@@ -298,3 +298,55 @@ def test_simulate_three_strains_returns_reference_bin_order():
     for got, ref in zip(sol.ys, H.seip_split_state(pk.model, want[0][-1])):
         assert np.abs(got[-1].cpu().numpy() - ref[:, masks]).max() < 5e-5 * 500
     assert np.array_equal(sol.ys[0][0].cpu().numpy(), state[0])
+
+
+@pytest.mark.gpu
+def test_simulate_batched_parameters_and_sub_save():
+    """A leading batch axis on the rates (one row per parameter sample) and ``sub_save_indices``: only the
+    cumulative infections come back, one block per sample, equal to the unbatched calls."""
+    import torch
+    from dynode_amd import SolverParams, simulate
+    from dynode_amd.seip import seip_ode
+    from examples import seip_immune_history as ex
+
+    cfg = ex.get_config()
+    state = cfg.initializer.get_initial_state(cfg)
+    p = ex.get_odeparams(cfg)
+    scale = np.array([0.8, 1.0, 1.3])
+    beta0 = np.asarray(p.beta)
+    p.beta = scale[:, None] * beta0[None, :]
+    sol = simulate(seip_ode, 120, state, p, SolverParams(), sub_save_indices=(cfg.idx.c,), save_step=7)
+    assert [tuple(y.shape) for y in sol.ys] == [(3, 18, 0), (3, 18, 0), (3, 18, 0), (3, 18, 3, 4, 3, 2)]
+    final = sol.ys[cfg.idx.c][:, -1].sum((1, 2, 3, 4)).cpu().numpy()
+    assert final[0] < final[1] < final[2]                      # more transmissible, more infections
+    p.beta = scale[2] * beta0
+    one = simulate(seip_ode, 120, state, p, SolverParams(), sub_save_indices=(cfg.idx.c,), save_step=7)
+    assert torch.equal(one.ys[cfg.idx.c], sol.ys[cfg.idx.c][2])
+
+
+@pytest.mark.gpu
+def test_randomized_seip_sweep():
+    """Random SEIP shapes, methods, horizons, save grids and masks in float64 under a constant step: the HIP
+    solve equals the oracle to rounding (on-demand builds for shapes that are not compiled in)."""
+    import torch
+    from dynode_amd.engine import solve_batch
+
+    rng = np.random.default_rng(2024)
+    shapes = [SHAPES[0], SHAPES[1], dict(A=3, L=1, K1=2, M1=5, n_knots=1), SHAPES[4]]
+    for case in range(12):
+        shape = dict(shapes[case % len(shapes)])
+        shape["seasonal"] = bool(rng.integers(2)) if "seasonal" not in shape else shape["seasonal"]
+        method = "tsit5" if shape is not SHAPES[1] and case % 2 == 0 else ("dopri5" if shape["A"] == 2 else "tsit5")
+        t1 = float(rng.uniform(20, 200))
+        wl = synthetic.seip(B=int(rng.integers(1, 12)), seed=int(rng.integers(1 << 30)), t1=t1, **shape)
+        ts = np.sort(rng.uniform(0, t1, int(rng.integers(1, 40))))
+        mask = rng.integers(0, 2, 4).astype(np.uint8)
+        if not mask.any():
+            mask[3] = 1
+        dt = float(rng.choice([0.25, 0.5, 1.0]))
+        r = solve_batch(wl.model, wl.y0, wl.params, wl.contact, t1, ts, dtype=torch.float64, method=method, constant_dt=dt, save_mask=mask)
+        want, st, na, nr = O.solve(H.omodel(wl.model), wl.y0, wl.params, wl.contact, t1, ts, dtype=np.float64, method=method,
+                                   n_threads=8, constant_dt=dt, save_mask=mask)
+        assert int(r.status.max()) == 0 and st.max() == 0, (case, shape)
+        assert np.abs(r.ys.cpu().numpy() - want).max() / 1000.0 < 1e-10, (case, shape, method)
+        assert np.array_equal(r.n_accept.cpu().numpy(), na)
