@@ -139,7 +139,8 @@ class ModelDesc:
     def param_dim(self) -> int:
         if self.family == 1:
             A, L, H, K1, M1, nk = self.seip_dims
-            return 3 * L + M1 + (3 if self.seasonal else 0) + int(self.seasonal_vax) + A + H * K1 * M1 * L + A * K1 * (4 + 2 * nk)
+            return (3 * L + M1 + (3 * L if self.has_intro else 0) + (3 if self.seasonal else 0) + int(self.seasonal_vax) + A
+                    + H * K1 * M1 * L + A * K1 * (4 + 2 * nk))
         vax = self.n_age * (self.n_strain + 4 + 2 * self.n_vax_knots) if self.n_vax_tiers > 1 else 0
         return self.n_strain * (2 + int(self.has_e) + int(self.has_wane) + (3 if self.has_intro else 0)) + (
             3 if self.seasonal else 0) + vax

@@ -137,8 +137,7 @@ static int check_model(const dyn_model_desc *m) {
     if (m->family != 0 && m->family != 1) return DYN_ERR_MODEL;
     if (m->family == 1) { /* SEIP: groups = age x 2^strains lanes */
         if (m->n_strain > 4 || (group_width(m->n_age) << m->n_strain) > 64 || m->n_vax_tiers < 0 || m->n_vax_tiers > 4 ||
-            m->n_vax_knots < 0 || m->n_vax_knots > 4 || !m->has_e || !m->has_c || !m->has_wane || m->normalize ||
-            m->has_intro)
+            m->n_vax_knots < 0 || m->n_vax_knots > 4 || !m->has_e || !m->has_c || !m->has_wane || m->normalize)
             return DYN_ERR_MODEL;
         return 0;
     }
@@ -201,6 +200,7 @@ static int enqueue(const Entry *e, const dyn_model_desc *m, const dyn_solver_opt
     ka.n_vax_tiers = m->n_vax_tiers;
     ka.n_vax_knots = m->n_vax_knots;
     ka.seasonal_vax = m->seasonal_vax ? 1 : 0;
+    ka.has_intro = m->has_intro ? 1 : 0;
 
     // saved-row layout: saved compartments concatenated in state order
     int32_t off[8];
@@ -322,7 +322,7 @@ int32_t dyn_state_dim(const dyn_model_desc *m) {
 int32_t dyn_param_dim(const dyn_model_desc *m) {
     if (m->family == 1) {
         const int L = m->n_strain, K1 = dyn::seip_tiers(m);
-        return 3 * L + m->n_wane + (m->seasonal ? 3 : 0) + (m->seasonal_vax ? 1 : 0) + m->n_age +
+        return 3 * L + m->n_wane + (m->has_intro ? 3 * L : 0) + (m->seasonal ? 3 : 0) + (m->seasonal_vax ? 1 : 0) + m->n_age +
                (1 << L) * K1 * m->n_wane * L + m->n_age * K1 * (4 + 2 * m->n_vax_knots);
     }
     return m->n_strain * (2 + (m->has_e ? 1 : 0) + (m->has_wane ? 1 : 0) + (m->has_intro ? 3 : 0)) +

@@ -33,11 +33,12 @@ struct Seip {
     T beta[L], gamma[L], sigma[L], omega[M1];
     Lanes ages;        // only Cx (pre-permuted contact row) is used
     T amp, phase, w_season, tau;
+    T itime[L], iinv[L], iamp[L]; // external introductions: day, 1 / scale, pct / (scale sqrt(2 pi)) * pop * [age receives it]
     T pop;             // population of this lane's age (doses per day = nu * pop)
     const T *sus;      // LDS: sus[K1][M1][L] of this lane's history
     const T *spl;      // LDS: spline[K1][4 + 2 nk] of this lane's age
     int nk, hist;
-    bool pad, seasonal, seasonal_vax;
+    bool pad, seasonal, seasonal_vax, intro;
 
     __device__ __forceinline__ static T hist_sum(T v) {
         if constexpr (H >= 2) v += xchg_xor<GA>(v);
@@ -70,6 +71,13 @@ struct Seip {
 #pragma unroll
             for (int k = 1; k < K1; ++k) a += y[II + k * L + l];
             x[l] = hist_sum(a);
+        }
+        if (intro) { // infectious visitors: I_b + Normal(t; time, scale) * pct * P_b (ode_model.md:176-183)
+#pragma unroll
+            for (int l = 0; l < L; ++l) {
+                const T u = (t - itime[l]) * iinv[l];
+                x[l] += iamp[l] * M::exp(T(-0.5) * u * u);
+            }
         }
         ages.contract(x, lam);
         T season = T(1), phi = T(0);
@@ -217,6 +225,11 @@ struct Seip {
         T *const tab = ts_tab + n_save + grp * (SUSN + spln);
         const T *p = ka.params + traj * ka.P;
         const T *q = p + 3 * L + M1;
+        S.intro = ka.has_intro != 0;
+#pragma unroll
+        for (int l = 0; l < L; ++l) S.itime[l] = S.iinv[l] = S.iamp[l] = T(0);
+        const T *intro_p = q;
+        if (S.intro) q += 3 * L;
         S.amp = S.phase = S.w_season = S.tau = T(0);
         if (S.seasonal) {
             S.amp = q[0];
@@ -230,6 +243,16 @@ struct Seip {
         }
         S.pop = S.pad ? T(0) : q[aa];
         q += A;
+        if (S.intro) {
+#pragma unroll
+            for (int l = 0; l < L; ++l) {
+                const T scale = intro_p[L + l];
+                const bool here = !S.pad && ((ka.intro_mask[l] >> aa) & 1ull);
+                S.itime[l] = intro_p[l];
+                S.iinv[l] = T(1) / scale;
+                S.iamp[l] = here ? intro_p[2 * L + l] / (scale * T(2.5066282746310002)) * S.pop : T(0);
+            }
+        }
         for (int n = lane; n < n_save; n += 64) ts_tab[n] = ka.save_ts[n];
         for (int n = lane % G; n < SUSN + spln; n += G) tab[n] = q[n];
         __syncthreads();

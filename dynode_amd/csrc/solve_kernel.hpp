@@ -40,7 +40,7 @@ struct KArgs {
     int32_t save_off[5]; // offset of s,e,i,r,c inside a saved row; -1 = not saved
     uint64_t intro_mask[8]; // per strain: bit a set = age bin a receives external introductions
     int32_t n_vax_tiers, n_vax_knots; // vaccination tiers actually used (<= KV) and spline knots (<= 4)
-    int32_t seasonal_vax;             // SEIP family (seip_kernel.hpp): yearly reset of the top vaccination tier
+    int32_t seasonal_vax, has_intro;  // SEIP family (seip_kernel.hpp): yearly reset of the top vaccination tier; introductions on
     // fused observation likelihood (tangent kernels only; obs == nullptr: off)
     const T *obs;        // [n_obs][ll_row] observed counts, shared by the batch
     double *ll_out;      // [B] sum of obs * log(rate) - rate

@@ -24,7 +24,8 @@ from typing import Any, Optional
 import numpy as np
 
 from ._abi import ModelDesc
-from .rhs import AbstractODEParams, CompartmentalODE, Packed, SeasonalityParams, VaccinationParams, _np
+from .rhs import (AbstractODEParams, CompartmentalODE, IntroductionParams, Packed, SeasonalityParams, VaccinationParams,
+                  _np)
 
 
 def history_masks(n_strains: int) -> np.ndarray:
@@ -70,6 +71,7 @@ class SEIP_ODEParams(AbstractODEParams):
     seasonality_params: Optional[SeasonalityParams] = None
     seasonal_vaccination_tau: Optional[float] = None         # tau = 182.5 - days to the season change; None = off
     population: Any = None      # [A]; default: the initial state's population per age
+    introduction_params: Optional[IntroductionParams] = None   # externally introduced strains (rhs.introduction_params)
     idx: Optional[SimpleNamespace] = None
 
 
@@ -116,6 +118,14 @@ class SEIPODE(CompartmentalODE):
             batch = sus.shape[0]
         B = batch or 1
         cols = [np.broadcast_to(a.reshape(-1, a.shape[-1]), (B, a.shape[-1])) for a in rates]
+        intro, masks_intro = p.introduction_params, ()
+        if intro is not None:
+            for name in ("time", "scale", "percentage"):
+                a = _np(getattr(intro, name))
+                if a.shape != (L,):
+                    raise ValueError(f"introduction {name} must have shape {(L,)}")
+                cols.append(np.broadcast_to(a, (B, L)))
+            masks_intro = self._intro_masks(p, A, L)
         seas = p.seasonality_params
         if seas is not None:
             cols += [np.full((B, 1), float(_np(getattr(seas, n)).reshape(-1)[0])) for n in ("forcing_amp", "forcing_phase", "forcing_period")]
@@ -144,7 +154,8 @@ class SEIPODE(CompartmentalODE):
         inv_pop = np.where(pop > 0, 1.0 / np.where(pop > 0, pop, 1.0), 0.0)   # an empty age group infects nobody
         model = ModelDesc(n_age=A, n_strain=L, has_e=True, has_wane=True, has_c=True, n_wane=M1, normalize=False,
                           seasonal=seas is not None, n_vax_tiers=K1, n_vax_knots=nk, family=1,
-                          seasonal_vax=p.seasonal_vaccination_tau is not None)
+                          seasonal_vax=p.seasonal_vaccination_tau is not None, has_intro=intro is not None,
+                          intro_age_mask=masks_intro)
         params = np.ascontiguousarray(np.concatenate(cols, axis=1))
         assert params.shape[1] == model.param_dim
         y0 = np.concatenate([a[:, inv].reshape(-1) for a in (s, e, i, c)])
@@ -162,7 +173,11 @@ class SEIPODE(CompartmentalODE):
         s, e, i, _ = (pk.y0[a:b].reshape(shape) for (a, b), shape in zip(_bounds(pk.shapes), pk.shapes))
         beta, gamma, sigma, omega = q[:L], q[L:2 * L], q[2 * L:3 * L], q[3 * L:3 * L + M1]
         pos = 3 * L + M1
-        season = phi = None
+        season = phi = visitors = None
+        if m.has_intro:
+            when, scale, pct = q[pos:pos + 3 * L].reshape(3, L); pos += 3 * L
+            mask = np.array([[(int(m.intro_age_mask[l]) >> b) & 1 for l in range(L)] for b in range(A)], dtype=float)
+            visitors = mask * (pct * np.exp(-0.5 * ((t - when) / scale) ** 2) / (scale * np.sqrt(2 * np.pi)))[None, :]
         if m.seasonal:
             season = 1.0 + q[pos] * np.sin(2 * np.pi * t / q[pos + 2] + q[pos + 1]); pos += 3
         if m.seasonal_vax:
@@ -170,7 +185,8 @@ class SEIPODE(CompartmentalODE):
         pop = q[pos:pos + A]; pos += A
         sus = q[pos:pos + H * K1 * M1 * L].reshape(H, K1, M1, L); pos += H * K1 * M1 * L
         spl = q[pos:].reshape(A, K1, 4 + 2 * nk)
-        lam = beta * (season if season is not None else 1.0) * (C @ i.sum((1, 2)))
+        infectious = i.sum((1, 2)) + (visitors * pop[:, None] if visitors is not None else 0.0)
+        lam = beta * (season if season is not None else 1.0) * (C @ infectious)
         infect = lam[:, None, None, None, :] * sus[None] * s[..., None]
         ds, inflow = -infect.sum(-1), infect.sum(3)
         wane = omega * s

@@ -135,15 +135,17 @@ def seip_protection_table(*args, **kwargs) -> np.ndarray:
 
 
 def seip(B: int = 4096, seed: int = 7, A: int = 8, L: int = 2, K1: int = 3, M1: int = 4, n_knots: int = 2,
-         seasonal: bool = False, seasonal_vax: bool = False, t1: float = 365.0) -> Workload:
+         seasonal: bool = False, seasonal_vax: bool = False, t1: float = 365.0, intro: bool = False) -> Workload:
     """SEIP ensemble (ode_model.md; include/dynode_hip.h "SEIP"): A ages x 2^L immune histories x K1 vaccination
     tiers x M1 waning states, L strains.  Rates as cfg 3; everyone starts unexposed and unvaccinated in the
     last waning state; doses start between day 20 and 120 at 0.2-1 % of the age group per day; cross-immunity
     0.4-0.9, vaccine efficacy rising with doses, protection falling over the waning states."""
     rng = np.random.default_rng(seed)
     H = 1 << L
+    masks = tuple(int(v) for v in rng.integers(1, 1 << A, L)) if intro else ()   # ages that receive each strain's visitors
     model = ModelDesc(n_age=A, n_strain=L, has_e=True, has_wane=True, has_c=True, n_wane=M1, normalize=False,
-                      seasonal=seasonal, n_vax_tiers=K1, n_vax_knots=n_knots, family=1, seasonal_vax=seasonal_vax)
+                      seasonal=seasonal, n_vax_tiers=K1, n_vax_knots=n_knots, family=1, seasonal_vax=seasonal_vax,
+                      has_intro=intro, intro_age_mask=masks)
     w = rng.dirichlet(5.0 * np.ones(A))
     pop = 1000.0 * w
     C = contact_matrix(rng, A) / pop[None, :]                          # lambda_a = beta sum_b C_ab I_b / P_b
@@ -151,6 +153,8 @@ def seip(B: int = 4096, seed: int = 7, A: int = 8, L: int = 2, K1: int = 3, M1: 
     t_inf, t_lat = rng.uniform(5.0, 9.0, (B, L)), rng.uniform(2.0, 4.0, (B, L))
     omega = 1.0 / rng.uniform(20.0, 60.0, (B, M1))
     cols = [r0 / t_inf, 1.0 / t_inf, 1.0 / t_lat, omega]
+    if intro:     # visitors around day 20-100, spread over 3-10 days, worth 0.1-1 % of the receiving age groups
+        cols += [rng.uniform(20.0, 100.0, (B, L)), rng.uniform(3.0, 10.0, (B, L)), rng.uniform(0.001, 0.01, (B, L))]
     if seasonal:
         cols += [rng.uniform(0.0, 0.4, (B, 1)), rng.uniform(0.0, 2 * np.pi, (B, 1)), np.full((B, 1), 365.0)]
     if seasonal_vax:

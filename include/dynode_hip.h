@@ -75,11 +75,13 @@ extern "C" {
  * (M1 = n_wane states).  The reference describes it in prose only; this is the concrete form built here.
  * State, compartment-major, row-major blocks:   s[A][H][K1][M1] | e[A][H][K1][L] | i[A][H][K1][L] | c[A][H][K1][L]
  * Parameters:  beta[L] gamma[L] sigma[L] | omega[M1] (rate of leaving waning state m; the last entry is ignored,
- *     the last state keeps its people) | amp phase period (seasonal) | tau (seasonal_vax) | pop[A] |
+ *     the last state keeps its people) | intro_time[L] intro_scale[L] intro_pct[L] (has_intro) |
+ *     amp phase period (seasonal) | tau (seasonal_vax) | pop[A] |
  *     sus[H][K1][M1][L] | spline[A][K1][4 + 2 n_vax_knots] (base[4] knot[] coef[] as above)
- * Right-hand side (has_e = has_c = has_wane = 1, normalize = has_intro = 0; `contact` is used as given, the
- * caller folds 1 / P into it):
- *     lambda_{a,l} = beta_l season(t) sum_b C[a][b] sum_{j,k} i_{b,j,k,l}           (ode_model.md:176-183)
+ * Right-hand side (has_e = has_c = has_wane = 1, normalize = 0; `contact` is used as given, the caller folds
+ * 1 / P into it):
+ *     lambda_{a,l} = beta_l season(t) sum_b C[a][b] ( sum_{j,k} i_{b,j,k,l} + visitors_{b,l}(t) )   (ode_model.md:176-183)
+ *     visitors_{b,l}(t) = intro_pct_l NormalPdf(t; intro_time_l, intro_scale_l) pop_b for ages b of intro_age_mask[l] (has_intro)
  *     infection     f_{a,j,k,m,l} = lambda_{a,l} sus_{j,k,m,l} s_{a,j,k,m}: leaves s, enters e_{a,j,k,l} and c
  *         (sus = 1 - WI of ode_model.md:185-211: the host evaluates cross-immunity, vaccine efficacy, waning
  *          protection and minimum homologous immunity into the table)

@@ -96,10 +96,10 @@ int32_t dyo_state_dim(const dyo_model_desc *m) {
 
 int32_t dyo_param_dim(const dyo_model_desc *m) {
     if (m->family == 1) {
-        /* beta gamma sigma [L] | omega [M1] | (amp phase period) | (tau) | pop [A] | sus [H][K1][M1][L] |
+        /* beta gamma sigma [L] | omega [M1] | (intro time scale pct [L]) | (amp phase period) | (tau) | pop [A] | sus [H][K1][M1][L] |
          * spline [A][K1][4 + 2 nk] */
         const int L = m->n_strain, K1 = seip_tiers(m);
-        return 3 * L + m->n_wane + (m->seasonal ? 3 : 0) + (m->seasonal_vax ? 1 : 0) + m->n_age +
+        return 3 * L + m->n_wane + (m->has_intro ? 3 * L : 0) + (m->seasonal ? 3 : 0) + (m->seasonal_vax ? 1 : 0) + m->n_age +
                (1 << L) * K1 * m->n_wane * L + m->n_age * K1 * (4 + 2 * m->n_vax_knots);
     }
     return m->n_strain * (2 + (m->has_e ? 1 : 0) + (m->has_wane ? 1 : 0) + (m->has_intro ? 3 : 0)) +
@@ -170,7 +170,7 @@ static int check_model(const dyo_model_desc *m) {
     if (m->n_wane > 1 && !m->has_wane) return -2;
     if (m->family != 0 && m->family != 1) return -2;
     if (m->family == 1 && (m->n_strain > 4 || m->n_vax_tiers > 4 || m->n_vax_knots < 0 || m->n_vax_knots > 4 ||
-                           m->has_intro || m->normalize))
+                           m->normalize))
         return -2;
     return 0;
 }

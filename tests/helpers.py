@@ -143,12 +143,14 @@ def seip_dims(m):
     return m.n_age, m.n_strain, 1 << m.n_strain, max(int(m.n_vax_tiers), 1), m.n_wane, int(m.n_vax_knots)
 
 
-def seip_pack_params(m, beta, gamma, sigma, omega, pop, sus, spline, seasonal=None, tau=None):
+def seip_pack_params(m, beta, gamma, sigma, omega, pop, sus, spline, seasonal=None, tau=None, intro=None):
     """Parameter row of the SEIP family: beta gamma sigma [L] | omega [M1] | (amp phase period) | (tau) |
     pop [A] | sus [H, K1, M1, L] | spline [A, K1, 4 + 2 nk]."""
     A, L, H, K1, M1, nk = seip_dims(m)
     parts = [np.asarray(beta, float).reshape(L), np.asarray(gamma, float).reshape(L), np.asarray(sigma, float).reshape(L),
              np.asarray(omega, float).reshape(M1)]
+    if getattr(m, "has_intro", False):
+        parts.append(np.asarray(intro, float).reshape(3 * L))            # time[L] scale[L] pct[L]
     if m.seasonal:
         parts.append(np.asarray(seasonal, float).reshape(3))
     if m.seasonal_vax:
@@ -174,7 +176,9 @@ def rhs_seip_numpy(m, t, y, p, C):
     p = np.asarray(p, float)
     beta, gamma, sigma, omega = p[:L], p[L:2 * L], p[2 * L:3 * L], p[3 * L:3 * L + M1]
     pos = 3 * L + M1
-    season, phi = 1.0, 0.0
+    season, phi, intro = 1.0, 0.0, None
+    if getattr(m, "has_intro", False):
+        intro = p[pos:pos + 3 * L].reshape(3, L); pos += 3 * L
     if m.seasonal:
         amp, phase, period = p[pos:pos + 3]; pos += 3
         season = 1.0 + amp * np.sin(2 * np.pi * t / period + phase)
@@ -184,7 +188,12 @@ def rhs_seip_numpy(m, t, y, p, C):
     sus = p[pos:pos + H * K1 * M1 * L].reshape(H, K1, M1, L); pos += H * K1 * M1 * L
     spl = p[pos:].reshape(A, K1, 4 + 2 * nk)
     s, e, i, _ = seip_split_state(m, np.asarray(y, float))
-    lam = beta * season * (np.asarray(C, float) @ i.sum((1, 2)))                       # [A, L]
+    infectious = i.sum((1, 2))                                                         # [A, L]
+    if intro is not None:
+        mask = np.array([[(int(m.intro_age_mask[l]) >> b) & 1 for l in range(L)] for b in range(A)], dtype=float)
+        pdf = np.exp(-0.5 * ((t - intro[0]) / intro[1]) ** 2) / (intro[1] * np.sqrt(2 * np.pi))
+        infectious = infectious + mask * (intro[2] * pdf)[None, :] * pop[:, None]
+    lam = beta * season * (np.asarray(C, float) @ infectious)                          # [A, L]
     infect = lam[:, None, None, None, :] * sus[None] * s[..., None]                     # [A, H, K1, M1, L]
     ds = -infect.sum(-1)
     inflow = infect.sum(3)                                                             # [A, H, K1, L]

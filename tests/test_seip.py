@@ -19,7 +19,15 @@ SHAPES = [
     dict(A=3, L=2, K1=3, M1=4, n_knots=2, seasonal=True),
     dict(A=8, L=2, K1=3, M1=4, n_knots=2, seasonal_vax=True),
     dict(A=4, L=3, K1=2, M1=3, n_knots=3, seasonal=True, seasonal_vax=True),
+    dict(A=2, L=2, K1=2, M1=2, n_knots=1, intro=True),
+    dict(A=8, L=2, K1=3, M1=4, n_knots=2, intro=True, seasonal=True),
 ]
+
+
+def _pop(m, row):
+    """pop[A] inside a SEIP parameter row."""
+    start = 3 * m.n_strain + m.n_wane + (3 * m.n_strain if m.has_intro else 0) + (3 if m.seasonal else 0) + int(m.seasonal_vax)
+    return row[start:start + m.n_age]
 
 
 def _ids(v):
@@ -45,6 +53,28 @@ def test_rhs_oracle_matches_numpy_twin_and_conserves_people(shape):
             assert np.all(dc >= 0)
 
 
+def test_introduced_strain_arrives_through_visitors_only():
+    """A strain with no initial infections and no visitors never appears; with visitors it does, in the ages of
+    its mask first, and the visitors themselves are not counted as people (population conserved)."""
+    wl = synthetic.seip(B=1, seed=4, A=3, L=2, K1=2, M1=2, n_knots=0, intro=True, t1=150.0)
+    m = wl.model
+    y0 = wl.y0[0].copy()
+    s, e, i, c = H.seip_split_state(m, y0)
+    i[..., 1] = 0.0                                             # strain 1 starts absent
+    y0 = np.concatenate([a.ravel() for a in (s, e, i, c)])
+    p = wl.params[0].copy()
+    ts = np.array([0.0, 150.0])
+    off = 3 * 2 + 2
+    p[off + 2 * 2 + 1] = 0.0                                    # intro_pct of strain 1 = 0
+    ys, st, _, _ = O.solve(H.omodel(m), y0, p[None], wl.contact, 150.0, ts, dtype=np.float64)
+    assert st[0] == 0 and H.seip_split_state(m, ys[0][-1])[3][..., 1].sum() == 0.0
+    p[off + 2 * 2 + 1] = 0.005
+    ys, st, _, _ = O.solve(H.omodel(m), y0, p[None], wl.contact, 150.0, ts, dtype=np.float64)
+    s1, e1, i1, c1 = H.seip_split_state(m, ys[0][-1])
+    assert st[0] == 0 and c1[..., 1].sum() > 1.0
+    assert np.allclose(s1.sum((1, 2, 3)) + (e1 + i1).sum((1, 2, 3)), s.sum((1, 2, 3)) + (e + i).sum((1, 2, 3)), rtol=1e-9)
+
+
 def test_seasonal_vaccination_pulse_moves_the_top_tier_down():
     wl = synthetic.seip(B=1, seed=3, A=2, L=2, K1=3, M1=2, n_knots=0, seasonal_vax=True)
     m = wl.model
@@ -61,7 +91,7 @@ def test_seasonal_vaccination_pulse_moves_the_top_tier_down():
         assert np.allclose(d_on[:, :, 0], d_off[:, :, 0], rtol=1e-12)
 
 
-@pytest.mark.parametrize("shape", SHAPES[1:4], ids=_ids)
+@pytest.mark.parametrize("shape", SHAPES[1:4] + SHAPES[5:6], ids=_ids)
 def test_oracle_solution_vs_scipy(shape):
     wl = synthetic.seip(B=2, seed=21, t1=120.0, **shape)
     m, ts = wl.model, np.arange(0.0, 121.0, 20.0)
@@ -72,7 +102,7 @@ def test_oracle_solution_vs_scipy(shape):
         assert np.abs(ys[b] - want).max() < 2e-5                   # of 1000 people; the dose cap has kinks
     s, e, i, c = H.seip_split_state(m, ys[0][-1])
     A = m.n_age
-    assert np.allclose((s.sum((1, 2, 3)) + (e + i).sum((1, 2, 3))), wl.params[0][3 * m.n_strain + m.n_wane + (3 if m.seasonal else 0) + int(m.seasonal_vax):][:A], rtol=1e-9)
+    assert np.allclose((s.sum((1, 2, 3)) + (e + i).sum((1, 2, 3))), _pop(m, wl.params[0]), rtol=1e-9)
     assert s[:, 0].sum() < s.sum() and s[:, 1:].sum() > 0           # recovered people carry a history
     assert s[:, :, 1:].sum() > 0                                    # and doses were given
 
@@ -125,7 +155,7 @@ def test_protection_table_follows_ode_model_md():
 # ------------------------------------------------------------------------------------------- GPU
 GPU_CASES = [(SHAPES[0], "f64", "tsit5"), (SHAPES[1], "f64", "tsit5"), (SHAPES[1], "f64", "dopri5"), (SHAPES[4], "f64", "tsit5"),
              (SHAPES[0], "f32", "tsit5"), (SHAPES[1], "f32", "dopri5"), (SHAPES[2], "f32", "tsit5"), (SHAPES[3], "f32", "tsit5"),
-             (SHAPES[3], "f32", "dopri5"), (SHAPES[4], "f32", "tsit5")]
+             (SHAPES[3], "f32", "dopri5"), (SHAPES[4], "f32", "tsit5"), (SHAPES[5], "f64", "tsit5"), (SHAPES[6], "f32", "tsit5")]
 
 
 @pytest.mark.gpu
@@ -153,7 +183,7 @@ def test_hip_matches_oracle(shape, prec, method):
     assert np.abs(steps - (na + nr)).max() <= max(8, 0.2 * (na + nr).max())
     assert np.array_equal(got[:, 0], wl.y0.astype(npd))                     # first row = initial state, exactly
     s, e, i, c = H.seip_split_state(m, got[0, -1].astype(np.float64))
-    pop = wl.params[0][3 * m.n_strain + m.n_wane + (3 if m.seasonal else 0) + int(m.seasonal_vax):][:m.n_age]
+    pop = _pop(m, wl.params[0])
     assert np.allclose(s.sum((1, 2, 3)) + (e + i).sum((1, 2, 3)), pop, rtol=1e-9 if prec == "f64" else 2e-5)
 
 
@@ -350,3 +380,25 @@ def test_randomized_seip_sweep():
         assert int(r.status.max()) == 0 and st.max() == 0, (case, shape)
         assert np.abs(r.ys.cpu().numpy() - want).max() / 1000.0 < 1e-10, (case, shape, method)
         assert np.array_equal(r.n_accept.cpu().numpy(), na)
+
+
+def test_front_end_introduction_params_reach_the_parameter_row():
+    from dynode_amd.rhs import IntroductionParams
+    from dynode_amd.seip import history_masks, seip_ode
+
+    p, state = _three_strain_case()
+    p.introduction_params = IntroductionParams(time=np.array([0.0, 30.0, 45.0]), scale=np.array([1.0, 5.0, 8.0]),
+                                               percentage=np.array([0.0, 0.01, 0.02]), ages_mask=np.array([[0, 0], [1, 0], [1, 1]]))
+    pk = seip_ode.pack(state, p)
+    m = pk.model
+    assert m.has_intro and m.intro_age_mask == (0, 1, 3) and pk.params.shape[1] == m.param_dim
+    assert np.array_equal(pk.params[0][9 + 3:9 + 3 + 9], [0.0, 30.0, 45.0, 1.0, 5.0, 8.0, 0.0, 0.01, 0.02])
+    masks = history_masks(3)
+    for t in (28.0, 47.0):
+        got = seip_ode(t, state, p)
+        twin = H.seip_split_state(m, H.rhs_seip_numpy(m, t, pk.y0, pk.params[0], pk.contact))
+        orc = H.seip_split_state(m, O.rhs(H.omodel(m), t, pk.y0, pk.params[0], pk.contact))
+        for g, tw, o in zip(got, twin, orc):
+            assert np.allclose(g, tw[:, masks], rtol=1e-12, atol=1e-12) and np.allclose(o, tw, rtol=1e-12, atol=1e-12)
+    p.introduction_params = None
+    assert not np.allclose(seip_ode(47.0, state, p)[1], got[1])       # the visitors do infect
