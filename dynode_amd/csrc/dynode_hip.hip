@@ -377,9 +377,8 @@ static int solve_impl(const dyn_model_desc *m, const dyn_solver_opts *o, const v
     }
     for (int j = 1; j < o->n_jump; ++j)
         if (!(o->jump_ts[j] > o->jump_ts[j - 1])) return DYN_ERR_JUMP; /* must be strictly increasing */
-    if (m->family == 1 && (n_dir > 0 || o->n_jump > 0)) {
-        snprintf(dyn::tl_error, sizeof(dyn::tl_error), "the SEIP kernels have no %s yet",
-                 n_dir > 0 ? "tangent planes" : "discontinuity_points");
+    if (m->family == 1 && n_dir > 0) {
+        snprintf(dyn::tl_error, sizeof(dyn::tl_error), "the SEIP kernels have no tangent planes yet");
         return DYN_ERR_UNSUPPORTED;
     }
     const dyn::Entry *e = dyn::find_entry(m, o->dtype, o->method, n_dir);
@@ -395,7 +394,7 @@ static int solve_impl(const dyn_model_desc *m, const dyn_solver_opts *o, const v
     if (e && m->family == 1) { // susceptibility table and splines of every trajectory of a wave sit in LDS
         const size_t per_traj = (size_t)(1 << m->n_strain) * dyn::seip_tiers(m) * m->n_wane * m->n_strain +
                                 (size_t)m->n_age * dyn::seip_tiers(m) * (4 + 2 * m->n_vax_knots);
-        const size_t bytes = ((size_t)n_save + (64 / dyn::entry_lanes(e)) * per_traj) * (o->dtype == DYN_F64 ? 8 : 4);
+        const size_t bytes = ((size_t)n_save + dyn::kMaxJumps + (64 / dyn::entry_lanes(e)) * per_traj) * (o->dtype == DYN_F64 ? 8 : 4);
         if (bytes > 64 * 1024) {
             snprintf(dyn::tl_error, sizeof(dyn::tl_error), "SEIP tables need %zu bytes of LDS per wave (limit 65536)", bytes);
             return DYN_ERR_UNSUPPORTED;

@@ -12,7 +12,7 @@
 //     recovery  eta(j, l) = j | 2^l: lanes whose bit l is set take gamma_l i from lane j ^ 2^l (and keep their own)
 // Infection, waning, vaccination and the seasonal reset move people inside a lane.  The susceptibility
 // table sus[H][K1][M1][L] and the dose-rate splines of a trajectory are staged in LDS.
-// Primal only (no tangent planes), no discontinuity points, no replication: one group per trajectory.
+// Primal only (no tangent planes), no replication: one group per trajectory.
 #pragma once
 #include "solve_kernel.hpp"
 
@@ -222,7 +222,9 @@ struct Seip {
         const int n_save = ka.n_save;
         constexpr int SUSN = H * NS * L;
         const int spln = A * K1 * (4 + 2 * nk);
-        T *const tab = ts_tab + n_save + grp * (SUSN + spln);
+        const int n_jump = ka.n_jump;
+        T *const jt_tab = ts_tab + n_save; // discontinuity points follow the save grid
+        T *const tab = jt_tab + (n_jump > 0 ? kMaxJumps : 0) + grp * (SUSN + spln);
         const T *p = ka.params + traj * ka.P;
         const T *q = p + 3 * L + M1;
         S.intro = ka.has_intro != 0;
@@ -255,6 +257,7 @@ struct Seip {
         }
         for (int n = lane; n < n_save; n += 64) ts_tab[n] = ka.save_ts[n];
         for (int n = lane % G; n < SUSN + spln; n += G) tab[n] = q[n];
+        if (n_jump > 0 && lane < kMaxJumps) jt_tab[lane] = ka.jump_ts[lane];
         __syncthreads();
         S.sus = tab + j * (NS * L);
         S.spl = tab + SUSN + aa * K1 * (4 + 2 * nk);
@@ -332,6 +335,19 @@ struct Seip {
         }
         tnext = M::min(tnext, t_end);
 
+        // discontinuity_points, as in solve_kernel.hpp: steps are clipped to land just before a jump and restart
+        // just after it with the first stage recomputed and the unclipped step size
+        int jidx = 0;
+        bool at_jump = false;
+        T dt_unclipped = T(0);
+        if (n_jump > 0) {
+            while (jidx < n_jump && jt_tab[jidx] <= tprev) ++jidx;
+            if (jidx < n_jump && jt_tab[jidx] < tnext) {
+                dt_unclipped = tnext - tprev;
+                tnext = M::next(jt_tab[jidx], -M::inf());
+                at_jump = true;
+            }
+        }
         int save_idx = 0;
         T ts_next = save_idx < n_save ? ts_tab[save_idx] : M::inf();
         int64_t steps = 0;
@@ -407,10 +423,37 @@ struct Seip {
             } else if (act && finite) {
                 ++n_rej;
             }
-            const T next_t0 = accept ? tnext : tprev;
+            T next_t0 = accept ? tnext : tprev;
             T next_t1 = next_t0 + (constant ? ka.constant_dt : dt * factor);
+            if (n_jump > 0) { // wave-uniform
+                const bool landed = at_jump && accept;
+                if (landed) {
+                    next_t0 = M::next(jt_tab[jidx], M::inf());
+                    next_t1 = next_t0 + (constant ? ka.constant_dt : dt_unclipped * factor);
+                    ++jidx;
+                }
+                if (__any(landed)) { // FSAL is invalid across a jump: k[0] = f(t_jump+, y)
+                    S.rhs(next_t0, y, k[1]);
+                    if (landed) {
+#pragma unroll
+                        for (int v = 0; v < NV; ++v) k[0][v] = k[1][v];
+                    }
+                }
+                if (act) at_jump = false;
+                if (act && jidx < n_jump) {
+                    const T tj = jt_tab[jidx];
+                    if (tj < next_t1 && tj > next_t0) {
+                        dt_unclipped = next_t1 - next_t0;
+                        next_t1 = M::next(tj, -M::inf());
+                        at_jump = true;
+                    }
+                }
+            }
             const T tp = M::min(next_t0, t_end);
-            if (next_t1 > t_end - M::clip_tol) next_t1 = accept ? t_end : tp + T(0.5) * (t_end - tp);
+            if (next_t1 > t_end - M::clip_tol) {
+                next_t1 = accept ? t_end : tp + T(0.5) * (t_end - tp);
+                at_jump = false;
+            }
             if (!done) {
                 tprev = tp;
                 tnext = next_t1;
@@ -452,7 +495,7 @@ hipError_t launch_seip(const KArgs<T> &ka, hipStream_t stream) {
     const int64_t blocks = (ka.B + TPW - 1) / TPW;
     if (blocks <= 0) return hipSuccess;
     const size_t per_traj = (size_t)(1 << L) * K1 * M1 * L + (size_t)ka.A * K1 * (4 + 2 * ka.n_vax_knots);
-    const size_t lds = ((size_t)ka.n_save + TPW * per_traj) * sizeof(T);
+    const size_t lds = ((size_t)ka.n_save + (ka.n_jump > 0 ? kMaxJumps : 0) + TPW * per_traj) * sizeof(T);
     hipLaunchKernelGGL((seip_kernel<T, METHOD, GA, L, K1, M1>), dim3((unsigned)blocks), dim3(64), lds, stream, ka);
     return hipGetLastError();
 }

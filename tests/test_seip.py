@@ -207,9 +207,6 @@ def test_hip_sub_save_and_batch_invariance():
 def test_hip_rejects_what_the_family_does_not_have(monkeypatch):
     from dynode_amd.engine import SolveError, solve_batch
 
-    wl = synthetic.seip(B=2, seed=5, t1=50.0, **SHAPES[1])
-    with pytest.raises(SolveError, match="discontinuity_points"):
-        solve_batch(wl.model, wl.y0, wl.params, wl.contact, 50.0, synthetic.save_grid(50.0), jump_ts=[10.0])
     monkeypatch.setenv("DYNODE_HIP_JIT", "0")
     odd = synthetic.seip(B=2, seed=5, t1=50.0, A=3, L=1, K1=2, M1=5, n_knots=1)
     with pytest.raises(SolveError, match="seip_instances.def"):
@@ -402,3 +399,24 @@ def test_front_end_introduction_params_reach_the_parameter_row():
             assert np.allclose(g, tw[:, masks], rtol=1e-12, atol=1e-12) and np.allclose(o, tw, rtol=1e-12, atol=1e-12)
     p.introduction_params = None
     assert not np.allclose(seip_ode(47.0, state, p)[1], got[1])       # the visitors do infect
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method", ["tsit5", "dopri5"])
+def test_hip_discontinuity_points(method):
+    """SolverParams.discontinuity_points on the SEIP kernels (the dose-rate knots are the natural ones): same
+    accepted / rejected counts and values as the oracle in float64."""
+    import torch
+    from dynode_amd.engine import solve_batch
+
+    wl = synthetic.seip(B=7, seed=13, t1=150.0, **SHAPES[1])
+    ts = synthetic.save_grid(150.0)
+    jumps = [30.0, 61.5, 100.0]
+    r = solve_batch(wl.model, wl.y0, wl.params, wl.contact, 150.0, ts, dtype=torch.float64, method=method, jump_ts=jumps)
+    want, st, na, nr = O.solve(H.omodel(wl.model), wl.y0, wl.params, wl.contact, 150.0, ts, dtype=np.float64, method=method,
+                               jump_ts=jumps, n_threads=4)
+    assert int(r.status.max()) == 0 and st.max() == 0
+    assert np.abs(r.ys.cpu().numpy() - want).max() / 1000.0 < 5e-5
+    assert np.abs((r.n_accept + r.n_reject).cpu().numpy() - (na + nr)).max() <= 4
+    plain = solve_batch(wl.model, wl.y0, wl.params, wl.contact, 150.0, ts, dtype=torch.float64, method=method)
+    assert int((r.n_accept != plain.n_accept).sum()) > 0                 # the points do change the stepping
