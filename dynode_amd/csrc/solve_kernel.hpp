@@ -310,8 +310,7 @@ template <typename T, int METHOD, int GA, int ST, bool HAS_E, bool HAS_WANE, boo
 struct Solver {
     static constexpr bool INTRO = (FEAT & 1) != 0;
     static constexpr int KV = FEAT >> 1;
-    static_assert(KV == 0 || ((KV == 2 || KV == 4) && GA % KV == 0 && ND == 0),
-                  "vaccination tiers: 2 or 4 lanes per age, no tangent kernels yet");
+    static_assert(KV == 0 || ((KV == 2 || KV == 4) && GA % KV == 0), "vaccination tiers: 2 or 4 lanes per age");
     static_assert(ST % SPL == 0, "strains per lane must divide the strain count");
     static constexpr int S = SPL;        // strains held by one lane (all per-lane arrays use S)
     static constexpr int GS = ST / SPL;  // strain lanes
@@ -344,6 +343,8 @@ struct Solver {
     // vaccination tiers (KV): susceptibility 1 - efficacy of this group's tier per strain; this group's
     // vaccination-rate spline a + b t + c t^2 + d t^3 + sum_i coef_i (t - knot_i)^3 [t > knot_i]
     T sus[KV ? S : 1], vbase[KV ? 4 : 1], vknot[KV ? 4 : 1], vcoef[KV ? 4 : 1];
+    T dsus[KV ? NDA : 1][KV ? S : 1], dvbase[KV ? NDA : 1][KV ? 4 : 1], dvknot[KV ? NDA : 1][KV ? 4 : 1],
+        dvcoef[KV ? NDA : 1][KV ? 4 : 1]; // their seeds per direction
     int vnk;
     bool vax_top, vax_first;  // last tracked tier (nobody leaves) / tier 0 (nobody arrives)
     bool pad, normalize, seasonal;
@@ -445,6 +446,8 @@ struct Solver {
             if constexpr (HAS_C) dy[0][IC + l] = flux;
         }
         dy[0][0] = strain_sum(back_s - out_s);
+        T v_rate = T(0), v_nage = T(0);       // max(nu, 0) and the age's population, reused by the tangents
+        bool v_nu_pos = false, v_capped = false, v_has_s = false;
         if constexpr (KV > 0) {
             // vaccination (ode_model.md): per day nu_{age,tier}(t) * (population of the age) doses go to
             // the susceptibles of the tier, at most as many as there are; they move up one tier
@@ -458,6 +461,11 @@ struct Solver {
             if constexpr (KV == 4) n_age += xchg_xor<2>(n_age);
             const T doses = M::max(nu, T(0)) * n_age;
             const T leave = vax_top ? T(0) : M::min(doses, M::max(y0[0], T(0)));
+            v_rate = M::max(nu, T(0));
+            v_nage = n_age;
+            v_nu_pos = nu > T(0);
+            v_has_s = y0[0] > T(0);
+            v_capped = !(doses < M::max(y0[0], T(0))); // the tier runs empty: everyone left is vaccinated
             // lane of tier k receives what tier k - 1 of the same age gives up
             const T from_below = KV == 2 ? xchg_xor<1>(leave) : dpp_mov<0x90>(leave); // quad_perm [0,0,1,2]
             dy[0][0] += (vax_first ? T(0) : from_below) - leave;
@@ -502,7 +510,8 @@ struct Solver {
                 for (int l = 0; l < S; ++l) {
                     const T bs = beta[l] * season;
                     const T dbs = dbeta[j][l] * season + beta[l] * dseason;
-                    const T dfoi = dbs * acc[l] + bs * dacc[l];
+                    T dfoi = dbs * acc[l] + bs * dacc[l];
+                    if constexpr (KV > 0) dfoi = dfoi * sus[l] + (bs * acc[l]) * dsus[j][l];
                     const T dflux = dfoi * y0[0] + foi[l] * u[0];
                     const T dg_i = dgamma[j][l] * y0[II + l] + gamma[l] * u[II + l];
                     dout_s += dflux;
@@ -531,6 +540,22 @@ struct Solver {
                     if constexpr (HAS_C) du[IC + l] = dflux;
                 }
                 du[0] = strain_sum(dback_s - dout_s);
+                if constexpr (KV > 0) {
+                    // d min(max(nu, 0) * P_a, max(s, 0)): doses while they last, else the remaining susceptibles
+                    T dnu = dvbase[j][0] + t * (dvbase[j][1] + t * (dvbase[j][2] + t * dvbase[j][3]));
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const T lag = t - vknot[q];
+                        if (q < vnk && lag > T(0))
+                            dnu += (dvcoef[j][q] * lag - T(3) * vcoef[q] * dvknot[j][q]) * (lag * lag);
+                    }
+                    T dn_age = dN + xchg_xor<1>(dN);
+                    if constexpr (KV == 4) dn_age += xchg_xor<2>(dn_age);
+                    const T ddoses = (v_nu_pos ? dnu : T(0)) * v_nage + v_rate * dn_age;
+                    const T dleave = vax_top ? T(0) : (v_capped ? (v_has_s ? u[0] : T(0)) : ddoses);
+                    const T dfrom_below = KV == 2 ? xchg_xor<1>(dleave) : dpp_mov<0x90>(dleave);
+                    du[0] += (vax_first ? T(0) : dfrom_below) - dleave;
+                }
             }
         }
     }
@@ -869,6 +894,19 @@ struct Solver {
                             L.ditime[j][l] = dp[oI * ST + s0 + l];
                             L.discale[j][l] = dp[(oI + 1) * ST + s0 + l];
                             L.dipct[j][l] = dp[(oI + 2) * ST + s0 + l];
+                        }
+                    }
+                    if constexpr (KV > 0) {
+                        const int nk = ka.n_vax_knots;
+                        const T *dvp = dp + oSe * ST + (ka.seasonal ? 3 : 0);
+                        const T *dsp_ = dvp + A * ST + aa * (4 + 2 * nk);
+#pragma unroll
+                        for (int l = 0; l < S; ++l) L.dsus[j][l] = L.pad ? T(0) : dvp[aa * ST + s0 + l];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            L.dvbase[j][q] = L.pad ? T(0) : dsp_[q];
+                            L.dvknot[j][q] = (!L.pad && q < nk) ? dsp_[4 + q] : T(0);
+                            L.dvcoef[j][q] = (!L.pad && q < nk) ? dsp_[4 + nk + q] : T(0);
                         }
                     }
                     if (L.seasonal) {

@@ -327,3 +327,43 @@ def test_fused_likelihood_on_random_calls():
         assert torch.allclose(dlp[:, 0], dwant, rtol=1e-9, atol=1e-7 * (1.0 + float(dwant.abs().max()))), (seed, m, kw, comp, inc)
         ran += 1
     assert ran >= 40
+
+
+VAX_CASES = [
+    (2, ModelDesc(n_age=4, normalize=False, n_vax_tiers=2, n_vax_knots=2), 2),
+    (2, ModelDesc(n_age=8, normalize=False, n_vax_tiers=3, n_vax_knots=1), 1),
+    (4, ModelDesc(n_age=8, n_strain=2, has_e=True, has_wane=True, has_c=True, normalize=False, n_vax_tiers=2, n_vax_knots=3), 2),
+]
+
+
+@pytest.mark.parametrize("ages,m,nd", VAX_CASES, ids=lambda v: str(v) if isinstance(v, int) else f"G{v.n_age}S{v.n_strain}K{v.n_vax_tiers}")
+@pytest.mark.parametrize("dose_scale", [1.0, 6.0], ids=["doses_last", "tier_runs_empty"])
+def test_vaccination_tangents_equal_derivative_of_the_discrete_solve(ages, m, nd, dose_scale):
+    """Seeds on every column of a vaccinated model's parameter row -- rates, susceptibilities (1 - efficacy), spline
+    base / knots / coefficients -- and on the initial state, against central differences of the fp64 oracle.  With
+    dose_scale = 6 the unvaccinated tier runs empty during the run, so both branches of min(doses, s) are taken."""
+    from test_gpu_parity import vax_workload
+
+    B = 9
+    y0, p, C, t1, ts, pop = vax_workload(ages, m, B, seed=3 + nd, t1=90.0)
+    G, S, nk = m.n_age, m.n_strain, m.n_vax_knots
+    at = m.param_dim - G * (4 + 2 * nk)
+    spl = p[:, at:].reshape(B, G, 4 + 2 * nk)
+    spl[:, :, :2] *= dose_scale
+    rng = np.random.default_rng(1)
+    dp = rng.normal(size=(B, nd, m.param_dim)) * 0.05 * np.abs(p)[:, None, :]
+    dy0 = rng.normal(size=(B, nd, m.state_dim)) * (y0 > 0)[:, None, :]         # keep empty tiers empty (no negative people)
+    r = solve_batch(m, y0, p, C, t1, ts, dtype=torch.float64, constant_dt=0.25, dparams=dp, dy0=dy0)
+    want_y, st, _, _ = O.solve(H.omodel(m), y0, p, C, t1, ts, dtype=np.float64, constant_dt=0.25)
+    assert int(r.status.max()) == 0 and np.abs(r.ys.cpu().numpy() - want_y).max() / 1000 < 1e-11
+    if dose_scale > 1:
+        KV = m.vax_lanes
+        assert (want_y[:, -1, :G].reshape(B, -1, KV)[:, :, 0] < 1e-2 * pop).any()     # tier 0 did run empty somewhere
+    dys = r.dys.cpu().numpy()
+    for j in range(nd):
+        want = fd_oracle(m, y0, p, C, t1, ts, dp[:, j], dy0[:, j], eps=1e-6, constant_dt=0.25)
+        scale = np.abs(want).max() + 1e-12
+        err = np.abs(dys[:, :, j] - want).max(axis=(1, 2)) / scale
+        # a trajectory whose difference quotient straddles the instant a tier runs empty sees the kink of min():
+        # its quotient is off by O(1) of the jump in slope -- allow one such trajectory per direction
+        assert np.sort(err)[-2] < 1e-5 and err.max() < 5e-2, err
