@@ -287,13 +287,31 @@ class CompartmentalODE:
             if a.dim() == 1:
                 B = max(B, a.shape[0])
         S = arrays[0].shape[-1] if self.multi_strain else 1
+        vp = getattr(p, "vaccination_params", None)
+        blocks = []
+        if vp is not None:
+            # sus[A, KV, S] = 1 - efficacy (padded tier slots: 1), then [base(4) knots coefs] per (age, slot);
+            # the efficacy may carry a leading batch axis (one row per chain / parameter sample)
+            base, knots, coefs, ve = tt(vp.base_equations), tt(vp.knot_locations), tt(vp.knot_coefficients), tt(vp.vaccine_efficacy)
+            A, K = base.shape[-3], base.shape[-2]
+            KV = 2 if K == 2 else 4
+            ve = ve.reshape((-1,) + tuple(ve.shape[-2:]))                    # [b, S, K]
+            sus = torch.cat([1.0 - ve.transpose(1, 2), ve.new_ones((ve.shape[0], KV - K, S))], dim=1)      # [b, KV, S]
+            blocks.append(sus[:, None].expand(ve.shape[0], A, KV, S).reshape(ve.shape[0], -1))
+            spl = torch.cat([base, knots, coefs], dim=-1)
+            spl = spl.reshape((-1,) + tuple(spl.shape[-3:]))                 # [b, A, K, 4 + 2 nk]
+            spl = torch.cat([spl, spl.new_zeros((spl.shape[0], A, KV - K, spl.shape[-1]))], dim=2)
+            blocks.append(spl.reshape(spl.shape[0], -1))
+            B = max([B] + [b.shape[0] for b in blocks])
         cols = [a.reshape(-1, S).expand(B, S) for a in arrays] + [a.reshape(-1, 1).expand(B, 1) for a in extra]
+        cols += [b.expand(B, b.shape[1]) for b in blocks]
         return torch.cat(cols, dim=1)
 
     def wants_grad(self, p) -> bool:
         leaves = [getattr(p, f.name) for f in fields(p)]
-        if getattr(p, "vaccination_params", None) is not None:
-            return False      # no tangent kernels for vaccination tiers yet: the solve is not differentiable
+        vp = getattr(p, "vaccination_params", None)
+        if vp is not None:
+            leaves += [vp.vaccine_efficacy, vp.base_equations, vp.knot_locations, vp.knot_coefficients]
         seas = getattr(p, "seasonality_params", None)
         if seas is not None:
             leaves += [seas.forcing_amp, seas.forcing_phase, seas.forcing_period]
@@ -350,7 +368,7 @@ class CompartmentalODE:
             raise ValueError(f"{self.__name__} expects compartments {self.compartments}, got "
                              f"{len(initial_state)} arrays")
         if getattr(p, "vaccination_params", None) is not None:
-            return self._pack_vaccination(initial_state, p)
+            return self._pack_vaccination(initial_state, p, with_params)
         if with_params:
             params, pbatch, seasonal = self._param_matrix(p)
         else:
@@ -402,7 +420,7 @@ class CompartmentalODE:
         return Packed(model, np.ascontiguousarray(y0), params, self._contact(p, A, contact_shape), batch,
                       tuple(shapes))
 
-    def _pack_vaccination(self, initial_state, p) -> Packed:
+    def _pack_vaccination(self, initial_state, p, with_params: bool = True) -> Packed:
         """Vaccination tiers: the (age, tier) pairs become the groups of the kernel's contact axis
         (include/dynode_hip.h, "n_vax_tiers"), tier padded to 2 or 4 slots; the caller's age contact
         matrix is turned into the group matrix C[a][b] / P_b (P_b = population of age b in the initial
@@ -410,18 +428,32 @@ class CompartmentalODE:
         if not self.multi_strain or self.contact_ndim != 1:
             raise ValueError(f"{self.__name__}: vaccination tiers are available for the multi-strain family")
         vp = p.vaccination_params
-        base, knots, coefs, ve = (_np(vp.base_equations), _np(vp.knot_locations), _np(vp.knot_coefficients),
-                                  _np(vp.vaccine_efficacy))
+        # with_params = False (differentiable path): shapes only, no device-to-host copy of tensor-valued fields --
+        # the parameter matrix is then built on the device by param_tensor
+        get = _np if with_params else (lambda v: np.empty(tuple(getattr(v, "shape", np.shape(v)))))
+        base, knots, coefs, ve = get(vp.base_equations), get(vp.knot_locations), get(vp.knot_coefficients), get(vp.vaccine_efficacy)
         A, K = base.shape[:2]
         nk = knots.shape[-1] if knots.ndim == 3 else 0
         if base.shape != (A, K, 4) or knots.shape != (A, K, nk) or coefs.shape != (A, K, nk) or not 2 <= K <= 4 or nk > 4:
             raise ValueError("vaccination splines must be base_equations [A, K, 4], knot_locations / knot_coefficients "
                              "[A, K, n_knots] with 2 <= K <= 4 tiers and n_knots <= 4")
         KV = 2 if K == 2 else 4
-        rates, pbatch, seasonal = self._param_matrix(p)
+        if with_params:
+            rates, pbatch, seasonal = self._param_matrix(p)
+        else:
+            n_rates, pbatch, seasonal = self._param_meta(p)
+            rates = np.zeros((pbatch or 1, n_rates))
         S = (rates.shape[1] - (3 if seasonal else 0)) // len(self._strain_columns(p))
-        if ve.shape != (S, K) or ve.min() < 0 or ve.max() > 1:
-            raise ValueError(f"vaccine_efficacy must have shape (strains, tiers) = {(S, K)} with values in [0, 1]")
+        if ve.shape[-2:] != (S, K) or ve.ndim not in (2, 3) or (with_params and (ve.min() < 0 or ve.max() > 1)):
+            raise ValueError(f"vaccine_efficacy must have shape (strains, tiers) = {(S, K)}, optionally with a leading "
+                             "batch axis, and values in [0, 1]")
+        if ve.ndim == 3:
+            if pbatch not in (None, ve.shape[0]):
+                raise ValueError("inconsistent batch sizes in ode parameters (vaccine_efficacy)")
+            pbatch = ve.shape[0]
+            rates = np.broadcast_to(rates, (pbatch, rates.shape[1]))
+        if not with_params:
+            ve, base, knots, coefs = np.zeros_like(ve), np.zeros_like(base), np.zeros_like(knots), np.zeros_like(coefs)
         arrs = [_np(a).astype(np.float64) for a in initial_state]
         flat, shapes, pop = [], [], np.zeros(A)
         for name, a in zip(self.compartments, arrs):
@@ -439,12 +471,13 @@ class CompartmentalODE:
             raise ValueError(f"contact_matrix has shape {C.shape}, expected {(A, A)}")
         inv_pop = np.where(pop > 0, 1.0 / np.where(pop > 0, pop, 1.0), 0.0)   # an empty age group infects nobody
         Cg = np.repeat(np.repeat(C * inv_pop[None, :], KV, axis=0), KV, axis=1)
-        sus = np.ones((A, KV, S))
-        sus[:, :K, :] = 1.0 - ve.T[None, :, :]
+        ve3 = ve.reshape((-1, S, K))
+        sus = np.ones((ve3.shape[0], A, KV, S))
+        sus[:, :, :K, :] = 1.0 - np.swapaxes(ve3, 1, 2)[:, None, :, :]
         spl = np.zeros((A, KV, 4 + 2 * nk))
         spl[:, :K, :4], spl[:, :K, 4:4 + nk], spl[:, :K, 4 + nk:] = base, knots, coefs
         B = rates.shape[0]
-        params = np.concatenate([rates, np.broadcast_to(sus.reshape(1, -1), (B, sus.size)),
+        params = np.concatenate([rates, np.broadcast_to(sus.reshape(sus.shape[0], -1), (B, sus[0].size)),
                                  np.broadcast_to(spl.reshape(1, -1), (B, spl.size))], axis=1)
         masks = self._intro_masks(p, A, S)
         if masks:

@@ -193,6 +193,9 @@ def simulate(ode, duration_days, initial_state: CompartmentState, ode_parameters
               constant_dt=sp.constant_step_size if sp.constant_step_size > 0.0 else 0.0,
               jump_ts=sp.discontinuity_points, save_mask=saveat.mask)
     if observe is not None:
+        if packed.tiers is not None:
+            raise ValueError("the fused observation likelihood is not available for vaccinated models yet: score the "
+                             "saved trajectory instead (examples/infer_vaccine_efficacy.py)")
         return _simulate_observed(ode, ode_parameters, packed, saveat, float(duration_days), kw, observe,
                                   differentiable, sp, len(initial_state))
     if differentiable:

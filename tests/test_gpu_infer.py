@@ -389,3 +389,22 @@ def test_nuts_recovers_the_introduction_time():
     # noiseless data: the posterior sits on the truth (time and size trade off along a ridge)
     assert abs(t.mean() - 60.0) < max(3 * t.std(), 1.0) and abs(pct.mean() - 0.005) < max(3 * pct.std(), 5e-4)
     assert t.std() < 5.0 and int(mcmc.nuts.diverging.sum()) <= 10
+
+
+def test_nuts_recovers_the_vaccine_efficacy():
+    """Inference on a vaccinated model (examples/infer_vaccine_efficacy.py): the two latent numbers reach the
+    kernel through the tiers' susceptibilities; tangents are seeded along the latent coordinates."""
+    from examples import infer_vaccine_efficacy as ex_v
+    from examples import seirs_vaccination as base_v
+
+    config = base_v.get_config()
+    obs = ex_v.synthetic_incidence(config, 200)
+    assert obs.shape == (200, 3)
+    process = MCMCProcess(numpyro_model=ex_v.model, num_warmup=150, num_samples=150, num_chains=16, nuts_max_tree_depth=8,
+                          progress_bar=False)
+    mcmc = process.infer(config=config, tf=200, obs_data=obs)
+    post = process.get_samples()
+    one, boost = post["efficacy_one_dose"].cpu().numpy(), post["second_dose_boost"].cpu().numpy()
+    print("one dose %.4f +- %.4f, boost %.4f +- %.4f" % (one.mean(), one.std(), boost.mean(), boost.std()))
+    assert abs(one.mean() - 0.45) < max(3 * one.std(), 0.01) and abs(boost.mean() - 0.5) < max(3 * boost.std(), 0.01)
+    assert one.std() < 0.03 and boost.std() < 0.05 and int(mcmc.nuts.diverging.sum()) <= 5

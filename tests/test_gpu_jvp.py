@@ -367,3 +367,44 @@ def test_vaccination_tangents_equal_derivative_of_the_discrete_solve(ages, m, nd
         # a trajectory whose difference quotient straddles the instant a tier runs empty sees the kink of min():
         # its quotient is off by O(1) of the jump in slope -- allow one such trajectory per direction
         assert np.sort(err)[-2] < 1e-5 and err.max() < 5e-2, err
+
+
+def test_gradient_with_respect_to_vaccine_efficacy_through_simulate():
+    """autograd through simulate for a vaccinated model (examples/seirs_vaccination.py): d(infections by day 150) /
+    d(vaccine efficacy, beta) against central differences of the same float64 solve."""
+    from dynode_amd import SolverParams, simulate
+    from dynode_amd.rhs import SEIRS_MultiStrain_ODEParams, VaccinationParams, seirs_multi_strain_ode
+    from examples import seirs_vaccination as ex
+
+    cfg = ex.get_config()
+    p0 = ex.get_odeparams(cfg)
+    y0 = cfg.initializer.get_initial_state(cfg)
+    vp0 = p0.vaccination_params
+    sp = SolverParams(constant_step_size=0.25)
+    dev = "cuda"
+
+    def loss(ve, beta):
+        vp = VaccinationParams(vp0.knot_locations, vp0.base_equations, vp0.knot_coefficients, ve)
+        q = SEIRS_MultiStrain_ODEParams(beta=beta, gamma=p0.gamma, sigma=p0.sigma, omega=p0.omega,
+                                        contact_matrix=p0.contact_matrix, vaccination_params=vp)
+        sol = simulate(seirs_multi_strain_ode, 150, y0, q, sp, dtype=torch.float64)
+        assert sol.ys[cfg.idx.c].shape == (151, 3, 3, 2)
+        return sol.ys[cfg.idx.c][-1].sum()
+
+    ve_np = np.asarray(vp0.vaccine_efficacy, dtype=float).copy()
+    ve_np[:, 0] = 0.05                                      # off the boundary of [0, 1]: the difference quotient stays valid
+    ve = torch.tensor(ve_np, dtype=torch.float64, device=dev, requires_grad=True)
+    beta = torch.tensor(np.asarray(p0.beta), dtype=torch.float64, device=dev, requires_grad=True)
+    val = loss(ve, beta)
+    g_ve, g_beta = torch.autograd.grad(val, (ve, beta))
+    assert g_ve.shape == (2, 3) and float(g_ve[:, 0].abs().max()) > 0 and bool((g_ve[:, 1:] < 0).all())   # protection prevents infections
+    eps = 1e-6
+    with torch.no_grad():
+        for l in range(2):
+            for k in range(3):
+                d = torch.zeros_like(ve); d[l, k] = eps
+                fd = (loss(ve + d, beta) - loss(ve - d, beta)) / (2 * eps)
+                assert abs(float(g_ve[l, k]) - float(fd)) < 2e-4 * abs(float(fd)) + 1e-6, (l, k, float(g_ve[l, k]), float(fd))
+            d = torch.zeros_like(beta); d[l] = eps
+            fd = (loss(ve, beta + d) - loss(ve, beta - d)) / (2 * eps)
+            assert abs(float(g_beta[l]) - float(fd)) < 2e-4 * abs(float(fd)), (l, float(g_beta[l]), float(fd))
