@@ -47,6 +47,9 @@ struct Entry {
 // SEIP shapes (seip_kernel.hpp) share the table: G = age lanes, S = strains, W = waning states,
 // FEAT = kSeip | tiers; the lane group is G * 2^S
 constexpr int kSeip = 0x100;
+// FEAT bit 14 (solve_kernel.hpp SAVE_ALL): variant without the per-round save-offset / store-width tests, picked by
+// enqueue when every compartment is saved into 16-byte aligned rows
+constexpr int kSaveAll = 0x4000;
 
 static const Entry kEntries[] = {
 #define X(T, METHOD, G, S, E, WN, C, W, ND, SPL)              \
@@ -125,6 +128,20 @@ static const Entry *find_entry(const dyn_model_desc *m, int dtype, int method, i
         }
     }
     return first;
+}
+
+// the same shape with another feature word (nullptr if it is not compiled in / registered)
+static const Entry *find_variant(const Entry *e, int feat) {
+    auto same = [&](const Entry &c) {
+        return c.dtype == e->dtype && c.method == e->method && c.G == e->G && c.S == e->S && c.E == e->E && c.WN == e->WN &&
+               c.C == e->C && c.W == e->W && c.ND == e->ND && c.SPL == e->SPL && c.FEAT == feat;
+    };
+    for (int i = 0; i < kNumEntries; ++i)
+        if (same(kEntries[i])) return &kEntries[i];
+    const int n_extra = g_n_extra.load(std::memory_order_acquire);
+    for (int i = 0; i < n_extra; ++i)
+        if (same(g_extra[i])) return &g_extra[i];
+    return nullptr;
 }
 
 static thread_local char tl_error[512] = "";
@@ -214,10 +231,13 @@ static int enqueue(const Entry *e, const dyn_model_desc *m, const dyn_solver_opt
     if (m->has_c) slot_of[n++] = 4;
     for (int s = 0; s < 5; ++s) ka.save_off[s] = -1;
     int pos = 0;
-    bool aligned = true;
+    bool aligned = true, all_saved = true;
     const int per16 = 16 / (int)sizeof(T);
     for (int c = 0; c < ncomp; ++c) {
-        if (save_mask && !save_mask[c]) continue;
+        if (save_mask && !save_mask[c]) {
+            all_saved = false;
+            continue;
+        }
         ka.save_off[slot_of[c]] = pos;
         if (pos % per16) aligned = false;
         pos += off[c + 1] - off[c];
@@ -264,6 +284,10 @@ static int enqueue(const Entry *e, const dyn_model_desc *m, const dyn_solver_opt
                                (size_t)(1 + e->ND) * sizeof(T);
             if (tab + (size_t)(n_save + dyn::kMaxJumps) * sizeof(T) > 60 * 1024) ka.rep_log2 = 0;
         }
+    }
+    if (all_saved && ka.vec_ok && n_save > 0 && !ll && !(e->FEAT & kSaveAll)) {
+        const Entry *fast = find_variant(e, e->FEAT | kSaveAll);
+        if (fast) e = fast;
     }
     typedef hipError_t (*fn_t)(const KArgs<T> &, hipStream_t);
     const hipError_t err = ((fn_t)e->fn)(ka, stream);

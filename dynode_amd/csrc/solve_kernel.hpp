@@ -309,7 +309,10 @@ template <typename T, int METHOD, int GA, int ST, bool HAS_E, bool HAS_WANE, boo
           int FEAT = 0>
 struct Solver {
     static constexpr bool INTRO = (FEAT & 1) != 0;
-    static constexpr int KV = FEAT >> 1;
+    static constexpr int KV = (FEAT >> 1) & 0x7f;
+    // bit 14: every compartment is saved into 16-byte aligned rows (the host checks) -- the per-round tests of
+    // the save offsets and of the store width fold away (the save loop is half of a daily-output solve)
+    static constexpr bool SAVE_ALL = (FEAT & 0x4000) != 0;
     static_assert(KV == 0 || ((KV == 2 || KV == 4) && GA % KV == 0), "vaccination tiers: 2 or 4 lanes per age");
     static_assert(ST % SPL == 0, "strains per lane must divide the strain count");
     static constexpr int S = SPL;        // strains held by one lane (all per-lane arrays use S)
@@ -640,8 +643,12 @@ struct Solver {
 #pragma unroll
         for (int q = 0; q < CNT; ++q) {
             const int j = FIRST + q;
+#ifdef DYN_DIAG_NOINTERP   // diagnostic builds (tools/probes): what does the save loop cost without its arithmetic / stores?
+            v[q] = y[j] + d.b[q % 7];
+#else
             v[q] = dense_eval(d, dt, y[j], y1[j], k[0][plane][j], k[1][plane][j], k[2][plane][j],
                               k[3][plane][j], k[4][plane][j], k[5][plane][j], k[6][plane][j]);
+#endif
         }
         store_run<T, CNT>(dst, v, vec_ok);
     }
@@ -744,20 +751,21 @@ struct Solver {
                                                     const T (&y)[NC][NV], const T (&yt)[NC][NV],
                                                     const T (&k)[7][NC][NV], T *row, int a, int as,
                                                     bool lead, bool vec_ok) {
-        if (ka.save_off[0] >= 0 && lead)
+        if constexpr (SAVE_ALL) vec_ok = true;
+        if ((SAVE_ALL || ka.save_off[0] >= 0) && lead)
             save_block<0, 1>(dn, dt, y[PLANE], yt[PLANE], k, PLANE, row + ka.save_off[0] + a, false);
         if constexpr (HAS_E)
-            if (ka.save_off[1] >= 0)
+            if (SAVE_ALL || ka.save_off[1] >= 0)
                 save_block<IE, S>(dn, dt, y[PLANE], yt[PLANE], k, PLANE, row + ka.save_off[1] + as,
                                   vec_ok);
-        if (ka.save_off[2] >= 0)
+        if (SAVE_ALL || ka.save_off[2] >= 0)
             save_block<II, S>(dn, dt, y[PLANE], yt[PLANE], k, PLANE, row + ka.save_off[2] + as,
                               vec_ok);
-        if (ka.save_off[3] >= 0)
+        if (SAVE_ALL || ka.save_off[3] >= 0)
             save_block<IR, S * W>(dn, dt, y[PLANE], yt[PLANE], k, PLANE,
                                   row + ka.save_off[3] + as * W, vec_ok);
         if constexpr (HAS_C)
-            if (ka.save_off[4] >= 0)
+            if (SAVE_ALL || ka.save_off[4] >= 0)
                 save_block<IC, S>(dn, dt, y[PLANE], yt[PLANE], k, PLANE, row + ka.save_off[4] + as,
                                   vec_ok);
     }
@@ -1184,7 +1192,11 @@ struct Solver {
                             ll_row(ka, dn, dt, y, yt, k, ll, save_idx, a, as, L.lead,
                                    ll_table ? ll_lane + (int64_t)save_idx * LL_ROW : nullptr);
                     } else if (writer) {
+#ifdef DYN_DIAG_SAMEROW   // diagnostic build: every round overwrites one of two rows (stores hit in L2, no HBM stream)
+                        save_row<0>(ka, dn, dt, y, yt, k, out_traj + (int64_t)(save_idx & 1) * ka.d_saved,
+#else
                         save_row<0>(ka, dn, dt, y, yt, k, out_traj + (int64_t)save_idx * ka.d_saved,
+#endif
                                     a, as, L.lead, vec_ok);
                         if constexpr (ND > 0)
                             save_tangents<1>(ka, dn, dt, y, yt, k,
