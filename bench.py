@@ -75,7 +75,8 @@ def cpu_baseline(wl, sample: int):
 
     cores = effective_cpus()
     m = wl.model
-    om = O.Model(m.n_age, m.n_strain, m.has_e, m.has_wane, m.has_c, m.n_wane, m.normalize, m.seasonal)
+    om = O.Model(m.n_age, m.n_strain, m.has_e, m.has_wane, m.has_c, m.n_wane, m.normalize, m.seasonal, m.has_intro,
+                 tuple(m.intro_age_mask), m.n_vax_tiers, m.n_vax_knots, m.family, m.seasonal_vax)
     y0 = wl.y0[:sample] if wl.y0.ndim == 2 else wl.y0
     p = wl.params[:sample]
     O.solve(om, y0[:cores] if wl.y0.ndim == 2 else y0, p[:cores], wl.contact, wl.t1, wl.save_ts,
@@ -88,8 +89,13 @@ def cpu_baseline(wl, sample: int):
         times.append(time.perf_counter() - t)
     assert int(st.max()) == 0
     med = float(np.median(times))
+    # one thread, for a per-core figure: a 1/32 slice of the sample
+    n1 = max(sample // 32, 1)
+    t = time.perf_counter()
+    O.solve(om, y0[:n1] if wl.y0.ndim == 2 else y0, p[:n1], wl.contact, wl.t1, wl.save_ts, dtype=np.float32, n_threads=1)
+    single = n1 / (time.perf_counter() - t)
     return {
-        "value": sample / med, "unit": "trajectories/s", "cores": cores, "kind": "port",
+        "value": sample / med, "unit": "trajectories/s", "cores": cores, "kind": "port", "single_thread_value": single,
         "sample": f"first {sample} trajectories of the same workload, fp32 oracle (oracle/dynode_oracle.c), "
                   f"{cores} OpenMP threads, {len(times)} passes in {sum(times):.1f} s, median pass {med:.3f} s "
                   f"(best {min(times):.3f} s)",
@@ -282,7 +288,7 @@ def main():
             line["other_workloads"]["cfg4"] = nuts_side_measurement(dev)
             line["other_workloads"]["cfg4_fused_likelihood"] = nuts_side_measurement(dev, fused=True)
         if world == 1 and not args.no_cpu_baseline:
-            sample = args.cpu_sample or (16384 if m.state_dim >= 100 else 65536)
+            sample = args.cpu_sample or (1024 if m.family == 1 else 16384 if m.state_dim >= 100 else 65536)
             line["cpu_baseline"] = cpu_baseline(wl, min(sample, B))
         print(json.dumps(line), flush=True)
     if world > 1:
