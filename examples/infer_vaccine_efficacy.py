@@ -7,7 +7,6 @@ Poisson on the daily infections by dose count (increments of the cumulative-infe
 over ages and strains).  The gradient-solve seeds its tangents along the two latent coordinates.
 """
 
-import numpy as np
 import torch
 
 from dynode_amd import SimulationConfig, simulate

@@ -11,7 +11,6 @@ import helpers as H
 from helpers import O
 
 from dynode_amd.rhs import SEIRS_MultiStrain_ODEParams, VaccinationParams, seirs_multi_strain_ode
-from examples import seirs_multi_strain_age_stratified as plain
 from examples import seirs_vaccination as ex
 
 
