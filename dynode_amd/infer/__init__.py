@@ -10,6 +10,7 @@ _PUBLIC = {
     "checkpointing": ("checkpoint_compartment_sizes",),
     "predictive": ("Predictive",),
     "inference": ("InferenceProcess", "MCMCProcess", "SVIProcess"),
+    "ensemble": ("EnsembleSampler",),
 }
 
 __all__ = ["distributions", "handlers"]

@@ -300,6 +300,24 @@ class MCMCProcess(InferenceProcess):
         # mcmc_kwargs={"sampler": "graph"} replays the torch-op sampler step instead,
         # {"sampler": "eager"} (or the older {"hip_graph": False}) runs it op by op.
         kind = self.mcmc_kwargs.get("sampler", "kernel" if self.mcmc_kwargs.get("hip_graph", True) else "eager")
+        if kind == "ensemble":
+            # gradient-free: the walkers are the chains, every move scores half of them in one batched solve
+            # (infer/ensemble.py) -- for members of the kernel family without tangent planes (SEIP)
+            from .ensemble import EnsembleSampler
+
+            sampler = EnsembleSampler(lambda z: pot.log_joint(z)[0], stretch=self.mcmc_kwargs.get("stretch", 2.0),
+                                      seed=self.inference_prngkey + 7919 * rank)
+            total = self.num_warmup + self.num_samples * int(self.mcmc_kwargs.get("thin", 1))
+
+            def progress_e(it, warm):
+                if self.progress_bar and rank == 0 and (it + 1) % max(1, total // 10) == 0:
+                    print(f"[ensemble] {'warmup' if warm else 'sample'} {it + 1}/{total} ({local} walkers on this GPU)", flush=True)
+
+            res = sampler.run(z0, self.num_warmup, self.num_samples, thin=int(self.mcmc_kwargs.get("thin", 1)), progress=progress_e)
+            out = MCMCResult(pot, res, local)
+            self._inference_complete, self._inferer, self._inference_state = True, out, out.last_state
+            self._inferer_kwargs = kwargs
+            return out
         if kind == "kernel" and (pot.dim > 8 or self.nuts_max_tree_depth > 10):
             kind = "graph"
         cls = {"kernel": KernelNUTS, "graph": GraphNUTS, "eager": BatchedNUTS}[kind]

@@ -44,16 +44,19 @@ def protection_table(crossimmunity, vaccine_efficacy, wane_protection, min_homol
     (``WaneBin.base_protection``), homologous floor ``WIM = (1 - WIB) * M_HI`` if ``l`` is in ``j``;
     ``WI = WIB + WIM``."""
     chi, ve, prot = (np.asarray(v, dtype=float) for v in (crossimmunity, vaccine_efficacy, wane_protection))
-    L, K1, M1 = chi.shape[0], ve.shape[1], prot.shape[0]
-    sus = np.empty((1 << L, K1, M1, L))
+    floor = np.asarray(min_homologous_immunity, dtype=float)
+    L, K1, M1 = chi.shape[-1], ve.shape[-1], prot.shape[-1]
+    # leading axes (one table per parameter sample) broadcast: chi[..., L, L], ve[..., L, K1], prot[..., M1], floor[...]
+    lead = np.broadcast_shapes(chi.shape[:-2], ve.shape[:-2], prot.shape[:-1], floor.shape)
+    sus = np.empty(lead + (1 << L, K1, M1, L))
     for j in range(1 << L):
         past = [q for q in range(L) if (j >> q) & 1]
         for l in range(L):
-            escape = float(np.prod([1.0 - chi[l, q] for q in past])) if past else 1.0
-            initial = 1.0 - (1.0 - ve[l, :]) * escape
-            wib = initial[:, None] * prot[None, :]
-            wim = (1.0 - wib) * (min_homologous_immunity if (j >> l) & 1 else 0.0)
-            sus[j, :, :, l] = 1.0 - (wib + wim)
+            escape = np.prod([1.0 - chi[..., l, q] for q in past], axis=0) if past else 1.0
+            initial = 1.0 - (1.0 - ve[..., l, :]) * np.asarray(escape)[..., None]            # [..., K1]
+            wib = initial[..., :, None] * prot[..., None, :]                                  # [..., K1, M1]
+            wim = (1.0 - wib) * (floor[..., None, None] if (j >> l) & 1 else 0.0)
+            sus[..., j, :, :, l] = 1.0 - (wib + wim)
     return sus
 
 

@@ -1,0 +1,66 @@
+"""How much does a past infection with the first strain protect against the second?  Inference on the SEIP model.
+
+The SEIP kernels have no tangent planes yet, so NUTS is not available for them; the model is still solved in
+large batches, and the affine-invariant ensemble sampler (``mcmc_kwargs={"sampler": "ensemble"}``,
+dynode_amd/infer/ensemble.py) needs nothing else: every move scores half of the walkers in one batched solve.
+Latent: the cross-immunity ``strain_interactions["beta"]["alpha"]`` and the second strain's R0; data: weekly
+infections by strain and immune history from the run of examples/seip_immune_history.py at TRUTH.
+"""
+
+import numpy as np
+import torch
+
+from dynode_amd import SimulationConfig, simulate
+from dynode_amd.infer import distributions as dist
+from dynode_amd.infer import handlers
+from dynode_amd.infer.inference import MCMCProcess
+from dynode_amd.seip import protection_table, seip_ode
+from examples import seip_immune_history as base
+
+TRUTH = dict(cross_immunity=0.45, r0_beta=2.4)
+
+
+def _odeparams(config: SimulationConfig, cross_immunity, r0_beta):
+    """examples/seip_immune_history.get_odeparams with the two latent numbers (arrays: one entry per walker)."""
+    p = base.get_odeparams(config)
+    tp = config.parameters.transmission_params
+    names = [s.strain_name for s in tp.strains]
+    cross, r0b = np.atleast_1d(np.asarray(cross_immunity, float)), np.atleast_1d(np.asarray(r0_beta, float))
+    n = max(cross.size, r0b.size)
+    chi = np.broadcast_to(np.array([[tp.strain_interactions[a][b] for b in names] for a in names]), (n, 2, 2)).copy()
+    chi[:, 1, 0] = cross
+    s_comp = config.get_compartment("s")
+    ve = np.array([[s.vaccine_efficacy[k] for k in range(len(s_comp.dimensions[2]))] for s in tp.strains])
+    p.susceptibility = protection_table(chi, ve, [b.base_protection for b in s_comp.dimensions[3].bins], base.MIN_HOMOLOGOUS_IMMUNITY)
+    beta = np.broadcast_to(np.asarray(p.beta, float), (n, 2)).copy()
+    beta[:, 1] = r0b * np.asarray(p.gamma)[1]
+    p.beta = beta
+    if n == 1:
+        p.susceptibility, p.beta = p.susceptibility[0], p.beta[0]
+    return p
+
+
+def weekly_infections(config: SimulationConfig, tf, cross_immunity, r0_beta):
+    """New infections per week, by immune history of the infected and by strain: (..., weeks, hist, strain)."""
+    sol = simulate(ode=seip_ode, duration_days=tf, initial_state=config.initializer.get_initial_state(config),
+                   ode_parameters=_odeparams(config, cross_immunity, r0_beta), solver_parameters=config.parameters.solver_params,
+                   sub_save_indices=(config.idx.c,), save_step=7)
+    c = sol.ys[config.idx.c]                                    # (weeks + 1, age, hist, vax, strain), walkers in front
+    return torch.diff(c, dim=-5).sum(dim=(-4, -2))
+
+
+def model(config: SimulationConfig, tf, obs_data):
+    cross = handlers.sample("cross_immunity", dist.Beta(2.0, 2.0))
+    r0b = handlers.sample("r0_beta", dist.Uniform(1.2, 4.0))
+    rate = weekly_infections(config, tf, cross.detach().cpu().numpy(), r0b.detach().cpu().numpy())
+    handlers.sample("weekly_infections", dist.Poisson(torch.clamp(rate, min=1e-6)), obs=obs_data)
+
+
+if __name__ == "__main__":
+    config = base.get_config()
+    data = weekly_infections(config, 210, **TRUTH).cpu()
+    process = MCMCProcess(numpyro_model=model, num_warmup=300, num_samples=300, num_chains=64, nuts_max_tree_depth=10,
+                          mcmc_kwargs={"sampler": "ensemble"})
+    mcmc = process.infer(config=config, tf=210, obs_data=data)
+    mcmc.print_summary()
+    print("truth:", TRUTH)

@@ -1,0 +1,50 @@
+"""The affine-invariant ensemble sampler (dynode_amd/infer/ensemble.py) on analytic targets, on the CPU."""
+
+import numpy as np
+import pytest
+import torch
+
+from dynode_amd.infer.ensemble import EnsembleSampler
+
+
+def test_correlated_gaussian_moments():
+    cov = torch.tensor([[1.0, 0.9 * 3.0], [0.9 * 3.0, 9.0]], dtype=torch.float64)
+    prec = torch.linalg.inv(cov)
+    mean = torch.tensor([2.0, -1.0], dtype=torch.float64)
+    logp = lambda z: -0.5 * torch.einsum("ci,ij,cj->c", z - mean, prec, z - mean)
+    s = EnsembleSampler(logp, seed=3)
+    res = s.run(torch.zeros((64, 2), dtype=torch.float64), 500, 1500)          # identical starts are spread by the sampler
+    x = res.samples.reshape(-1, 2)
+    assert res.samples.shape == (64, 1500, 2) and s.evals == 1 + 2 * 2000
+    assert torch.allclose(x.mean(0), mean, atol=0.15)
+    assert torch.allclose(torch.cov(x.T), cov, rtol=0.15, atol=0.15)
+    assert 0.5 < float(res.accept_prob.mean()) < 0.9                            # stretch a = 2 in two dimensions
+
+
+def test_affine_invariance_and_rejection_of_failed_points():
+    """A badly scaled target mixes as well as a round one (that is the point of the stretch move); points where
+    the density is NaN / -inf (failed solves) are never accepted."""
+    scale = torch.tensor([1e-3, 1e3], dtype=torch.float64)
+
+    def logp(z):
+        lp = -0.5 * ((z / scale) ** 2).sum(-1)
+        return torch.where(z[:, 0] > 2e-3, torch.full_like(lp, float("nan")), lp)       # a forbidden half-space
+
+    s = EnsembleSampler(logp, seed=5)
+    z0 = torch.randn((40, 2), dtype=torch.float64) * scale * 0.1
+    res = s.run(z0, 300, 700)
+    x = res.samples.reshape(-1, 2)
+    assert float(x[:, 0].max()) <= 2e-3
+    assert abs(float(x[:, 1].std()) / 1e3 - 1.0) < 0.2
+    # truncated normal on (-inf, 2 sd]: mean = -phi(2) / Phi(2) = -0.05525 sd
+    assert abs(float(x[:, 0].mean()) / 1e-3 + 0.05525) < 0.08
+
+
+def test_argument_checks():
+    s = EnsembleSampler(lambda z: -(z ** 2).sum(-1))
+    with pytest.raises(ValueError, match="even number of walkers"):
+        s.run(torch.zeros((5, 2), dtype=torch.float64), 1, 1)
+    with pytest.raises(ValueError, match="2 D \\+ 2"):
+        s.run(torch.zeros((4, 3), dtype=torch.float64), 1, 1)
+    with pytest.raises(RuntimeError, match="finite density"):
+        EnsembleSampler(lambda z: torch.full((z.shape[0],), float("nan"), dtype=z.dtype)).run(torch.zeros((8, 2), dtype=torch.float64), 1, 1)

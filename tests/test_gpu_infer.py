@@ -408,3 +408,37 @@ def test_nuts_recovers_the_vaccine_efficacy():
     print("one dose %.4f +- %.4f, boost %.4f +- %.4f" % (one.mean(), one.std(), boost.mean(), boost.std()))
     assert abs(one.mean() - 0.45) < max(3 * one.std(), 0.01) and abs(boost.mean() - 0.5) < max(3 * boost.std(), 0.01)
     assert one.std() < 0.03 and boost.std() < 0.05 and int(mcmc.nuts.diverging.sum()) <= 5
+
+
+def test_ensemble_sampler_matches_grid_quadrature(data):
+    """The gradient-free sampler (infer/ensemble.py) on the same 2-parameter SIR posterior: KS against quadrature."""
+    process = MCMCProcess(numpyro_model=ex.model, num_warmup=400, num_samples=400, num_chains=96, nuts_max_tree_depth=10,
+                          progress_bar=False, mcmc_kwargs={"sampler": "ensemble"})
+    mcmc = process.infer(config=ex.get_config(), tf=100, obs_data=data)
+    post = process.get_samples(group_by_chain=True)
+    assert post["strains_0_r0"].shape == (96, 400) and 0.3 < float(mcmc.nuts.accept_prob.mean()) < 0.9
+    (g_r0, cdf_r0), (g_ti, cdf_ti) = _grid_marginals(data)
+    for name, grid, cdf in (("strains_0_r0", g_r0, cdf_r0), ("strains_0_infectious_period", g_ti, cdf_ti)):
+        thin = post[name][:, ::40].reshape(-1).cpu().numpy()          # stretch moves decorrelate slowly: every 40th
+        ks = stats.kstest(thin, lambda x: np.interp(x, grid, cdf))
+        print(name, "ensemble posterior mean %.4f sd %.4f KS p=%.3f" % (thin.mean(), thin.std(), ks.pvalue))
+        assert ks.pvalue > 1e-3, (name, ks)
+
+
+def test_ensemble_sampler_fits_the_seip_model():
+    """Inference on the SEIP family (no tangent kernels): examples/infer_seip_cross_immunity.py recovers the
+    cross-immunity and the second strain's R0 from weekly infections by history and strain."""
+    from examples import infer_seip_cross_immunity as ex_s
+    from examples import seip_immune_history as base_s
+
+    config = base_s.get_config()
+    obs = ex_s.weekly_infections(config, 210, **ex_s.TRUTH).cpu()
+    assert obs.shape == (30, 4, 2)
+    process = MCMCProcess(numpyro_model=ex_s.model, num_warmup=250, num_samples=150, num_chains=48, nuts_max_tree_depth=10,
+                          progress_bar=False, mcmc_kwargs={"sampler": "ensemble"})
+    process.infer(config=config, tf=210, obs_data=obs)
+    post = process.get_samples()
+    chi, r0 = post["cross_immunity"].cpu().numpy(), post["r0_beta"].cpu().numpy()
+    print("cross-immunity %.4f +- %.4f, r0 %.4f +- %.4f" % (chi.mean(), chi.std(), r0.mean(), r0.std()))
+    assert abs(chi.mean() - 0.45) < max(3 * chi.std(), 0.02) and abs(r0.mean() - 2.4) < max(3 * r0.std(), 0.01)
+    assert chi.std() < 0.05 and r0.std() < 0.02
