@@ -1,6 +1,6 @@
 """dev probe: one fuzz seed in detail."""
 import os, sys, numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # tests/probes/x.py -> repo root
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import helpers as H
 from dynode_amd.engine import solve_batch

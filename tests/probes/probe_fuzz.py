@@ -1,9 +1,9 @@
 """dev probe: the randomized parity sweep of tests/test_gpu_parity.py (fuzz_case / fuzz_compare) at scale.
-    python tools/probes/probe_fuzz.py [n_cases] [first_seed] [f32]"""
+    python tests/probes/probe_fuzz.py [n_cases] [first_seed] [f32]"""
 import os, sys
 
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # tests/probes/x.py -> repo root
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from test_gpu_parity import fuzz_case, fuzz_compare
 

@@ -1,6 +1,6 @@
 """dev probe: introduction tangents, one parameter family at a time, against central differences of the oracle."""
 import os, sys, numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # tests/probes/x.py -> repo root
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import helpers as H
 from dynode_amd import ModelDesc

@@ -450,7 +450,7 @@ def fuzz_compare(case, dtype=F64):
 
 
 def test_randomized_parity_sweep():
-    """80 random draws of `fuzz_case` (tools/probes/probe_fuzz.py runs thousands): float64 values to
+    """80 random draws of `fuzz_case` (tests/probes/probe_fuzz.py runs thousands): float64 values to
     1e-10 of scale, identical status, accepted and rejected step counts, identical +inf pattern."""
     ran = 0
     # 22857: a Dopri5 trial step of ~120 days right after a discontinuity point blows up (stage values
