@@ -217,6 +217,50 @@ class SEIPODE(CompartmentalODE):
         return tuple(d[:, pk.history_perm] for d in (ds, de, di, dc))
 
 
+def params_from_config(config, vaccination_params: Optional[VaccinationParams] = None, min_homologous_immunity: float = 0.0,
+                       seasonality_params: Optional[SeasonalityParams] = None, seasonal_vaccination_tau: Optional[float] = None,
+                       compartment: str = "s") -> SEIP_ODEParams:
+    """:class:`SEIP_ODEParams` from a ``SimulationConfig`` whose ``s`` compartment is stratified by
+    (age, immune history, vaccination, waning) -- the mapping examples/seip_immune_history.py spells out:
+
+    * ``beta = r0 / infectious_period``, ``gamma = 1 / infectious_period``, ``sigma = 1 / exposed_to_infectious`` per strain;
+    * waning rates ``1 / WaneBin.waiting_time`` (``inf`` -> 0), protections ``WaneBin.base_protection``;
+    * cross-immunity ``strain_interactions[challenger][past strain]`` and ``Strain.vaccine_efficacy[doses]`` folded into the
+      susceptibility table by :func:`protection_table` (ode_model.md:185-211);
+    * externally introduced strains (``Strain.is_introduced``) through ``rhs.introduction_params``.
+    Values must be resolved numbers (call ``sample_then_resolve`` first when the config carries priors)."""
+    import math
+
+    from .rhs import introduction_params
+
+    tp = config.parameters.transmission_params
+    strains = tp.strains
+    names = [s.strain_name for s in strains]
+    dims = config.get_compartment(compartment).dimensions
+    if len(dims) != 4:
+        raise ValueError(f"compartment {compartment!r} must be stratified by (age, immune history, vaccination, waning)")
+    n_tiers, wane_bins = len(dims[2]), dims[3].bins
+    if not all(hasattr(b, "waiting_time") and hasattr(b, "base_protection") for b in wane_bins):
+        raise ValueError(f"compartment {compartment!r} must be stratified by (age, immune history, vaccination, waning): "
+                         "its last dimension has no WaneBin bins")
+    if len(dims[1]) != 1 << len(strains):
+        raise ValueError(f"the immune-history dimension has {len(dims[1])} bins; the SEIP model needs all 2^{len(strains)} subsets "
+                         "(FullStratifiedImmuneHistoryDimension)")
+    r0 = np.array([float(s.r0) for s in strains])
+    t_inf = np.array([float(s.infectious_period) for s in strains])
+    t_lat = np.array([float(s.exposed_to_infectious) for s in strains])
+    chi = np.array([[float(tp.strain_interactions[a][b]) for b in names] for a in names])
+    ve = np.array([[float((s.vaccine_efficacy or {}).get(k, 0.0)) for k in range(n_tiers)] for s in strains])
+    sus = protection_table(chi, ve, [float(b.base_protection) for b in wane_bins], min_homologous_immunity)
+    init = getattr(config.initializer, "initialize_date", None)
+    return SEIP_ODEParams(
+        beta=r0 / t_inf, gamma=1.0 / t_inf, sigma=1.0 / t_lat,
+        waning_rates=np.array([0.0 if math.isinf(b.waiting_time) else 1.0 / float(b.waiting_time) for b in wane_bins]),
+        contact_matrix=tp.contact_matrix, susceptibility=sus, vaccination_params=vaccination_params,
+        seasonality_params=seasonality_params, seasonal_vaccination_tau=seasonal_vaccination_tau,
+        introduction_params=introduction_params(strains, init), idx=config.idx)
+
+
 def _bounds(shapes):
     pos = 0
     for shape in shapes:

@@ -19,7 +19,7 @@ import numpy as np
 from dynode_amd import (AgeBin, Bin, Compartment, Dimension, FullStratifiedImmuneHistoryDimension, Initializer, Params,
                         SimulationConfig, SolverParams, Strain, TransmissionParams, VaccinationDimension, WaneDimension, simulate)
 from dynode_amd.rhs import VaccinationParams
-from dynode_amd.seip import SEIP_ODEParams, history_masks, protection_table, seip_ode
+from dynode_amd.seip import SEIP_ODEParams, history_masks, params_from_config, seip_ode
 
 AGES = [AgeBin(min_value=0, max_value=17), AgeBin(min_value=18, max_value=64), AgeBin(min_value=65, max_value=99)]
 DEMOGRAPHICS = np.array([0.22, 0.61, 0.17])
@@ -78,23 +78,12 @@ def dose_splines(n_ages, n_tiers, start=60.0, ramp=20.0, rates=(0.001, 0.004, 0.
 
 
 def get_odeparams(config: SimulationConfig) -> SEIP_ODEParams:
-    tp = config.parameters.transmission_params
-    strains = tp.strains
-    names = [s.strain_name for s in strains]
-    s_comp = config.get_compartment("s")
-    n_tiers = len(s_comp.dimensions[2])
-    wane_bins = s_comp.dimensions[3].bins
-    r0 = np.array([s.r0 for s in strains], dtype=float)
-    t_inf = np.array([s.infectious_period for s in strains], dtype=float)
-    t_lat = np.array([s.exposed_to_infectious for s in strains], dtype=float)
-    chi = np.array([[tp.strain_interactions[a][b] for b in names] for a in names])
-    ve = np.array([[s.vaccine_efficacy[k] for k in range(n_tiers)] for s in strains])
-    sus = protection_table(chi, ve, [b.base_protection for b in wane_bins], MIN_HOMOLOGOUS_IMMUNITY)
-    return SEIP_ODEParams(
-        beta=r0 / t_inf, gamma=1.0 / t_inf, sigma=1.0 / t_lat,
-        waning_rates=np.array([0.0 if math.isinf(b.waiting_time) else 1.0 / b.waiting_time for b in wane_bins]),
-        contact_matrix=tp.contact_matrix, susceptibility=sus, vaccination_params=dose_splines(len(AGES), n_tiers),
-        idx=config.idx)
+    """Object -> vector flattening, the SEIP counterpart of the reference examples' ``get_odeparams``: rates from the
+    strains, waning rates and protections from the ``WaneBin`` chain, the susceptibility table from
+    ``strain_interactions`` and ``Strain.vaccine_efficacy`` (``dynode_amd.seip.params_from_config`` does the mapping)."""
+    n_tiers = len(config.get_compartment("s").dimensions[2])
+    return params_from_config(config, vaccination_params=dose_splines(len(AGES), n_tiers),
+                              min_homologous_immunity=MIN_HOMOLOGOUS_IMMUNITY)
 
 
 def run_simulation(config: SimulationConfig, tf=365):

@@ -420,3 +420,36 @@ def test_hip_discontinuity_points(method):
     assert np.abs((r.n_accept + r.n_reject).cpu().numpy() - (na + nr)).max() <= 4
     plain = solve_batch(wl.model, wl.y0, wl.params, wl.contact, 150.0, ts, dtype=torch.float64, method=method)
     assert int((r.n_accept != plain.n_accept).sum()) > 0                 # the points do change the stepping
+
+
+def test_params_from_config_maps_the_reference_configuration_objects():
+    import math
+    from datetime import date
+
+    from dynode_amd.seip import params_from_config, protection_table, seip_ode
+    from examples import seip_immune_history as ex
+
+    cfg = ex.get_config()
+    p = params_from_config(cfg, min_homologous_immunity=0.1)
+    tp = cfg.parameters.transmission_params
+    assert np.allclose(p.beta, [1.8 / 7.0, 2.4 / 6.0]) and np.allclose(p.sigma, [1 / 3.0, 1 / 2.5])
+    assert np.allclose(p.waning_rates, [1 / 60.0, 1 / 60.0, 1 / 90.0, 0.0])
+    chi = np.array([[1.0, 0.8], [0.45, 1.0]])
+    ve = np.array([[0.0, 0.35, 0.6], [0.0, 0.2, 0.4]])
+    assert np.allclose(p.susceptibility, protection_table(chi, ve, [1.0, 0.7, 0.4, 0.0], 0.1))
+    assert p.introduction_params is None and p.vaccination_params is None and p.idx is cfg.idx
+    # an introduced strain reaches the kernel's parameter row through the same path as in the s/e/i/r/c family
+    newcomer = tp.strains[1]
+    newcomer.is_introduced, newcomer.introduction_time, newcomer.introduction_scale = True, 40.0, 5.0
+    newcomer.introduction_percentage, newcomer.introduction_ages = 0.01, [ex.AGES[1]]
+    newcomer.introduction_ages_mask_vector = [0, 1, 0]
+    q = params_from_config(cfg)
+    assert q.introduction_params is not None and np.allclose(_to_np(q.introduction_params.time), [0.0, 40.0])
+    pk = seip_ode.pack(cfg.initializer.get_initial_state(cfg), q)
+    assert pk.model.has_intro and pk.model.intro_age_mask == (0, 0b010)
+    with pytest.raises(ValueError, match="stratified by"):
+        params_from_config(cfg, compartment="e")
+
+
+def _to_np(x):
+    return x.detach().cpu().numpy() if hasattr(x, "detach") else np.asarray(x, dtype=float)
