@@ -114,16 +114,24 @@ def build_saveat(start: float, stop, step: int = 1,
 _OBS_CACHE: dict = {}
 
 
-def _observation_constants(data, dtype, device):
-    """(observations as a flat device tensor of the solve dtype, sum lgamma(data + 1)); cached per data object."""
-    key = (id(data), dtype, str(device))
+def _observation_constants(data, dtype, device, pad_tiers=None):
+    """(observations as a flat device tensor of the solve dtype, sum lgamma(data + 1)); cached per data object.
+    ``pad_tiers`` = (tiers, slots): vaccinated models keep 2 or 4 tier slots per age on the kernel's contact axis
+    (axis 2 of the observation array, after time and age); the extra slots are filled with zeros."""
+    key = (id(data), dtype, str(device), pad_tiers)
     hit = _OBS_CACHE.get(key)
     if hit is None or hit[0] is not data:
         if len(_OBS_CACHE) > 16:
             _OBS_CACHE.clear()
         t = data.detach() if isinstance(data, torch.Tensor) else torch.as_tensor(np.asarray(data))
         t64 = t.to(device=device, dtype=torch.float64)
-        hit = (data, t64.to(dtype).contiguous(), torch.lgamma(t64 + 1.0).sum(), tuple(t.shape))
+        shape = tuple(t.shape)
+        lg = torch.lgamma(t64 + 1.0).sum()
+        if pad_tiers is not None and t64.dim() >= 3 and t64.shape[2] == pad_tiers[0] and pad_tiers[1] > pad_tiers[0]:
+            extra = list(t64.shape)
+            extra[2] = pad_tiers[1] - pad_tiers[0]
+            t64 = torch.cat([t64, t64.new_zeros(extra)], dim=2)
+        hit = (data, t64.to(dtype).contiguous(), lg, shape)
         _OBS_CACHE[key] = hit
     return hit[1], hit[2], hit[3]
 
@@ -134,11 +142,20 @@ def _simulate_observed(ode, ode_parameters, packed, saveat, t1, kw, observe, dif
 
     device = require_gpu()
     comp = int(observe.compartment) % n_comp
-    obs_t, const, shape = _observation_constants(observe.data, kw["dtype"], device)
+    want = tuple(packed.shapes[comp])
+    pad = None
+    if packed.tiers is not None:              # vaccinated model: the caller's arrays carry the tracked tiers only
+        pad = (packed.tiers, want[1])
+        want = (want[0], packed.tiers) + want[2:]
+    obs_t, const, shape = _observation_constants(observe.data, kw["dtype"], device, pad)
     n_obs = len(saveat.ts) - int(bool(observe.increments))
-    if tuple(shape) != (n_obs,) + tuple(packed.shapes[comp]):
-        raise ValueError(f"observations have shape {tuple(shape)}; expected {(n_obs,) + tuple(packed.shapes[comp])} "
+    if tuple(shape) != (n_obs,) + want:
+        raise ValueError(f"observations have shape {tuple(shape)}; expected {(n_obs,) + want} "
                          f"({'increments between' if observe.increments else 'values at'} {len(saveat.ts)} save times)")
+    if pad is not None and pad[1] > pad[0]:
+        # the padded tier slots stay empty: each scores 0 * log(floor) - floor; take that constant out again
+        cells = n_obs * int(np.prod(packed.shapes[comp])) // pad[1] * (pad[1] - pad[0])
+        const = const - float(observe.floor) * cells
     kw = {k: v for k, v in kw.items() if k != "save_mask"}
     if differentiable:
         params_t = ode.param_tensor(ode_parameters, device)
@@ -193,9 +210,6 @@ def simulate(ode, duration_days, initial_state: CompartmentState, ode_parameters
               constant_dt=sp.constant_step_size if sp.constant_step_size > 0.0 else 0.0,
               jump_ts=sp.discontinuity_points, save_mask=saveat.mask)
     if observe is not None:
-        if packed.tiers is not None:
-            raise ValueError("the fused observation likelihood is not available for vaccinated models yet: score the "
-                             "saved trajectory instead (examples/infer_vaccine_efficacy.py)")
         return _simulate_observed(ode, ode_parameters, packed, saveat, float(duration_days), kw, observe,
                                   differentiable, sp, len(initial_state))
     if differentiable:

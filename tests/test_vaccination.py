@@ -164,3 +164,43 @@ def test_simulate_vaccination_example_matches_oracle_and_protects():
     # protection: with the same dose schedule but no efficacy more people are infected
     naive = ex.run_simulation(ex.get_config(efficacy=({0: 0, 1: 0, 2: 0}, {0: 0, 1: 0, 2: 0})), tf=300)
     assert naive.ys[4][-1].sum() > 1.02 * sol.ys[4][-1].sum()
+
+
+@pytest.mark.gpu
+def test_fused_observation_likelihood_for_a_vaccinated_model():
+    """simulate(..., observe=...) with tiers: the caller's observation array has the tracked tiers only; the padded
+    tier slots of the kernel layout are filled and their constant contribution removed on the host.  Value and
+    gradient (with respect to the vaccine efficacy) equal scoring the saved trajectory."""
+    import torch
+    from dynode_amd import PoissonObservation, SolverParams, simulate
+    from dynode_amd.rhs import SEIRS_MultiStrain_ODEParams, VaccinationParams
+
+    cfg = ex.get_config()
+    p0 = ex.get_odeparams(cfg)
+    vp0 = p0.vaccination_params
+    y0 = cfg.initializer.get_initial_state(cfg)
+    sp = SolverParams()
+    rng = np.random.default_rng(0)
+    base = ex.run_simulation(cfg, tf=120).ys[cfg.idx.c].cpu().numpy()
+    obs = torch.as_tensor(rng.poisson(np.clip(np.diff(base, axis=0), 0, None)).astype(np.float64))     # (120, 3, 3, 2)
+
+    def both(ve):
+        q = SEIRS_MultiStrain_ODEParams(beta=p0.beta, gamma=p0.gamma, sigma=p0.sigma, omega=p0.omega, contact_matrix=p0.contact_matrix,
+                                        vaccination_params=VaccinationParams(vp0.knot_locations, vp0.base_equations, vp0.knot_coefficients, ve))
+        fused = simulate(seirs_multi_strain_ode, 120, y0, q, sp, dtype=torch.float64,
+                         observe=PoissonObservation(compartment=cfg.idx.c, data=obs, increments=True, floor=1e-6)).log_likelihood
+        sol = simulate(seirs_multi_strain_ode, 120, y0, q, sp, dtype=torch.float64)
+        rate = torch.clamp(torch.diff(sol.ys[cfg.idx.c], dim=0), min=1e-6)
+        o = obs.to(rate.device)
+        plain = (o * torch.log(rate) - rate - torch.lgamma(o + 1.0)).sum()
+        return fused.reshape(()), plain
+
+    ve = torch.tensor(np.asarray(vp0.vaccine_efficacy, dtype=float) + np.array([[0.05, 0, 0], [0.05, 0, 0]]), dtype=torch.float64,
+                      device="cuda", requires_grad=True)
+    fused, plain = both(ve)
+    assert abs(float(fused.detach()) - float(plain.detach())) < 1e-7 * abs(float(plain.detach()))
+    (g_f,) = torch.autograd.grad(fused, ve)
+    (g_p,) = torch.autograd.grad(plain, ve)
+    assert torch.allclose(g_f, g_p, rtol=1e-6, atol=1e-8)
+    with pytest.raises(ValueError, match="observations have shape"):
+        simulate(seirs_multi_strain_ode, 120, y0, p0, sp, observe=PoissonObservation(compartment=cfg.idx.c, data=obs[:, :, :2], increments=True))
