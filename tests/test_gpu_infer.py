@@ -442,3 +442,20 @@ def test_ensemble_sampler_fits_the_seip_model():
     print("cross-immunity %.4f +- %.4f, r0 %.4f +- %.4f" % (chi.mean(), chi.std(), r0.mean(), r0.std()))
     assert abs(chi.mean() - 0.45) < max(3 * chi.std(), 0.02) and abs(r0.mean() - 2.4) < max(3 * r0.std(), 0.01)
     assert chi.std() < 0.05 and r0.std() < 0.02
+
+
+def test_predictive_on_the_seip_model():
+    """Posterior predictive for the SEIP example: the draws are pushed through the model as ONE batched solve."""
+    from dynode_amd.infer import Predictive
+    from examples import infer_seip_cross_immunity as ex_s
+    from examples import seip_immune_history as base_s
+
+    config = base_s.get_config()
+    post = {"cross_immunity": torch.tensor([0.3, 0.45, 0.6, 0.45]), "r0_beta": torch.tensor([2.4, 2.4, 2.4, 2.0])}
+    pp = Predictive(ex_s.model, posterior_samples=post)(rng_key=3, config=config, tf=140, obs_data=None)
+    w = pp["weekly_infections"]
+    assert w.shape == (4, 20, 4, 2)
+    total_beta = w[..., 1].sum((1, 2)).double()
+    reinfections = w[:, :, 1, 1].sum(1).double()            # strain beta in people with history "alpha"
+    assert reinfections[0] > reinfections[1] > reinfections[2]          # more cross-immunity, fewer reinfections
+    assert total_beta[3] < total_beta[1]                                # a less transmissible strain infects fewer
