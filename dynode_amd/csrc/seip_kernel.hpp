@@ -1,6 +1,7 @@
 // seip_kernel.hpp -- the SEIP family (include/dynode_hip.h "SEIP"; ode_model.md:15-53, 70-105, 176-211):
 // age x immune history x vaccination tier x waning state, fused with the same adaptive Tsit5 / Dopri5
-// stepper as solve_kernel.hpp (same controller, same dense output, same status codes).
+// stepper as solve_kernel.hpp (the controller is the shared Control<T>, the dense output and the age contraction are
+// Solver's own functions; same status codes).
 //
 // Lane mapping: a trajectory owns GA x H lanes, GA = power of two >= n_age in the low lane bits (so the
 // age contraction is the DPP gather of solve_kernel.hpp, unchanged), H = 2^L immune histories above
@@ -330,8 +331,7 @@ struct Seip {
             }
             const T d2 = M::sqrt(group_sum<G>(s2) / Dn) / h0;
             const T max_d = M::max(d1, d2);
-            const T h1 = (max_d <= T(1e-15)) ? M::max(T(1e-6), h0 * T(1e-3)) : M::pow_fast(T(0.01) / max_d, T(0.2));
-            tnext = tprev + M::min(T(100) * h0, h1);
+            tnext = tprev + M::min(T(100) * h0, Control<T>::initial_h1(max_d, h0));
         }
         tnext = M::min(tnext, t_end);
 
@@ -373,13 +373,7 @@ struct Seip {
                     const T r = (dt * e) * M::rcp_fast(atol + ym * rtol);
                     ss += r * r;
                 }
-                T err = M::sqrt(group_sum<G>(ss) / Dn);
-                if (!(err == err)) err = M::inf();
-                keep = err < T(1);
-                finite = !(err == M::inf() && !(tprev + T(0.2) * dt > tprev));
-                T f = T(0.9) * M::pow_fast(err, T(-0.2));
-                f = M::max(f, keep ? T(1) : T(0.2));
-                factor = M::min(f, T(10));
+                Control<T>::decide(M::sqrt(group_sum<G>(ss) / Dn), tprev, dt, keep, finite, factor);
             } else {
                 bool ok = true;
 #pragma unroll
@@ -450,10 +444,7 @@ struct Seip {
                 }
             }
             const T tp = M::min(next_t0, t_end);
-            if (next_t1 > t_end - M::clip_tol) {
-                next_t1 = accept ? t_end : tp + T(0.5) * (t_end - tp);
-                at_jump = false;
-            }
+            if (Control<T>::clip_to_end(next_t1, tp, accept, t_end)) at_jump = false;
             if (!done) {
                 tprev = tp;
                 tnext = next_t1;

@@ -290,6 +290,38 @@ __device__ __forceinline__ void store_run(T *p, const T (&v)[CNT], bool vec_ok) 
     for (int q = 0; q < CNT; ++q) p[q] = v[q];
 }
 
+// ---------------------------------------------------------------- step-size control (shared by the kernel families)
+// diffrax's defaults as called from the reference (odes.py:107-144): I-controller with safety 0.9 and factor in
+// [0.2, 10], Hairer-Norsett-Wanner starting step, clip-to-end.  solve_kernel.hpp and seip_kernel.hpp both step with
+// these, so the two families cannot drift apart.
+template <typename T>
+struct Control {
+    using M = Mth<T>;
+    // second half of the starting-step heuristic: h1 from max(d1, d2)
+    static __device__ __forceinline__ T initial_h1(T max_d, T h0) {
+        return (max_d <= T(1e-15)) ? M::max(T(1e-6), h0 * T(1e-3)) : M::pow_fast(T(0.01) / max_d, T(0.2));
+    }
+    // error norm -> accept?, can the solve go on?, next step factor.  A NaN / inf estimate is a rejected step with
+    // infinite error (diffeqsolve replaces NaN by inf before the controller); the solve only fails when the step cannot
+    // shrink any further.  factor = clip(safety * err^(-1/order), keep ? 1 : factormin, factormax); err == 0 -> factormax
+    static __device__ __forceinline__ void decide(T err, T tprev, T dt, bool &keep, bool &finite, T &factor) {
+        if (!(err == err)) err = M::inf();
+        keep = err < T(1);
+        finite = !(err == M::inf() && !(tprev + T(0.2) * dt > tprev));
+        T f = T(0.9) * M::pow_fast(err, T(-0.2));
+        f = M::max(f, keep ? T(1) : T(0.2));
+        factor = M::min(f, T(10));
+    }
+    // diffeqsolve's clip-to-end; returns true when the step was clipped (a pending jump clip is then void)
+    static __device__ __forceinline__ bool clip_to_end(T &next_t1, T tp, bool accept, T t_end) {
+        if (next_t1 > t_end - M::clip_tol) {
+            next_t1 = accept ? t_end : tp + T(0.5) * (t_end - tp);
+            return true;
+        }
+        return false;
+    }
+};
+
 // ---------------------------------------------------------------- the kernel
 // ND > 0 adds forward-mode tangents: NC = 1 + ND "planes" of every state array, plane 0 the
 // primal.  RK stages, FSAL and the dense output are linear in (y, k), so they are applied
@@ -1002,9 +1034,7 @@ struct Solver {
             }
             const T d2 = M::sqrt(group_sum<G>(s2) / Dn) / h0;
             const T max_d = M::max(d1, d2);
-            const T h1 = (max_d <= T(1e-15)) ? M::max(T(1e-6), h0 * T(1e-3))
-                                              : M::pow_fast(T(0.01) / max_d, T(0.2));
-            tnext = tprev + M::min(T(100) * h0, h1);
+            tnext = tprev + M::min(T(100) * h0, Control<T>::initial_h1(max_d, h0));
         }
         tnext = M::min(tnext, t_end);
 
@@ -1111,18 +1141,7 @@ struct Solver {
                     else
                         ss += r * r;
                 }
-                T err = M::sqrt(group_sum<G>(ss) / Dn);
-                // a trial step that blows up (NaN / inf estimate) is a rejected step with infinite
-                // error -- diffeqsolve turns NaN error estimates into inf before the controller --
-                // and only fails the solve when the step cannot shrink any further
-                if (!(err == err)) err = M::inf();
-                keep = err < T(1);
-                finite = !(err == M::inf() && !(tprev + T(0.2) * dt > tprev));
-                // factor = clip(safety * err^(-1/order), keep ? 1 : factormin, factormax)
-                // err == 0 -> +inf -> clipped to factormax
-                T f = T(0.9) * M::pow_fast(err, T(-0.2));
-                f = M::max(f, keep ? T(1) : T(0.2));
-                factor = M::min(f, T(10));
+                Control<T>::decide(M::sqrt(group_sum<G>(ss) / Dn), tprev, dt, keep, finite, factor);
             } else {
                 T chk = 0;
 #pragma unroll
@@ -1254,10 +1273,7 @@ struct Solver {
                 }
             }
             const T tp = M::min(next_t0, t_end);
-            if (next_t1 > t_end - M::clip_tol) {
-                next_t1 = accept ? t_end : tp + T(0.5) * (t_end - tp);
-                at_jump = false;
-            }
+            if (Control<T>::clip_to_end(next_t1, tp, accept, t_end)) at_jump = false;
             if (!done) {
                 tprev = tp;
                 tnext = next_t1;
