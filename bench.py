@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="cfg3", choices=["cfg2", "cfg3", "cfg3w8", "cfg5", "seip"])
+    ap.add_argument("--workload", default="cfg3", choices=["cfg2", "cfg3", "cfg3w8", "cfg5", "seip", "seip3"])
     ap.add_argument("--batch", type=int, default=0, help="trajectories per GPU (0 = config default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the short cfg2/cfg5 side measurements (N=1 only)")
@@ -164,7 +164,7 @@ def main():
     gen = synthetic.WORKLOADS[args.workload]
     base = gen()
     B = args.batch or base.B
-    seed = {"cfg2": 0, "cfg3": 1, "cfg3w8": 1, "cfg5": 5, "seip": 7}[args.workload] + 1000 * rank
+    seed = {"cfg2": 0, "cfg3": 1, "cfg3w8": 1, "cfg5": 5, "seip": 7, "seip3": 7}[args.workload] + 1000 * rank
     wl = gen(B, seed)
     m = wl.model
     f32 = torch.float32
@@ -259,7 +259,7 @@ def main():
         if world == 1 and not args.no_extra and args.workload == "cfg3":
             # the other single-GPU configs of BASELINE.json, 20 launches each (not the headline value)
             line["other_workloads"] = {}
-            for name in ("cfg2", "cfg5", "cfg3w8", "seip"):
+            for name in ("cfg2", "cfg5", "cfg3w8", "seip", "seip3"):
                 w2 = synthetic.WORKLOADS[name]()
                 a = [torch.as_tensor(x, dtype=f32, device=dev) for x in (w2.y0, w2.params, w2.contact, w2.save_ts)]
                 o2 = torch.empty((w2.B, w2.n_save, w2.model.state_dim), dtype=f32, device=dev)

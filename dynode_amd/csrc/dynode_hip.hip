@@ -26,7 +26,10 @@ namespace dyn {
 #undef X
 #define Y(T, METHOD, GA, L, K1, M1) \
     extern template hipError_t launch_seip<T, METHOD, GA, L, K1, M1>(const KArgs<T> &, hipStream_t);
+#define YT(T, METHOD, GA, L, K1, M1) \
+    extern template hipError_t launch_seip<T, METHOD, GA, L, K1, M1, 2>(const KArgs<T> &, hipStream_t);
 #include "seip_instances.def"
+#undef YT
 #undef Y
 
 template <typename T>
@@ -47,6 +50,7 @@ struct Entry {
 // SEIP shapes (seip_kernel.hpp) share the table: G = age lanes, S = strains, W = waning states,
 // FEAT = kSeip | tiers; the lane group is G * 2^S
 constexpr int kSeip = 0x100;
+constexpr int kSeipTierLanes = 0x20; // SEIP entry with the tiers dealt over two lanes (seip_kernel.hpp, KT = 2)
 // FEAT bit 14 (solve_kernel.hpp SAVE_ALL): variant without the per-round save-offset / store-width tests, picked by
 // enqueue when every compartment is saved into 16-byte aligned rows
 constexpr int kSaveAll = 0x4000;
@@ -71,7 +75,11 @@ static const Entry kEntries[] = {
 #define Y(T, METHOD, GA, L, K1, M1)                                          \
     {DType<T>::id, METHOD, GA, L, 1, 1, 1, M1, 0, 1, kSeip | K1,             \
      (void *)(hipError_t(*)(const KArgs<T> &, hipStream_t)) & launch_seip<T, METHOD, GA, L, K1, M1>},
+#define YT(T, METHOD, GA, L, K1, M1)                                         \
+    {DType<T>::id, METHOD, GA, L, 1, 1, 1, M1, 0, 1, kSeip | kSeipTierLanes | K1, \
+     (void *)(hipError_t(*)(const KArgs<T> &, hipStream_t)) & launch_seip<T, METHOD, GA, L, K1, M1, 2>},
 #include "seip_instances.def"
+#undef YT
 #undef Y
 };
 static constexpr int kNumEntries = sizeof(kEntries) / sizeof(kEntries[0]);
@@ -98,7 +106,9 @@ static int model_features(const dyn_model_desc *m) {
     return (m->has_intro ? 1 : 0) | (vax_lanes(m) << 1);
 }
 // lanes one trajectory occupies in a wave
-static int entry_lanes(const Entry *e) { return (e->FEAT & kSeip) ? (e->G << e->S) : e->G * (e->S / e->SPL); }
+static int entry_lanes(const Entry *e) {
+    return (e->FEAT & kSeip) ? (e->G << e->S) * ((e->FEAT & kSeipTierLanes) ? 2 : 1) : e->G * (e->S / e->SPL);
+}
 
 static bool matches(const Entry &e, const dyn_model_desc *m, int G, int dtype, int method, int nd) {
     return e.dtype == dtype && e.method == method && e.G == G && e.S == m->n_strain &&
@@ -364,6 +374,10 @@ int32_t dyn_trajectories_per_wave(const dyn_model_desc *m) {
 
 int32_t dyn_is_supported(const dyn_model_desc *m, const dyn_solver_opts *o) {
     if (dyn::check_model(m) || !o) return 0;
+    if (m->family == 1) { // either lane mapping will do
+        dyn::Entry probe{o->dtype, o->method, dyn::group_width(m->n_age), m->n_strain, 1, 1, 1, m->n_wane, 0, 1, 0, nullptr};
+        if (dyn::find_variant(&probe, dyn::kSeip | dyn::kSeipTierLanes | dyn::seip_tiers(m))) return 1;
+    }
     return dyn::find_entry(m, o->dtype, o->method) ? 1 : 0;
 }
 
@@ -406,6 +420,15 @@ static int solve_impl(const dyn_model_desc *m, const dyn_solver_opts *o, const v
         return DYN_ERR_UNSUPPORTED;
     }
     const dyn::Entry *e = dyn::find_entry(m, o->dtype, o->method, n_dir);
+    if (m->family == 1) {
+        // states that would spill (more than 32 values per lane) run with the tiers dealt over two lanes when that
+        // variant exists and the lane group still fits a wave; it is also the fallback when only it is compiled in
+        dyn::Entry probe{o->dtype, o->method, dyn::group_width(m->n_age), m->n_strain, 1, 1, 1, m->n_wane, 0, 1, 0, nullptr};
+        const dyn::Entry *two = dyn::find_variant(&probe, dyn::kSeip | dyn::kSeipTierLanes | dyn::seip_tiers(m));
+        const int per_lane = dyn::seip_tiers(m) * (m->n_wane + 3 * m->n_strain);
+        const char *force = getenv("DYNODE_HIP_SEIP_TIER_LANES"); // tuning aid: 0 / 1
+        if (two && (!e || (force ? atoi(force) != 0 : per_lane > 32))) e = two;
+    }
     if (!e && m->family == 1) {
         snprintf(dyn::tl_error, sizeof(dyn::tl_error),
                  "no SEIP kernel compiled for A=%d strains=%d tiers=%d waning states=%d dtype=%d method=%d; to add it "

@@ -7,6 +7,8 @@
 
 namespace dyn {
 #define Y(T, METHOD, GA, L, K1, M1) template hipError_t launch_seip<T, METHOD, GA, L, K1, M1>(const KArgs<T> &, hipStream_t);
+#define YT(T, METHOD, GA, L, K1, M1) template hipError_t launch_seip<T, METHOD, GA, L, K1, M1, 2>(const KArgs<T> &, hipStream_t);
 #include "seip_instances.def"
+#undef YT
 #undef Y
 } // namespace dyn

@@ -19,11 +19,16 @@
 
 namespace dyn {
 
-template <typename T, int METHOD, int GA, int L, int K1, int M1>
+// KT = 2 ("tier lanes"): the vaccination tiers of an (age, history) pair are dealt over two lanes -- lane bit above the
+// history bits, tier k on lane k % 2, slot k / 2 -- so a lane holds ceil(K1 / 2) * (M1 + 3 L) values instead of
+// K1 * (M1 + 3 L): three strains x three tiers no longer spill.  Every tier-to-tier flow (vaccination k -> k + 1, the
+// seasonal reset K -> K - 1) then crosses to the partner lane with one xor exchange.
+template <typename T, int METHOD, int GA, int L, int K1, int M1, int KT = 1>
 struct Seip {
-    static constexpr int H = 1 << L, G = GA * H, TPW = 64 / G, K = K1 - 1;
-    static_assert(G <= 64 && L >= 1 && L <= 4 && K1 >= 1 && K1 <= 4 && M1 >= 1, "SEIP lane group");
-    static constexpr int NS = K1 * M1, NE = K1 * L, NV = NS + 3 * NE;
+    static constexpr int H = 1 << L, G = GA * H * KT, TPW = 64 / G, K = K1 - 1;
+    static_assert(G <= 64 && L >= 1 && L <= 4 && K1 >= 1 && K1 <= 4 && M1 >= 1 && (KT == 1 || KT == 2), "SEIP lane group");
+    static constexpr int KL = (K1 + KT - 1) / KT; // tier slots per lane
+    static constexpr int NS = KL * M1, NE = KL * L, NV = NS + 3 * NE;
     static constexpr int IE = NS, II = NS + NE, IC = NS + 2 * NE;
     using M = Mth<T>;
     using TB = Tab<METHOD>;
@@ -38,7 +43,7 @@ struct Seip {
     T pop;             // population of this lane's age (doses per day = nu * pop)
     const T *sus;      // LDS: sus[K1][M1][L] of this lane's history
     const T *spl;      // LDS: spline[K1][4 + 2 nk] of this lane's age
-    int nk, hist;
+    int nk, hist, tl; // tl: tier lane (KT = 2), 0 otherwise
     bool pad, seasonal, seasonal_vax, intro;
 
     __device__ __forceinline__ static T hist_sum(T v) {
@@ -65,6 +70,10 @@ struct Seip {
     }
 
     __device__ __forceinline__ void rhs(T t, const T (&y)[NV], T (&dy)[NV]) const {
+        if constexpr (KT == 2) {
+            rhs_tier_lanes(t, y, dy);
+            return;
+        }
         T x[L], lam[L];
 #pragma unroll
         for (int l = 0; l < L; ++l) {
@@ -172,6 +181,142 @@ struct Seip {
         }
     }
 
+    // ---- the same right-hand side with the tiers dealt over two lanes (KT = 2): slot s of this lane is tier 2 s + tl
+    __device__ __forceinline__ void rhs_tier_lanes(T t, const T (&y)[NV], T (&dy)[NV]) const {
+        constexpr int TB_ = GA * H; // lane distance to the tier partner
+        T x[L], lam[L];
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            T a = y[II + l];
+#pragma unroll
+            for (int sl = 1; sl < KL; ++sl) a += y[II + sl * L + l];
+            a = hist_sum(a);
+            x[l] = a + xchg_xor<TB_>(a);
+        }
+        if (intro) {
+#pragma unroll
+            for (int l = 0; l < L; ++l) {
+                const T u = (t - itime[l]) * iinv[l];
+                x[l] += iamp[l] * M::exp(T(-0.5) * u * u);
+            }
+        }
+        ages.contract(x, lam);
+        T season = T(1), phi = T(0);
+        if (seasonal) season = T(1) + amp * M::sin(w_season * t + phase);
+        if (seasonal_vax) {
+            const T sn = M::sin(T(6.283185307179586476925286766559) * (t + tau) / T(730));
+            const T u = sn * sn, u2 = u * u, u4 = u2 * u2, u8 = u4 * u4, u16 = u8 * u8, u32 = u16 * u16,
+                    u64 = u32 * u32, u128 = u64 * u64, u256 = u128 * u128;
+            phi = ((((u256 * u128) * u64) * u32) * u16) * u4;
+        }
+#pragma unroll
+        for (int l = 0; l < L; ++l) lam[l] = (beta[l] * season) * lam[l];
+#pragma unroll
+        for (int v = 0; v < NS; ++v) dy[v] = T(0);
+        T send[KL];
+#pragma unroll
+        for (int sl = 0; sl < KL; ++sl) {
+            const int k = sl * 2 + tl;          // this slot's tier
+            const bool live = k < K1, top = k == K;
+            const int kc = live ? k : K;        // padded slots hold nobody: any valid table row will do
+            const T *c = spl + kc * (4 + 2 * nk);
+            T nu = c[0] + t * (c[1] + t * (c[2] + t * c[3]));
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const bool on = n < nk;
+                const T knot = c[on ? 4 + n : 0], coef = on ? c[on ? 4 + nk + n : 0] : T(0);
+                const T lag = M::max(t - knot, T(0));
+                nu += coef * (lag * lag * lag);
+            }
+            T tot = y[sl * M1];
+#pragma unroll
+            for (int m = 1; m < M1; ++m) tot += y[sl * M1 + m];
+            tot = hist_sum(tot);
+            const T doses = M::max(nu, T(0)) * pop;
+            const T share = doses * M::recip(tot > T(0) ? tot : T(1));
+            const T rate = (live && tot > T(0)) ? (doses < tot ? share : T(1)) : T(0);
+            T inflow[L], moved = T(0);
+#pragma unroll
+            for (int l = 0; l < L; ++l) inflow[l] = T(0);
+#pragma unroll
+            for (int m = 0; m < M1; ++m) {
+                const T S = y[sl * M1 + m];
+                const T *su = sus + (kc * M1 + m) * L;
+                T out = T(0);
+#pragma unroll
+                for (int l = 0; l < L; ++l) {
+                    const T f = (lam[l] * su[l]) * S;
+                    inflow[l] += f;
+                    out += f;
+                }
+                dy[sl * M1 + m] -= out;
+                if (m + 1 < M1) {
+                    const T wn = omega[m] * S;
+                    dy[sl * M1 + m] -= wn;
+                    dy[sl * M1 + m + 1] += wn;
+                }
+                const T v = (top && m == 0) ? T(0) : rate * S; // the freshest state of the top tier stays
+                dy[sl * M1 + m] -= v;
+                moved += v;
+            }
+            dy[sl * M1] += top ? moved : T(0);  // top tier: refreshed in place
+            send[sl] = top ? T(0) : moved;      // everyone else: up one tier = over to the partner lane
+#pragma unroll
+            for (int l = 0; l < L; ++l) {
+                const int q = sl * L + l;
+                const T s_e = sigma[l] * y[IE + q], g_i = gamma[l] * y[II + q];
+                dy[IE + q] = inflow[l] - s_e;
+                dy[II + q] = s_e - g_i;
+                dy[IC + q] = inflow[l];
+            }
+        }
+        // tier 2 s (lane 0) -> 2 s + 1 (lane 1, same slot); tier 2 s + 1 (lane 1) -> 2 s + 2 (lane 0, next slot)
+#pragma unroll
+        for (int sl = 0; sl < KL; ++sl) {
+            const T got = xchg_xor<TB_>(send[sl]);
+            dy[sl * M1] += tl ? got : T(0);
+            if (sl + 1 < KL) dy[(sl + 1) * M1] += tl ? T(0) : got;
+        }
+        recover_slots<0>(y, dy);
+        if constexpr (K > 0) {
+            if (seasonal_vax) { // wave-uniform: the top tier falls back one -- to the partner lane
+                constexpr int sK = K / 2, tK = K % 2, sD = (K - 1) / 2;
+                const bool holder = tl == tK;
+#pragma unroll
+                for (int m = 0; m < M1; ++m) {
+                    const T f = holder ? phi * y[sK * M1 + m] : T(0);
+                    dy[sK * M1 + m] -= f; // the partner subtracts 0 from whatever it keeps in this slot
+                    const T got = xchg_xor<TB_>(f);
+                    dy[sD * M1 + m] += holder ? T(0) : got;
+                }
+#pragma unroll
+                for (int l = 0; l < L; ++l) {
+                    const T fe = holder ? phi * y[IE + sK * L + l] : T(0), fi = holder ? phi * y[II + sK * L + l] : T(0);
+                    dy[IE + sK * L + l] -= fe;
+                    dy[II + sK * L + l] -= fi;
+                    const T ge = xchg_xor<TB_>(fe), gi = xchg_xor<TB_>(fi);
+                    dy[IE + sD * L + l] += holder ? T(0) : ge;
+                    dy[II + sD * L + l] += holder ? T(0) : gi;
+                }
+            }
+        }
+    }
+
+    // recovery for the KL local slots (the same exchange over the history bits as recover<>)
+    template <int l>
+    __device__ __forceinline__ void recover_slots(const T (&y)[NV], T (&dy)[NV]) const {
+        if constexpr (l < L) {
+            const bool has = (hist >> l) & 1;
+#pragma unroll
+            for (int sl = 0; sl < KL; ++sl) {
+                const T g_i = gamma[l] * y[II + sl * L + l];
+                const T partner = xchg_xor<(GA << l)>(g_i);
+                dy[sl * M1] += has ? partner + g_i : T(0);
+            }
+            recover_slots<l + 1>(y, dy);
+        }
+    }
+
     // stages SG..6 of the step (k[0] is FSAL); compile-time stage index: every k[q][v] is a named register
     template <int SG>
     __device__ __forceinline__ void stages(T tprev, T dt, const T (&y)[NV], T (&yt)[NV], T (&k)[7][NV]) const {
@@ -201,9 +346,26 @@ struct Seip {
         store_run<T, CNT>(dst, v, vec_ok);
     }
 
+    // KT = 2: one block per live tier slot and compartment
+    template <int SL>
+    __device__ __forceinline__ static void save_slots(const KArgs<T> &ka, const Dense &d, T dt, const T (&y)[NV], const T (&y1)[NV],
+                                                      const T (&k)[7][NV], T *row, int g, int tl, bool vec_ok) {
+        if constexpr (SL < KL) {
+            const int kt = SL * KT + tl;
+            if (kt < K1) {
+                const int gk = g * K1 + kt;
+                if (ka.save_off[0] >= 0) save_block<SL * M1, M1>(d, dt, y, y1, k, row + ka.save_off[0] + gk * M1, vec_ok);
+                if (ka.save_off[1] >= 0) save_block<IE + SL * L, L>(d, dt, y, y1, k, row + ka.save_off[1] + gk * L, vec_ok);
+                if (ka.save_off[2] >= 0) save_block<II + SL * L, L>(d, dt, y, y1, k, row + ka.save_off[2] + gk * L, vec_ok);
+                if (ka.save_off[4] >= 0) save_block<IC + SL * L, L>(d, dt, y, y1, k, row + ka.save_off[4] + gk * L, vec_ok);
+            }
+            save_slots<SL + 1>(ka, d, dt, y, y1, k, row, g, tl, vec_ok);
+        }
+    }
+
     __device__ __forceinline__ static void run(const KArgs<T> &ka) {
         const int lane = threadIdx.x & 63;
-        const int a = lane % GA, j = (lane / GA) % H, grp = lane / G;
+        const int a = lane % GA, j = (lane / GA) % H, tl = (lane / (GA * H)) % KT, grp = lane / G;
         int64_t traj = (int64_t)blockIdx.x * TPW + grp;
         const bool valid_traj = traj < ka.B;
         if (!valid_traj) traj = ka.B - 1;
@@ -211,6 +373,7 @@ struct Seip {
         Seip S;
         S.pad = a >= A;
         S.hist = j;
+        S.tl = tl;
         S.nk = nk;
         S.seasonal = ka.seasonal != 0;
         S.seasonal_vax = ka.seasonal_vax != 0;
@@ -221,7 +384,7 @@ struct Seip {
         extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
         T *const ts_tab = reinterpret_cast<T *>(dyn_smem);
         const int n_save = ka.n_save;
-        constexpr int SUSN = H * NS * L;
+        constexpr int SUSN = H * K1 * M1 * L;
         const int spln = A * K1 * (4 + 2 * nk);
         const int n_jump = ka.n_jump;
         T *const jt_tab = ts_tab + n_save; // discontinuity points follow the save grid
@@ -260,7 +423,7 @@ struct Seip {
         for (int n = lane % G; n < SUSN + spln; n += G) tab[n] = q[n];
         if (n_jump > 0 && lane < kMaxJumps) jt_tab[lane] = ka.jump_ts[lane];
         __syncthreads();
-        S.sus = tab + j * (NS * L);
+        S.sus = tab + j * (K1 * M1 * L);
         S.spl = tab + SUSN + aa * K1 * (4 + 2 * nk);
 #pragma unroll
         for (int l = 0; l < L; ++l) {
@@ -278,18 +441,25 @@ struct Seip {
 
         // ---- state: this lane's chunk of every compartment
         const int g = aa * H + j; // (age, history) group in memory order
-        const int offE = A * H * NS, nE = A * H * NE;
+        // memory layout: every (age, history) group holds K1 tiers; a lane holds them all (KT = 1) or tiers tl, tl + 2 (KT = 2)
+        const int offE = A * H * K1 * M1, nE = A * H * K1 * L;
         const int D = offE + 3 * nE;
         T y[NV], yt[NV], k[7][NV];
         {
             const T *src = ka.y0 + (ka.y0_batched ? traj * D : 0);
 #pragma unroll
-            for (int v = 0; v < NS; ++v) y[v] = S.pad ? T(0) : src[g * NS + v];
+            for (int sl = 0; sl < KL; ++sl) {
+                const int kt = sl * KT + tl;           // tier of this slot
+                const bool live = !S.pad && kt < K1;
+                const int gk = g * K1 + (kt < K1 ? kt : 0);
 #pragma unroll
-            for (int v = 0; v < NE; ++v) {
-                y[IE + v] = S.pad ? T(0) : src[offE + g * NE + v];
-                y[II + v] = S.pad ? T(0) : src[offE + nE + g * NE + v];
-                y[IC + v] = S.pad ? T(0) : src[offE + 2 * nE + g * NE + v];
+                for (int m = 0; m < M1; ++m) y[sl * M1 + m] = live ? src[gk * M1 + m] : T(0);
+#pragma unroll
+                for (int l = 0; l < L; ++l) {
+                    y[IE + sl * L + l] = live ? src[offE + gk * L + l] : T(0);
+                    y[II + sl * L + l] = live ? src[offE + nE + gk * L + l] : T(0);
+                    y[IC + sl * L + l] = live ? src[offE + 2 * nE + gk * L + l] : T(0);
+                }
             }
         }
 
@@ -396,10 +566,14 @@ struct Seip {
                     Lanes::dense_prepare((ts_next - tprev) * inv_dt, dn);
                     if (writer) {
                         T *row = out_traj + (int64_t)save_idx * ka.d_saved;
-                        if (ka.save_off[0] >= 0) save_block<0, NS>(dn, dt, y, yt, k, row + ka.save_off[0] + g * NS, vec_ok);
-                        if (ka.save_off[1] >= 0) save_block<IE, NE>(dn, dt, y, yt, k, row + ka.save_off[1] + g * NE, vec_ok);
-                        if (ka.save_off[2] >= 0) save_block<II, NE>(dn, dt, y, yt, k, row + ka.save_off[2] + g * NE, vec_ok);
-                        if (ka.save_off[4] >= 0) save_block<IC, NE>(dn, dt, y, yt, k, row + ka.save_off[4] + g * NE, vec_ok);
+                        if constexpr (KT == 1) {
+                            if (ka.save_off[0] >= 0) save_block<0, NS>(dn, dt, y, yt, k, row + ka.save_off[0] + g * NS, vec_ok);
+                            if (ka.save_off[1] >= 0) save_block<IE, NE>(dn, dt, y, yt, k, row + ka.save_off[1] + g * NE, vec_ok);
+                            if (ka.save_off[2] >= 0) save_block<II, NE>(dn, dt, y, yt, k, row + ka.save_off[2] + g * NE, vec_ok);
+                            if (ka.save_off[4] >= 0) save_block<IC, NE>(dn, dt, y, yt, k, row + ka.save_off[4] + g * NE, vec_ok);
+                        } else {
+                            save_slots<0>(ka, dn, dt, y, yt, k, row, g, tl, vec_ok);
+                        }
                     }
                     ++save_idx;
                     ts_next = save_idx < n_save ? ts_tab[save_idx] : M::inf();
@@ -460,13 +634,18 @@ struct Seip {
         if (writer) {
             for (; save_idx < n_save; ++save_idx) { // rows never reached: +inf, like an unfilled SaveAt buffer
                 T *row = out_traj + (int64_t)save_idx * ka.d_saved;
-                if (ka.save_off[0] >= 0)
-                    for (int v = 0; v < NS; ++v) row[ka.save_off[0] + g * NS + v] = M::inf();
-                for (int c = 1; c <= 4; ++c)
-                    if (c != 3 && ka.save_off[c] >= 0)
-                        for (int v = 0; v < NE; ++v) row[ka.save_off[c] + g * NE + v] = M::inf();
+                for (int sl = 0; sl < KL; ++sl) {
+                    const int kt = sl * KT + tl;
+                    if (kt >= K1) continue;
+                    const int gk = g * K1 + kt;
+                    if (ka.save_off[0] >= 0)
+                        for (int m = 0; m < M1; ++m) row[ka.save_off[0] + gk * M1 + m] = M::inf();
+                    for (int c = 1; c <= 4; ++c)
+                        if (c != 3 && ka.save_off[c] >= 0)
+                            for (int l = 0; l < L; ++l) row[ka.save_off[c] + gk * L + l] = M::inf();
+                }
             }
-            if (a == 0 && j == 0) {
+            if (a == 0 && j == 0 && tl == 0) {
                 ka.status[traj] = st;
                 ka.n_acc[traj] = n_acc;
                 ka.n_rej[traj] = n_rej;
@@ -475,19 +654,19 @@ struct Seip {
     }
 };
 
-template <typename T, int METHOD, int GA, int L, int K1, int M1>
+template <typename T, int METHOD, int GA, int L, int K1, int M1, int KT = 1>
 __global__ void __launch_bounds__(64) seip_kernel(const KArgs<T> ka) {
-    Seip<T, METHOD, GA, L, K1, M1>::run(ka);
+    Seip<T, METHOD, GA, L, K1, M1, KT>::run(ka);
 }
 
-template <typename T, int METHOD, int GA, int L, int K1, int M1>
+template <typename T, int METHOD, int GA, int L, int K1, int M1, int KT = 1>
 hipError_t launch_seip(const KArgs<T> &ka, hipStream_t stream) {
-    constexpr int TPW = 64 / (GA << L);
+    constexpr int TPW = 64 / ((GA << L) * KT);
     const int64_t blocks = (ka.B + TPW - 1) / TPW;
     if (blocks <= 0) return hipSuccess;
     const size_t per_traj = (size_t)(1 << L) * K1 * M1 * L + (size_t)ka.A * K1 * (4 + 2 * ka.n_vax_knots);
     const size_t lds = ((size_t)ka.n_save + (ka.n_jump > 0 ? kMaxJumps : 0) + TPW * per_traj) * sizeof(T);
-    hipLaunchKernelGGL((seip_kernel<T, METHOD, GA, L, K1, M1>), dim3((unsigned)blocks), dim3(64), lds, stream, ka);
+    hipLaunchKernelGGL((seip_kernel<T, METHOD, GA, L, K1, M1, KT>), dim3((unsigned)blocks), dim3(64), lds, stream, ka);
     return hipGetLastError();
 }
 

@@ -44,10 +44,17 @@ def _group_width(n_age: int) -> int:
     return g
 
 
+def _seip_tier_lanes(model: _abi.ModelDesc) -> bool:
+    """SEIP states of more than 32 values per lane would spill: deal the tiers over two lanes when the group still fits
+    a wave (csrc/seip_kernel.hpp, KT = 2)."""
+    A, L, H, K1, M1, _ = model.seip_dims
+    return K1 * (M1 + 3 * L) > 32 and _group_width(A) * H * 2 <= 64
+
+
 def _features(model: _abi.ModelDesc) -> int:
     """The kernel template's FEAT word: bit 0 = externally introduced strains, the rest = vaccination-tier lanes."""
-    if model.family == 1:
-        return 0x100 | max(int(model.n_vax_tiers), 1)        # kSeip | tiers (csrc/dynode_hip.hip)
+    if model.family == 1:                                    # kSeip | tiers [| tier lanes] (csrc/dynode_hip.hip)
+        return 0x100 | max(int(model.n_vax_tiers), 1) | (0x20 if _seip_tier_lanes(model) else 0)
     return int(model.has_intro) | (model.vax_lanes << 1)
 
 
@@ -103,7 +110,7 @@ def _source(model, dtype, method, n_dir, spl) -> str:
     b = lambda v: "true" if v else "false"
     if model.family == 1:
         A, L, _, K1, M1, _ = model.seip_dims
-        args = f"{t}, {method}, {_group_width(A)}, {L}, {K1}, {M1}"
+        args = f"{t}, {method}, {_group_width(A)}, {L}, {K1}, {M1}" + (", 2" if _seip_tier_lanes(model) else "")
         return (f'#include "{os.path.join(_CSRC, "seip_kernel.hpp")}"\n'
                 f"namespace dyn {{ template hipError_t launch_seip<{args}>(const KArgs<{t}> &, hipStream_t); }}\n"
                 f'extern "C" void *dyn_extra_launch(void) {{\n'

@@ -199,5 +199,6 @@ WORKLOADS = {
     "cfg3": lambda B=16384, seed=1: seirs_multi_strain(B, seed),
     "cfg3w8": lambda B=16384, seed=1: seirs_multi_strain(B, seed, W=8),
     "seip": lambda B=4096, seed=7: seip(B, seed),
+    "seip3": lambda B=4096, seed=7: seip(B, seed, A=4, L=3),      # three strains: tiers dealt over two lanes
     "cfg5": lambda B=8192, seed=5: seirs_multi_strain(B, seed, seasonal=True),
 }

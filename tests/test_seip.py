@@ -453,3 +453,39 @@ def test_params_from_config_maps_the_reference_configuration_objects():
 
 def _to_np(x):
     return x.detach().cpu().numpy() if hasattr(x, "detach") else np.asarray(x, dtype=float)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,prec", [(dict(A=2, L=2, K1=3, M1=2, n_knots=1, seasonal_vax=True), "f64"),
+                                        (dict(A=2, L=2, K1=3, M1=2, n_knots=2, intro=True), "f32"),
+                                        (dict(A=4, L=3, K1=3, M1=4, n_knots=2, seasonal=True, seasonal_vax=True), "f32"),
+                                        (dict(A=8, L=2, K1=3, M1=4, n_knots=2), "f32")], ids=lambda v: _ids(v) if isinstance(v, dict) else v)
+def test_tier_lanes_variant_matches_oracle(shape, prec, monkeypatch):
+    """The second lane mapping (tiers dealt over two lanes, `YT` entries): forced on, same bars as the first one;
+    and both mappings agree with each other to rounding."""
+    import torch
+    from dynode_amd.engine import solve_batch
+
+    dtype, npd = (torch.float64, np.float64) if prec == "f64" else (torch.float32, np.float32)
+    wl = synthetic.seip(B=7, seed=41, t1=120.0, **shape)
+    m, ts = wl.model, synthetic.save_grid(120.0)
+    want, st, _, _ = O.solve(H.omodel(m), wl.y0, wl.params, wl.contact, 120.0, ts, dtype=npd, n_threads=8, constant_dt=0.5)
+    monkeypatch.setenv("DYNODE_HIP_SEIP_TIER_LANES", "1")
+    two = solve_batch(m, wl.y0, wl.params, wl.contact, 120.0, ts, dtype=dtype, constant_dt=0.5)
+    assert int(two.status.max()) == 0 and st.max() == 0
+    assert np.abs(two.ys.cpu().numpy() - want).max() / 1000.0 < (1e-11 if prec == "f64" else 2e-5)
+    mask = np.array([1, 0, 0, 1], dtype=np.uint8)
+    sub = solve_batch(m, wl.y0, wl.params, wl.contact, 120.0, ts, dtype=dtype, constant_dt=0.5, save_mask=mask)
+    nS, nC = m.compartment_sizes[0], m.compartment_sizes[3]
+    full = two.ys.cpu().numpy()
+    assert np.array_equal(sub.ys.cpu().numpy(), np.concatenate([full[:, :, :nS], full[:, :, -nC:]], axis=2))
+    adaptive = solve_batch(m, wl.y0, wl.params, wl.contact, 120.0, ts, dtype=dtype)
+    wa, sa, na, nr = O.solve(H.omodel(m), wl.y0, wl.params, wl.contact, 120.0, ts, dtype=npd, n_threads=8)
+    assert int(adaptive.status.max()) == 0 and np.abs(adaptive.ys.cpu().numpy() - wa).max() / 1000.0 < (5e-5 if prec == "f64" else 2e-4)
+    if shape["A"] * (1 << shape["L"]) <= 32 or prec == "f32":
+        monkeypatch.setenv("DYNODE_HIP_SEIP_TIER_LANES", "0")
+        try:
+            one = solve_batch(m, wl.y0, wl.params, wl.contact, 120.0, ts, dtype=dtype, constant_dt=0.5)
+        except Exception:       # the one-lane mapping of this shape is not compiled in and the JIT picks tier lanes for it
+            return
+        assert np.abs(one.ys.cpu().numpy() - full).max() / 1000.0 < (1e-11 if prec == "f64" else 2e-5)

@@ -8,8 +8,10 @@ from dynode_amd.engine import solve_batch
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 L = int(sys.argv[2]) if len(sys.argv) > 2 else 2
-wl = synthetic.seip(B, L=L)
-print(f"shape: 8 ages x {1 << L} histories x 3 tiers x 4 waning states, {L} strains, D = {wl.model.state_dim}", flush=True)
+A = int(sys.argv[3]) if len(sys.argv) > 3 else 8
+wl = synthetic.seip(B, L=L, A=A)
+print(f"shape: {A} ages x {1 << L} histories x 3 tiers x 4 waning states, {L} strains, D = {wl.model.state_dim}; "
+      f"DYNODE_HIP_SEIP_TIER_LANES={os.environ.get('DYNODE_HIP_SEIP_TIER_LANES', 'auto')}", flush=True)
 m = wl.model
 a = [torch.as_tensor(x, dtype=torch.float32, device="cuda") for x in (wl.y0, wl.params, wl.contact, wl.save_ts)]
 for label, mask in (("all compartments", None), ("cumulative infections only", np.array([0, 0, 0, 1], np.uint8))):

@@ -10,7 +10,7 @@ import csv, glob, json, os, sys, collections
 out_dir, tag = sys.argv[1], sys.argv[2]
 extra = sys.argv[3:]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNEL = "seip_kernel" if "seip" in extra else "solve_kernel"
+KERNEL = "seip_kernel" if any(a.startswith("seip") for a in extra) else "solve_kernel"
 
 stats = None
 for f in glob.glob(os.path.join(out_dir, "trace", "**", "*kernel_stats.csv"), recursive=True):
@@ -30,7 +30,7 @@ workload, batch = "cfg3", None
 for i, a in enumerate(extra):
     if a == "--workload": workload = extra[i + 1]
     if a == "--batch": batch = int(extra[i + 1])
-defaults = {"cfg2": 4096, "cfg3": 16384, "cfg3w8": 16384, "cfg5": 8192, "seip": 4096}
+defaults = {"cfg2": 4096, "cfg3": 16384, "cfg3w8": 16384, "cfg5": 8192, "seip": 4096, "seip3": 4096}
 batch = batch or defaults[workload]
 
 lines = [f"# rocprofv3 summary `{tag}` -- bench.py --workload {workload} (B={batch} per GPU)", ""]
