@@ -447,6 +447,16 @@ struct Seip {
         T y[NV], yt[NV], k[7][NV];
         {
             const T *src = ka.y0 + (ka.y0_batched ? traj * D : 0);
+            if constexpr (KT == 1) { // a lane's tiers are contiguous in memory
+#pragma unroll
+                for (int v = 0; v < NS; ++v) y[v] = S.pad ? T(0) : src[g * NS + v];
+#pragma unroll
+                for (int v = 0; v < NE; ++v) {
+                    y[IE + v] = S.pad ? T(0) : src[offE + g * NE + v];
+                    y[II + v] = S.pad ? T(0) : src[offE + nE + g * NE + v];
+                    y[IC + v] = S.pad ? T(0) : src[offE + 2 * nE + g * NE + v];
+                }
+            } else
 #pragma unroll
             for (int sl = 0; sl < KL; ++sl) {
                 const int kt = sl * KT + tl;           // tier of this slot
@@ -634,15 +644,23 @@ struct Seip {
         if (writer) {
             for (; save_idx < n_save; ++save_idx) { // rows never reached: +inf, like an unfilled SaveAt buffer
                 T *row = out_traj + (int64_t)save_idx * ka.d_saved;
-                for (int sl = 0; sl < KL; ++sl) {
-                    const int kt = sl * KT + tl;
-                    if (kt >= K1) continue;
-                    const int gk = g * K1 + kt;
+                if constexpr (KT == 1) {
                     if (ka.save_off[0] >= 0)
-                        for (int m = 0; m < M1; ++m) row[ka.save_off[0] + gk * M1 + m] = M::inf();
+                        for (int v = 0; v < NS; ++v) row[ka.save_off[0] + g * NS + v] = M::inf();
                     for (int c = 1; c <= 4; ++c)
                         if (c != 3 && ka.save_off[c] >= 0)
-                            for (int l = 0; l < L; ++l) row[ka.save_off[c] + gk * L + l] = M::inf();
+                            for (int v = 0; v < NE; ++v) row[ka.save_off[c] + g * NE + v] = M::inf();
+                } else {
+                    for (int sl = 0; sl < KL; ++sl) {
+                        const int kt = sl * KT + tl;
+                        if (kt >= K1) continue;
+                        const int gk = g * K1 + kt;
+                        if (ka.save_off[0] >= 0)
+                            for (int m = 0; m < M1; ++m) row[ka.save_off[0] + gk * M1 + m] = M::inf();
+                        for (int c = 1; c <= 4; ++c)
+                            if (c != 3 && ka.save_off[c] >= 0)
+                                for (int l = 0; l < L; ++l) row[ka.save_off[c] + gk * L + l] = M::inf();
+                    }
                 }
             }
             if (a == 0 && j == 0 && tl == 0) {

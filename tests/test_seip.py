@@ -489,3 +489,19 @@ def test_tier_lanes_variant_matches_oracle(shape, prec, monkeypatch):
         except Exception:       # the one-lane mapping of this shape is not compiled in and the JIT picks tier lanes for it
             return
         assert np.abs(one.ys.cpu().numpy() - full).max() / 1000.0 < (1e-11 if prec == "f64" else 2e-5)
+
+
+@pytest.mark.gpu
+def test_tier_lanes_shape_built_on_demand():
+    """A three-strain shape that is not compiled in (3 ages, 3 tiers, 3 waning states: 36 values per lane): the on-demand
+    build picks the tier-lane mapping and registers it with the matching feature word."""
+    import torch
+    from dynode_amd import jit
+    from dynode_amd.engine import solve_batch
+
+    wl = synthetic.seip(B=5, seed=23, t1=90.0, A=3, L=3, K1=3, M1=3, n_knots=1, seasonal_vax=True)
+    assert jit._seip_tier_lanes(wl.model) and jit._features(wl.model) == 0x100 | 0x20 | 3
+    ts = synthetic.save_grid(90.0)
+    r = solve_batch(wl.model, wl.y0, wl.params, wl.contact, 90.0, ts, dtype=torch.float64, constant_dt=0.5)
+    want, st, _, _ = O.solve(H.omodel(wl.model), wl.y0, wl.params, wl.contact, 90.0, ts, dtype=np.float64, n_threads=8, constant_dt=0.5)
+    assert int(r.status.max()) == 0 and np.abs(r.ys.cpu().numpy() - want).max() / 1000.0 < 1e-11
