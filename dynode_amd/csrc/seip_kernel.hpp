@@ -677,6 +677,12 @@ __global__ void __launch_bounds__(64) seip_kernel(const KArgs<T> ka) {
     Seip<T, METHOD, GA, L, K1, M1, KT>::run(ka);
 }
 
+// small per-lane states (tier lanes, <= 20 values): cap the registers at 256 so that two waves share a SIMD
+template <typename T, int METHOD, int GA, int L, int K1, int M1, int KT = 1>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) seip_kernel_two_waves(const KArgs<T> ka) {
+    Seip<T, METHOD, GA, L, K1, M1, KT>::run(ka);
+}
+
 template <typename T, int METHOD, int GA, int L, int K1, int M1, int KT = 1>
 hipError_t launch_seip(const KArgs<T> &ka, hipStream_t stream) {
     constexpr int TPW = 64 / ((GA << L) * KT);
@@ -684,7 +690,10 @@ hipError_t launch_seip(const KArgs<T> &ka, hipStream_t stream) {
     if (blocks <= 0) return hipSuccess;
     const size_t per_traj = (size_t)(1 << L) * K1 * M1 * L + (size_t)ka.A * K1 * (4 + 2 * ka.n_vax_knots);
     const size_t lds = ((size_t)ka.n_save + (ka.n_jump > 0 ? kMaxJumps : 0) + TPW * per_traj) * sizeof(T);
-    hipLaunchKernelGGL((seip_kernel<T, METHOD, GA, L, K1, M1, KT>), dim3((unsigned)blocks), dim3(64), lds, stream, ka);
+    if constexpr (sizeof(T) == 4 && Seip<T, METHOD, GA, L, K1, M1, KT>::NV <= 20)
+        hipLaunchKernelGGL((seip_kernel_two_waves<T, METHOD, GA, L, K1, M1, KT>), dim3((unsigned)blocks), dim3(64), lds, stream, ka);
+    else
+        hipLaunchKernelGGL((seip_kernel<T, METHOD, GA, L, K1, M1, KT>), dim3((unsigned)blocks), dim3(64), lds, stream, ka);
     return hipGetLastError();
 }
 

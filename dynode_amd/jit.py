@@ -44,17 +44,20 @@ def _group_width(n_age: int) -> int:
     return g
 
 
-def _seip_tier_lanes(model: _abi.ModelDesc) -> bool:
-    """SEIP states of more than 32 values per lane would spill: deal the tiers over two lanes when the group still fits
-    a wave (csrc/seip_kernel.hpp, KT = 2)."""
+def _seip_tier_lanes(model: _abi.ModelDesc, dtype=torch.float32) -> bool:
+    """SEIP states of more than 32 values per lane would spill, and float states of at most 20 values per half fit two
+    waves per SIMD: deal the tiers over two lanes when the group still fits a wave (csrc/seip_kernel.hpp, KT = 2; the
+    same rule as solve_impl in csrc/dynode_hip.hip)."""
     A, L, H, K1, M1, _ = model.seip_dims
-    return K1 * (M1 + 3 * L) > 32 and _group_width(A) * H * 2 <= 64
+    per_tier = M1 + 3 * L
+    small = dtype == torch.float32 and ((K1 + 1) // 2) * per_tier <= 20
+    return (K1 * per_tier > 32 or small) and K1 > 1 and _group_width(A) * H * 2 <= 64
 
 
-def _features(model: _abi.ModelDesc) -> int:
+def _features(model: _abi.ModelDesc, dtype=torch.float32) -> int:
     """The kernel template's FEAT word: bit 0 = externally introduced strains, the rest = vaccination-tier lanes."""
     if model.family == 1:                                    # kSeip | tiers [| tier lanes] (csrc/dynode_hip.hip)
-        return 0x100 | max(int(model.n_vax_tiers), 1) | (0x20 if _seip_tier_lanes(model) else 0)
+        return 0x100 | max(int(model.n_vax_tiers), 1) | (0x20 if _seip_tier_lanes(model, dtype) else 0)
     return int(model.has_intro) | (model.vax_lanes << 1)
 
 
@@ -102,7 +105,7 @@ def _stamp() -> str:
 def _name(model, dtype, method, n_dir, spl) -> str:
     return (f"{'f64' if dtype == torch.float64 else 'f32'}_m{method}_g{_group_width(model.n_age)}_s{model.n_strain}"
             f"_e{int(model.has_e)}w{int(model.has_wane)}c{int(model.has_c)}_W{model.n_wane}_nd{n_dir}_spl{spl}"
-            f"_f{_features(model)}_{_stamp()}")
+            f"_f{_features(model, dtype)}_{_stamp()}")
 
 
 def _source(model, dtype, method, n_dir, spl) -> str:
@@ -110,7 +113,7 @@ def _source(model, dtype, method, n_dir, spl) -> str:
     b = lambda v: "true" if v else "false"
     if model.family == 1:
         A, L, _, K1, M1, _ = model.seip_dims
-        args = f"{t}, {method}, {_group_width(A)}, {L}, {K1}, {M1}" + (", 2" if _seip_tier_lanes(model) else "")
+        args = f"{t}, {method}, {_group_width(A)}, {L}, {K1}, {M1}" + (", 2" if _seip_tier_lanes(model, dtype) else "")
         return (f'#include "{os.path.join(_CSRC, "seip_kernel.hpp")}"\n'
                 f"namespace dyn {{ template hipError_t launch_seip<{args}>(const KArgs<{t}> &, hipStream_t); }}\n"
                 f'extern "C" void *dyn_extra_launch(void) {{\n'
@@ -157,7 +160,7 @@ def ensure_kernel(model: _abi.ModelDesc, dtype=torch.float32, method: str = "tsi
         extra.dyn_extra_launch.restype = ctypes.c_void_p
         rc = L.dyn_register_instance(opts.dtype, mid, _group_width(model.n_age), model.n_strain, int(model.has_e),
                                      int(model.has_wane), int(model.has_c), model.n_wane, n_dir, spl,
-                                     _features(model), ctypes.c_void_p(extra.dyn_extra_launch()))
+                                     _features(model, dtype), ctypes.c_void_p(extra.dyn_extra_launch()))
         if rc:
             raise RuntimeError(f"dyn_register_instance: {_abi.ERR_NAMES.get(rc, rc)}")
         _LOADED[name] = extra
