@@ -19,7 +19,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1000)
     ap.add_argument("--samples", type=int, default=1000)
     ap.add_argument("--depth", type=int, default=10)
-    ap.add_argument("--sampler", default="kernel", choices=["kernel", "graph", "eager"])
+    ap.add_argument("--sampler", default="kernel", choices=["kernel", "graph", "eager", "ensemble"])
     ap.add_argument("--adaptation", default="pooled", choices=["per_chain", "pooled"])
     ap.add_argument("--target-accept", type=float, default=0.8)
     ap.add_argument("--fused-likelihood", action="store_true", help="score the observations inside the solve kernel (examples model_fused)")
