@@ -93,6 +93,9 @@ extern "C" {
  *         the m' = 0 term of ode_model.md's top-tier gain has no matching loss and is dropped, so people are conserved
  *     seasonal vaccination (seasonal_vax)   phi(t) = sin(2 pi (t + tau) / 730)^1000 moves s, e, i of tier K to K - 1
  *         (ode_model.md:70-84; applied at all times -- the power makes it vanish outside the yearly window)
+ * Limits: group_width(n_age) * 2^n_strain <= 64 lanes (one trajectory must fit a wavefront), n_strain <= 4, tiers <= 4;
+ * all solver options of dyn_solve_batch apply (both methods, constant steps, discontinuity points, sub-save masks);
+ * dyn_solve_batch_jvp / _loglik return DYN_ERR_UNSUPPORTED for this family (no tangent planes yet).
  */
 #define DYN_MAX_STRAINS 8
 typedef struct dyn_model_desc {
