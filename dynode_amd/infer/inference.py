@@ -20,6 +20,7 @@ import sys
 from collections import OrderedDict
 from typing import Any, Callable, Optional
 
+import numpy as np
 import torch
 from pydantic import BaseModel, ConfigDict, Field, PositiveInt, PrivateAttr
 
@@ -169,11 +170,26 @@ class MCMCResult:
     def last_state(self):
         return self.nuts.samples[:, -1]
 
+    def summary(self) -> dict:
+        """site -> {mean, std, median, 5.0%, 95.0%, n_eff, r_hat}: the columns of numpyro's ``MCMC.print_summary``
+        (effective sample size and split R-hat from ``infer/diagnostics.py``), scalar sites only."""
+        from .diagnostics import effective_sample_size, split_rhat
+
+        out = {}
+        for n, v in self.get_samples(group_by_chain=True).items():
+            if v.dim() != 2:
+                continue
+            x = v.detach().double().cpu().numpy()
+            q = np.quantile(x, [0.05, 0.5, 0.95])
+            out[n] = {"mean": float(x.mean()), "std": float(x.std(ddof=1)), "median": float(q[1]), "5.0%": float(q[0]),
+                      "95.0%": float(q[2]), "n_eff": effective_sample_size(x), "r_hat": split_rhat(x)}
+        return out
+
     def print_summary(self) -> str:
-        lines = [f"{'site':32s} {'mean':>10s} {'std':>10s} {'5%':>10s} {'95%':>10s}"]
-        for n, v in self.get_samples().items():
-            q = torch.quantile(v, torch.tensor([0.05, 0.95], dtype=v.dtype, device=v.device))
-            lines.append(f"{n:32s} {float(v.mean()):10.4f} {float(v.std()):10.4f} {float(q[0]):10.4f} {float(q[1]):10.4f}")
+        lines = [f"{'site':32s} {'mean':>10s} {'std':>10s} {'median':>10s} {'5.0%':>10s} {'95.0%':>10s} {'n_eff':>10s} {'r_hat':>7s}"]
+        for n, r in self.summary().items():
+            lines.append(f"{n:32s} {r['mean']:10.4f} {r['std']:10.4f} {r['median']:10.4f} {r['5.0%']:10.4f} {r['95.0%']:10.4f} "
+                         f"{r['n_eff']:10.1f} {r['r_hat']:7.3f}")
         lines.append(f"divergences: {int(self.nuts.diverging.sum())}, mean accept prob: {float(self.nuts.accept_prob.mean()):.3f}, "
                      f"mean leapfrogs/transition: {float(self.nuts.num_steps.double().mean()):.2f}")
         text = "\n".join(lines)

@@ -48,3 +48,18 @@ def test_argument_checks():
         s.run(torch.zeros((4, 3), dtype=torch.float64), 1, 1)
     with pytest.raises(RuntimeError, match="finite density"):
         EnsembleSampler(lambda z: torch.full((z.shape[0],), float("nan"), dtype=z.dtype)).run(torch.zeros((8, 2), dtype=torch.float64), 1, 1)
+
+
+def test_diagnostics_on_known_chains():
+    """Effective sample size and split R-hat (infer/diagnostics.py, the two extra columns of print_summary)."""
+    from dynode_amd.infer.diagnostics import effective_sample_size, split_rhat
+
+    rng = np.random.default_rng(0)
+    iid = rng.normal(size=(8, 1000))
+    assert abs(split_rhat(iid) - 1.0) < 0.01 and 0.85 * 8000 < effective_sample_size(iid) < 1.1 * 8000
+    x, e = np.zeros((8, 4000)), rng.normal(size=(8, 4000))
+    for t in range(1, 4000):                                   # AR(1), rho = 0.9: integrated autocorrelation time 19
+        x[:, t] = 0.9 * x[:, t - 1] + e[:, t]
+    assert abs(effective_sample_size(x) / (8 * 4000 / 19.0) - 1.0) < 0.2 and split_rhat(x) < 1.02
+    shifted = iid + np.arange(8)[:, None]                      # chains that disagree
+    assert split_rhat(shifted) > 2.0 and effective_sample_size(shifted) < 20
