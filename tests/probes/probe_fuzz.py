@@ -10,7 +10,6 @@ from test_gpu_parity import fuzz_case, fuzz_compare
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 dtype = torch.float32 if len(sys.argv) > 3 and sys.argv[3] == "f32" else torch.float64
-bound = 1e-10 if dtype == torch.float64 else 2e-5
 bad = ran = 0
 worst = 0.0
 for seed in range(seed0, seed0 + N):
@@ -18,6 +17,10 @@ for seed in range(seed0, seed0 + N):
     if case is None:
         continue
     ran += 1
+    # float64: rounding level.  float32: the two runs may take different accept / reject decisions where the error
+    # estimate sits at 1, so they agree to the solver tolerance of the case (a few rtol), or to rounding for constant steps
+    rtol = case[6].get("rtol", 0.0) if "constant_dt" not in case[6] else 0.0
+    bound = 1e-10 if dtype == torch.float64 else 2e-5 + 30.0 * rtol
     try:
         err, same = fuzz_compare(case, dtype)
     except Exception as e:  # noqa: BLE001
