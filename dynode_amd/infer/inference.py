@@ -120,6 +120,22 @@ class Potential:
         (g,) = torch.autograd.grad(lj, z, minus)             # gradient of the potential U = -log joint
         return -lj.detach(), g
 
+    def potential_and_grad_fd(self, z: torch.Tensor, eps: float = 1e-4):
+        """The same pair by central differences of the log density along the D unconstrained coordinates: ONE batched
+        evaluation of (1 + 2 D) C rows, no autograd -- for models whose solve has no tangent kernels (the SEIP family).
+        The discrete solve must be a smooth function of the parameters for this to be accurate: use
+        ``SolverParams(constant_step_size=...)`` (an adaptive controller changes its accept / reject decisions between
+        the perturbed rows).  A sampler stays exact with an approximate gradient -- the leapfrog map is reversible and
+        volume preserving for any position-dependent force, the accept step uses the true density -- only less efficient."""
+        C, D = z.shape
+        z = z.detach()
+        steps = eps * torch.eye(D, dtype=z.dtype, device=z.device)
+        rows = [z] + [z + sign * steps[d] for d in range(D) for sign in (1.0, -1.0)]
+        with torch.no_grad():
+            lj = self.log_joint(torch.cat(rows, dim=0))[0].reshape(1 + 2 * D, C)
+        grad = torch.stack([-(lj[1 + 2 * d] - lj[2 + 2 * d]) / (2.0 * eps) for d in range(D)], dim=1)
+        return -lj[0], grad
+
     def graphed(self, chains: int):
         """``potential_and_grad`` for a fixed number of chains as ONE HIP-graph replay.
 
@@ -338,7 +354,14 @@ class MCMCProcess(InferenceProcess):
             kind = "graph"
         cls = {"kernel": KernelNUTS, "graph": GraphNUTS, "eager": BatchedNUTS}[kind]
         extra = {"adaptation": self.mcmc_kwargs.get("adaptation", "pooled")} if kind == "kernel" else {}
-        sampler = cls(pot.potential_and_grad, max_tree_depth=self.nuts_max_tree_depth,
+        pg = pot.potential_and_grad
+        if self.mcmc_kwargs.get("gradient", "autograd") == "finite_difference":
+            # NUTS for models without tangent kernels: central differences over the latent coordinates (Potential above)
+            fd_step = float(self.mcmc_kwargs.get("fd_step", 1e-4))
+            pg = lambda z: pot.potential_and_grad_fd(z, fd_step)  # noqa: E731
+            if kind == "kernel":
+                extra["use_graph"] = False          # the model usually syncs with the host (numpy-built parameter tables)
+        sampler = cls(pg, max_tree_depth=self.nuts_max_tree_depth,
                       target_accept=self.nuts_kwargs.get("target_accept_prob", 0.8),
                       seed=self.inference_prngkey + 7919 * rank, **extra)
         total = self.num_warmup + self.num_samples
