@@ -3,6 +3,7 @@
 The SEIP kernels have no tangent planes yet, so NUTS is not available for them; the model is still solved in
 large batches, and the affine-invariant ensemble sampler (``mcmc_kwargs={"sampler": "ensemble"}``,
 dynode_amd/infer/ensemble.py) needs nothing else: every move scores half of the walkers in one batched solve.
+``python -m examples.infer_seip_cross_immunity --nuts`` runs NUTS on finite-difference gradients instead.
 Latent: the cross-immunity ``strain_interactions["beta"]["alpha"]`` and the second strain's R0; data: weekly
 infections by strain and immune history from the run of examples/seip_immune_history.py at TRUTH.
 """
@@ -57,10 +58,21 @@ def model(config: SimulationConfig, tf, obs_data):
 
 
 if __name__ == "__main__":
+    import sys
+
     config = base.get_config()
+    if "--nuts" in sys.argv:
+        # NUTS on finite-difference gradients: (1 + 2 D) batched solves per gradient; the difference quotient needs a solve
+        # that is smooth in the parameters, hence the constant step
+        from dynode_amd import SolverParams
+
+        config.parameters.solver_params = SolverParams(constant_step_size=0.25)
+        kwargs = dict(num_warmup=200, num_samples=200, num_chains=32, nuts_max_tree_depth=6,
+                      mcmc_kwargs={"gradient": "finite_difference", "fd_step": 1e-3})
+    else:
+        kwargs = dict(num_warmup=300, num_samples=300, num_chains=64, nuts_max_tree_depth=10, mcmc_kwargs={"sampler": "ensemble"})
     data = weekly_infections(config, 210, **TRUTH).cpu()
-    process = MCMCProcess(numpyro_model=model, num_warmup=300, num_samples=300, num_chains=64, nuts_max_tree_depth=10,
-                          mcmc_kwargs={"sampler": "ensemble"})
+    process = MCMCProcess(numpyro_model=model, **kwargs)
     mcmc = process.infer(config=config, tf=210, obs_data=data)
     mcmc.print_summary()
     print("truth:", TRUTH)
