@@ -305,6 +305,16 @@ class MCMCProcess(InferenceProcess):
     Under ``torch.distributed`` (one process per GPU) every rank runs ``num_chains / world``
     chains with a rank-offset seed; ``get_samples(gather=True)`` collects them on rank 0 over
     RCCL -- the only collective of the inference path.
+
+    ``mcmc_kwargs`` (the reference forwards them to numpyro's ``MCMC``; here they select the machinery):
+
+    ``sampler``      ``"kernel"`` (default: sampler iteration as one HIP kernel, whole iteration replayed as a HIP graph),
+                     ``"graph"`` / ``"eager"`` (torch-op sampler step, replayed / op by op), ``"ensemble"`` (gradient-free
+                     stretch moves, ``infer/ensemble.py``; ``stretch``, ``thin``)
+    ``adaptation``   ``"pooled"`` (default: mass-matrix windows merged over the chains of this GPU) or ``"per_chain"`` (numpyro)
+    ``gradient``     ``"autograd"`` (default: tangent kernels + autograd) or ``"finite_difference"`` (central differences of the
+                     log density, ``fd_step``; for models without tangent kernels, with a constant solver step)
+    ``nuts_kwargs``: ``target_accept_prob`` (0.8), ``step_size`` (1.0).
     """
 
     num_samples: PositiveInt
