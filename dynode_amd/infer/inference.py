@@ -171,6 +171,22 @@ class Potential:
         return replay
 
 
+class _FiniteDifferenceLogJoint(torch.autograd.Function):
+    """log density of a batch of unconstrained points as a differentiable tensor whose backward pass uses the
+    finite-difference gradient of :meth:`Potential.potential_and_grad_fd` (for SVI on models without tangent kernels)."""
+
+    @staticmethod
+    def forward(ctx, z, potential, eps):
+        u, g = potential.potential_and_grad_fd(z, eps)
+        ctx.save_for_backward(g)
+        return -u
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (g,) = ctx.saved_tensors
+        return -(g * grad_out[:, None]), None, None
+
+
 class MCMCResult:
     """What ``infer`` returns: the sampler output plus numpyro-style accessors."""
 
@@ -516,6 +532,7 @@ class SVIProcess(InferenceProcess):
     num_particles: PositiveInt = 8
     progress_bar: bool = True
     guide_kwargs: dict = Field(default_factory=dict)
+    svi_kwargs: dict = Field(default_factory=dict)      # {"gradient": "finite_difference", "fd_step": 1e-4}: see MCMCProcess
 
     def infer(self, **kwargs) -> SVIResult:
         from ..engine import require_gpu
@@ -531,7 +548,10 @@ class SVIProcess(InferenceProcess):
         for it in range(self.num_iterations):
             opt.zero_grad()
             z, _ = guide.sample(self.num_particles, gen)
-            lj, _ = pot.log_joint(z)
+            if self.svi_kwargs.get("gradient", "autograd") == "finite_difference":
+                lj = _FiniteDifferenceLogJoint.apply(z, pot, float(self.svi_kwargs.get("fd_step", 1e-4)))
+            else:
+                lj, _ = pot.log_joint(z)
             finite = torch.isfinite(lj)
             lj = torch.where(finite, lj, torch.zeros_like(lj))
             loss = -(lj.sum() / finite.sum().clamp_min(1) + guide.entropy())      # -ELBO, reparameterised

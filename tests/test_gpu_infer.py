@@ -506,3 +506,25 @@ def test_nuts_with_finite_difference_gradients_fits_the_seip_model():
         chi.mean(), chi.std(), r0.mean(), r0.std(), float(mcmc.nuts.accept_prob.mean()), float(mcmc.nuts.num_steps.double().mean())))
     assert abs(chi.mean() - 0.45) < max(3 * chi.std(), 0.02) and abs(r0.mean() - 2.4) < max(3 * r0.std(), 0.01)
     assert chi.std() < 0.05 and r0.std() < 0.02
+
+
+def test_svi_with_finite_difference_gradients(data):
+    """SVIProcess(svi_kwargs={"gradient": "finite_difference"}): the ELBO gradient flows through the difference
+    quotient of the log density; same fit as with the tangent kernels."""
+    from dynode_amd import SolverParams
+    from dynode_amd.infer.inference import SVIProcess
+
+    cfg = ex.get_config()
+    cfg.parameters.solver_params = SolverParams(constant_step_size=0.25)
+    fits = {}
+    for mode in ("autograd", "finite_difference"):
+        proc = SVIProcess(numpyro_model=ex.model, num_iterations=300, num_samples=2000, num_particles=16, progress_bar=False,
+                          svi_kwargs={"gradient": mode, "fd_step": 1e-3})
+        proc.infer(config=cfg, tf=100, obs_data=data)
+        post = proc.get_samples()
+        fits[mode] = (float(post["strains_0_r0"].mean()), float(post["strains_0_r0"].std()),
+                      float(post["strains_0_infectious_period"].mean()), float(post["strains_0_infectious_period"].std()))
+    a, f = fits["autograd"], fits["finite_difference"]
+    print("SVI autograd", a, "finite differences", f)
+    assert abs(a[0] - f[0]) < 0.02 and abs(a[2] - f[2]) < 0.1 and abs(a[1] - f[1]) < 0.03 and abs(a[3] - f[3]) < 0.12
+    assert abs(f[0] - 2.046) < 0.04 and abs(f[2] - 7.2) < 0.2
