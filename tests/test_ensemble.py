@@ -63,3 +63,28 @@ def test_diagnostics_on_known_chains():
     assert abs(effective_sample_size(x) / (8 * 4000 / 19.0) - 1.0) < 0.2 and split_rhat(x) < 1.02
     shifted = iid + np.arange(8)[:, None]                      # chains that disagree
     assert split_rhat(shifted) > 2.0 and effective_sample_size(shifted) < 20
+
+
+def test_finite_difference_gradient_of_the_potential_on_the_cpu():
+    """Potential.potential_and_grad_fd against autograd on a model without any ODE (runs on the CPU): two latent
+    sites with constrained supports, a Gaussian likelihood."""
+    from dynode_amd.infer import distributions as dist
+    from dynode_amd.infer import handlers
+    from dynode_amd.infer.inference import Potential, _FiniteDifferenceLogJoint
+
+    obs = torch.tensor([1.2, 0.7, 1.9, 1.4], dtype=torch.float64)
+
+    def model(obs_data):
+        loc = handlers.sample("loc", dist.Uniform(-3.0, 3.0))
+        scale = handlers.sample("scale", dist.TransformedDistribution(dist.Beta(2.0, 2.0), dist.transforms.AffineTransform(0.2, 2.0)))
+        handlers.sample("y", dist.Normal(loc[..., None], scale[..., None]), obs=obs_data)
+
+    pot = Potential(model, dict(obs_data=obs), 0, torch.device("cpu"))
+    z = torch.tensor([[0.3, -0.2], [-1.0, 0.8], [1.5, 0.1]], dtype=torch.float64)
+    u, g = pot.potential_and_grad(z)
+    u_fd, g_fd = pot.potential_and_grad_fd(z, 1e-6)
+    assert torch.allclose(u, u_fd, rtol=1e-13) and torch.allclose(g, g_fd, rtol=1e-6, atol=1e-7)
+    zz = z.clone().requires_grad_(True)
+    lj = _FiniteDifferenceLogJoint.apply(zz, pot, 1e-6)
+    (weights,) = torch.autograd.grad((lj * torch.tensor([1.0, 2.0, 3.0], dtype=torch.float64)).sum(), zz)
+    assert torch.allclose(weights, -g * torch.tensor([[1.0], [2.0], [3.0]], dtype=torch.float64), rtol=1e-6, atol=1e-7)
