@@ -428,7 +428,10 @@ static int solve_impl(const dyn_model_desc *m, const dyn_solver_opts *o, const v
         const int per_tier = m->n_wane + 3 * m->n_strain, per_lane = dyn::seip_tiers(m) * per_tier;
         // ... and small float states: half the tiers per lane fit 256 registers, so two waves share a SIMD (measured on the
         // D = 960 shape: 6.5 vs 6.7 ms at 4096 trajectories, 23.3 vs 25.4 ms at 16384)
-        const bool small = o->dtype == DYN_F32 && dyn::seip_tiers(m) > 1 && ((dyn::seip_tiers(m) + 1) / 2) * per_tier <= 20;
+        // (only when the one-lane mapping is down to two trajectories per wave: with 4 ages x 4 histories it keeps four per
+        // wave and wins, 6.15 vs 6.70 ms at 8192 trajectories)
+        const bool small = o->dtype == DYN_F32 && dyn::seip_tiers(m) > 1 && ((dyn::seip_tiers(m) + 1) / 2) * per_tier <= 20 &&
+                           (dyn::group_width(m->n_age) << m->n_strain) >= 32;
         const char *force = getenv("DYNODE_HIP_SEIP_TIER_LANES"); // tuning aid: 0 / 1
         if (two && (!e || (force ? atoi(force) != 0 : (per_lane > 32 || small)))) e = two;
     }

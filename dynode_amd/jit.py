@@ -50,7 +50,7 @@ def _seip_tier_lanes(model: _abi.ModelDesc, dtype=torch.float32) -> bool:
     same rule as solve_impl in csrc/dynode_hip.hip)."""
     A, L, H, K1, M1, _ = model.seip_dims
     per_tier = M1 + 3 * L
-    small = dtype == torch.float32 and ((K1 + 1) // 2) * per_tier <= 20
+    small = dtype == torch.float32 and ((K1 + 1) // 2) * per_tier <= 20 and _group_width(A) * H >= 32
     return (K1 * per_tier > 32 or small) and K1 > 1 and _group_width(A) * H * 2 <= 64
 
 
