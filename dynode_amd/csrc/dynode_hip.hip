@@ -154,6 +154,23 @@ static const Entry *find_variant(const Entry *e, int feat) {
     return nullptr;
 }
 
+// SEIP: which lane mapping runs a model.  States that would spill (more than 32 values per lane) take the tiers dealt
+// over two lanes when that variant exists and the lane group still fits a wave; it is also the fallback when only it is
+// compiled in ...
+static const Entry *select_seip_entry(const dyn_model_desc *m, int dtype, int method, const Entry *e) {
+    Entry probe{dtype, method, group_width(m->n_age), m->n_strain, 1, 1, 1, m->n_wane, 0, 1, 0, nullptr};
+    const Entry *two = find_variant(&probe, kSeip | kSeipTierLanes | seip_tiers(m));
+    const int per_tier = m->n_wane + 3 * m->n_strain, per_lane = seip_tiers(m) * per_tier;
+    // ... and small float states: half the tiers per lane fit 256 registers, so two waves share a SIMD (measured on the
+    // D = 960 shape: 6.5 vs 6.7 ms at 4096 trajectories, 23.3 vs 25.4 ms at 16384) -- only when the one-lane mapping is
+    // down to two trajectories per wave: with 4 ages x 4 histories it keeps four per wave and wins (6.15 vs 6.70 ms at 8192)
+    const bool small = dtype == DYN_F32 && seip_tiers(m) > 1 && ((seip_tiers(m) + 1) / 2) * per_tier <= 20 &&
+                       (group_width(m->n_age) << m->n_strain) >= 32;
+    const char *force = getenv("DYNODE_HIP_SEIP_TIER_LANES"); // tuning aid: 0 / 1
+    if (two && (!e || (force ? atoi(force) != 0 : (per_lane > 32 || small)))) return two;
+    return e;
+}
+
 static thread_local char tl_error[512] = "";
 
 static int check_model(const dyn_model_desc *m) {
@@ -367,7 +384,10 @@ int32_t dyn_param_dim(const dyn_model_desc *m) {
 int32_t dyn_trajectories_per_wave(const dyn_model_desc *m) {
     if (dyn::check_model(m)) return 0;
     const dyn::Entry *e = dyn::find_entry(m, DYN_F32, DYN_TSIT5, 0);
-    if (m->family == 1) return 64 / (dyn::group_width(m->n_age) << m->n_strain);
+    if (m->family == 1) {
+        e = dyn::select_seip_entry(m, DYN_F32, DYN_TSIT5, e);
+        return e ? 64 / dyn::entry_lanes(e) : 64 / (dyn::group_width(m->n_age) << m->n_strain);
+    }
     const int gs = e ? e->S / e->SPL : 1;
     return 64 / (dyn::group_width(m->n_age) * gs);
 }
@@ -420,21 +440,7 @@ static int solve_impl(const dyn_model_desc *m, const dyn_solver_opts *o, const v
         return DYN_ERR_UNSUPPORTED;
     }
     const dyn::Entry *e = dyn::find_entry(m, o->dtype, o->method, n_dir);
-    if (m->family == 1) {
-        // states that would spill (more than 32 values per lane) run with the tiers dealt over two lanes when that
-        // variant exists and the lane group still fits a wave; it is also the fallback when only it is compiled in
-        dyn::Entry probe{o->dtype, o->method, dyn::group_width(m->n_age), m->n_strain, 1, 1, 1, m->n_wane, 0, 1, 0, nullptr};
-        const dyn::Entry *two = dyn::find_variant(&probe, dyn::kSeip | dyn::kSeipTierLanes | dyn::seip_tiers(m));
-        const int per_tier = m->n_wane + 3 * m->n_strain, per_lane = dyn::seip_tiers(m) * per_tier;
-        // ... and small float states: half the tiers per lane fit 256 registers, so two waves share a SIMD (measured on the
-        // D = 960 shape: 6.5 vs 6.7 ms at 4096 trajectories, 23.3 vs 25.4 ms at 16384)
-        // (only when the one-lane mapping is down to two trajectories per wave: with 4 ages x 4 histories it keeps four per
-        // wave and wins, 6.15 vs 6.70 ms at 8192 trajectories)
-        const bool small = o->dtype == DYN_F32 && dyn::seip_tiers(m) > 1 && ((dyn::seip_tiers(m) + 1) / 2) * per_tier <= 20 &&
-                           (dyn::group_width(m->n_age) << m->n_strain) >= 32;
-        const char *force = getenv("DYNODE_HIP_SEIP_TIER_LANES"); // tuning aid: 0 / 1
-        if (two && (!e || (force ? atoi(force) != 0 : (per_lane > 32 || small)))) e = two;
-    }
+    if (m->family == 1) e = dyn::select_seip_entry(m, o->dtype, o->method, e);
     if (!e && m->family == 1) {
         snprintf(dyn::tl_error, sizeof(dyn::tl_error),
                  "no SEIP kernel compiled for A=%d strains=%d tiers=%d waning states=%d dtype=%d method=%d; to add it "

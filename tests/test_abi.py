@@ -175,3 +175,14 @@ def test_library_links_only_the_hip_runtime():
     names = [line.split()[0] for line in deps.splitlines() if line.strip()]
     assert any("amdhip64" in n for n in names)
     assert not any(bad in n for n in names for bad in ("torch", "c10", "python", "numpy"))
+
+
+def test_trajectories_per_wave_follows_the_seip_lane_mapping():
+    """SEIP: 8 ages x 4 histories is 32 lanes (2 trajectories per wave) with all tiers on one lane; the float kernel
+    that is compiled in deals the tiers over two lanes (64 lanes, 1 per wave).  Three strains x 4 ages: 64 lanes."""
+    lib = _abi.lib()
+    seip = lambda **kw: ModelDesc(has_e=True, has_wane=True, has_c=True, normalize=False, family=1, **kw)
+    assert lib.dyn_trajectories_per_wave(ctypes.byref(seip(n_age=8, n_strain=2, n_wane=4, n_vax_tiers=3).c())) == 1
+    assert lib.dyn_trajectories_per_wave(ctypes.byref(seip(n_age=4, n_strain=2, n_wane=4, n_vax_tiers=3).c())) == 4
+    assert lib.dyn_trajectories_per_wave(ctypes.byref(seip(n_age=4, n_strain=3, n_wane=4, n_vax_tiers=3).c())) == 1
+    assert lib.dyn_trajectories_per_wave(ctypes.byref(seip(n_age=2, n_strain=2, n_wane=2, n_vax_tiers=2).c())) == 8
