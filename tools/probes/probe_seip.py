@@ -9,8 +9,10 @@ from dynode_amd.engine import solve_batch
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 L = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 A = int(sys.argv[3]) if len(sys.argv) > 3 else 8
-wl = synthetic.seip(B, L=L, A=A)
-print(f"shape: {A} ages x {1 << L} histories x 3 tiers x 4 waning states, {L} strains, D = {wl.model.state_dim}; "
+K1 = int(sys.argv[4]) if len(sys.argv) > 4 else 3
+M1 = int(sys.argv[5]) if len(sys.argv) > 5 else 4
+wl = synthetic.seip(B, L=L, A=A, K1=K1, M1=M1)
+print(f"shape: {A} ages x {1 << L} histories x {K1} tiers x {M1} waning states, {L} strains, D = {wl.model.state_dim}; "
       f"DYNODE_HIP_SEIP_TIER_LANES={os.environ.get('DYNODE_HIP_SEIP_TIER_LANES', 'auto')}", flush=True)
 m = wl.model
 a = [torch.as_tensor(x, dtype=torch.float32, device="cuda") for x in (wl.y0, wl.params, wl.contact, wl.save_ts)]
