@@ -586,12 +586,3 @@ seirs_multi_strain_ode = CompartmentalODE(
     multi_strain=True, has_e=True, has_wane=True, has_c=True, seasonal=None,
     doc="Age x strain SEIRS + cumulative incidence: examples/seirs_multi_strain_age_stratified.py:213-243; "
         "seasonal when p.seasonality_params is set (BASELINE cfg 5).")
-
-
-def check_param_fields(p) -> None:
-    """Reject parameter containers with non-array leaves early (clear error instead of a bad pack)."""
-    for f in fields(p):
-        v = getattr(p, f.name)
-        if f.name in ("idx",) or v is None or isinstance(v, SeasonalityParams):
-            continue
-        np.asarray(_np(v))
