@@ -1,22 +1,29 @@
 #!/usr/bin/env python3
 """bench.py -- trajectories/sec of the fused 365-day solve on N MI355X GPUs.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3|cfg2|cfg5|cfg3w8|seip]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3|cfg3d136|cfg2|cfg5|seip|seip3]
+                    [--scaling weak|strong] [--batch B]
 
 A "step" is one pass of the hot path over one batch of synthetic parameter samples: ONE launch
 of the fused Tsit5+RHS kernel integrating B trajectories over 365 days with daily dense output
 (366 rows x D floats per trajectory written to HBM).  Inputs are resident in HBM before the
-timed region.  Default workload = BASELINE.json cfg 3, `seirs_multi_strain_age_stratified`
-(8 age x 4 strain SEIRS, D = 136, 16384 samples per GPU), the configuration the north-star
-target ("365-day SEIRS trajectories/sec ... % of HBM roofline") is quoted on.
+timed region.  Default workload = BASELINE.json cfg 3 AS WORDED, `seirs_multi_strain_age_stratified`
+with 8 age x 4 strain x 8 immunity bins (the Erlang waning chain of SURVEY.md 8d: D = 360),
+16384 samples per GPU.  The same model without the bins axis (the reference's own RHS, D = 136)
+is `--workload cfg3d136`; at N = 1 its roofline is reported as a second block, `roofline_d136`.
 
-N > 1: one process per GPU (torchrun), trajectories sharded in contiguous blocks with
-rank-offset seeds, NO data-path collective (trajectories are independent); a barrier +
-synchronize brackets the timed region and the MAX over ranks is taken.  Weak scaling.
+N > 1: one process per GPU (torchrun), trajectories sharded in contiguous blocks, NO data-path
+collective (trajectories are independent); a barrier + synchronize brackets the timed region and
+the MAX over ranks is taken.  `--scaling weak` (default): B trajectories per GPU, rank-offset
+seeds.  `--scaling strong`: one global batch (`--batch`, default 65536) split by
+`sharding.shard_bounds`.  After the timed region rank 0 re-solves every other rank's shard itself
+and compares status / step-count / output checksums (`config.shards_match_single_process`).
 
 Rank 0 prints ONE JSON line, including
   roofline     : algorithmic HBM bytes per launch / mean kernel duration (HIP events on the
-                 launch stream) against the 8 TB/s HBM3E peak,
+                 launch stream) against the 8 TB/s HBM3E peak, with the name of the kernel instance
+                 that was dispatched (dyn_last_kernel_name) and, when profiles/traffic.json holds a
+                 PMC measurement of that same instance, the measured HBM traffic per launch,
   cpu_baseline : the CPU oracle (oracle/, "port") timed on this host's cores on a bounded sample.
 """
 
@@ -32,6 +39,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy peak ~6290
+SEEDS = {"cfg2": 0, "cfg3": 1, "cfg3d136": 1, "cfg5": 5, "seip": 7, "seip3": 7}
 
 
 def parse():
@@ -39,10 +47,13 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="cfg3", choices=["cfg2", "cfg3", "cfg3w8", "cfg5", "seip", "seip3"])
-    ap.add_argument("--batch", type=int, default=0, help="trajectories per GPU (0 = config default)")
+    ap.add_argument("--workload", default="cfg3", choices=sorted(SEEDS))
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--batch", type=int, default=0,
+                    help="weak: trajectories per GPU (0 = config default); strong: trajectories of the whole job (0 = 65536)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip the short cfg2/cfg5 side measurements (N=1 only)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the side measurements (N=1 only): roofline_d136, cfg2/cfg5/seip, cfg4")
+    ap.add_argument("--no-shard-check", action="store_true", help="N>1: skip rank 0's re-solve of the other ranks' shards")
     ap.add_argument("--cpu-sample", type=int, default=0, help="trajectories in the CPU sample (0 = auto)")
     return ap.parse_args()
 
@@ -102,42 +113,129 @@ def cpu_baseline(wl, sample: int):
     }
 
 
-def nuts_side_measurement(dev, chains=128, warmup=300, samples=300, fused=False):
-    """cfg 4 in short form: NUTS on the 2-age SIR (tf=100, Poisson incidence), 128 chains on this GPU,
-    300 + 300 transitions (BASELINE's cfg 4 runs 1000 + 1000; tools/bench_nuts.py is the full form).
-    Unit of work = one gradient-solve (fused solve + tangents for every chain) per sampler iteration."""
+def nuts_side_measurement(chains=128, warmup=1000, samples=1000, fused=True, adaptation="per_chain"):
+    """cfg 4 at one GPU's share: NUTS on the 2-age SIR (tf=100, Poisson incidence), 1024 / 8 = 128 chains x
+    (1000 warm-up + 1000 draws), tree depth 10, with the KS test of the draws against tensor-grid quadrature of the
+    2-parameter posterior.  Unit of work = one gradient-solve (fused solve + tangents for every chain) per iteration."""
     import torch
 
-    from dynode_amd.infer.inference import MCMCProcess
+    from dynode_amd.infer.inference import MCMCProcess, Potential, ks_against_quadrature
+    from dynode_amd.simulation import odes
     from examples import sir_infer_parameters as ex
 
     data = ex.synthetic_incidence(100)
+    kw = dict(config=ex.get_config(), tf=100, obs_data=data)
     proc = MCMCProcess(numpyro_model=ex.model_fused if fused else ex.model, num_warmup=warmup, num_samples=samples, num_chains=chains,
-                       nuts_max_tree_depth=10, progress_bar=False)
+                       nuts_max_tree_depth=10, progress_bar=False, mcmc_kwargs={"adaptation": adaptation})
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    mcmc = proc.infer(config=ex.get_config(), tf=100, obs_data=data)
+    mcmc = proc.infer(**kw)
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
-    post = proc.get_samples()
-    return {"workload": f"cfg4 sir_infer_parameters: NUTS {chains} chains x ({warmup} warm-up + {samples} draws), tree depth 10"
+    post = proc.get_samples(group_by_chain=True)
+    odes.enable_x64(True)
+    try:
+        pot = Potential(ex.model, kw, 0, torch.device("cuda"))
+        z0 = torch.linspace(-14.0, 14.0, 1001, dtype=torch.float64)
+        z1 = torch.linspace(-6.0, 6.0, 701, dtype=torch.float64)
+        ks = ks_against_quadrature(pot, post, [z0, z1], thin=10)
+    finally:
+        odes.enable_x64(False)
+    return {"workload": f"cfg4 sir_infer_parameters: NUTS {chains} chains (one GPU's share of 1024) x ({warmup} warm-up + {samples} draws), "
+                        f"tree depth 10, warm-up adaptation {adaptation}"
                         + (", Poisson likelihood fused into the solve kernel (examples model_fused)" if fused else ""),
             "seconds": el, "transitions_per_s": chains * (warmup + samples) / el,
             "gradient_solves_per_s": mcmc.nuts.potential_evals / el,
             "chain_gradients_per_s": mcmc.nuts.potential_evals * chains / el,
             "mean_leapfrogs_per_transition": float(mcmc.nuts.num_steps.double().mean()),
             "divergences": int(mcmc.nuts.diverging.sum()),
-            "posterior_mean": {k: float(v.mean()) for k, v in post.items()}}
+            "posterior_vs_quadrature": ks}
+
+
+def kernel_name() -> str:
+    from dynode_amd import _abi
+
+    return _abi.lib().dyn_last_kernel_name().decode()
+
+
+def profiled_traffic(workload: str, B: int, name: str):
+    """HBM bytes per launch from the committed PMC passes (tools/profile.sh), only for the instance that ran."""
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(tpath):
+        return None
+    rec = json.load(open(tpath)).get(f"{workload}:{B}")
+    if rec and rec.get("kernel") == name:
+        return rec["hbm_bytes_per_launch"]
+    return None
+
+
+def measure(wl, dev, steps: int, warmup: int, fence):
+    """Resident inputs, `warmup` untimed launches, then `steps` launches with a HIP event pair around each."""
+    import numpy as np
+    import torch
+
+    from dynode_amd.engine import solve_batch
+
+    m, f32 = wl.model, torch.float32
+    y0 = torch.as_tensor(wl.y0, dtype=f32, device=dev)
+    params = torch.as_tensor(wl.params, dtype=f32, device=dev)
+    contact = torch.as_tensor(wl.contact, dtype=f32, device=dev)
+    ts = torch.as_tensor(wl.save_ts, dtype=f32, device=dev)
+    out = torch.empty((wl.B, wl.n_save, m.state_dim), dtype=f32, device=dev)
+    stats = torch.empty((3, wl.B), dtype=torch.int32, device=dev)
+
+    def step():
+        return solve_batch(m, y0, params, contact, wl.t1, ts, dtype=f32, out=out, stats_out=(stats[0], stats[1], stats[2]))
+
+    for _ in range(warmup):
+        step()
+    fence()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    t0 = time.perf_counter()
+    for e0, e1 in ev:
+        e0.record()
+        step()
+        e1.record()
+    fence()
+    elapsed = time.perf_counter() - t0
+    kern_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev]))
+    return {"elapsed": elapsed, "kernel_ms": kern_ms, "out": out, "stats": stats, "kernel": kernel_name()}
+
+
+def checksums(out, stats):
+    """Order-sensitive integer / float64 digests of one shard's results (bit-exact comparable across GPUs)."""
+    import torch
+
+    idx = torch.arange(1, stats.shape[1] + 1, device=stats.device, dtype=torch.int64)
+    return [int(stats[0].sum()), int((stats[1].long() * idx).sum()), int((stats[2].long() * idx).sum()),
+            float(out.sum(dtype=torch.float64)), float(out[:, -1].abs().sum(dtype=torch.float64))]
+
+
+def roofline_block(wl, workload: str, res):
+    bytes_traj = wl.bytes_per_trajectory(4)
+    achieved = bytes_traj * wl.B / (res["kernel_ms"] * 1e-3) / 1e9  # GB/s per GPU, dominant (only) kernel
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": profiled_traffic(workload, wl.B, res["kernel"]), "kernel": res["kernel"], "kernel_ms": res["kernel_ms"],
+            "algorithmic_bytes_per_trajectory": bytes_traj, "trajectories_per_launch": wl.B}
+
+
+def describe(wl, workload: str) -> str:
+    m = wl.model
+    if m.family == 1:
+        return ("seip (ode_model.md): {0} ages x {2} immune histories x {3} vaccination tiers x {4} waning states, {1} strains, "
+                "D={5}").format(*m.seip_dims[:5], m.state_dim)
+    tag = {"cfg3": " = BASELINE cfg 3 (8 age x 4 strain x 8 immunity bins)",
+           "cfg3d136": " = the cfg 3 model without the immunity-bins axis (reference RHS)",
+           "cfg2": " = BASELINE cfg 2", "cfg5": " = BASELINE cfg 5, one GPU's share"}.get(workload, "")
+    return f"{wl.name} ({workload}{tag}): A={m.n_age} S={m.n_strain} W={m.n_wane} D={m.state_dim}"
 
 
 def main():
     args = parse()
-    import numpy as np
     import torch
     import torch.distributed as dist
 
-    from dynode_amd import synthetic
-    from dynode_amd.engine import solve_batch
+    from dynode_amd import sharding, synthetic
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -159,25 +257,26 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
+    cdev = torch.device("cpu") if rehearsal else dev     # where collectives run
 
-    # ---- synthetic workload: same recipe on every rank, rank-offset seed (weak scaling)
+    # ---- synthetic workload: weak = same recipe on every rank with a rank-offset seed; strong = one global batch
     gen = synthetic.WORKLOADS[args.workload]
-    base = gen()
-    B = args.batch or base.B
-    seed = {"cfg2": 0, "cfg3": 1, "cfg3w8": 1, "cfg5": 5, "seip": 7, "seip3": 7}[args.workload] + 1000 * rank
-    wl = gen(B, seed)
-    m = wl.model
-    f32 = torch.float32
-    y0 = torch.as_tensor(wl.y0, dtype=f32, device=dev)
-    params = torch.as_tensor(wl.params, dtype=f32, device=dev)
-    contact = torch.as_tensor(wl.contact, dtype=f32, device=dev)
-    ts = torch.as_tensor(wl.save_ts, dtype=f32, device=dev)
-    out = torch.empty((B, wl.n_save, m.state_dim), dtype=f32, device=dev)
-    stats = torch.empty((3, B), dtype=torch.int32, device=dev)
+    seed0 = SEEDS[args.workload]
 
-    def step():
-        return solve_batch(m, y0, params, contact, wl.t1, ts, dtype=f32, out=out,
-                           stats_out=(stats[0], stats[1], stats[2]))
+    def shard_of(r: int):
+        if args.scaling == "weak":
+            return gen(args.batch or gen.__defaults__[0], seed0 + 1000 * r)
+        full = gen(args.batch or 65536, seed0)
+        lo, hi = sharding.shard_bounds(full.B, r, world)
+        full.params = full.params[lo:hi]
+        if full.y0.ndim == 2:
+            full.y0 = full.y0[lo:hi]
+        return full
+
+    wl = shard_of(rank)
+    m = wl.model
+    B = wl.B
+    total_per_step = (args.batch or 65536) if args.scaling == "strong" else B * world
 
     def fence():
         torch.cuda.synchronize()
@@ -185,110 +284,89 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    # HIP events on the launch stream (torch's current stream) around every launch
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for e0, e1 in ev:
-        e0.record()
-        step()
-        e1.record()
-    fence()
-    elapsed = time.perf_counter() - t0
-    kern_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev]))
-    ok = int(stats[0].max()) == 0
-    steps_mean = float((stats[1] + stats[2]).float().mean())
+    res = measure(wl, dev, args.steps, args.warmup, fence)
+    elapsed, kern_ms = res["elapsed"], res["kernel_ms"]
+    ok = int(res["stats"][0].max()) == 0
+    steps_mean = float((res["stats"][1] + res["stats"][2]).float().mean())
 
+    shards_match = None
     if world > 1:
-        cdev = torch.device("cpu") if rehearsal else dev
         t = torch.tensor([elapsed, kern_ms], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kern_ms = float(t[0]), float(t[1])
+        res["kernel_ms"] = kern_ms
         okt = torch.tensor([int(ok)], device=cdev)
         dist.all_reduce(okt, op=dist.ReduceOp.MIN)
         ok = bool(okt.item())
+        if not args.no_shard_check:
+            # every rank's digests travel to rank 0, which repeats each shard on its own GPU (outside the timed region)
+            mine = torch.tensor(checksums(res["out"], res["stats"]), dtype=torch.float64, device=cdev)
+            every = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(every, mine)
+            if rank == 0:
+                shards_match = True
+                for r in range(1, world):
+                    del res["out"]
+                    again = measure(shard_of(r), dev, 1, 0, torch.cuda.synchronize)
+                    res["out"] = again["out"]
+                    want = torch.tensor(checksums(again["out"], again["stats"]), dtype=torch.float64)
+                    shards_match = shards_match and bool(torch.equal(want, every[r].cpu()))
 
     if rank == 0:
-        total = B * world * args.steps
-        bytes_traj = wl.bytes_per_trajectory(4)
-        achieved = bytes_traj * B / (kern_ms * 1e-3) / 1e9  # GB/s per GPU, dominant (only) kernel
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            rec = json.load(open(tpath)).get(f"{args.workload}:{B}")
-            if rec:
-                traffic = rec["hbm_bytes_per_launch"]
         line = {
             "metric": "trajectories/sec (365-day solve)",
-            "value": total / elapsed,
+            "value": total_per_step * args.steps / elapsed,
             "unit": "trajectories/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"{wl.name} ({args.workload}): A={m.n_age} S={m.n_strain} W={m.n_wane} D={m.state_dim}, "
-                            f"{B} parameter samples per GPU, 365 days, Tsit5 rtol=1e-5 atol=1e-6, "
-                            f"daily save (n_save={wl.n_save}), all compartments saved",
+                "workload": f"{describe(wl, args.workload)}, "
+                            + (f"{B} parameter samples per GPU" if args.scaling == "weak" else f"{total_per_step} parameter samples split over {world} GPU(s)")
+                            + f", 365 days, Tsit5 rtol=1e-5 atol=1e-6, daily save (n_save={wl.n_save}), all compartments saved",
                 "trajectories_per_gpu": B,
                 "state_dim": m.state_dim,
                 "solver": "tsit5",
                 "mean_steps_per_trajectory": steps_mean,
                 "all_status_ok": ok,
                 "parallelism": f"{world} x independent shards, no data-path collective",
+                "shards_match_single_process": shards_match,
             },
-            "roofline": {
-                "bound": "hbm",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic,
-                "kernel": "dyn::seip_kernel" if m.family == 1 else "dyn::solve_kernel",
-                "kernel_ms": kern_ms,
-                "algorithmic_bytes_per_trajectory": bytes_traj,
-            },
+            "roofline": roofline_block(wl, args.workload, res),
         }
+        del res
         if world == 1 and not args.no_extra and args.workload == "cfg3":
+            torch.cuda.empty_cache()
+            # the same model without the bins axis, as a second full roofline block (20 launches, one event pair each)
+            w2 = synthetic.WORKLOADS["cfg3d136"]()
+            r2 = measure(w2, dev, 20, 3, torch.cuda.synchronize)
+            line["roofline_d136"] = dict(roofline_block(w2, "cfg3d136", r2), workload=describe(w2, "cfg3d136") + f", B={w2.B}",
+                                         trajectories_per_s=w2.B / (r2["kernel_ms"] * 1e-3),
+                                         all_status_ok=int(r2["stats"][0].max()) == 0)
+            del r2
             # the other single-GPU configs of BASELINE.json, 20 launches each (not the headline value)
             line["other_workloads"] = {}
-            for name in ("cfg2", "cfg5", "cfg3w8", "seip", "seip3"):
+            for name in ("cfg2", "cfg5", "seip", "seip3"):
+                torch.cuda.empty_cache()
                 w2 = synthetic.WORKLOADS[name]()
-                a = [torch.as_tensor(x, dtype=f32, device=dev) for x in (w2.y0, w2.params, w2.contact, w2.save_ts)]
-                o2 = torch.empty((w2.B, w2.n_save, w2.model.state_dim), dtype=f32, device=dev)
-                st2 = torch.empty((3, w2.B), dtype=torch.int32, device=dev)
-                run = lambda: solve_batch(w2.model, a[0], a[1], a[2], w2.t1, a[3], dtype=f32, out=o2,
-                                          stats_out=(st2[0], st2[1], st2[2]))
-                for _ in range(3):
-                    run()
-                torch.cuda.synchronize()
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                for _ in range(20):
-                    run()
-                e1.record()
-                torch.cuda.synchronize()
-                ms = e0.elapsed_time(e1) / 20
-                gbs = w2.bytes_per_trajectory(4) * w2.B / (ms * 1e-3) / 1e9
+                r2 = measure(w2, dev, 20, 3, torch.cuda.synchronize)
+                blk = roofline_block(w2, name, r2)
                 line["other_workloads"][name] = {
-                    "workload": (f"{w2.name}: A={w2.model.n_age} S={w2.model.n_strain} W={w2.model.n_wane} D={w2.model.state_dim}, B={w2.B}"
-                                 if w2.model.family == 0 else
-                                 "seip (ode_model.md): {0} ages x {2} immune histories x {3} vaccination tiers x {4} waning states, "
-                                 "{1} strains, D={5}, B={6}".format(*w2.model.seip_dims[:5], w2.model.state_dim, w2.B)),
-                    "trajectories_per_s": w2.B / (ms * 1e-3), "ms_per_launch": ms, "hbm_frac": gbs / HBM_PEAK_GBS,
-                    "all_status_ok": int(st2[0].max()) == 0}
-                del o2
-            line["other_workloads"]["cfg4"] = nuts_side_measurement(dev)
-            line["other_workloads"]["cfg4_fused_likelihood"] = nuts_side_measurement(dev, fused=True)
+                    "workload": describe(w2, name) + f", B={w2.B}", "trajectories_per_s": w2.B / (r2["kernel_ms"] * 1e-3),
+                    "ms_per_launch": r2["kernel_ms"], "hbm_frac": blk["frac"], "kernel": blk["kernel"],
+                    "all_status_ok": int(r2["stats"][0].max()) == 0}
+                del r2
+            torch.cuda.empty_cache()
+            line["other_workloads"]["cfg4"] = nuts_side_measurement()                       # numpyro's per-chain adaptation
+            line["other_workloads"]["cfg4_pooled_adaptation"] = nuts_side_measurement(adaptation="pooled")
         if world == 1 and not args.no_cpu_baseline:
-            sample = args.cpu_sample or (1024 if m.family == 1 else 16384 if m.state_dim >= 100 else 65536)
+            sample = args.cpu_sample or (1024 if m.family == 1 else 8192 if m.state_dim >= 300 else 16384 if m.state_dim >= 100 else 65536)
             line["cpu_baseline"] = cpu_baseline(wl, min(sample, B))
         print(json.dumps(line), flush=True)
     if world > 1:

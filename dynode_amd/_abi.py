@@ -29,7 +29,7 @@ EXPORTED_SYMBOLS = (
     "dyn_compartment_offsets", "dyn_is_supported", "dyn_trajectories_per_wave",
     "dyn_last_error", "dyn_solve_batch", "dyn_solve_batch_jvp", "dyn_is_supported_jvp",
     "dyn_nuts_advance", "dyn_nuts_state_size", "dyn_philox4x32_10", "dyn_latent_sites",
-    "dyn_solve_batch_loglik", "dyn_register_instance",
+    "dyn_solve_batch_loglik", "dyn_register_instance", "dyn_last_kernel_name",
 )
 
 MAX_SITES = 8
@@ -179,6 +179,8 @@ def lib() -> ctypes.CDLL:
         L.dyn_is_supported.argtypes = [pm, po]
         L.dyn_is_supported.restype = ctypes.c_int32
         L.dyn_last_error.restype = ctypes.c_char_p
+        L.dyn_last_kernel_name.restype = ctypes.c_char_p
+        L.dyn_last_kernel_name.argtypes = []
         L.dyn_solve_batch.restype = ctypes.c_int
         L.dyn_solve_batch.argtypes = [
             pm, po, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,

@@ -172,6 +172,23 @@ static const Entry *select_seip_entry(const dyn_model_desc *m, int dtype, int me
 }
 
 static thread_local char tl_error[512] = "";
+static thread_local char tl_kernel[160] = "";
+
+// the instance an entry launches, in rocprofv3's spelling (dyn_last_kernel_name)
+static void note_kernel(const Entry *e) {
+    const char *t = e->dtype == DYN_F64 ? "double" : "float";
+    if (e->FEAT & kSeip) {
+        const int k1 = e->FEAT & 0x1f, kt = (e->FEAT & kSeipTierLanes) ? 2 : 1;
+        const int nv = ((k1 + kt - 1) / kt) * (e->W + 3 * e->S);
+        snprintf(tl_kernel, sizeof(tl_kernel), "dyn::%s<%s, %d, %d, %d, %d, %d, %d>",
+                 (e->dtype == DYN_F32 && nv <= 20) ? "seip_kernel_two_waves" : "seip_kernel", t, e->method, e->G, e->S, k1,
+                 e->W, kt);
+        return;
+    }
+    snprintf(tl_kernel, sizeof(tl_kernel), "dyn::solve_kernel<%s, %d, %d, %d, %s, %s, %s, %d, %d, %d, %d>", t, e->method,
+             e->G, e->S, e->E ? "true" : "false", e->WN ? "true" : "false", e->C ? "true" : "false", e->W, e->ND, e->SPL,
+             e->FEAT);
+}
 
 static int check_model(const dyn_model_desc *m) {
     if (!m) return DYN_ERR_NULL;
@@ -322,6 +339,7 @@ static int enqueue(const Entry *e, const dyn_model_desc *m, const dyn_solver_opt
         snprintf(tl_error, sizeof(tl_error), "kernel launch failed: %s", hipGetErrorString(err));
         return DYN_ERR_LAUNCH;
     }
+    note_kernel(e);
     return 0;
 }
 
@@ -402,6 +420,7 @@ int32_t dyn_is_supported(const dyn_model_desc *m, const dyn_solver_opts *o) {
 }
 
 const char *dyn_last_error(void) { return dyn::tl_error; }
+const char *dyn_last_kernel_name(void) { return dyn::tl_kernel; }
 
 static int solve_impl(const dyn_model_desc *m, const dyn_solver_opts *o, const void *y0,
                       int32_t y0_is_batched, const void *params, const void *contact, int64_t B,

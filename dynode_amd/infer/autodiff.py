@@ -6,7 +6,9 @@ src/dynode/infer/inference.py:149-163).  Here the kernel itself returns the Jaco
 trajectory with respect to the P entries of the parameter vector (forward mode, identity seeds,
 ``dyn_solve_batch_jvp``); the backward pass is one contraction with the incoming cotangent, so any
 torch code around ``simulate`` -- ``get_odeparams`` arithmetic, ``diff``/``clamp``, the Poisson
-log-likelihood -- is differentiated by torch autograd.
+log-likelihood -- is differentiated by torch autograd.  An initial state that itself depends on a latent
+site (a sampled initial-infection scale) is differentiated the same way: its D entries join the P parameters
+as extra columns and are seeded through the kernel's ``dy0`` planes (`_joined`).
 """
 
 from __future__ import annotations
@@ -102,20 +104,39 @@ def _latent_seeds(params: torch.Tensor, leaf: torch.Tensor, dtype) -> torch.Tens
     return rows.permute(1, 2, 0).to(dtype).contiguous()          # [P, B, D] -> [B, D, P]
 
 
+def _split_joined(model, q: torch.Tensor, seeds: torch.Tensor, y0, dtype):
+    """``q`` = [params | y0] when the initial state carries an autograd graph (`_joined`), else the parameter
+    matrix alone: -> (params, y0, dparams seeds, dy0 seeds or None) for one tangent solve."""
+    P = model.param_dim
+    if q.shape[1] == P:
+        return q.to(dtype), y0, seeds, None
+    return q[:, :P].to(dtype).contiguous(), q[:, P:].to(dtype).contiguous(), seeds[:, :, :P], seeds[:, :, P:]
+
+
+def _joined(params: torch.Tensor, y0) -> torch.Tensor:
+    """[params | y0] per trajectory when ``y0`` is a tensor that requires grad (a compartment computed from a latent
+    site): the initial state is then differentiated like P + D more parameters, through the kernel's dy0 planes."""
+    if not (isinstance(y0, torch.Tensor) and y0.requires_grad):
+        return params
+    y0b = y0 if y0.dim() == 2 else y0.unsqueeze(0).expand(params.shape[0], y0.shape[0])
+    return torch.cat([params, y0b.to(device=params.device, dtype=params.dtype)], dim=1)
+
+
 class _DiffSolveLatent(torch.autograd.Function):
     """`_DiffSolve` differentiated along the sampler's D latent coordinates instead of the P ODE
-    parameters: ``seeds`` [B, D, P] = d params / d z; the gradient is returned to ``leaf`` directly."""
+    parameters: ``seeds`` [B, D, P (+ state)] = d [params | y0] / d z; the gradient is returned to ``leaf`` directly."""
 
     @staticmethod
     def forward(ctx, leaf, params, seeds, model, y0, contact, t1, save_ts, kw):
         dtype = kw.get("dtype", torch.float32)
         method = kw.get("method", "tsit5")
         D = seeds.shape[1]
-        pk = params.to(dtype)
+        pk, y0, dps, dys = _split_joined(model, params, seeds, y0, dtype)
         ctx.set_materialize_grads(False)
         jac, res, start = [], None, 0
         for n in direction_chunks(model, method, dtype, D):
-            res = solve_batch(model, y0, pk, contact, t1, save_ts, dparams=seeds[:, start:start + n].contiguous(), **kw)
+            res = solve_batch(model, y0, pk, contact, t1, save_ts, dparams=dps[:, start:start + n].contiguous(),
+                              dy0=None if dys is None else dys[:, start:start + n].contiguous(), **kw)
             jac.append(res.dys)
             start += n
         J = jac[0] if len(jac) == 1 else torch.cat(jac, dim=2)     # [B, n_save, D, D_saved]
@@ -141,12 +162,13 @@ class _DiffLogLikLatent(torch.autograd.Function):
         dtype = kw.get("dtype", torch.float32)
         method = kw.get("method", "tsit5")
         D = seeds.shape[1]
-        pk = params.to(dtype)
+        pk, y0, dps, dys = _split_joined(model, params, seeds, y0, dtype)
         ctx.set_materialize_grads(False)
         grads, logp, stats, start = [], None, None, 0
         for n in direction_chunks(model, method, dtype, D):
             lp, dlp, st, na, nr = solve_batch_loglik(model, y0, pk, contact, t1, save_ts, obs, comp,
-                                                     dparams=seeds[:, start:start + n].contiguous(),
+                                                     dparams=dps[:, start:start + n].contiguous(),
+                                                     dy0=None if dys is None else dys[:, start:start + n].contiguous(),
                                                      increments=increments, floor=floor, **kw)
             logp = lp if logp is None else logp
             stats = (st, na, nr)
@@ -171,13 +193,13 @@ class _DiffSolve(torch.autograd.Function):
     def forward(ctx, params, model, y0, contact, t1, save_ts, kw):
         dtype = kw.get("dtype", torch.float32)
         method = kw.get("method", "tsit5")
-        B, P = params.shape
-        pk = params.detach().to(dtype)
+        B, P = params.shape             # P counts the state columns too when `params` is [params | y0] (`_joined`)
         ctx.set_materialize_grads(False)          # no zero tensors for the integer outputs' "gradients"
         jac, res, start = [], None, 0
         for n in direction_chunks(model, method, dtype, P):
-            seeds = _identity_seeds(B, P, start, n, dtype, params.device)
-            res = solve_batch(model, y0, pk, contact, t1, save_ts, dparams=seeds, **kw)
+            pk, y0_n, dps, dys = _split_joined(model, params.detach(), _identity_seeds(B, P, start, n, dtype, params.device), y0, dtype)
+            res = solve_batch(model, y0_n, pk, contact, t1, save_ts, dparams=dps.contiguous(),
+                              dy0=None if dys is None else dys.contiguous(), **kw)
             jac.append(res.dys)
             start += n
         J = jac[0] if len(jac) == 1 else torch.cat(jac, dim=2)     # [B, n_save, P, D_saved]
@@ -200,6 +222,8 @@ def solve_batch_diff(model, y0, params: torch.Tensor, contact, t1, save_ts, **kw
     """Like ``engine.solve_batch`` but differentiable with respect to ``params`` ([B, P] tensor)."""
     from ..engine import BatchResult, save_mask_bytes
 
+    params = _joined(params, y0)          # [params | y0] when the initial state carries a graph of its own
+    y0 = y0.detach() if isinstance(y0, torch.Tensor) else y0
     leaf = _rowwise_leaf(params)
     if leaf is not None:      # D latent coordinates < P parameters: D tangent directions are enough
         seeds = _latent_seeds(params, leaf, kw.get("dtype", torch.float32))
@@ -219,12 +243,12 @@ class _DiffLogLik(torch.autograd.Function):
         dtype = kw.get("dtype", torch.float32)
         method = kw.get("method", "tsit5")
         B, P = params.shape
-        pk = params.detach().to(dtype)
         ctx.set_materialize_grads(False)
         grads, logp, stats, start = [], None, None, 0
         for n in direction_chunks(model, method, dtype, P):
-            seeds = _identity_seeds(B, P, start, n, dtype, params.device)
-            lp, dlp, st, na, nr = solve_batch_loglik(model, y0, pk, contact, t1, save_ts, obs, comp, dparams=seeds,
+            pk, y0_n, dps, dys = _split_joined(model, params.detach(), _identity_seeds(B, P, start, n, dtype, params.device), y0, dtype)
+            lp, dlp, st, na, nr = solve_batch_loglik(model, y0_n, pk, contact, t1, save_ts, obs, comp, dparams=dps.contiguous(),
+                                                     dy0=None if dys is None else dys.contiguous(),
                                                      increments=increments, floor=floor, **kw)
             logp = lp if logp is None else logp
             stats = (st, na, nr)
@@ -247,6 +271,8 @@ class _DiffLogLik(torch.autograd.Function):
 def solve_loglik_diff(model, y0, params: torch.Tensor, contact, t1, save_ts, obs, obs_compartment: int, *,
                       increments: bool = True, floor: float = 1e-6, **kw):
     """``(logp [B], status, n_accept, n_reject)``, differentiable with respect to ``params``."""
+    params = _joined(params, y0)
+    y0 = y0.detach() if isinstance(y0, torch.Tensor) else y0
     leaf = _rowwise_leaf(params)
     if leaf is not None:
         seeds = _latent_seeds(params, leaf, kw.get("dtype", torch.float32))

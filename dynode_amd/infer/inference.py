@@ -322,15 +322,28 @@ class MCMCProcess(InferenceProcess):
     chains with a rank-offset seed; ``get_samples(gather=True)`` collects them on rank 0 over
     RCCL -- the only collective of the inference path.
 
-    ``mcmc_kwargs`` (the reference forwards them to numpyro's ``MCMC``; here they select the machinery):
+    The reference forwards ``nuts_kwargs`` to ``numpyro.infer.NUTS`` and ``mcmc_kwargs`` to ``numpyro.infer.MCMC``
+    verbatim (reference inference.py:127-131,149-162).  Here every key is either honoured or refused -- nothing is
+    dropped silently (`_check_kwargs`):
 
-    ``sampler``      ``"kernel"`` (default: sampler iteration as one HIP kernel, whole iteration replayed as a HIP graph),
-                     ``"graph"`` / ``"eager"`` (torch-op sampler step, replayed / op by op), ``"ensemble"`` (gradient-free
-                     stretch moves, ``infer/ensemble.py``; ``stretch``, ``thin``)
-    ``adaptation``   ``"pooled"`` (default: mass-matrix windows merged over the chains of this GPU) or ``"per_chain"`` (numpyro)
-    ``gradient``     ``"autograd"`` (default: tangent kernels + autograd) or ``"finite_difference"`` (central differences of the
-                     log density, ``fd_step``; for models without tangent kernels, with a constant solver step)
-    ``nuts_kwargs``: ``target_accept_prob`` (0.8), ``step_size`` (1.0).
+    ``nuts_kwargs``  ``target_accept_prob`` (0.8), ``step_size`` (1.0); ``adapt_step_size`` / ``adapt_mass_matrix`` /
+                     ``regularize_mass_matrix`` / ``find_heuristic_step_size`` only at numpyro's defaults (True, True,
+                     True, False: what the sampler kernels implement); ``forward_mode_differentiation`` either way (the
+                     gradient-solve IS forward mode; the value is the same).  ``dense_mass``, ``max_tree_depth`` and
+                     ``init_strategy`` raise ``TypeError`` exactly as in the reference, whose ``NUTS(...)`` call passes
+                     them itself ("got multiple values for keyword argument").
+    ``mcmc_kwargs``  numpyro's: ``chain_method`` ("parallel" | "vectorized" | "sequential": the chains of a rank always
+                     advance together in one batch, which is what all three produce draw for draw), ``thinning``
+                     (keep every n-th draw), ``jit_model_args`` (ignored: nothing is traced per argument),
+                     ``postprocess_fn`` refused.  This build's own switches:
+                     ``sampler``    ``"kernel"`` (default: sampler iteration as one HIP kernel, whole iteration replayed as a
+                                    HIP graph), ``"graph"`` / ``"eager"`` (torch-op sampler step, replayed / op by op),
+                                    ``"ensemble"`` (gradient-free stretch moves, ``infer/ensemble.py``; ``stretch``, ``thin``)
+                     ``adaptation`` ``"per_chain"`` (default, numpyro's behaviour: every chain adapts its own mass matrix
+                                    and step size) or ``"pooled"`` (opt-in: window statistics merged over the chains of
+                                    this GPU -- shorter warm-up tails for many chains, not what numpyro does)
+                     ``gradient``   ``"autograd"`` (default: tangent kernels + autograd) or ``"finite_difference"``
+                                    (``fd_step``; for models without tangent kernels, with a constant solver step)
     """
 
     num_samples: PositiveInt
@@ -342,9 +355,48 @@ class MCMCProcess(InferenceProcess):
     nuts_kwargs: dict = Field(default_factory=dict)
     progress_bar: bool = True
 
+    _NUTS_FIXED = {"adapt_step_size": True, "adapt_mass_matrix": True, "regularize_mass_matrix": True,
+                   "find_heuristic_step_size": False}
+    _MCMC_OWN = ("sampler", "adaptation", "gradient", "fd_step", "stretch", "thin", "hip_graph")
+
+    def _check_kwargs(self) -> int:
+        """Every key of ``nuts_kwargs`` / ``mcmc_kwargs`` is honoured or refused; returns the thinning factor."""
+        for k, v in self.nuts_kwargs.items():
+            if k in ("dense_mass", "max_tree_depth", "init_strategy"):
+                # the reference's NUTS(model, dense_mass=True, max_tree_depth=..., init_strategy=..., **nuts_kwargs)
+                raise TypeError(f"NUTS() got multiple values for keyword argument '{k}'")
+            if k in ("target_accept_prob", "step_size", "forward_mode_differentiation"):
+                continue
+            if k in self._NUTS_FIXED:
+                if bool(v) != self._NUTS_FIXED[k]:
+                    raise NotImplementedError(f"nuts_kwargs[{k!r}] = {v!r}: the sampler kernels implement numpyro's default "
+                                              f"({self._NUTS_FIXED[k]}) only")
+                continue
+            raise TypeError(f"nuts_kwargs: unsupported NUTS argument {k!r} (supported: target_accept_prob, step_size, "
+                            f"forward_mode_differentiation, {', '.join(self._NUTS_FIXED)})")
+        thinning = 1
+        for k, v in self.mcmc_kwargs.items():
+            if k in self._MCMC_OWN or k == "jit_model_args":
+                continue
+            if k == "chain_method":
+                if v not in ("parallel", "vectorized", "sequential"):
+                    raise ValueError(f"mcmc_kwargs['chain_method'] = {v!r}: only 'parallel', 'sequential' or 'vectorized' are supported")
+                continue
+            if k == "thinning":
+                thinning = int(v)
+                if thinning < 1 or self.num_samples % thinning:
+                    raise ValueError("mcmc_kwargs['thinning'] must be a positive divisor of num_samples")
+                continue
+            if k in ("num_warmup", "num_samples", "num_chains", "progress_bar"):
+                raise TypeError(f"MCMC() got multiple values for keyword argument '{k}'")
+            raise TypeError(f"mcmc_kwargs: unsupported MCMC argument {k!r} (supported: chain_method, thinning, jit_model_args, "
+                            f"{', '.join(self._MCMC_OWN)})")
+        return thinning
+
     def infer(self, **kwargs) -> MCMCResult:
         from ..engine import require_gpu
 
+        thinning = self._check_kwargs()
         device = require_gpu()
         rank, world = sharding.world()
         lo, hi = sharding.shard_bounds(self.num_chains, rank, world)
@@ -353,8 +405,8 @@ class MCMCProcess(InferenceProcess):
         z0 = pot.initial(self.num_chains, self.nuts_init_strategy, self.inference_prngkey)[lo:hi]
         # default ("kernel"): an iteration = the potential (model, fused gradient-solve kernel,
         # autograd) + ONE hand-written sampler kernel (dyn_nuts_advance), captured as a HIP graph.
-        # Mass-matrix windows are pooled over the chains of this GPU by default
-        # (mcmc_kwargs={"adaptation": "per_chain"} gives numpyro's chain-by-chain adaptation).
+        # Chains adapt one by one as in numpyro; mcmc_kwargs={"adaptation": "pooled"} merges the mass-matrix
+        # windows over the chains of this GPU instead.
         # mcmc_kwargs={"sampler": "graph"} replays the torch-op sampler step instead,
         # {"sampler": "eager"} (or the older {"hip_graph": False}) runs it op by op.
         kind = self.mcmc_kwargs.get("sampler", "kernel" if self.mcmc_kwargs.get("hip_graph", True) else "eager")
@@ -379,7 +431,7 @@ class MCMCProcess(InferenceProcess):
         if kind == "kernel" and (pot.dim > 8 or self.nuts_max_tree_depth > 10):
             kind = "graph"
         cls = {"kernel": KernelNUTS, "graph": GraphNUTS, "eager": BatchedNUTS}[kind]
-        extra = {"adaptation": self.mcmc_kwargs.get("adaptation", "pooled")} if kind == "kernel" else {}
+        extra = {"adaptation": self.mcmc_kwargs.get("adaptation", "per_chain")} if kind == "kernel" else {}
         pg = pot.potential_and_grad
         if self.mcmc_kwargs.get("gradient", "autograd") == "finite_difference":
             # NUTS for models without tangent kernels: central differences over the latent coordinates (Potential above)
@@ -398,6 +450,10 @@ class MCMCProcess(InferenceProcess):
 
         res = sampler.run(z0, self.num_warmup, self.num_samples,
                           init_step_size=self.nuts_kwargs.get("step_size", 1.0), progress=progress)
+        if thinning > 1:   # numpyro keeps the draws whose (1-based) index is a multiple of `thinning`
+            keep = slice(thinning - 1, None, thinning)
+            res.samples, res.accept_prob = res.samples[:, keep].contiguous(), res.accept_prob[:, keep].contiguous()
+            res.num_steps, res.diverging = res.num_steps[:, keep].contiguous(), res.diverging[:, keep].contiguous()
         out = MCMCResult(pot, res, local)
         self._inference_complete, self._inferer, self._inference_state = True, out, out.last_state
         self._inferer_kwargs = kwargs
@@ -478,6 +534,30 @@ def marginal_cdfs_by_quadrature(potential: Potential, z_grids: list) -> list:
         marginal = p.sum(other) if other else p
         cdf = torch.cumsum(marginal, 0) - 0.5 * marginal            # midpoint rule
         out.append((bij(grid.to(torch.float64)).cpu().numpy(), cdf.numpy(), marginal.numpy()))
+    return out
+
+
+def ks_against_quadrature(potential: Potential, draws: dict, z_grids: list, thin: int = 20) -> dict:
+    """Kolmogorov-Smirnov test of every latent site's draws (``[chains, draws]``, thinned by ``thin`` along the draws
+    axis to decorrelate them) against the marginal CDF from :func:`marginal_cdfs_by_quadrature`, with the moments of
+    both: ``{site: {"ks_p", "ks_stat", "n", "mean", "sd", "quad_mean", "quad_sd", "mean_z"}}`` where ``mean_z`` is
+    the error of the sample mean in Monte-Carlo standard errors (sd / sqrt(effective sample size))."""
+    import numpy as np
+    from scipy import stats
+
+    from .diagnostics import effective_sample_size
+
+    out = {}
+    for (name, v), (grid, cdf, pmf) in zip(((n, draws[n]) for n in potential.bij), marginal_cdfs_by_quadrature(potential, z_grids)):
+        x = v.detach().cpu().numpy().astype(np.float64)
+        thinned = x[:, ::thin].reshape(-1)
+        res = stats.kstest(thinned, lambda q: np.interp(q, grid, cdf))
+        qm = float((grid * pmf).sum())
+        qs = float(np.sqrt((((grid - qm) ** 2) * pmf).sum()))
+        ess = effective_sample_size(x)
+        out[name] = {"ks_p": float(res.pvalue), "ks_stat": float(res.statistic), "n": int(thinned.size), "mean": float(x.mean()),
+                     "sd": float(x.std()), "quad_mean": qm, "quad_sd": qs, "ess": float(ess),
+                     "mean_z": float((x.mean() - qm) / (qs / np.sqrt(max(ess, 1.0))))}
     return out
 
 

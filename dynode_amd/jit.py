@@ -94,10 +94,16 @@ def _stamp() -> str:
     global _STAMP
     if _STAMP is None:
         h = hashlib.sha1()
-        for f in sorted(os.listdir(_CSRC)):
-            if f.endswith((".hpp", ".h")):
-                with open(os.path.join(_CSRC, f), "rb") as fh:
+        files = [os.path.join(_CSRC, f) for f in sorted(os.listdir(_CSRC)) if f.endswith((".hpp", ".h"))]
+        files.append(os.path.join(os.path.dirname(os.path.dirname(_CSRC)), "include", "dynode_hip.h"))   # the argument structs
+        for path in files:
+            if os.path.exists(path):
+                with open(path, "rb") as fh:
                     h.update(fh.read())
+        try:   # another compiler, another code object
+            h.update(subprocess.run([HIPCC, "--version"], capture_output=True, timeout=60).stdout)
+        except (OSError, subprocess.SubprocessError):
+            pass
         _STAMP = h.hexdigest()[:10]
     return _STAMP
 
@@ -148,14 +154,31 @@ def ensure_kernel(model: _abi.ModelDesc, dtype=torch.float32, method: str = "tsi
             if not os.path.exists(HIPCC):
                 raise RuntimeError(f"{HIPCC} not found: cannot build the kernel for {model}; add it to csrc/instances.def "
                                    "on a machine with ROCm and rebuild")
-            src = os.path.join(_OUT, name + ".hip")
-            with open(src, "w") as f:
-                f.write(_source(model, dtype, mid, n_dir, spl))
-            tmp = so + f".{os.getpid()}.tmp"
-            print(f"[dynode_amd] building the kernel for {name} (one-off, ~15 s) ...", file=sys.stderr, flush=True)
-            subprocess.run([HIPCC, "-O3", "-std=c++17", "-fPIC", "-shared", "--offload-arch=gfx950", src, "-o", tmp],
-                           check=True)
-            os.replace(tmp, so)            # atomic: concurrent ranks never load a half-written file
+            # one builder per shape across processes (torchrun ranks miss the same shape at the same moment): the others
+            # wait on the lock file and then find the finished library
+            import fcntl
+
+            with open(os.path.join(_OUT, name + ".lock"), "w") as lock:
+                fcntl.flock(lock, fcntl.LOCK_EX)
+                try:
+                    if not os.path.exists(so):
+                        tag = f"{name}.{os.getpid()}"
+                        src, tmp = os.path.join(_OUT, tag + ".hip"), os.path.join(_OUT, tag + ".tmp.so")
+                        with open(src, "w") as f:          # a source file of this process's own: never rewritten under a reader
+                            f.write(_source(model, dtype, mid, n_dir, spl))
+                        print(f"[dynode_amd] building the kernel for {name} (one-off, ~15 s) ...", file=sys.stderr, flush=True)
+                        try:
+                            subprocess.run([HIPCC, "-O3", "-std=c++17", "-fPIC", "-shared", "--offload-arch=gfx950", src, "-o", tmp],
+                                           check=True)
+                            probe = ctypes.CDLL(tmp)           # refuse to publish a library without its entry point
+                            probe.dyn_extra_launch
+                            os.replace(tmp, so)                # atomic: nobody ever loads a half-written file
+                        finally:
+                            for leftover in (src, tmp):
+                                if os.path.exists(leftover):
+                                    os.remove(leftover)
+                finally:
+                    fcntl.flock(lock, fcntl.LOCK_UN)
         extra = ctypes.CDLL(so)
         extra.dyn_extra_launch.restype = ctypes.c_void_p
         rc = L.dyn_register_instance(opts.dtype, mid, _group_width(model.n_age), model.n_strain, int(model.has_e),

@@ -320,6 +320,27 @@ class CompartmentalODE:
             leaves += [intro.time, intro.scale, intro.percentage]
         return any(isinstance(v, torch.Tensor) and v.requires_grad for v in leaves)
 
+    @staticmethod
+    def state_wants_grad(initial_state) -> bool:
+        return any(isinstance(c, torch.Tensor) and c.requires_grad for c in initial_state)
+
+    def state_tensor(self, initial_state, packed: "Packed", device) -> "torch.Tensor":
+        """The flat initial state ``[D]`` / ``[B, D]`` in `pack`'s layout, built with torch ops so that compartments
+        computed from a latent site (a sampled initial-infection scale, say) keep their autograd graph; the
+        differentiable solve seeds the kernel's ``dy0`` planes from it (infer/autodiff.py)."""
+        if packed.tiers is not None or packed.history_perm is not None:
+            raise NotImplementedError(f"{self.__name__}: gradients with respect to the initial state are available for models "
+                                      "without vaccination tiers / immune histories; detach the initial state")
+        f64 = torch.float64
+        flat = []
+        for a, shape in zip(initial_state, packed.shapes):
+            t = a.to(device=device, dtype=f64) if isinstance(a, torch.Tensor) else torch.as_tensor(np.asarray(a, dtype=np.float64), device=device)
+            flat.append(t.reshape(-1) if tuple(t.shape) == tuple(shape) else t.reshape(t.shape[0], -1))
+        if any(f.dim() == 2 for f in flat):
+            B = max(f.shape[0] for f in flat if f.dim() == 2)
+            return torch.cat([f if f.dim() == 2 else f.unsqueeze(0).expand(B, f.shape[0]) for f in flat], dim=1)
+        return torch.cat(flat)
+
     def _contact(self, p, A: int, contact_shape: tuple) -> np.ndarray:
         C = getattr(p, "contact_matrix", None)
         if C is None:

@@ -131,7 +131,11 @@ class SEIPODE(CompartmentalODE):
             masks_intro = self._intro_masks(p, A, L)
         seas = p.seasonality_params
         if seas is not None:
-            cols += [np.full((B, 1), float(_np(getattr(seas, n)).reshape(-1)[0])) for n in ("forcing_amp", "forcing_phase", "forcing_period")]
+            for n in ("forcing_amp", "forcing_phase", "forcing_period"):      # a scalar, or one value per trajectory
+                a = _np(getattr(seas, n)).reshape(-1)
+                if a.size not in (1, B):
+                    raise ValueError(f"seasonality_params.{n} has {a.size} values; expected a scalar or one per trajectory ({B})")
+                cols.append(np.broadcast_to(a.reshape(-1, 1), (B, 1)))
         if p.seasonal_vaccination_tau is not None:
             cols.append(np.full((B, 1), float(p.seasonal_vaccination_tau)))
         pop = (s.sum((1, 2, 3)) + e.sum((1, 2, 3)) + i.sum((1, 2, 3))) if p.population is None else _np(p.population)

@@ -114,13 +114,23 @@ def build_saveat(start: float, stop, step: int = 1,
 _OBS_CACHE: dict = {}
 
 
+def _observation_key(data):
+    """Cache key that changes when the observations do: a tensor's storage pointer and in-place version counter,
+    a numpy array's bytes (observation tables are small: time x groups)."""
+    if isinstance(data, torch.Tensor):
+        return ("t", data.data_ptr(), data._version, tuple(data.shape), str(data.dtype), str(data.device))
+    arr = np.ascontiguousarray(np.asarray(data))
+    return ("n", arr.dtype.str, arr.shape, arr.tobytes())
+
+
 def _observation_constants(data, dtype, device, pad_tiers=None):
-    """(observations as a flat device tensor of the solve dtype, sum lgamma(data + 1)); cached per data object.
+    """(observations as a flat device tensor of the solve dtype, sum lgamma(data + 1)); cached by CONTENT (see
+    `_observation_key`), so a caller that refills one buffer with the next data set is scored on the new values.
     ``pad_tiers`` = (tiers, slots): vaccinated models keep 2 or 4 tier slots per age on the kernel's contact axis
     (axis 2 of the observation array, after time and age); the extra slots are filled with zeros."""
-    key = (id(data), dtype, str(device), pad_tiers)
+    key = (_observation_key(data), dtype, str(device), pad_tiers)
     hit = _OBS_CACHE.get(key)
-    if hit is None or hit[0] is not data:
+    if hit is None:
         if len(_OBS_CACHE) > 16:
             _OBS_CACHE.clear()
         t = data.detach() if isinstance(data, torch.Tensor) else torch.as_tensor(np.asarray(data))
@@ -131,12 +141,12 @@ def _observation_constants(data, dtype, device, pad_tiers=None):
             extra = list(t64.shape)
             extra[2] = pad_tiers[1] - pad_tiers[0]
             t64 = torch.cat([t64, t64.new_zeros(extra)], dim=2)
-        hit = (data, t64.to(dtype).contiguous(), lg, shape)
+        hit = (t64.to(dtype).contiguous(), lg, shape)
         _OBS_CACHE[key] = hit
-    return hit[1], hit[2], hit[3]
+    return hit
 
 
-def _simulate_observed(ode, ode_parameters, packed, saveat, t1, kw, observe, differentiable, sp, n_comp):
+def _simulate_observed(ode, ode_parameters, packed, saveat, t1, kw, observe, differentiable, sp, n_comp, y0_arg=None):
     from ..engine import require_gpu
     from ..infer.autodiff import solve_loglik_diff
 
@@ -161,7 +171,7 @@ def _simulate_observed(ode, ode_parameters, packed, saveat, t1, kw, observe, dif
         params_t = ode.param_tensor(ode_parameters, device)
     else:
         params_t = torch.as_tensor(packed.params, dtype=torch.float64, device=device)
-    lp, status, n_acc, n_rej = solve_loglik_diff(packed.model, packed.y0, params_t, packed.contact, t1, saveat.ts, obs_t,
+    lp, status, n_acc, n_rej = solve_loglik_diff(packed.model, packed.y0 if y0_arg is None else y0_arg, params_t, packed.contact, t1, saveat.ts, obs_t,
                                                  comp, increments=observe.increments, floor=observe.floor, **kw)
     lp = lp - const
     batched = packed.batch is not None
@@ -199,7 +209,9 @@ def simulate(ode, duration_days, initial_state: CompartmentState, ode_parameters
     assert isinstance(duration_days, (int, float)) and not isinstance(duration_days, bool), (
         "tf must be of type int or float")
 
-    differentiable = ode.wants_grad(ode_parameters)
+    # a compartment of the initial state may itself come from a latent site: its gradient flows through dy0 seeds
+    state_grad = ode.state_wants_grad(initial_state)
+    differentiable = ode.wants_grad(ode_parameters) or state_grad
     packed = ode.pack(initial_state, ode_parameters, with_params=not differentiable)
     saveat = build_saveat(0.0, duration_days, save_step, sub_save_indices, len(initial_state))
     if dtype is None:
@@ -208,10 +220,16 @@ def simulate(ode, duration_days, initial_state: CompartmentState, ode_parameters
     kw = dict(t0=0.0, method=sp.solver_method.method, dtype=dtype, rtol=sp.ode_solver_rel_tolerance,
               atol=sp.ode_solver_abs_tolerance, max_steps=sp.max_steps,
               constant_dt=sp.constant_step_size if sp.constant_step_size > 0.0 else 0.0,
-              jump_ts=sp.discontinuity_points, save_mask=saveat.mask)
+              # reference odes.py:115-131: the ConstantStepSize branch does not look at discontinuity_points
+              jump_ts=() if sp.constant_step_size > 0.0 else sp.discontinuity_points, save_mask=saveat.mask)
+    y0_arg = packed.y0
+    if state_grad:
+        from ..engine import require_gpu
+
+        y0_arg = ode.state_tensor(initial_state, packed, require_gpu())
     if observe is not None:
         return _simulate_observed(ode, ode_parameters, packed, saveat, float(duration_days), kw, observe,
-                                  differentiable, sp, len(initial_state))
+                                  differentiable, sp, len(initial_state), y0_arg)
     if differentiable:
         # a parameter carries an autograd graph (NUTS / SVI potential): differentiable solve.  No
         # host synchronisation here: a failed trajectory leaves +inf rows, which turn the
@@ -221,7 +239,7 @@ def simulate(ode, duration_days, initial_state: CompartmentState, ode_parameters
         from ..infer.autodiff import solve_batch_diff
 
         params_t = ode.param_tensor(ode_parameters, require_gpu())
-        res = solve_batch_diff(packed.model, packed.y0, params_t, packed.contact, float(duration_days), saveat.ts, **kw)
+        res = solve_batch_diff(packed.model, y0_arg, params_t, packed.contact, float(duration_days), saveat.ts, **kw)
     else:
         res = solve_batch(packed.model, packed.y0, packed.params, packed.contact, float(duration_days), saveat.ts, **kw)
 

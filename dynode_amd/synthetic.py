@@ -196,8 +196,10 @@ def seip(B: int = 4096, seed: int = 7, A: int = 8, L: int = 2, K1: int = 3, M1: 
 
 WORKLOADS = {
     "cfg2": lambda B=4096, seed=0: sir_age_stratified(B, seed),
-    "cfg3": lambda B=16384, seed=1: seirs_multi_strain(B, seed),
-    "cfg3w8": lambda B=16384, seed=1: seirs_multi_strain(B, seed, W=8),
+    # BASELINE.json cfg 3 as worded: 8 age x 4 strain x 8 immunity bins (Erlang waning chain, D = 360)
+    "cfg3": lambda B=16384, seed=1: seirs_multi_strain(B, seed, W=8),
+    # the reference's own RHS at that size (seirs_multi_strain_age_stratified.py:213-243, no bins axis): D = 136
+    "cfg3d136": lambda B=16384, seed=1: seirs_multi_strain(B, seed),
     "seip": lambda B=4096, seed=7: seip(B, seed),
     "seip3": lambda B=4096, seed=7: seip(B, seed, A=4, L=3),      # three strains: tiers dealt over two lanes
     "cfg5": lambda B=8192, seed=5: seirs_multi_strain(B, seed, seasonal=True),

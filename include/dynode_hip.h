@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define DYN_ABI_VERSION 4
+#define DYN_ABI_VERSION 5
 /* the save grid is staged in LDS: n_save * sizeof(real) must not exceed this */
 #define DYN_MAX_SAVE_BYTES 49152
 
@@ -158,6 +158,11 @@ int32_t dyn_is_supported(const dyn_model_desc *m, const dyn_solver_opts *o);
 int32_t dyn_trajectories_per_wave(const dyn_model_desc *m);
 /* last launch-failure text of the calling thread ("" if none) */
 const char *dyn_last_error(void);
+/* name of the kernel instance the calling thread's last successful dyn_solve_batch* call enqueued, spelled the way
+ * rocprofv3's kernel trace prints it without the return type and argument list, e.g.
+ * "dyn::solve_kernel<float, 0, 8, 4, true, true, true, 8, 0, 1, 16384>" ("" before the first launch).  bench.py
+ * quotes it in its roofline block and only attaches profiled HBM traffic recorded for the same instance. */
+const char *dyn_last_kernel_name(void);
 
 /*
  * Batched solve over [t0, t1]: replaces diffeqsolve at odes.py:133-144 for B independent

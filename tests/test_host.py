@@ -294,3 +294,42 @@ def test_reference_sample_tests_object_arrays_objects_and_prefixes():
     assert isinstance(held.x, torch.Tensor)
     both = sample_then_resolve({"a": dist.Normal(), "b": DeterministicParameter("a")}, rng_key=0)
     assert isinstance(both["a"], torch.Tensor) and both["a"] == both["b"]
+
+
+# ---- MCMCProcess kwargs: honoured or refused, never dropped (reference inference.py:127-131,149-162 forwards them verbatim)
+def _proc(**kw):
+    from dynode_amd.infer.inference import MCMCProcess
+
+    return MCMCProcess(numpyro_model=lambda: None, num_warmup=10, num_samples=20, num_chains=2, nuts_max_tree_depth=5,
+                       progress_bar=False, **kw)
+
+
+def test_nuts_kwargs_the_reference_sets_itself_raise_like_numpyro_would():
+    # reference: NUTS(model, dense_mass=True, max_tree_depth=..., init_strategy=..., **nuts_kwargs) -> duplicate keyword
+    for key in ("dense_mass", "max_tree_depth", "init_strategy"):
+        with pytest.raises(TypeError, match="multiple values"):
+            _proc(nuts_kwargs={key: True})._check_kwargs()
+    for key in ("num_warmup", "num_samples", "num_chains", "progress_bar"):
+        with pytest.raises(TypeError, match="multiple values"):
+            _proc(mcmc_kwargs={key: 1})._check_kwargs()
+
+
+def test_unknown_or_unimplemented_kwargs_are_refused_not_dropped():
+    with pytest.raises(TypeError, match="unsupported NUTS argument"):
+        _proc(nuts_kwargs={"trajectory_length": 3.0})._check_kwargs()
+    with pytest.raises(TypeError, match="unsupported MCMC argument"):
+        _proc(mcmc_kwargs={"postprocess_fn": print})._check_kwargs()
+    with pytest.raises(NotImplementedError, match="adapt_mass_matrix"):
+        _proc(nuts_kwargs={"adapt_mass_matrix": False})._check_kwargs()
+    with pytest.raises(ValueError, match="chain_method"):
+        _proc(mcmc_kwargs={"chain_method": "pmap"})._check_kwargs()
+    with pytest.raises(ValueError, match="thinning"):
+        _proc(mcmc_kwargs={"thinning": 3})._check_kwargs()          # 20 draws are not a multiple of 3
+
+
+def test_numpyro_kwargs_at_supported_values_pass():
+    p = _proc(nuts_kwargs={"target_accept_prob": 0.9, "step_size": 0.5, "adapt_step_size": True, "adapt_mass_matrix": True,
+                           "regularize_mass_matrix": True, "find_heuristic_step_size": False, "forward_mode_differentiation": True},
+              mcmc_kwargs={"chain_method": "vectorized", "thinning": 4, "jit_model_args": True, "adaptation": "pooled"})
+    assert p._check_kwargs() == 4
+    assert _proc()._check_kwargs() == 1

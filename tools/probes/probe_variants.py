@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from dynode_amd import synthetic
 from dynode_amd.engine import solve_batch
 
-for which in ("cfg2", "cfg3"):
+for which in ("cfg2", "cfg3d136", "cfg3"):
     wl = synthetic.WORKLOADS[which]()
     for dtype in (torch.float32, torch.float64):
         for method in ("tsit5", "dopri5"):

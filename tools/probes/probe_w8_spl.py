@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from dynode_amd import _abi, jit, synthetic
 from dynode_amd.engine import solve_batch
 
-wl = synthetic.WORKLOADS["cfg3w8"]()
+wl = synthetic.WORKLOADS["cfg3"]()
 m = wl.model
 L = _abi.lib()
 name = jit._name(m, torch.float32, 0, 0, 4)
@@ -34,6 +34,6 @@ for spl in (1, 2, 4):
     ms = e0.elapsed_time(e1) / 10
     gbs = wl.bytes_per_trajectory(4) * wl.B / ms / 1e6
     if ref is None: ref = out.clone()
-    print(f"cfg3w8 SPL={spl} ms={ms:7.3f} traj/s={wl.B / ms * 1e3:10.0f} frac={gbs / 8000:.3f} ok={int(r.status.max()) == 0} "
+    print(f"cfg3 SPL={spl} ms={ms:7.3f} traj/s={wl.B / ms * 1e3:10.0f} frac={gbs / 8000:.3f} ok={int(r.status.max()) == 0} "
           f"max |diff| vs SPL=1 = {float((out - ref).abs().max()):.3g}", flush=True)
     del out, r

@@ -26,18 +26,38 @@ for f in glob.glob(os.path.join(out_dir, "pmc_*", "**", "*counter_collection.csv
             meta = {k: r[k] for k in ("Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "Scratch_Size")}
 mean = {k: sum(v) / len(v) for k, v in counters.items()}
 
+def build_rev() -> str:
+    """Source revision the profiled library was built from (tools/stamp_rev.sh writes it before a gpurun call:
+    the GPU box has no .git)."""
+    try:
+        return open(os.path.join(root, "dynode_amd", "lib", "BUILD_REV")).read().strip()
+    except OSError:
+        return "unknown"
+
+
+def instance_name(raw: str) -> str:
+    """rocprofv3 prints `void dyn::solve_kernel<...>(dyn::KArgs<float>)`; dyn_last_kernel_name() returns the middle part."""
+    name = raw.strip().strip('"')
+    if name.startswith("void "):
+        name = name[5:]
+    cut = name.rfind(">(")
+    return name[:cut + 1] if cut > 0 else name
+
+
 workload, batch = "cfg3", None
 for i, a in enumerate(extra):
     if a == "--workload": workload = extra[i + 1]
     if a == "--batch": batch = int(extra[i + 1])
-defaults = {"cfg2": 4096, "cfg3": 16384, "cfg3w8": 16384, "cfg5": 8192, "seip": 4096, "seip3": 4096}
+defaults = {"cfg2": 4096, "cfg3": 16384, "cfg3d136": 16384, "cfg5": 8192, "seip": 4096, "seip3": 4096}
 batch = batch or defaults[workload]
 
-lines = [f"# rocprofv3 summary `{tag}` -- bench.py --workload {workload} (B={batch} per GPU)", ""]
+kernel = instance_name(stats["Name"]) if stats else None
+lines = [f"# rocprofv3 summary `{tag}` -- bench.py --workload {workload} (B={batch} per GPU)", "",
+         f"- source revision: `{build_rev()}`", f"- dispatched instance: `{kernel}`", ""]
 if stats:
     lines += ["## kernel-trace --stats (50 timed + 5 warm-up launches, the default bench.py command)", "",
               "| kernel | calls | avg ns | min ns | max ns | % of GPU time |", "|---|---|---|---|---|---|",
-              f"| `{stats['Name'][:90]}` | {stats['Calls']} | {float(stats['AverageNs']):.0f} | {stats['MinNs']} | {stats['MaxNs']} | {stats['Percentage']} |", ""]
+              f"| `{stats['Name'][:120]}` | {stats['Calls']} | {float(stats['AverageNs']):.0f} | {stats['MinNs']} | {stats['MaxNs']} | {stats['Percentage']} |", ""]
 if meta:
     lines += ["## dispatch", "", "| " + " | ".join(meta) + " |", "|" + "---|" * len(meta), "| " + " | ".join(meta.values()) + " |", ""]
 if mean:
@@ -69,6 +89,7 @@ open(os.path.join(root, "profiles", f"{tag}_rocprof_summary.md"), "w").write("\n
 if hbm:
     tp = os.path.join(root, "profiles", "traffic.json")
     rec = json.load(open(tp)) if os.path.exists(tp) else {}
-    rec[f"{workload}:{batch}"] = {"hbm_bytes_per_launch": hbm, "read_bytes": rd, "write_bytes": wr, "source": f"profiles/{tag}_rocprof_summary.md"}
+    rec[f"{workload}:{batch}"] = {"hbm_bytes_per_launch": hbm, "read_bytes": rd, "write_bytes": wr, "source": f"profiles/{tag}_rocprof_summary.md",
+                                  "kernel": kernel, "rev": build_rev(), "kernel_avg_ns": float(stats["AverageNs"]) if stats else None}
     json.dump(rec, open(tp, "w"), indent=1, sort_keys=True)
 print("\n".join(lines))
