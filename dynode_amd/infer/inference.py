@@ -397,7 +397,13 @@ class MCMCProcess(InferenceProcess):
         from ..engine import require_gpu
 
         thinning = self._check_kwargs()
-        device = require_gpu()
+        if torch.cuda.is_available() or self.mcmc_kwargs.get("sampler") != "eager":
+            device = require_gpu()
+        else:
+            # the op-by-op torch sampler, asked for by name, also runs on the host -- for models that are plain torch
+            # code (the reference's tests/test_infer/test_inference_processes.py fits a Normal); a model that calls
+            # simulate() still needs the GPU and says so (engine.require_gpu)
+            device = torch.device("cpu")
         rank, world = sharding.world()
         lo, hi = sharding.shard_bounds(self.num_chains, rank, world)
         local = hi - lo

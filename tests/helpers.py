@@ -28,6 +28,29 @@ def omodel(m) -> "O.Model":
                    int(getattr(m, "n_vax_knots", 0)), int(getattr(m, "family", 0)), bool(getattr(m, "seasonal_vax", False)))
 
 
+# the north star's trajectory bar in float32, element by element: |hip - oracle| <= ATOL * scale + RTOL * |oracle|
+PARITY_RTOL, PARITY_ATOL = 1e-5, 1e-6
+
+
+def parity_report(m, got, want, scale, label=""):
+    """Worst cases of ``got`` against ``want`` ([B, n_save, D]) per compartment: absolute error over the population
+    scale, relative error where the value matters (|want| > 1e-3 scale), and the mixed figure
+    |d| / (ATOL scale + RTOL |want|) whose bar is 1.  Prints one line per compartment; returns
+    ``(normwise, mixed)`` maxima over the whole state."""
+    got, want = np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64)
+    d = np.abs(got - want)
+    mix = d / (PARITY_ATOL * scale + PARITY_RTOL * np.abs(want))
+    pos, lines = 0, []
+    for name, size in zip(m.compartment_names, m.compartment_sizes):
+        blk = slice(pos, pos + size)
+        big = np.abs(want[..., blk]) > 1e-3 * scale
+        rel = float((d[..., blk][big] / np.abs(want[..., blk][big])).max()) if big.any() else 0.0
+        lines.append(f"{name}: abs/scale {d[..., blk].max() / scale:.2e}  rel {rel:.2e}  mixed {mix[..., blk].max():.3f}")
+        pos += size
+    print(f"[parity {label}] " + " | ".join(lines))
+    return float(d.max() / scale), float(mix.max())
+
+
 def split_state(m, y):
     """Flat state -> dict of compartment arrays shaped like the reference ([A], [A,S], [A,S,W])."""
     A, S, W = m.n_age, m.n_strain, m.n_wane

@@ -144,6 +144,7 @@ def test_sampler_entry_validates_before_launching():
     assert lib.dyn_nuts_advance(ctypes.byref(st), None) == 0
 
 
+@pytest.mark.on_demand_build
 def test_on_demand_kernel_build_and_registration():
     """dynode_amd/jit.py without a GPU: lane mapping choices, and a full build + dyn_register_instance
     round trip for a shape instances.def does not list (hipcc cross-compiles here)."""

@@ -92,6 +92,31 @@ def test_nuts_posterior_matches_grid_quadrature(data, sampler, adaptation):
     print("mean leapfrogs/transition %.2f, gradient-solves %d" % (float(mcmc.nuts.num_steps.double().mean()), mcmc.nuts.potential_evals))
 
 
+def test_nuts_posterior_high_power_ks_and_moments(data):
+    """cfg 4 at one GPU's share (128 chains), default per-chain adaptation as in numpyro, 12,800 thinned draws per
+    site: KS p > 0.01 against the quadrature CDF, sample mean within 3 Monte-Carlo standard errors and standard
+    deviation within 3 of its standard errors of the quadrature moments."""
+    from dynode_amd.infer.inference import ks_against_quadrature
+
+    kw = dict(config=ex.get_config(), tf=100, obs_data=data)
+    process = MCMCProcess(numpyro_model=ex.model_fused, num_warmup=500, num_samples=1000, num_chains=128,
+                          nuts_max_tree_depth=10, progress_bar=False)
+    process.infer(**kw)
+    post = process.get_samples(group_by_chain=True)
+    odes.enable_x64(True)
+    try:
+        pot = Potential(ex.model, kw, 0, torch.device("cuda"))
+        rep = ks_against_quadrature(pot, post, [torch.linspace(-14.0, 14.0, 1401, dtype=torch.float64),
+                                                 torch.linspace(-6.0, 6.0, 1001, dtype=torch.float64)], thin=10)
+    finally:
+        odes.enable_x64(False)
+    for name, r in rep.items():
+        print(name, {k: (round(v, 5) if isinstance(v, float) else v) for k, v in r.items()})
+        assert r["n"] >= 10_000 and r["ks_p"] > 0.01, (name, r)
+        assert abs(r["mean_z"]) < 3.0, (name, r)
+        assert abs(r["sd"] / r["quad_sd"] - 1.0) < 3.0 / np.sqrt(2.0 * r["ess"]) + 2e-3, (name, r)
+
+
 def test_get_samples_before_infer_raises():
     with pytest.raises(AssertionError):
         MCMCProcess(numpyro_model=ex.model, num_warmup=1, num_samples=1, num_chains=1, nuts_max_tree_depth=1).get_samples()

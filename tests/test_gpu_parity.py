@@ -3,7 +3,9 @@
 Bars (north_star: trajectories within rtol=1e-5 of the CPU path):
   fp64 : |hip - oracle| / scale < 1e-11 and IDENTICAL accepted/rejected step counts -- the
          two implementations run the same algorithm; only summation order / FMA contraction differ.
-  fp32 : |hip - oracle| / scale < 1e-5 (norm-wise, scale = population), the reference's dtype.
+  fp32 : the reference's dtype.  Element by element |hip - oracle| <= 1e-6 scale + 1e-5 |oracle| (the north star's
+         rtol with an absolute floor of one millionth of the population) AND norm-wise < 2e-6 of the scale, which is
+         4x what is measured (5e-7; helpers.parity_report prints the worst case of every compartment).
 At BASELINE.json's full sizes the oracle is too slow, so size-independent properties are used:
 mass conservation, exact first row, batch-position invariance, bitwise determinism.
 """
@@ -95,7 +97,11 @@ def test_hip_matches_oracle(m, dtype, method):
         assert err < 1e-11, err
         assert np.array_equal(na, na_o) and np.array_equal(nr, nr_o)
     else:
-        assert err < 1e-5, err
+        normwise, mixed = H.parity_report(m, got, want, 1000.0, f"{method} A{m.n_age} S{m.n_strain} W{m.n_wane}")
+        assert mixed <= 1.0 and normwise < 2e-6, (normwise, mixed)
+        same = (na == na_o) & (nr == nr_o)          # same accept / reject sequence: agreement to rounding
+        if same.any():
+            assert np.abs(got[same] - want[same]).max() / 1000.0 < 1e-6
         # fp32 error estimates carry ~1e-3 relative rounding noise (cancellation in sum berr*k), so
         # accept/reject decisions with err within that band of 1 flip between implementations
         d = np.abs(na.astype(int) + nr - na_o - nr_o)
@@ -123,7 +129,8 @@ def test_hip_vs_scipy_ground_truth(name):
 # ------------------------------------------------------------------ BASELINE sizes, property checks
 @pytest.mark.parametrize("wl", [synthetic.sir_age_stratified(4096, seed=0), synthetic.seirs_multi_strain(16384, seed=1),
                                 synthetic.seirs_multi_strain(8192, seed=5, seasonal=True),
-                                synthetic.seirs_multi_strain(4096, seed=1, W=8)], ids=lambda w: f"{w.name}_D{w.model.state_dim}")
+                                synthetic.seirs_multi_strain(16384, seed=1, W=8)],      # BASELINE cfg 2, cfg 3 (D=136), cfg 5 share, cfg 3 as worded (D=360)
+                         ids=lambda w: f"{w.name}_D{w.model.state_dim}")
 def test_full_size_properties(wl):
     m = wl.model
     r = solve_batch(m, wl.y0, wl.params, wl.contact, wl.t1, wl.save_ts, dtype=F32)
@@ -151,7 +158,10 @@ def test_full_size_properties(wl):
     idx = np.arange(0, wl.B, wl.B // 64)[:64]
     y0s = wl.y0[idx] if wl.y0.ndim == 2 else wl.y0
     want, _, _, _ = O.solve(H.omodel(m), y0s, wl.params[idx], wl.contact, wl.t1, wl.save_ts, dtype=np.float32, n_threads=8)
-    assert np.abs(ys[torch.as_tensor(idx, device="cuda")].cpu().numpy() - want).max() / 1000.0 < 1e-5
+    normwise, mixed = H.parity_report(m, ys[torch.as_tensor(idx, device="cuda")].cpu().numpy(), want, 1000.0, f"{wl.name} D{m.state_dim} B{wl.B}")
+    assert mixed <= 1.0 and normwise < 2e-6, (normwise, mixed)
+    del r, r2, rp, ys
+    torch.cuda.empty_cache()
 
 
 def test_output_offsets_beyond_2_to_the_31():
@@ -167,7 +177,8 @@ def test_output_offsets_beyond_2_to_the_31():
     y0s = wl.y0[idx] if wl.y0.ndim == 2 else wl.y0
     want, _, _, _ = O.solve(H.omodel(m), y0s, wl.params[idx], wl.contact, wl.t1, wl.save_ts, dtype=np.float32, n_threads=8)
     got = r.ys[torch.as_tensor(idx, device="cuda")].cpu().numpy()
-    assert np.abs(got - want).max() / 1000.0 < 1e-5
+    normwise, mixed = H.parity_report(m, got, want, 1000.0, "cfg5 global batch on one GPU")
+    assert mixed <= 1.0 and normwise < 2e-6, (normwise, mixed)
     # every trajectory conserves mass, checked in chunks to keep temporaries small
     n_pop = m.state_dim - m.n_age * m.n_strain
     for lo in range(0, wl.B, 8192):
@@ -465,6 +476,7 @@ def test_randomized_parity_sweep():
     assert ran >= 60
 
 
+@pytest.mark.on_demand_build
 def test_kernel_shapes_are_built_on_demand():
     """A member of the RHS family that instances.def does not list (5 ages x 2 strains, SEIR with
     cumulative incidence, no waning) is compiled with hipcc on first use, registered with the library
@@ -605,6 +617,7 @@ def test_vaccination_tiers_match_oracle_and_move_people_up(ages, m, dtype):
     assert np.all(np.diff(tiers[:, :, 0], axis=1) <= 2e-3)                                 # tier 0 only loses people (up to interpolation ripple at the kink)
 
 
+@pytest.mark.on_demand_build
 def test_vaccination_shape_built_on_demand():
     """A vaccinated member of the family that instances.def does not list (5 ages x 2 tiers, one strain,
     SEIRS): the on-demand build passes the vaccination lanes in the template's feature word."""

@@ -107,7 +107,7 @@ def test_sir_mass_conservation(s0, i0, r0):
     assert np.allclose(total, total[0], atol=1e-6)
 
 
-@pytest.mark.parametrize("r0,ti,tl,tw", [(2.0, 7.0, 3.0, 60.0), (3.0, 5.0, 2.0, 90.0)])
+@pytest.mark.parametrize("r0,ti,tl,tw", [(2.0, 7.0, 3.0, 60.0), (3.0, 5.0, 2.0, 100.0)])
 def test_seirs_endemic_equilibrium(r0, ti, tl, tw):
     """reference tests/test_seirs_dynamics/test_seirs.py:8-65 (rel=1e-2; last-100-day std < 1e-4)."""
     beta, gamma, sigma, omega = r0 / ti, 1 / ti, 1 / tl, 1 / tw

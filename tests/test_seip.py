@@ -214,6 +214,7 @@ def test_hip_rejects_what_the_family_does_not_have(monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.on_demand_build
 def test_seip_shape_built_on_demand():
     import torch
     from dynode_amd.engine import solve_batch
@@ -493,6 +494,7 @@ def test_tier_lanes_variant_matches_oracle(shape, prec, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.on_demand_build
 def test_tier_lanes_shape_built_on_demand():
     """A three-strain shape that is not compiled in (3 ages, 3 tiers, 3 waning states: 36 values per lane): the on-demand
     build picks the tier-lane mapping and registers it with the matching feature word."""

@@ -87,3 +87,64 @@ def test_single_process_is_a_no_op_group():
     assert sharding.gather_rows(t, 3) is t
     mean, var, n = sharding.allreduce_ensemble_moments(t.reshape(3, 1, 2))
     assert n == 3 and torch.allclose(mean, t.mean(0, keepdim=True).double())
+
+
+# ------------------------------------------------------------------ MCMCProcess: chains sharded over ranks
+def _normal_model(obs):
+    """The reference's inference smoke model (tests/test_infer/test_inference_processes.py:15-24): one Normal site."""
+    from dynode_amd.infer import distributions as dist_
+    from dynode_amd.infer import handlers
+
+    mu = handlers.sample("mu", dist_.Normal(0.0, 5.0))
+    handlers.sample("obs", dist_.Normal(mu[..., None], 1.0), obs=obs)
+
+
+def _mcmc(num_chains):
+    from dynode_amd.infer.inference import MCMCProcess
+
+    return MCMCProcess(numpyro_model=_normal_model, num_warmup=60, num_samples=40, num_chains=num_chains,
+                       nuts_max_tree_depth=6, progress_bar=False, mcmc_kwargs={"sampler": "eager"})
+
+
+_OBS = torch.tensor([0.3, 1.1, 0.8, 1.6, 0.9, 1.3], dtype=torch.float64)
+
+
+def _mcmc_worker(rank, size, port, chains, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=size)
+    try:
+        proc = _mcmc(chains)
+        proc.infer(obs=_OBS)
+        local = proc.get_samples(group_by_chain=True)["mu"]
+        lo, hi = sharding.shard_bounds(chains, rank, size)
+        assert local.shape == (hi - lo, 40)                                   # every rank holds its own chains only
+        gathered = proc.get_samples(group_by_chain=True, gather=True)         # the one collective of the inference path
+        flat = proc.get_samples(gather=True)
+        if rank == 0:
+            assert flat["mu"].shape == (chains * 40,)
+            torch.save({"all": gathered["mu"], "local": local}, os.path.join(out_dir, "r0.pt"))
+        else:
+            assert gathered == {} and flat == {}
+            torch.save({"local": local}, os.path.join(out_dir, f"r{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("chains", [6, 7])   # even and ragged split
+def test_two_rank_gloo_mcmc_chains_are_sharded_gathered_in_order_and_seeded_per_rank(tmp_path, chains, monkeypatch):
+    mp.spawn(_mcmc_worker, args=(2, _free_port(), chains, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / "r0.pt"), torch.load(tmp_path / "r1.pt")
+    lo1, hi1 = sharding.shard_bounds(chains, 1, 2)
+    assert r0["all"].shape == (chains, 40)
+    assert torch.equal(r0["all"][:lo1], r0["local"]) and torch.equal(r0["all"][lo1:hi1], r1["local"])   # chain order = rank order
+    assert not torch.equal(r0["local"][:2], r1["local"][:2])                   # ranks do not repeat each other's streams
+    # what a rank draws depends on (its rank, the world size) only: repeat each rank's share in this process
+    for rank, got in ((0, r0["local"]), (1, r1["local"])):
+        monkeypatch.setattr(sharding, "world", lambda rank=rank: (rank, 2))
+        proc = _mcmc(chains)
+        proc.infer(obs=_OBS)
+        assert torch.equal(proc.get_samples(group_by_chain=True)["mu"], got)
+    monkeypatch.undo()
+    post = r0["all"].reshape(-1)
+    want_mean = float(_OBS.sum() / (len(_OBS) + 1 / 25.0))                     # conjugate posterior: N(sum / (n + 1/25), 1 / (n + 1/25))
+    assert abs(float(post.mean()) - want_mean) < 0.15 and 0.25 < float(post.std()) < 0.6
