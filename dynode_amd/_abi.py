@@ -29,7 +29,8 @@ EXPORTED_SYMBOLS = (
     "dyn_compartment_offsets", "dyn_is_supported", "dyn_trajectories_per_wave",
     "dyn_last_error", "dyn_solve_batch", "dyn_solve_batch_jvp", "dyn_is_supported_jvp",
     "dyn_nuts_advance", "dyn_nuts_state_size", "dyn_philox4x32_10", "dyn_latent_sites",
-    "dyn_solve_batch_loglik", "dyn_register_instance", "dyn_last_kernel_name",
+    "dyn_solve_batch_loglik", "dyn_register_instance", "dyn_last_kernel_name", "dyn_solve_batch_record",
+    "dyn_solve_batch_replay",
 )
 
 MAX_SITES = 8
@@ -188,6 +189,13 @@ def lib() -> ctypes.CDLL:
             ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
             ctypes.c_void_p,
         ]
+        base = [pm, po, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_double,
+                ctypes.c_double, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                ctypes.c_void_p, ctypes.c_void_p]
+        L.dyn_solve_batch_record.restype = ctypes.c_int
+        L.dyn_solve_batch_record.argtypes = base + [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p]
+        L.dyn_solve_batch_replay.restype = ctypes.c_int
+        L.dyn_solve_batch_replay.argtypes = base + [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p]
         L.dyn_is_supported_jvp.argtypes = [pm, po, ctypes.c_int32]
         L.dyn_is_supported_jvp.restype = ctypes.c_int32
         L.dyn_solve_batch_jvp.restype = ctypes.c_int

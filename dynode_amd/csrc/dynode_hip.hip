@@ -208,6 +208,16 @@ static int check_model(const dyn_model_desc *m) {
     return 0;
 }
 
+// step schedules (dyn_solve_batch_record / dyn_solve_batch_replay)
+struct SchedArgs {
+    void *out;                 // record: [B][cap][2]
+    int32_t *n_out;            // record: [B]
+    const void *in;            // replay: [n_leaders][cap][2]
+    const int32_t *n_in;       // replay: [n_leaders]
+    const int64_t *leader;     // replay: [B] or nullptr
+    int32_t cap;
+};
+
 // fused observation likelihood (dyn_solve_batch_loglik)
 struct LLArgs {
     const void *obs;
@@ -223,8 +233,14 @@ static int enqueue(const Entry *e, const dyn_model_desc *m, const dyn_solver_opt
                    const uint8_t *save_mask, void *ys_out, int32_t *status, int32_t *n_accept,
                    int32_t *n_reject, hipStream_t stream, const void *dparams = nullptr,
                    const void *dy0 = nullptr, int32_t dy0_is_batched = 0, void *dys_out = nullptr,
-                   const LLArgs *ll = nullptr) {
+                   const LLArgs *ll = nullptr, const SchedArgs *sc = nullptr) {
     KArgs<T> ka;
+    ka.sched_out = sc ? (T *)sc->out : nullptr;
+    ka.sched_n_out = sc ? sc->n_out : nullptr;
+    ka.sched_in = sc ? (const T *)sc->in : nullptr;
+    ka.sched_n_in = sc ? sc->n_in : nullptr;
+    ka.sched_leader = sc ? sc->leader : nullptr;
+    ka.sched_cap = sc ? sc->cap : 0;
     ka.obs = ll ? (const T *)ll->obs : nullptr;
     ka.ll_out = ll ? ll->ll_out : nullptr;
     ka.dll_out = ll ? ll->dll_out : nullptr;
@@ -428,7 +444,7 @@ static int solve_impl(const dyn_model_desc *m, const dyn_solver_opts *o, const v
                       const uint8_t *save_mask, void *ys_out, int32_t *status, int32_t *n_accept,
                       int32_t *n_reject, void *stream, int32_t n_dir, const void *dparams,
                       const void *dy0, int32_t dy0_is_batched, void *dys_out,
-                      const dyn::LLArgs *ll = nullptr) {
+                      const dyn::LLArgs *ll = nullptr, const dyn::SchedArgs *sc = nullptr) {
     dyn::tl_error[0] = 0;
     int rc = dyn::check_model(m);
     if (rc) return rc;
@@ -455,7 +471,8 @@ static int solve_impl(const dyn_model_desc *m, const dyn_solver_opts *o, const v
     for (int j = 1; j < o->n_jump; ++j)
         if (!(o->jump_ts[j] > o->jump_ts[j - 1])) return DYN_ERR_JUMP; /* must be strictly increasing */
     if (m->family == 1 && n_dir > 0) {
-        snprintf(dyn::tl_error, sizeof(dyn::tl_error), "the SEIP kernels have no tangent planes yet");
+        snprintf(dyn::tl_error, sizeof(dyn::tl_error), "the SEIP kernels have no tangent planes: differentiate them with "
+                 "dyn_solve_batch_record + dyn_solve_batch_replay (central differences on the recorded step sequence)");
         return DYN_ERR_UNSUPPORTED;
     }
     const dyn::Entry *e = dyn::find_entry(m, o->dtype, o->method, n_dir);
@@ -469,9 +486,16 @@ static int solve_impl(const dyn_model_desc *m, const dyn_solver_opts *o, const v
                  dyn::seip_tiers(m), m->n_wane);
         return DYN_ERR_UNSUPPORTED;
     }
+    if (sc && m->family != 1) {
+        snprintf(dyn::tl_error, sizeof(dyn::tl_error), "step schedules are implemented for the SEIP family (the s/e/i/r/c "
+                 "kernels have tangent planes: dyn_solve_batch_jvp)");
+        return DYN_ERR_UNSUPPORTED;
+    }
+    if (sc && (sc->cap < 1 || (sc->out && !sc->n_out) || (sc->in && !sc->n_in))) return DYN_ERR_SIZE;
     if (e && m->family == 1) { // susceptibility table and splines of every trajectory of a wave sit in LDS
         const size_t per_traj = (size_t)(1 << m->n_strain) * dyn::seip_tiers(m) * m->n_wane * m->n_strain +
-                                (size_t)m->n_age * dyn::seip_tiers(m) * (4 + 2 * m->n_vax_knots);
+                                (size_t)m->n_age * dyn::seip_tiers(m) * (4 + 2 * m->n_vax_knots) +
+                                (sc && sc->in ? (size_t)2 * sc->cap : 0); /* replayed schedule */
         const size_t bytes = ((size_t)n_save + dyn::kMaxJumps + (64 / dyn::entry_lanes(e)) * per_traj) * (o->dtype == DYN_F64 ? 8 : 4);
         if (bytes > 64 * 1024) {
             snprintf(dyn::tl_error, sizeof(dyn::tl_error), "SEIP tables need %zu bytes of LDS per wave (limit 65536)", bytes);
@@ -495,10 +519,10 @@ static int solve_impl(const dyn_model_desc *m, const dyn_solver_opts *o, const v
     if (o->dtype == DYN_F64)
         return dyn::enqueue<double>(e, m, o, y0, y0_is_batched, params, contact, B, t0, t1,
                                     save_ts, n_save, save_mask, ys_out, status, n_accept, n_reject,
-                                    (hipStream_t)stream, dparams, dy0, dy0_is_batched, dys_out, ll);
+                                    (hipStream_t)stream, dparams, dy0, dy0_is_batched, dys_out, ll, sc);
     return dyn::enqueue<float>(e, m, o, y0, y0_is_batched, params, contact, B, t0, t1, save_ts,
                                n_save, save_mask, ys_out, status, n_accept, n_reject,
-                               (hipStream_t)stream, dparams, dy0, dy0_is_batched, dys_out, ll);
+                               (hipStream_t)stream, dparams, dy0, dy0_is_batched, dys_out, ll, sc);
 }
 
 int dyn_solve_batch(const dyn_model_desc *m, const dyn_solver_opts *o, const void *y0,
@@ -509,6 +533,27 @@ int dyn_solve_batch(const dyn_model_desc *m, const dyn_solver_opts *o, const voi
     return solve_impl(m, o, y0, y0_is_batched, params, contact, B, t0, t1, save_ts, n_save,
                       save_mask, ys_out, status, n_accept, n_reject, stream, 0, nullptr, nullptr, 0,
                       nullptr);
+}
+
+int dyn_solve_batch_record(const dyn_model_desc *m, const dyn_solver_opts *o, const void *y0, int32_t y0_is_batched,
+                           const void *params, const void *contact, int64_t B, double t0, double t1, const void *save_ts,
+                           int32_t n_save, const uint8_t *save_mask, void *ys_out, int32_t *status, int32_t *n_accept,
+                           int32_t *n_reject, void *sched_out, int32_t *sched_n_out, int32_t sched_cap, void *stream) {
+    if (!sched_out || !sched_n_out) return DYN_ERR_NULL;
+    const dyn::SchedArgs sc{sched_out, sched_n_out, nullptr, nullptr, nullptr, sched_cap};
+    return solve_impl(m, o, y0, y0_is_batched, params, contact, B, t0, t1, save_ts, n_save, save_mask, ys_out, status,
+                      n_accept, n_reject, stream, 0, nullptr, nullptr, 0, nullptr, nullptr, &sc);
+}
+
+int dyn_solve_batch_replay(const dyn_model_desc *m, const dyn_solver_opts *o, const void *y0, int32_t y0_is_batched,
+                           const void *params, const void *contact, int64_t B, double t0, double t1, const void *save_ts,
+                           int32_t n_save, const uint8_t *save_mask, void *ys_out, int32_t *status, int32_t *n_accept,
+                           int32_t *n_reject, const void *sched, const int32_t *sched_n, const int64_t *leader,
+                           int32_t sched_cap, void *stream) {
+    if (!sched || !sched_n) return DYN_ERR_NULL;
+    const dyn::SchedArgs sc{nullptr, nullptr, sched, sched_n, leader, sched_cap};
+    return solve_impl(m, o, y0, y0_is_batched, params, contact, B, t0, t1, save_ts, n_save, save_mask, ys_out, status,
+                      n_accept, n_reject, stream, 0, nullptr, nullptr, 0, nullptr, nullptr, &sc);
 }
 
 int dyn_solve_batch_jvp(const dyn_model_desc *m, const dyn_solver_opts *o, const void *y0,

@@ -422,6 +422,17 @@ struct Seip {
         for (int n = lane; n < n_save; n += 64) ts_tab[n] = ka.save_ts[n];
         for (int n = lane % G; n < SUSN + spln; n += G) tab[n] = q[n];
         if (n_jump > 0 && lane < kMaxJumps) jt_tab[lane] = ka.jump_ts[lane];
+        // replay: the (t_prev, t_next) pairs this trajectory must take, staged in LDS behind the tables (a global load
+        // inside the stepping loop would wait for every store issued before it: the loads and stores share vmcnt)
+        const bool replay = ka.sched_in != nullptr;
+        T *const sch = jt_tab + (n_jump > 0 ? kMaxJumps : 0) + TPW * (SUSN + spln) + grp * (2 * ka.sched_cap);
+        int n_sch = 0;
+        if (replay) {
+            const int64_t lead = ka.sched_leader ? ka.sched_leader[traj] : traj;
+            n_sch = ka.sched_n_in[lead];
+            const T *src = ka.sched_in + lead * (int64_t)(2 * ka.sched_cap);
+            for (int n = lane % G; n < 2 * (n_sch > 0 ? n_sch : 0); n += G) sch[n] = src[n];
+        }
         __syncthreads();
         S.sus = tab + j * (K1 * M1 * L);
         S.spl = tab + SUSN + aa * K1 * (4 + 2 * nk);
@@ -485,7 +496,9 @@ struct Seip {
         const unsigned long long group_mask = (G == 64 ? ~0ull : ((1ull << G) - 1ull)) << (grp * G);
         const bool start_ok = (bad_lanes & group_mask) == 0ull;
 
-        if (constant) {
+        if (replay) {
+            tnext = n_sch > 0 ? sch[1] : tprev;
+        } else if (constant) {
             tnext = tprev + ka.constant_dt;
         } else { // Hairer-Norsett-Wanner II.4 starting step, as in solve_kernel.hpp
             T n0 = 0, n1 = 0;
@@ -520,7 +533,7 @@ struct Seip {
         int jidx = 0;
         bool at_jump = false;
         T dt_unclipped = T(0);
-        if (n_jump > 0) {
+        if (n_jump > 0 && !replay) {
             while (jidx < n_jump && jt_tab[jidx] <= tprev) ++jidx;
             if (jidx < n_jump && jt_tab[jidx] < tnext) {
                 dt_unclipped = tnext - tprev;
@@ -528,20 +541,26 @@ struct Seip {
                 at_jump = true;
             }
         }
+        int si = 0;          // replay: index of the step being taken
         int save_idx = 0;
         T ts_next = save_idx < n_save ? ts_tab[save_idx] : M::inf();
         int64_t steps = 0;
         int32_t n_acc = 0, n_rej = 0, st = start_ok ? ST_OK : ST_NONFINITE;
         bool done = !(tprev < t_end) || !start_ok;
+        if (replay && n_sch <= 0) {     // the leader ran out of schedule space (or never stepped): nothing to follow
+            if (n_sch < 0) st = ST_MAX_STEPS;
+            done = true;
+        }
         T *const out_traj = ka.out + traj * (int64_t)n_save * ka.d_saved;
         const bool vec_ok = ka.vec_ok != 0;
+        const bool fixed = constant || replay;   // every step is taken as given: no error estimate, no rejection
 
         while (__any(!done)) {
             const T dt = tnext - tprev;
             S.template stages<1>(tprev, dt, y, yt, k);
             bool keep = true, finite = true;
             T factor = T(1);
-            if (!constant) {
+            if (!fixed) {
                 T ss = 0;
 #pragma unroll
                 for (int v = 0; v < NV; ++v) {
@@ -597,12 +616,41 @@ struct Seip {
                     y[v] = yt[v];
                     k[0][v] = k[6][v];
                 }
+                if (ka.sched_out != nullptr && writer && a == 0 && j == 0 && tl == 0 && n_acc < ka.sched_cap) {
+                    T *rec = ka.sched_out + (traj * (int64_t)ka.sched_cap + n_acc) * 2;
+                    rec[0] = tprev;
+                    rec[1] = tnext;
+                }
                 ++n_acc;
             } else if (act && finite) {
                 ++n_rej;
             }
             T next_t0 = accept ? tnext : tprev;
             T next_t1 = next_t0 + (constant ? ka.constant_dt : dt * factor);
+            if (replay) { // wave-uniform: the next recorded step; across a discontinuity point the first stage is recomputed
+                if (act) ++si;
+                const bool more = si < n_sch;
+                next_t0 = more ? sch[2 * si] : t_end;
+                next_t1 = more ? sch[2 * si + 1] : t_end;
+                const bool gap = act && accept && more && next_t0 != tnext;
+                if (__any(gap)) {
+                    S.rhs(next_t0, y, k[1]);
+                    if (gap) {
+#pragma unroll
+                        for (int v = 0; v < NV; ++v) k[0][v] = k[1][v];
+                    }
+                }
+                if (act && finite) {
+                    tprev = next_t0;
+                    tnext = next_t1;
+                    if (!more) done = true;
+                    else if (steps >= ka.max_steps) {
+                        st = ST_MAX_STEPS;
+                        done = true;
+                    }
+                }
+                continue;
+            }
             if (n_jump > 0) { // wave-uniform
                 const bool landed = at_jump && accept;
                 if (landed) {
@@ -667,6 +715,7 @@ struct Seip {
                 ka.status[traj] = st;
                 ka.n_acc[traj] = n_acc;
                 ka.n_rej[traj] = n_rej;
+                if (ka.sched_n_out != nullptr) ka.sched_n_out[traj] = n_acc <= ka.sched_cap ? n_acc : -1;
             }
         }
     }
@@ -689,7 +738,8 @@ hipError_t launch_seip(const KArgs<T> &ka, hipStream_t stream) {
     const int64_t blocks = (ka.B + TPW - 1) / TPW;
     if (blocks <= 0) return hipSuccess;
     const size_t per_traj = (size_t)(1 << L) * K1 * M1 * L + (size_t)ka.A * K1 * (4 + 2 * ka.n_vax_knots);
-    const size_t lds = ((size_t)ka.n_save + (ka.n_jump > 0 ? kMaxJumps : 0) + TPW * per_traj) * sizeof(T);
+    const size_t lds = ((size_t)ka.n_save + (ka.n_jump > 0 ? kMaxJumps : 0) + TPW * per_traj +
+                        (ka.sched_in != nullptr ? (size_t)TPW * 2 * ka.sched_cap : 0)) * sizeof(T);
     if constexpr (sizeof(T) == 4 && Seip<T, METHOD, GA, L, K1, M1, KT>::NV <= 20)
         hipLaunchKernelGGL((seip_kernel_two_waves<T, METHOD, GA, L, K1, M1, KT>), dim3((unsigned)blocks), dim3(64), lds, stream, ka);
     else

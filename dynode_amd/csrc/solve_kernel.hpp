@@ -57,6 +57,16 @@ struct KArgs {
     // discontinuity_points (ClipStepSizeController jump_ts), passed by value in the kernarg
     int32_t n_jump;
     T jump_ts[16];
+    // Step schedules (SEIP family, dyn_solve_batch_record / _replay): an adaptive solve can write down the (t_prev, t_next)
+    // of every accepted step, and a later launch can make other parameter rows take exactly those steps -- the discrete
+    // map is then smooth in the parameters, which is what differentiating through the reference's solve assumes (the
+    // step-size controller is not differentiated) and what central differences need.
+    T *sched_out;               // [B][sched_cap][2] accepted steps of this launch, or nullptr
+    int32_t *sched_n_out;       // [B] how many (-1: more than sched_cap)
+    const T *sched_in;          // [n_leaders][sched_cap][2] steps to replay, or nullptr (adaptive / constant stepping)
+    const int32_t *sched_n_in;  // [n_leaders]
+    const int64_t *sched_leader; // [B] schedule row of each trajectory, or nullptr (= its own index)
+    int32_t sched_cap;
     // Replication for small batches: 2^rep_log2 lane groups integrate the SAME trajectory
     // (bit-identical redundant stepping on otherwise idle SIMDs) and split its save times
     // round-robin, which divides the serial dense-output latency of a trajectory.

@@ -53,6 +53,7 @@ class BatchResult:
     saved: tuple            # names of the saved compartments, in row order
     sizes: tuple            # flat size of each saved compartment
     dys: Optional[torch.Tensor] = None  # [B, n_save, n_dir, D_saved] tangents (solve_batch_jvp)
+    schedule: Optional[tuple] = None    # (steps [B, cap, 2], count [B]) accepted steps, when recorded (record_steps=cap)
 
 
 def require_gpu() -> torch.device:
@@ -105,7 +106,7 @@ def solve_batch(model: ModelDesc, y0, params, contact, t1: float, save_ts, *, t0
                 jump_ts: Sequence[float] = (), save_mask: Optional[Sequence[bool]] = None,
                 out: Optional[torch.Tensor] = None, stats_out: Optional[tuple] = None,
                 stream: Optional[torch.cuda.Stream] = None, dparams=None, dy0=None,
-                dout: Optional[torch.Tensor] = None) -> BatchResult:
+                dout: Optional[torch.Tensor] = None, record_steps: int = 0, replay: Optional[tuple] = None) -> BatchResult:
     """Integrate B parameter samples of ``model`` over [t0, t1] on the current GPU.
 
     Replaces the per-sample ``diffeqsolve`` call of dynode.simulation.simulate
@@ -115,9 +116,18 @@ def solve_batch(model: ModelDesc, y0, params, contact, t1: float, save_ts, *, t0
     With ``dparams`` ([B, n_dir, P] seed directions, optionally ``dy0`` [n_dir, D] / [B, n_dir, D])
     the forward-mode tangents of the saved trajectory are computed in the same launch
     (``dyn_solve_batch_jvp``) and returned as ``BatchResult.dys`` [B, n_save, n_dir, D_saved].
+
+    Step schedules (SEIP family): ``record_steps=cap`` also returns the accepted steps of every trajectory
+    (``BatchResult.schedule``); ``replay=(steps, count, leader)`` makes every trajectory take the recorded steps of row
+    ``leader[b]`` of ``steps`` (``leader=None``: row b) instead of controlling its own.  For this family ``dparams`` is
+    served by `_replayed_tangents`: central differences of replayed solves on the primal's step sequence.
     """
     device = require_gpu()
     L = _abi.lib()
+    if model.family == 1 and dparams is not None:
+        return _replayed_tangents(model, y0, params, contact, t1, save_ts, dparams, dy0, t0=t0, method=method, dtype=dtype,
+                                  rtol=rtol, atol=atol, max_steps=max_steps, constant_dt=constant_dt, jump_ts=jump_ts,
+                                  save_mask=save_mask, out=out, stats_out=stats_out, stream=stream, dout=dout)
     D, P, A = model.state_dim, model.param_dim, model.n_age
     params_t = _dev(params, dtype, device).reshape(-1, P)
     B = params_t.shape[0]
@@ -164,7 +174,33 @@ def solve_batch(model: ModelDesc, y0, params, contact, t1: float, save_ts, *, t0
         float(constant_dt),
         jt.ctypes.data_as(ctypes.POINTER(ctypes.c_double)) if jt.size else None, int(jt.size))
     s = stream if stream is not None else torch.cuda.current_stream(device)
+    sched = sched_n = leader_t = None
+    if record_steps and replay is not None:
+        raise ValueError("record_steps and replay exclude each other")
+    if record_steps:
+        sched = torch.empty((B, int(record_steps), 2), dtype=dtype, device=device)
+        sched_n = torch.empty((B,), dtype=torch.int32, device=device)
+    if replay is not None:
+        sched, sched_n, leader = replay
+        if sched.dtype != dtype or sched.dim() != 3 or sched.shape[2] != 2 or not sched.is_contiguous():
+            raise ValueError("replay steps must be a contiguous [n_leaders, cap, 2] tensor of the solve dtype")
+        if leader is not None:
+            leader_t = torch.as_tensor(leader, dtype=torch.int64, device=device).contiguous()
+            if leader_t.shape != (B,):
+                raise ValueError(f"replay leader must have shape ({B},)")
+        elif sched.shape[0] != B:
+            raise ValueError("replay without a leader index needs one schedule row per trajectory")
+
     def call():
+        common = (ctypes.byref(model.c()), ctypes.byref(opts), y0_t.data_ptr(), int(batched),
+                  params_t.data_ptr(), contact_t.data_ptr(), B, float(t0), float(t1), ts_t.data_ptr(),
+                  n_save, mask_c, out.data_ptr(), status.data_ptr(), n_acc.data_ptr(), n_rej.data_ptr())
+        if record_steps:
+            return L.dyn_solve_batch_record(*common, sched.data_ptr(), sched_n.data_ptr(), int(record_steps), ctypes.c_void_p(s.cuda_stream))
+        if replay is not None:
+            return L.dyn_solve_batch_replay(*common, sched.data_ptr(), sched_n.data_ptr(),
+                                            leader_t.data_ptr() if leader_t is not None else None, int(sched.shape[1]),
+                                            ctypes.c_void_p(s.cuda_stream))
         if n_dir == 0:
             return L.dyn_solve_batch(
                 ctypes.byref(model.c()), ctypes.byref(opts), y0_t.data_ptr(), int(batched),
@@ -183,10 +219,83 @@ def solve_batch(model: ModelDesc, y0, params, contact, t1: float, save_ts, *, t0
     if rc != 0:
         raise SolveError(rc, L.dyn_last_error().decode())
     # keep inputs alive until the stream has consumed them
-    for t in (y0_t, params_t, contact_t, ts_t, dparams_t, dy0_t):
+    for t in (y0_t, params_t, contact_t, ts_t, dparams_t, dy0_t, sched, sched_n, leader_t):
         if t is not None:
             t.record_stream(s)
-    return BatchResult(out, status, n_acc, n_rej, saved, sizes, dout)
+    return BatchResult(out, status, n_acc, n_rej, saved, sizes, dout, (sched, sched_n) if record_steps else None)
+
+
+# relative size of the central-difference step of `_replayed_tangents`, per solve dtype: truncation ~ h^2, rounding ~ eps / h
+_FD_REL_STEP = {torch.float32: 2e-3, torch.float64: 1e-5}
+SCHEDULE_CAP = 2048      # accepted steps recorded per trajectory (the adaptive SEIP ensembles take about 250-350)
+
+
+def schedule_capacity(model: ModelDesc, dtype, n_save: int) -> int:
+    """Steps per trajectory a replayed schedule may hold: the kernel stages it in LDS next to the save grid and the
+    model's tables (64 KB per wave in all), at most `SCHEDULE_CAP`."""
+    L = _abi.lib()
+    tpw = max(1, int(L.dyn_trajectories_per_wave(ctypes.byref(model.c()))))
+    A, nL, H, K1, M1, nk = model.seip_dims
+    per_traj = H * K1 * M1 * nL + A * K1 * (4 + 2 * nk)
+    words = 65536 // (8 if dtype == torch.float64 else 4) - n_save - 16 - tpw * per_traj
+    return int(max(8, min(SCHEDULE_CAP, words // (2 * tpw))))
+
+
+def _replayed_tangents(model, y0, params, contact, t1, save_ts, dparams, dy0, *, out=None, stats_out=None, dout=None,
+                       dtype=torch.float32, **kw) -> BatchResult:
+    """Directional derivatives of a SEIP solve, with the outputs of ``dyn_solve_batch_jvp``.
+
+    The SEIP kernels have no tangent planes.  What differentiating through the reference's solve computes -- the
+    derivative of the trajectory with the step-size controller held fixed (its decisions are under stop_gradient) -- is
+    obtained as: (1) the primal solve, recording its accepted steps (``dyn_solve_batch_record``); (2) ONE batched launch
+    of the 2 n_dir B rows ``params +- h_k dparams[:, k]`` (and ``y0 +- h_k dy0[:, k]``) that replays, row by row, the
+    step sequence of its primal (``dyn_solve_batch_replay``): on a fixed step sequence the solve is a smooth map, so
+    (3) the central difference is its derivative to O(h^2).  ``h_k`` perturbs the most-moved parameter by
+    ``_FD_REL_STEP`` of its own magnitude."""
+    device = require_gpu()
+    P, D = model.param_dim, model.state_dim
+    params_t = _dev(params, dtype, device).reshape(-1, P)
+    B = params_t.shape[0]
+    dp = _dev(dparams, dtype, device)
+    if dp.dim() != 3 or dp.shape[0] != B or dp.shape[2] != P:
+        raise ValueError(f"dparams must have shape [B={B}, n_dir, P={P}], got {tuple(dp.shape)}")
+    n_dir = dp.shape[1]
+    y0_t = _dev(y0, dtype, device)
+    dy = None
+    if dy0 is not None:
+        dy = _dev(dy0, dtype, device)
+        if dy.dim() == 2:
+            dy = dy.unsqueeze(0).expand(B, n_dir, D)
+        if tuple(dy.shape) != (B, n_dir, D):
+            raise ValueError(f"dy0 must have shape {(n_dir, D)} or {(B, n_dir, D)}")
+    base = solve_batch(model, y0_t, params_t, contact, t1, save_ts, dtype=dtype, out=out, stats_out=stats_out,
+                       record_steps=schedule_capacity(model, dtype, len(save_ts)), **kw)
+    # step along direction k: the largest |dp_i| / (|p_i| + floor) becomes _FD_REL_STEP
+    rel = (dp.abs() / (params_t.abs().unsqueeze(1) + 1e-3)).amax(dim=2)
+    if dy is not None:
+        y0b = y0_t if y0_t.dim() == 2 else y0_t.unsqueeze(0).expand(B, D)
+        rel = torch.maximum(rel, (dy.abs() / (y0b.abs().unsqueeze(1) + 1e-3)).amax(dim=2))
+    h = _FD_REL_STEP[dtype] / rel.clamp_min(1e-30)                                   # [B, n_dir]
+    h = torch.where(rel > 0, h, torch.ones_like(h))                                   # a zero direction: derivative 0
+    shift = (h.unsqueeze(-1) * dp).reshape(B * n_dir, P)
+    rows = params_t.repeat_interleave(n_dir, dim=0)
+    p_all = torch.cat([rows + shift, rows - shift], dim=0)                            # [2 n_dir B, P]
+    if dy is not None:
+        ys = (h.unsqueeze(-1) * dy).reshape(B * n_dir, D)
+        yrows = (y0_t if y0_t.dim() == 2 else y0_t.unsqueeze(0).expand(B, D)).repeat_interleave(n_dir, dim=0)
+        y_all = torch.cat([yrows + ys, yrows - ys], dim=0)
+    else:
+        y_all = y0_t.repeat_interleave(n_dir, dim=0).repeat(2, 1) if y0_t.dim() == 2 else y0_t
+    leader = torch.arange(B, device=device).repeat_interleave(n_dir).repeat(2)
+    kw.pop("constant_dt", None)                                                       # the recording already holds the steps
+    pert = solve_batch(model, y_all, p_all, contact, t1, save_ts, dtype=dtype, replay=base.schedule + (leader,), **kw)
+    n = B * n_dir
+    dys = (pert.ys[:n] - pert.ys[n:]).reshape(B, n_dir, pert.ys.shape[1], -1) / (2.0 * h).reshape(B, n_dir, 1, 1)
+    dys = dys.permute(0, 2, 1, 3).contiguous()
+    if dout is not None:
+        dout.copy_(dys)
+        dys = dout
+    return BatchResult(base.ys, base.status, base.n_accept, base.n_reject, base.saved, base.sizes, dys, base.schedule)
 
 
 def solve_batch_loglik(model: ModelDesc, y0, params, contact, t1: float, save_ts, obs, obs_compartment: int, *,

@@ -28,6 +28,8 @@ def _supported_nd(model, method: str, dtype, nd: int) -> bool:
 
 def direction_chunks(model, method: str, dtype, P: int) -> list:
     """Split P seed directions into chunks the library has kernels for (largest first)."""
+    if model.family == 1:      # SEIP: central differences of replayed solves take any number of directions at once (engine)
+        return [P]
     sizes = [n for n in range(P, 0, -1) if _supported_nd(model, method, dtype, n)]
     if not sizes:
         from .. import jit

@@ -256,7 +256,7 @@ class CompartmentalODE:
             cols.append(np.broadcast_to(a.reshape(-1, 1), (B, 1)))
         return np.ascontiguousarray(np.concatenate(cols, axis=1)), batch, seasonal
 
-    def param_tensor(self, p, device) -> "torch.Tensor":
+    def param_tensor(self, p, device, packed=None) -> "torch.Tensor":
         """[B, P] parameter matrix built with torch ops, keeping the autograd graph of any field
         that is a tensor requiring grad (used by the differentiable solve under NUTS)."""
         strain_rank = 1 if self.multi_strain else 0

@@ -35,6 +35,35 @@ def history_masks(n_strains: int) -> np.ndarray:
     return np.asarray(masks, dtype=np.int64)
 
 
+def protection_table_torch(crossimmunity, vaccine_efficacy, wane_protection, min_homologous_immunity=0.0):
+    """:func:`protection_table` with torch ops (same formulas, same index order): a cross-immunity or vaccine efficacy that
+    is a tensor requiring grad keeps its autograd graph, so the susceptibility table can be differentiated -- the solve
+    itself through `engine._replayed_tangents`."""
+    import torch
+
+    f64 = torch.float64
+    dev = next((v.device for v in (crossimmunity, vaccine_efficacy, wane_protection, min_homologous_immunity)
+                if isinstance(v, torch.Tensor)), torch.device("cpu"))
+    chi, ve, prot, floor = (v.to(device=dev, dtype=f64) if isinstance(v, torch.Tensor) else torch.as_tensor(np.asarray(v, dtype=float), device=dev)
+                            for v in (crossimmunity, vaccine_efficacy, wane_protection, min_homologous_immunity))
+    L, K1, M1 = chi.shape[-1], ve.shape[-1], prot.shape[-1]
+    lead = torch.broadcast_shapes(chi.shape[:-2], ve.shape[:-2], prot.shape[:-1], floor.shape)
+    rows = []
+    for j in range(1 << L):
+        past = [q for q in range(L) if (j >> q) & 1]
+        cols = []
+        for l in range(L):
+            escape = torch.ones(lead, dtype=f64, device=dev)
+            for q in past:
+                escape = escape * (1.0 - chi[..., l, q])
+            initial = 1.0 - (1.0 - ve[..., l, :]) * escape[..., None]                          # [..., K1]
+            wib = initial[..., :, None] * prot[..., None, :]                                    # [..., K1, M1]
+            wim = (1.0 - wib) * floor[..., None, None] if (j >> l) & 1 else torch.zeros_like(wib)
+            cols.append((1.0 - (wib + wim)).expand(lead + (K1, M1)))
+        rows.append(torch.stack(cols, dim=-1))                                                   # [..., K1, M1, L]
+    return torch.stack(rows, dim=-4)                                                             # [..., H, K1, M1, L]
+
+
 def protection_table(crossimmunity, vaccine_efficacy, wane_protection, min_homologous_immunity=0.0) -> np.ndarray:
     """Susceptibility ``1 - WI`` of ode_model.md:185-211, indexed [history bit set, doses, waning state, strain].
 
@@ -86,8 +115,42 @@ class SEIPODE(CompartmentalODE):
                          has_c=True, seasonal=None, normalize=False,
                          doc="SEIP with immune histories, vaccination tiers and waning states: ode_model.md:15-53.")
 
+    _GRAD_FIELDS = ("beta", "gamma", "sigma", "waning_rates", "susceptibility")
+
     def wants_grad(self, p) -> bool:
-        return False          # primal kernels only: simulate, do not differentiate
+        """Rates or the susceptibility table given as tensors that require grad: the solve is then differentiated along
+        them (central differences of replayed solves on the primal's step sequence, `engine._replayed_tangents`)."""
+        import torch
+
+        return any(isinstance(getattr(p, f), torch.Tensor) and getattr(p, f).requires_grad for f in self._GRAD_FIELDS)
+
+    def param_tensor(self, p, device, packed: Optional[Packed] = None):
+        """[B, P] parameter matrix with the autograd graph of the tensor-valued fields: the columns of `pack` (host
+        constants) with the blocks of beta / gamma / sigma / waning_rates / susceptibility replaced by the tensors."""
+        import torch
+
+        if packed is None:
+            raise ValueError("seip_ode.param_tensor needs the packed call (simulate passes it)")
+        base = torch.as_tensor(packed.params, dtype=torch.float64, device=device)
+        B = base.shape[0]
+        A, L, H, K1, M1, _ = packed.model.seip_dims
+        m = packed.model
+        sus_at = 3 * L + M1 + (3 * L if m.has_intro else 0) + (3 if m.seasonal else 0) + (1 if m.seasonal_vax else 0) + A
+        blocks = {"beta": (0, L), "gamma": (L, L), "sigma": (2 * L, L), "waning_rates": (3 * L, M1), "susceptibility": (sus_at, H * K1 * M1 * L)}
+        pieces, pos = [], 0
+        for name in self._GRAD_FIELDS:
+            start, width = blocks[name]
+            v = getattr(p, name)
+            if isinstance(v, torch.Tensor) and v.requires_grad:
+                pieces.append(base[:, pos:start])
+                t = v.to(device=device, dtype=torch.float64)
+                t = t.reshape(-1, width) if name != "susceptibility" or t.dim() == 5 else t.reshape(1, width)
+                pieces.append(t.expand(B, width) if t.shape[0] == 1 else t)
+                pos = start + width
+        pieces.append(base[:, pos:])
+        out = torch.cat(pieces, dim=1)
+        assert out.shape == base.shape
+        return out
 
     def pack(self, initial_state, p, with_params: bool = True) -> Packed:
         if len(initial_state) != 4:

@@ -168,7 +168,7 @@ def _simulate_observed(ode, ode_parameters, packed, saveat, t1, kw, observe, dif
         const = const - float(observe.floor) * cells
     kw = {k: v for k, v in kw.items() if k != "save_mask"}
     if differentiable:
-        params_t = ode.param_tensor(ode_parameters, device)
+        params_t = ode.param_tensor(ode_parameters, device, packed)
     else:
         params_t = torch.as_tensor(packed.params, dtype=torch.float64, device=device)
     lp, status, n_acc, n_rej = solve_loglik_diff(packed.model, packed.y0 if y0_arg is None else y0_arg, params_t, packed.contact, t1, saveat.ts, obs_t,
@@ -238,7 +238,7 @@ def simulate(ode, duration_days, initial_state: CompartmentState, ode_parameters
         from ..engine import require_gpu
         from ..infer.autodiff import solve_batch_diff
 
-        params_t = ode.param_tensor(ode_parameters, require_gpu())
+        params_t = ode.param_tensor(ode_parameters, require_gpu(), packed)
         res = solve_batch_diff(packed.model, y0_arg, params_t, packed.contact, float(duration_days), saveat.ts, **kw)
     else:
         res = solve_batch(packed.model, packed.y0, packed.params, packed.contact, float(duration_days), saveat.ts, **kw)

@@ -183,6 +183,31 @@ int dyn_solve_batch(const dyn_model_desc *m, const dyn_solver_opts *opts, const 
                     int32_t *n_reject, void *stream);
 
 /*
+ * Step schedules (family = 1, SEIP).  The SEIP kernels carry no tangent planes (270 live values per lane as it is);
+ * they are differentiated the way jax differentiates the reference's solve -- with the step-size controller held
+ * fixed (src/dynode/infer/inference.py:149-163: value_and_grad through diffeqsolve, whose controller is under
+ * stop_gradient): dyn_solve_batch_record writes down the (t_prev, t_next) pair of every accepted step of an adaptive
+ * solve, dyn_solve_batch_replay makes any batch of parameter rows take exactly the steps of their "leader" row.  On a
+ * fixed step sequence the solve is a smooth map of the parameters, so central differences of replayed solves are the
+ * derivative of the adaptive solve (dynode_amd/engine.py composes them into the outputs of dyn_solve_batch_jvp).
+ *   sched_out    [B][sched_cap][2]  accepted steps (solve dtype), device;  sched_n_out [B]: their number, -1 if > sched_cap
+ *   sched        [n_leaders][sched_cap][2], sched_n [n_leaders];  leader [B] int64 row of `sched` per trajectory
+ *                (NULL: trajectory b follows row b).  A follower of a leader with sched_n < 0 ends with status 1.
+ * Discontinuity points are part of the recording (the gap between two recorded steps restarts the first stage).
+ * The replayed schedule is staged in LDS: 2 * sched_cap values per trajectory of a wave next to the model's tables
+ * (DYN_ERR_UNSUPPORTED when that exceeds 64 KB: lower sched_cap).  Other arguments as dyn_solve_batch.
+ */
+int dyn_solve_batch_record(const dyn_model_desc *m, const dyn_solver_opts *o, const void *y0, int32_t y0_is_batched,
+                           const void *params, const void *contact, int64_t B, double t0, double t1, const void *save_ts,
+                           int32_t n_save, const uint8_t *save_mask, void *ys_out, int32_t *status, int32_t *n_accept,
+                           int32_t *n_reject, void *sched_out, int32_t *sched_n_out, int32_t sched_cap, void *stream);
+int dyn_solve_batch_replay(const dyn_model_desc *m, const dyn_solver_opts *o, const void *y0, int32_t y0_is_batched,
+                           const void *params, const void *contact, int64_t B, double t0, double t1, const void *save_ts,
+                           int32_t n_save, const uint8_t *save_mask, void *ys_out, int32_t *status, int32_t *n_accept,
+                           int32_t *n_reject, const void *sched, const int32_t *sched_n, const int64_t *leader,
+                           int32_t sched_cap, void *stream);
+
+/*
  * Batched solve + forward-mode tangents: value and directional derivatives of the saved
  * trajectory with respect to the parameters / initial state, for n_dir directions at once.
  * This is the gradient-solve under the reference's NUTS loop, where numpyro takes

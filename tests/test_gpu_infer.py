@@ -553,3 +553,36 @@ def test_svi_with_finite_difference_gradients(data):
     print("SVI autograd", a, "finite differences", f)
     assert abs(a[0] - f[0]) < 0.02 and abs(a[2] - f[2]) < 0.1 and abs(a[1] - f[1]) < 0.03 and abs(a[3] - f[3]) < 0.12
     assert abs(f[0] - 2.046) < 0.04 and abs(f[2] - 7.2) < 0.2
+
+
+def test_default_nuts_fits_the_seip_model_with_adaptive_steps():
+    """NUTS with the default machinery (sampler kernel, autograd gradient, adaptive solver steps) on the SEIP family: the
+    gradient-solve is the primal solve plus one batched launch of perturbed rows replaying the primal's accepted steps
+    (engine._replayed_tangents).  First the gradient against differences of the potential itself under a constant step
+    (where the potential is smooth), then the fit of examples/infer_seip_cross_immunity.py."""
+    from dynode_amd import SolverParams
+    from examples import infer_seip_cross_immunity as ex_s
+    from examples import seip_immune_history as base_s
+
+    config = base_s.get_config()
+    obs = ex_s.weekly_infections(config, 210, **ex_s.TRUTH).cpu()
+    smooth = base_s.get_config()
+    smooth.parameters.solver_params = SolverParams(constant_step_size=0.25)
+    odes.enable_x64(True)
+    try:
+        pot = Potential(ex_s.model, dict(config=smooth, tf=210, obs_data=obs), 0, torch.device("cuda"))
+        z = torch.tensor([[-0.2, 0.1], [0.4, -0.3]], dtype=torch.float64, device="cuda")
+        u, g = pot.potential_and_grad(z)
+        u_fd, g_fd = pot.potential_and_grad_fd(z, 1e-5)
+        assert torch.allclose(u, u_fd, rtol=1e-12) and torch.allclose(g, g_fd, rtol=2e-4, atol=1e-3), (g, g_fd)
+    finally:
+        odes.enable_x64(False)
+    process = MCMCProcess(numpyro_model=ex_s.model, num_warmup=120, num_samples=80, num_chains=16, nuts_max_tree_depth=6,
+                          progress_bar=False)
+    mcmc = process.infer(config=config, tf=210, obs_data=obs)
+    post = process.get_samples()
+    chi, r0 = post["cross_immunity"].cpu().numpy(), post["r0_beta"].cpu().numpy()
+    print("NUTS on SEIP (adaptive steps, replayed tangents): cross-immunity %.4f +- %.4f, r0 %.4f +- %.4f, accept %.3f, leapfrogs %.1f" % (
+        chi.mean(), chi.std(), r0.mean(), r0.std(), float(mcmc.nuts.accept_prob.mean()), float(mcmc.nuts.num_steps.double().mean())))
+    assert abs(chi.mean() - 0.45) < max(3 * chi.std(), 0.02) and abs(r0.mean() - 2.4) < max(3 * r0.std(), 0.01)
+    assert chi.std() < 0.05 and r0.std() < 0.02 and float(mcmc.nuts.accept_prob.mean()) > 0.6

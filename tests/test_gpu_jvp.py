@@ -464,13 +464,13 @@ def test_initial_state_gradient_reaches_the_sampler_coordinates():
     from dynode_amd.infer.inference import Potential
     from dynode_amd.simulation import odes
 
-    pop = torch.tensor([600.0, 400.0], dtype=torch.float64, device="cuda")
     C = np.array([[0.7, 0.3], [0.3, 0.7]])
     data = torch.tensor(np.random.default_rng(4).uniform(0.5, 6.0, (30, 2)), dtype=torch.float64)
 
     def model(obs_data):
         share = handlers.sample("i0_share", dist.Uniform(0.001, 0.05))
         beta = handlers.sample("beta", dist.Uniform(0.15, 0.6))
+        pop = torch.tensor([600.0, 400.0], dtype=torch.float64, device=share.device)
         i0 = share[..., None] * pop
         p = rhs.SIR_ODEParams(beta=beta, gamma=torch.full_like(beta, 1.0 / 7.0), contact_matrix=C)
         sol = simulate(rhs.sir_ode, 30, (pop - i0, i0, torch.zeros_like(i0)), p, SolverParams(constant_step_size=0.25))
@@ -489,3 +489,97 @@ def test_initial_state_gradient_reaches_the_sampler_coordinates():
             assert torch.allclose(g[:, d], fd, rtol=2e-4, atol=1e-5), (d, g[:, d], fd)
     finally:
         odes.enable_x64(False)
+
+
+# ------------------------------------------------------------------ SEIP family: gradients by replaying the primal's steps
+def _seip_case(B=3, dtype=np.float64, **shape):
+    shape = shape or dict(A=2, L=2, K1=2, M1=2, n_knots=1)
+    wl = synthetic.seip(B=B, seed=17, t1=90.0, **shape)
+    return wl, synthetic.save_grid(90.0, 3)
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
+def test_seip_replay_of_the_own_schedule_reproduces_the_adaptive_solve(dtype):
+    """dyn_solve_batch_record writes down the accepted steps; replaying them with the same parameters takes the same
+    stages from the same states: bitwise the same trajectory, no rejected step, and a follower of ANOTHER row's schedule
+    takes that row's step count."""
+    wl, ts = _seip_case(B=5, A=4, L=2, K1=3, M1=4, n_knots=2)
+    m = wl.model
+    base = solve_batch(m, wl.y0, wl.params, wl.contact, 90.0, ts, dtype=dtype, record_steps=512)
+    steps, count = base.schedule
+    torch.cuda.synchronize()
+    assert int(base.status.max()) == 0 and torch.equal(count, base.n_accept) and int(count.min()) > 10
+    t = steps[0, :int(count[0])]
+    assert float(t[0, 0]) == 0.0 and float(t[-1, 1]) == 90.0 and bool((t[1:, 0] == t[:-1, 1]).all())   # contiguous cover of [0, 90]
+    again = solve_batch(m, wl.y0, wl.params, wl.contact, 90.0, ts, dtype=dtype, replay=(steps, count, None))
+    assert torch.equal(again.ys, base.ys) and torch.equal(again.n_accept, base.n_accept) and int(again.n_reject.max()) == 0
+    # every row on row 2's schedule: same number of steps everywhere, row 2 itself unchanged
+    lead = torch.full((5,), 2, dtype=torch.int64)
+    tied = solve_batch(m, wl.y0, wl.params, wl.contact, 90.0, ts, dtype=dtype, replay=(steps, count, lead))
+    assert int(tied.status.max()) == 0 and bool((tied.n_accept == count[2]).all()) and torch.equal(tied.ys[2], base.ys[2])
+    assert not torch.equal(tied.ys[0], base.ys[0])
+    # a schedule that did not fit is reported, and followers of it fail instead of stopping short
+    small = solve_batch(m, wl.y0, wl.params, wl.contact, 90.0, ts, dtype=dtype, record_steps=8)
+    assert int(small.schedule[1].max()) == -1
+    bad = solve_batch(m, wl.y0, wl.params, wl.contact, 90.0, ts, dtype=dtype, replay=small.schedule + (None,))
+    assert bool((bad.status == 1).all()) and bool(torch.isinf(bad.ys[:, -1]).all())
+
+
+def test_seip_tangents_equal_differences_of_the_oracle():
+    """solve_batch(dparams=..., dy0=...) on the SEIP family (central differences of replayed solves) against central
+    differences of the float64 ORACLE under the same constant step: rates, a susceptibility entry, a spline coefficient,
+    the initial state."""
+    wl, ts = _seip_case()
+    m = wl.model
+    B, P, D = wl.B, m.param_dim, m.state_dim
+    A, L, H, K1, M1, nk = m.seip_dims
+    sus_at = 3 * L + M1 + A
+    rng = np.random.default_rng(5)
+    dp = np.zeros((B, 4, P))
+    dp[:, 0, 0] = 1.0                                         # beta of strain 0
+    dp[:, 1, L + 1] = 1.0                                     # gamma of strain 1
+    dp[:, 2, sus_at + 5] = 1.0                                # one susceptibility entry
+    dp[:, 3, :3 * L] = rng.normal(size=(B, 3 * L))            # a mixed direction over all rates ...
+    dy = np.zeros((B, 4, D))
+    dy[:, 3] = rng.uniform(0.0, 1.0, (B, D)) * (wl.y0 > 0)    # ... and the occupied part of the initial state
+    got = solve_batch(m, wl.y0, wl.params, wl.contact, 90.0, ts, dtype=torch.float64, constant_dt=0.5, dparams=dp, dy0=dy)
+    import helpers as Hh
+
+    def orc(p, y0):
+        ys, st, _, _ = Hh.O.solve(Hh.omodel(m), y0, p, wl.contact, 90.0, ts, dtype=np.float64, n_threads=8, constant_dt=0.5)
+        assert st.max() == 0
+        return ys
+
+    base = orc(wl.params, wl.y0)
+    assert np.abs(got.ys.cpu().numpy() - base).max() / 1000.0 < 1e-11
+    for k in range(4):
+        eps = 1e-6
+        want = (orc(wl.params + eps * dp[:, k], wl.y0 + eps * dy[:, k]) - orc(wl.params - eps * dp[:, k], wl.y0 - eps * dy[:, k])) / (2 * eps)
+        have = got.dys[:, :, k].cpu().numpy()
+        scale = np.abs(want).max()
+        assert scale > 1.0 and np.abs(have - want).max() / scale < 2e-6, (k, np.abs(have - want).max() / scale)
+
+
+def test_seip_adaptive_tangents_and_autograd_through_simulate():
+    """With the step-size controller ON the tangents are those of the recorded step sequence; at tight tolerances that is
+    the sensitivity of the ODE itself (oracle differences at rtol 1e-11)."""
+    import helpers as Hh
+
+    wl, ts = _seip_case(B=2)
+    m = wl.model
+    P = m.param_dim
+    dp = np.zeros((2, 1, P))
+    dp[:, 0, 1] = 1.0                                          # beta of strain 1
+    got = solve_batch(m, wl.y0, wl.params, wl.contact, 90.0, ts, dtype=torch.float64, rtol=1e-9, atol=1e-9, dparams=dp)
+
+    def orc(p):
+        ys, st, _, _ = Hh.O.solve(Hh.omodel(m), wl.y0, p, wl.contact, 90.0, ts, dtype=np.float64, n_threads=8, rtol=1e-11, atol=1e-11)
+        assert st.max() == 0
+        return ys
+
+    want = (orc(wl.params + 1e-6 * dp[:, 0]) - orc(wl.params - 1e-6 * dp[:, 0])) / 2e-6
+    have = got.dys[:, :, 0].cpu().numpy()
+    assert np.abs(have - want).max() / np.abs(want).max() < 2e-5
+    # float32, default tolerances: the same sensitivities to a few parts in a thousand of their scale
+    g32 = solve_batch(m, wl.y0, wl.params, wl.contact, 90.0, ts, dtype=torch.float32, dparams=dp).dys[:, :, 0].cpu().numpy()
+    assert np.abs(g32 - want).max() / np.abs(want).max() < 5e-3
