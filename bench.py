@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- trajectories/sec of the fused 365-day solve on N MI355X GPUs.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3|cfg3d136|cfg2|cfg5|seip|seip3]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3|cfg3d136|cfg2|cfg5|seip|seip3|seip83|seip84]
                     [--scaling weak|strong] [--batch B]
 
 A "step" is one pass of the hot path over one batch of synthetic parameter samples: ONE launch
@@ -39,7 +39,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy peak ~6290
-SEEDS = {"cfg2": 0, "cfg3": 1, "cfg3d136": 1, "cfg5": 5, "seip": 7, "seip3": 7}
+SEEDS = {"cfg2": 0, "cfg3": 1, "cfg3d136": 1, "cfg5": 5, "seip": 7, "seip3": 7, "seip83": 7, "seip84": 7}
 
 
 def parse():
@@ -352,7 +352,7 @@ def main():
             del r2
             # the other single-GPU configs of BASELINE.json, 20 launches each (not the headline value)
             line["other_workloads"] = {}
-            for name in ("cfg2", "cfg5", "seip", "seip3"):
+            for name in ("cfg2", "cfg5", "seip", "seip3", "seip83", "seip84"):
                 torch.cuda.empty_cache()
                 w2 = synthetic.WORKLOADS[name]()
                 r2 = measure(w2, dev, 20, 3, torch.cuda.synchronize)

@@ -28,7 +28,10 @@ namespace dyn {
     extern template hipError_t launch_seip<T, METHOD, GA, L, K1, M1>(const KArgs<T> &, hipStream_t);
 #define YT(T, METHOD, GA, L, K1, M1) \
     extern template hipError_t launch_seip<T, METHOD, GA, L, K1, M1, 2>(const KArgs<T> &, hipStream_t);
+#define YW(T, METHOD, GA, L, K1, M1, KT, NW) \
+    extern template hipError_t launch_seip<T, METHOD, GA, L, K1, M1, KT, NW>(const KArgs<T> &, hipStream_t);
 #include "seip_instances.def"
+#undef YW
 #undef YT
 #undef Y
 
@@ -51,6 +54,7 @@ struct Entry {
 // FEAT = kSeip | tiers; the lane group is G * 2^S
 constexpr int kSeip = 0x100;
 constexpr int kSeipTierLanes = 0x20; // SEIP entry with the tiers dealt over two lanes (seip_kernel.hpp, KT = 2)
+constexpr int kSeipWaves2 = 0x40, kSeipWaves4 = 0x80; // ... whose trajectory is owned by a workgroup of 2 / 4 waves (NW)
 // FEAT bit 14 (solve_kernel.hpp SAVE_ALL): variant without the per-round save-offset / store-width tests, picked by
 // enqueue when every compartment is saved into 16-byte aligned rows
 constexpr int kSaveAll = 0x4000;
@@ -78,7 +82,12 @@ static const Entry kEntries[] = {
 #define YT(T, METHOD, GA, L, K1, M1)                                         \
     {DType<T>::id, METHOD, GA, L, 1, 1, 1, M1, 0, 1, kSeip | kSeipTierLanes | K1, \
      (void *)(hipError_t(*)(const KArgs<T> &, hipStream_t)) & launch_seip<T, METHOD, GA, L, K1, M1, 2>},
+#define YW(T, METHOD, GA, L, K1, M1, KT, NW)                                                                     \
+    {DType<T>::id, METHOD, GA, L, 1, 1, 1, M1, 0, 1,                                                             \
+     kSeip | (KT == 2 ? kSeipTierLanes : 0) | (NW == 2 ? kSeipWaves2 : kSeipWaves4) | K1,                        \
+     (void *)(hipError_t(*)(const KArgs<T> &, hipStream_t)) & launch_seip<T, METHOD, GA, L, K1, M1, KT, NW>},
 #include "seip_instances.def"
+#undef YW
 #undef YT
 #undef Y
 };
@@ -106,7 +115,10 @@ static int model_features(const dyn_model_desc *m) {
     return (m->has_intro ? 1 : 0) | (vax_lanes(m) << 1);
 }
 // lanes one trajectory occupies in a wave
+static int entry_waves(const Entry *e) { return (e->FEAT & kSeip) ? ((e->FEAT & kSeipWaves4) ? 4 : (e->FEAT & kSeipWaves2) ? 2 : 1) : 1; }
+// lanes of a WAVE one trajectory occupies (a wave group owns whole waves: 64)
 static int entry_lanes(const Entry *e) {
+    if ((e->FEAT & kSeip) && entry_waves(e) > 1) return 64;
     return (e->FEAT & kSeip) ? (e->G << e->S) * ((e->FEAT & kSeipTierLanes) ? 2 : 1) : e->G * (e->S / e->SPL);
 }
 
@@ -155,18 +167,29 @@ static const Entry *find_variant(const Entry *e, int feat) {
 }
 
 // SEIP: which lane mapping runs a model.  States that would spill (more than 32 values per lane) take the tiers dealt
-// over two lanes when that variant exists and the lane group still fits a wave; it is also the fallback when only it is
-// compiled in ...
+// over two lanes when that variant exists; it is also the fallback when only it is compiled in.  A lane group beyond a
+// wavefront (8 ages x 8 histories x 2 tier lanes; 16 histories) runs as a wave group: NW waves per trajectory.
 static const Entry *select_seip_entry(const dyn_model_desc *m, int dtype, int method, const Entry *e) {
     Entry probe{dtype, method, group_width(m->n_age), m->n_strain, 1, 1, 1, m->n_wane, 0, 1, 0, nullptr};
-    const Entry *two = find_variant(&probe, kSeip | kSeipTierLanes | seip_tiers(m));
-    const int per_tier = m->n_wane + 3 * m->n_strain, per_lane = seip_tiers(m) * per_tier;
+    const int k1 = seip_tiers(m), lanes = group_width(m->n_age) << m->n_strain;
+    const int per_tier = m->n_wane + 3 * m->n_strain, per_lane = k1 * per_tier;
+    const char *force = getenv("DYNODE_HIP_SEIP_TIER_LANES"); // tuning aid: 0 / 1
+    if (lanes > 64) { // histories across waves: tier lanes on top (four waves) for big per-lane states, else two waves
+        const Entry *w2 = find_variant(&probe, kSeip | kSeipWaves2 | k1);
+        const Entry *w4 = find_variant(&probe, kSeip | kSeipTierLanes | kSeipWaves4 | k1);
+        if (w4 && (!w2 || (force ? atoi(force) != 0 : per_lane > 32))) return w4;
+        return w2;
+    }
+    const Entry *two = find_variant(&probe, kSeip | kSeipTierLanes | k1);
+    if (lanes == 64) { // tier lanes would need 128: a wave group of two
+        const Entry *w2 = find_variant(&probe, kSeip | kSeipTierLanes | kSeipWaves2 | k1);
+        if (w2 && (!e || (force ? atoi(force) != 0 : per_lane > 32))) return w2;
+        return e;
+    }
     // ... and small float states: half the tiers per lane fit 256 registers, so two waves share a SIMD (measured on the
     // D = 960 shape: 6.5 vs 6.7 ms at 4096 trajectories, 23.3 vs 25.4 ms at 16384) -- only when the one-lane mapping is
     // down to two trajectories per wave: with 4 ages x 4 histories it keeps four per wave and wins (6.15 vs 6.70 ms at 8192)
-    const bool small = dtype == DYN_F32 && seip_tiers(m) > 1 && ((seip_tiers(m) + 1) / 2) * per_tier <= 20 &&
-                       (group_width(m->n_age) << m->n_strain) >= 32;
-    const char *force = getenv("DYNODE_HIP_SEIP_TIER_LANES"); // tuning aid: 0 / 1
+    const bool small = dtype == DYN_F32 && k1 > 1 && ((k1 + 1) / 2) * per_tier <= 20 && lanes >= 32;
     if (two && (!e || (force ? atoi(force) != 0 : (per_lane > 32 || small)))) return two;
     return e;
 }
@@ -180,9 +203,13 @@ static void note_kernel(const Entry *e) {
     if (e->FEAT & kSeip) {
         const int k1 = e->FEAT & 0x1f, kt = (e->FEAT & kSeipTierLanes) ? 2 : 1;
         const int nv = ((k1 + kt - 1) / kt) * (e->W + 3 * e->S);
-        snprintf(tl_kernel, sizeof(tl_kernel), "dyn::%s<%s, %d, %d, %d, %d, %d, %d>",
-                 (e->dtype == DYN_F32 && nv <= 20) ? "seip_kernel_two_waves" : "seip_kernel", t, e->method, e->G, e->S, k1,
-                 e->W, kt);
+        if (entry_waves(e) > 1)
+            snprintf(tl_kernel, sizeof(tl_kernel), "dyn::seip_kernel_wave_group<%s, %d, %d, %d, %d, %d, %d, %d>", t, e->method, e->G,
+                     e->S, k1, e->W, kt, entry_waves(e));
+        else
+            snprintf(tl_kernel, sizeof(tl_kernel), "dyn::%s<%s, %d, %d, %d, %d, %d, %d>",
+                     (e->dtype == DYN_F32 && nv <= 20) ? "seip_kernel_two_waves" : "seip_kernel", t, e->method, e->G, e->S, k1,
+                     e->W, kt);
         return;
     }
     snprintf(tl_kernel, sizeof(tl_kernel), "dyn::solve_kernel<%s, %d, %d, %d, %s, %s, %s, %d, %d, %d, %d>", t, e->method,
@@ -197,7 +224,7 @@ static int check_model(const dyn_model_desc *m) {
     if (m->has_intro && m->n_strain > DYN_MAX_STRAINS) return DYN_ERR_MODEL;
     if (m->family != 0 && m->family != 1) return DYN_ERR_MODEL;
     if (m->family == 1) { /* SEIP: groups = age x 2^strains lanes */
-        if (m->n_strain > 4 || (group_width(m->n_age) << m->n_strain) > 64 || m->n_vax_tiers < 0 || m->n_vax_tiers > 4 ||
+        if (m->n_strain > 4 || (group_width(m->n_age) << m->n_strain) > 128 || m->n_vax_tiers < 0 || m->n_vax_tiers > 4 ||
             m->n_vax_knots < 0 || m->n_vax_knots > 4 || !m->has_e || !m->has_c || !m->has_wane || m->normalize)
             return DYN_ERR_MODEL;
         return 0;
@@ -428,10 +455,8 @@ int32_t dyn_trajectories_per_wave(const dyn_model_desc *m) {
 
 int32_t dyn_is_supported(const dyn_model_desc *m, const dyn_solver_opts *o) {
     if (dyn::check_model(m) || !o) return 0;
-    if (m->family == 1) { // either lane mapping will do
-        dyn::Entry probe{o->dtype, o->method, dyn::group_width(m->n_age), m->n_strain, 1, 1, 1, m->n_wane, 0, 1, 0, nullptr};
-        if (dyn::find_variant(&probe, dyn::kSeip | dyn::kSeipTierLanes | dyn::seip_tiers(m))) return 1;
-    }
+    if (m->family == 1) // any lane mapping will do
+        return dyn::select_seip_entry(m, o->dtype, o->method, dyn::find_entry(m, o->dtype, o->method)) ? 1 : 0;
     return dyn::find_entry(m, o->dtype, o->method) ? 1 : 0;
 }
 
@@ -496,7 +521,9 @@ static int solve_impl(const dyn_model_desc *m, const dyn_solver_opts *o, const v
         const size_t per_traj = (size_t)(1 << m->n_strain) * dyn::seip_tiers(m) * m->n_wane * m->n_strain +
                                 (size_t)m->n_age * dyn::seip_tiers(m) * (4 + 2 * m->n_vax_knots) +
                                 (sc && sc->in ? (size_t)2 * sc->cap : 0); /* replayed schedule */
-        const size_t bytes = ((size_t)n_save + dyn::kMaxJumps + (64 / dyn::entry_lanes(e)) * per_traj) * (o->dtype == DYN_F64 ? 8 : 4);
+        const int nw = dyn::entry_waves(e), kl = (dyn::seip_tiers(m) + ((e->FEAT & dyn::kSeipTierLanes) ? 1 : 0)) / ((e->FEAT & dyn::kSeipTierLanes) ? 2 : 1);
+        const size_t mailbox = nw > 1 ? (size_t)2 * nw * 64 * (m->n_strain + kl * 4 + m->n_wane + 2 * m->n_strain) : 0; /* >= 2 NW NSLOT 64 */
+        const size_t bytes = ((size_t)n_save + dyn::kMaxJumps + (64 / dyn::entry_lanes(e)) * per_traj + mailbox) * (o->dtype == DYN_F64 ? 8 : 4);
         if (bytes > 64 * 1024) {
             snprintf(dyn::tl_error, sizeof(dyn::tl_error), "SEIP tables need %zu bytes of LDS per wave (limit 65536)", bytes);
             return DYN_ERR_UNSUPPORTED;

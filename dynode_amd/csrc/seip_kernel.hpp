@@ -23,10 +23,16 @@ namespace dyn {
 // history bits, tier k on lane k % 2, slot k / 2 -- so a lane holds ceil(K1 / 2) * (M1 + 3 L) values instead of
 // K1 * (M1 + 3 L): three strains x three tiers no longer spill.  Every tier-to-tier flow (vaccination k -> k + 1, the
 // seasonal reset K -> K - 1) then crosses to the partner lane with one xor exchange.
-template <typename T, int METHOD, int GA, int L, int K1, int M1, int KT = 1>
+// NW > 1 ("wave groups"): a trajectory whose G = GA * H * KT lanes exceed a wavefront is owned by a WORKGROUP of NW = G / 64
+// waves (one trajectory per workgroup).  The lane bits above 64 -- the top immune-history bit(s) and / or the tier-lane
+// bit -- select the wave; what crossed lanes with an xor exchange crosses waves through a small LDS mailbox, with ONE
+// workgroup barrier per right-hand side (two when the vaccination flow needs a cross-wave tier total first); the error
+// norm takes one more per step.  All waves of a trajectory see bit-identical norms, so their control flow is identical.
+template <typename T, int METHOD, int GA, int L, int K1, int M1, int KT = 1, int NW = 1>
 struct Seip {
-    static constexpr int H = 1 << L, G = GA * H * KT, TPW = 64 / G, K = K1 - 1;
-    static_assert(G <= 64 && L >= 1 && L <= 4 && K1 >= 1 && K1 <= 4 && M1 >= 1 && (KT == 1 || KT == 2), "SEIP lane group");
+    static constexpr int H = 1 << L, G = GA * H * KT, TPW = NW > 1 ? 1 : 64 / G, K = K1 - 1;
+    static_assert((NW == 1 ? G <= 64 : G == 64 * NW) && L >= 1 && L <= 4 && K1 >= 1 && K1 <= 4 && M1 >= 1 && (KT == 1 || KT == 2) &&
+                  (NW == 1 || NW == 2 || NW == 4), "SEIP lane group");
     static constexpr int KL = (K1 + KT - 1) / KT; // tier slots per lane
     static constexpr int NS = KL * M1, NE = KL * L, NV = NS + 3 * NE;
     static constexpr int IE = NS, II = NS + NE, IC = NS + 2 * NE;
@@ -35,6 +41,47 @@ struct Seip {
     // the age contraction and the dense output are the ones of the s/e/i/r/c kernels
     using Lanes = Solver<T, METHOD, GA, L, true, true, true, 1, 0, L>;
     using Dense = typename Lanes::Dense;
+    // ---- wave groups: which lane bits of the trajectory lie above the wavefront
+    static constexpr int LOGA = GA == 1 ? 0 : GA == 2 ? 1 : GA == 4 ? 2 : GA == 8 ? 3 : GA == 16 ? 4 : GA == 32 ? 5 : 6;
+    static constexpr int HB_IN = (6 - LOGA) < L ? (6 - LOGA) : L;   // immune-history bits inside a wave
+    static constexpr int HB_X = L - HB_IN;                           // ... selecting the wave (low wave bits)
+    static constexpr bool TIER_X = KT == 2 && GA * H >= 64;          // the tier-lane bit selects the wave (the top wave bit)
+    static constexpr int NXH = 1 << HB_X;                            // waves that differ in history bits only
+    static_assert(NW == 1 || NW == NXH * (TIER_X ? 2 : 1), "SEIP wave group: NW = 2^(cross-wave history bits) * (cross-wave tier lane ? 2 : 1)");
+    // mailbox slots of one round: infectious sums [L], tier totals [KL], recovery partners [HB_X][KL], tier flow [KL],
+    // seasonal fall-back of the top tier [M1 + 2 L]
+    static constexpr int NSLOT = L + (K1 + KT - 1) / KT * (2 + HB_X) + M1 + 2 * L;
+    T *xw;               // LDS mailbox [2][NW][NSLOT][64] (NW > 1)
+    int wv;              // this wave's index inside the trajectory's workgroup
+    mutable int xbuf;    // which half of the mailbox the next round writes
+    __device__ __forceinline__ T *xslot(int buf, int w, int slot) const {
+        return xw + ((buf * NW + w) * NSLOT + slot) * 64 + (threadIdx.x & 63);
+    }
+    // sum of v over ALL waves of the trajectory, the same bits in every wave (fixed order); one barrier
+    __device__ __forceinline__ T wg_sum(T v) const {
+        if constexpr (NW == 1) return v;
+        else {
+            const int b = xbuf;
+            xbuf ^= 1;
+            *xslot(b, wv, 0) = v;
+            __syncthreads();
+            T t = *xslot(b, 0, 0);
+#pragma unroll
+            for (int w = 1; w < NW; ++w) t += *xslot(b, w, 0);
+            return t;
+        }
+    }
+    // any lane of any wave of the trajectory has `flag` set
+    __device__ __forceinline__ bool wg_any(bool flag) const {
+        const bool mine = __any(flag);
+        if constexpr (NW == 1) return mine;
+        else return wg_sum(mine ? T(1) : T(0)) > T(0);
+    }
+    // sum over the lanes of a trajectory
+    __device__ __forceinline__ T traj_sum(T v) const {
+        if constexpr (NW == 1) return group_sum<G>(v);
+        else return wg_sum(group_sum<64>(v));
+    }
 
     T beta[L], gamma[L], sigma[L], omega[M1];
     Lanes ages;        // only Cx (pre-permuted contact row) is used
@@ -46,11 +93,12 @@ struct Seip {
     int nk, hist, tl; // tl: tier lane (KT = 2), 0 otherwise
     bool pad, seasonal, seasonal_vax, intro;
 
+    // sum over the immune histories that live in this wave (all of them unless NW > 1 splits the history bits)
     __device__ __forceinline__ static T hist_sum(T v) {
-        if constexpr (H >= 2) v += xchg_xor<GA>(v);
-        if constexpr (H >= 4) v += xchg_xor<2 * GA>(v);
-        if constexpr (H >= 8) v += xchg_xor<4 * GA>(v);
-        if constexpr (H >= 16) v += xchg_xor<8 * GA>(v);
+        if constexpr (HB_IN >= 1) v += xchg_xor<GA>(v);
+        if constexpr (HB_IN >= 2) v += xchg_xor<2 * GA>(v);
+        if constexpr (HB_IN >= 3) v += xchg_xor<4 * GA>(v);
+        if constexpr (HB_IN >= 4) v += xchg_xor<8 * GA>(v);
         return v;
     }
 
@@ -70,10 +118,13 @@ struct Seip {
     }
 
     __device__ __forceinline__ void rhs(T t, const T (&y)[NV], T (&dy)[NV]) const {
-        if constexpr (KT == 2) {
-            rhs_tier_lanes(t, y, dy);
-            return;
-        }
+        if constexpr (NW > 1) rhs_wave_group(t, y, dy);
+        else if constexpr (KT == 2) rhs_tier_lanes(t, y, dy);
+        else rhs_one_lane(t, y, dy);
+    }
+
+    // every tier of an (age, history) pair in one lane (KT = 1, NW = 1)
+    __device__ __forceinline__ void rhs_one_lane(T t, const T (&y)[NV], T (&dy)[NV]) const {
         T x[L], lam[L];
 #pragma unroll
         for (int l = 0; l < L; ++l) {
@@ -302,10 +353,252 @@ struct Seip {
         }
     }
 
+    // ---- the right-hand side for a trajectory spread over NW waves (see the struct comment).  Slot sl of a lane is tier
+    // sl * KT + tl.  Round 1 of the mailbox carries everything that depends on the state alone: the infectious sums, the
+    // tier totals (when histories cross waves), the recovery flows of the strains whose history bit selects the wave, the
+    // seasonal fall-back of the top tier, and -- when the tier totals are complete inside a wave -- the vaccination flow
+    // to the tier partner; otherwise that flow goes in a second round once the totals are known.
+    __device__ __forceinline__ void rhs_wave_group(T t, const T (&y)[NV], T (&dy)[NV]) const {
+        constexpr int S_TOT = L, S_REC = L + KL, S_SEND = L + KL * (1 + HB_X), S_SV = S_SEND + KL;
+        constexpr int sK = K / KT, tK = K % KT, sD = K > 0 ? (K - 1) / KT : 0;   // slot / tier lane of the top tier, slot below it
+        const int b = xbuf;
+        xbuf ^= 1;
+        const int tlw = TIER_X ? (wv >> HB_X) : 0, hw = wv & (NXH - 1);
+        (void)hw;
+        T phi = T(0), season = T(1);
+        if (seasonal) season = T(1) + amp * M::sin(w_season * t + phase);
+        if (seasonal_vax) {
+            const T sn = M::sin(T(6.283185307179586476925286766559) * (t + tau) / T(730));
+            const T u = sn * sn, u2 = u * u, u4 = u2 * u2, u8 = u4 * u4, u16 = u8 * u8, u32 = u16 * u16,
+                    u64 = u32 * u32, u128 = u64 * u64, u256 = u128 * u128;
+            phi = ((((u256 * u128) * u64) * u32) * u16) * u4;
+        }
+        // ---- lane-local and in-wave sums
+        T x[L], lam[L], totl[KL], tot[KL], dose[KL];
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            T a = y[II + l];
+#pragma unroll
+            for (int sl = 1; sl < KL; ++sl) a += y[II + sl * L + l];
+            a = hist_sum(a);
+            if constexpr (KT == 2 && !TIER_X) a += xchg_xor<GA * H>(a);
+            *xslot(b, wv, l) = a;
+        }
+#pragma unroll
+        for (int sl = 0; sl < KL; ++sl) {
+            const int k = sl * KT + tl;
+            const int kc = k < K1 ? k : K;
+            const T *c = spl + kc * (4 + 2 * nk);
+            T nu = c[0] + t * (c[1] + t * (c[2] + t * c[3]));
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const bool on = n < nk;
+                const T knot = c[on ? 4 + n : 0], coef = on ? c[on ? 4 + nk + n : 0] : T(0);
+                const T lag = M::max(t - knot, T(0));
+                nu += coef * (lag * lag * lag);
+            }
+            dose[sl] = M::max(nu, T(0)) * pop;
+            T tt = y[sl * M1];
+#pragma unroll
+            for (int m = 1; m < M1; ++m) tt += y[sl * M1 + m];
+            totl[sl] = tt;
+            tot[sl] = hist_sum(tt);
+            if constexpr (HB_X > 0) *xslot(b, wv, S_TOT + sl) = tot[sl];
+#pragma unroll
+            for (int q = 0; q < HB_X; ++q) *xslot(b, wv, S_REC + q * KL + sl) = gamma[HB_IN + q] * y[II + sl * L + HB_IN + q];
+        }
+        // share of a tier's susceptibles vaccinated per day, and what a slot hands to the next tier
+        auto share_of = [&](int sl, T total) -> T {
+            const int k = sl * KT + tl;
+            const T sh = dose[sl] * M::recip(total > T(0) ? total : T(1));
+            return (k < K1 && total > T(0)) ? (dose[sl] < total ? sh : T(1)) : T(0);
+        };
+        T rate[KL];
+        if constexpr (HB_X == 0) {
+#pragma unroll
+            for (int sl = 0; sl < KL; ++sl) {
+                rate[sl] = share_of(sl, tot[sl]);
+                if constexpr (TIER_X) *xslot(b, wv, S_SEND + sl) = (sl * KT + tl == K) ? T(0) : rate[sl] * totl[sl];
+            }
+        }
+        if constexpr (TIER_X && K > 0) {
+            if (seasonal_vax) { // the holder of the top tier offers what falls back one tier
+                const bool holder = tl == tK;
+#pragma unroll
+                for (int m = 0; m < M1; ++m) *xslot(b, wv, S_SV + m) = holder ? phi * y[sK * M1 + m] : T(0);
+#pragma unroll
+                for (int l = 0; l < L; ++l) {
+                    *xslot(b, wv, S_SV + M1 + l) = holder ? phi * y[IE + sK * L + l] : T(0);
+                    *xslot(b, wv, S_SV + M1 + L + l) = holder ? phi * y[II + sK * L + l] : T(0);
+                }
+            }
+        }
+        __syncthreads();
+        // ---- collect
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            T a = *xslot(b, 0, l);
+#pragma unroll
+            for (int w = 1; w < NW; ++w) a += *xslot(b, w, l);
+            x[l] = a;
+        }
+        if constexpr (HB_X > 0) {
+#pragma unroll
+            for (int sl = 0; sl < KL; ++sl) {
+                T a = *xslot(b, tlw << HB_X, S_TOT + sl);
+#pragma unroll
+                for (int h = 1; h < NXH; ++h) a += *xslot(b, (tlw << HB_X) | h, S_TOT + sl);
+                tot[sl] = a;
+                rate[sl] = share_of(sl, a);
+            }
+        }
+        T up[KL];   // arrivals from the tier below, per slot
+#pragma unroll
+        for (int sl = 0; sl < KL; ++sl) up[sl] = T(0);
+        if constexpr (KT == 2) {
+            T got[KL];
+            if constexpr (TIER_X && HB_X > 0) { // second round: the flows could only be formed now
+                const int b2 = xbuf;
+                xbuf ^= 1;
+#pragma unroll
+                for (int sl = 0; sl < KL; ++sl) *xslot(b2, wv, 0 + sl) = (sl * KT + tl == K) ? T(0) : rate[sl] * totl[sl];
+                __syncthreads();
+#pragma unroll
+                for (int sl = 0; sl < KL; ++sl) got[sl] = *xslot(b2, wv ^ NXH, sl);
+            } else if constexpr (TIER_X) {
+#pragma unroll
+                for (int sl = 0; sl < KL; ++sl) got[sl] = *xslot(b, wv ^ NXH, S_SEND + sl);
+            } else {
+#pragma unroll
+                for (int sl = 0; sl < KL; ++sl) got[sl] = xchg_xor<GA * H>((sl * KT + tl == K) ? T(0) : rate[sl] * totl[sl]);
+            }
+            // tier 2 s (lane 0) -> 2 s + 1 (lane 1, same slot); tier 2 s + 1 (lane 1) -> 2 s + 2 (lane 0, next slot)
+#pragma unroll
+            for (int sl = 0; sl < KL; ++sl) {
+                up[sl] += tl ? got[sl] : T(0);
+                if (sl + 1 < KL) up[sl + 1] += tl ? T(0) : got[sl];
+            }
+        } else {
+#pragma unroll
+            for (int sl = 0; sl + 1 < KL; ++sl) up[sl + 1] = rate[sl] * totl[sl];
+        }
+        if (intro) {
+#pragma unroll
+            for (int l = 0; l < L; ++l) {
+                const T u = (t - itime[l]) * iinv[l];
+                x[l] += iamp[l] * M::exp(T(-0.5) * u * u);
+            }
+        }
+        ages.contract(x, lam);
+#pragma unroll
+        for (int l = 0; l < L; ++l) lam[l] = (beta[l] * season) * lam[l];
+#pragma unroll
+        for (int v = 0; v < NS; ++v) dy[v] = T(0);
+#pragma unroll
+        for (int sl = 0; sl < KL; ++sl) {
+            const int k = sl * KT + tl;
+            const bool top = k == K;
+            const int kc = k < K1 ? k : K;
+            T inflow[L], moved = T(0);
+#pragma unroll
+            for (int l = 0; l < L; ++l) inflow[l] = T(0);
+#pragma unroll
+            for (int m = 0; m < M1; ++m) {
+                const T S = y[sl * M1 + m];
+                const T *su = sus + (kc * M1 + m) * L;
+                T out = T(0);
+#pragma unroll
+                for (int l = 0; l < L; ++l) {
+                    const T f = (lam[l] * su[l]) * S;
+                    inflow[l] += f;
+                    out += f;
+                }
+                dy[sl * M1 + m] -= out;
+                if (m + 1 < M1) {
+                    const T wn = omega[m] * S;
+                    dy[sl * M1 + m] -= wn;
+                    dy[sl * M1 + m + 1] += wn;
+                }
+                const T v = (top && m == 0) ? T(0) : rate[sl] * S; // the freshest state of the top tier stays
+                dy[sl * M1 + m] -= v;
+                moved += v;
+            }
+            dy[sl * M1] += (top ? moved : T(0)) + up[sl];   // top tier: refreshed in place; everyone: arrivals from below
+#pragma unroll
+            for (int l = 0; l < L; ++l) {
+                const int q = sl * L + l;
+                const T s_e = sigma[l] * y[IE + q], g_i = gamma[l] * y[II + q];
+                dy[IE + q] = inflow[l] - s_e;
+                dy[II + q] = s_e - g_i;
+                dy[IC + q] = inflow[l];
+            }
+        }
+        // ---- recovery eta(j, l) = j | 2^l: in-wave history bits by xor exchange, the others from the mailbox
+        recover_slots<0>(y, dy);
+#pragma unroll
+        for (int q = 0; q < HB_X; ++q) {
+            const bool has = (hist >> (HB_IN + q)) & 1;
+#pragma unroll
+            for (int sl = 0; sl < KL; ++sl) {
+                const T g_i = gamma[HB_IN + q] * y[II + sl * L + HB_IN + q];
+                const T partner = *xslot(b, wv ^ (1 << q), S_REC + q * KL + sl);
+                dy[sl * M1] += has ? partner + g_i : T(0);
+            }
+        }
+        // ---- seasonal vaccination: the top tier falls back one
+        if constexpr (K > 0) {
+            if (seasonal_vax) {
+                if constexpr (KT == 1) {
+#pragma unroll
+                    for (int m = 0; m < M1; ++m) {
+                        const T f = phi * y[K * M1 + m];
+                        dy[K * M1 + m] -= f;
+                        dy[(K - 1) * M1 + m] += f;
+                    }
+#pragma unroll
+                    for (int l = 0; l < L; ++l) {
+                        const T fe = phi * y[IE + K * L + l], fi = phi * y[II + K * L + l];
+                        dy[IE + K * L + l] -= fe;
+                        dy[II + K * L + l] -= fi;
+                        dy[IE + (K - 1) * L + l] += fe;
+                        dy[II + (K - 1) * L + l] += fi;
+                    }
+                } else {
+                    const bool holder = tl == tK;
+#pragma unroll
+                    for (int m = 0; m < M1; ++m) {
+                        const T f = holder ? phi * y[sK * M1 + m] : T(0);
+                        dy[sK * M1 + m] -= f;
+                        T got;
+                        if constexpr (TIER_X) got = *xslot(b, wv ^ NXH, S_SV + m);
+                        else got = xchg_xor<GA * H>(f);
+                        dy[sD * M1 + m] += holder ? T(0) : got;
+                    }
+#pragma unroll
+                    for (int l = 0; l < L; ++l) {
+                        const T fe = holder ? phi * y[IE + sK * L + l] : T(0), fi = holder ? phi * y[II + sK * L + l] : T(0);
+                        dy[IE + sK * L + l] -= fe;
+                        dy[II + sK * L + l] -= fi;
+                        T ge, gi;
+                        if constexpr (TIER_X) {
+                            ge = *xslot(b, wv ^ NXH, S_SV + M1 + l);
+                            gi = *xslot(b, wv ^ NXH, S_SV + M1 + L + l);
+                        } else {
+                            ge = xchg_xor<GA * H>(fe);
+                            gi = xchg_xor<GA * H>(fi);
+                        }
+                        dy[IE + sD * L + l] += holder ? T(0) : ge;
+                        dy[II + sD * L + l] += holder ? T(0) : gi;
+                    }
+                }
+            }
+        }
+    }
+
     // recovery for the KL local slots (the same exchange over the history bits as recover<>)
     template <int l>
     __device__ __forceinline__ void recover_slots(const T (&y)[NV], T (&dy)[NV]) const {
-        if constexpr (l < L) {
+        if constexpr (l < HB_IN) {   // (= L unless a wave group splits the history bits: rhs_wave_group serves the rest)
             const bool has = (hist >> l) & 1;
 #pragma unroll
             for (int sl = 0; sl < KL; ++sl) {
@@ -365,12 +658,16 @@ struct Seip {
 
     __device__ __forceinline__ static void run(const KArgs<T> &ka) {
         const int lane = threadIdx.x & 63;
-        const int a = lane % GA, j = (lane / GA) % H, tl = (lane / (GA * H)) % KT, grp = lane / G;
+        // position inside the trajectory's lane group: the lane itself, or (NW > 1) wave * 64 + lane of the workgroup
+        const int tlane = NW > 1 ? (int)threadIdx.x : lane;
+        const int a = tlane % GA, j = (tlane / GA) % H, tl = (tlane / (GA * H)) % KT, grp = NW > 1 ? 0 : lane / G;
         int64_t traj = (int64_t)blockIdx.x * TPW + grp;
         const bool valid_traj = traj < ka.B;
         if (!valid_traj) traj = ka.B - 1;
         const int A = ka.A, nk = ka.n_vax_knots;
         Seip S;
+        S.wv = NW > 1 ? (int)(threadIdx.x >> 6) : 0;
+        S.xbuf = 0;
         S.pad = a >= A;
         S.hist = j;
         S.tl = tl;
@@ -419,9 +716,9 @@ struct Seip {
                 S.iamp[l] = here ? intro_p[2 * L + l] / (scale * T(2.5066282746310002)) * S.pop : T(0);
             }
         }
-        for (int n = lane; n < n_save; n += 64) ts_tab[n] = ka.save_ts[n];
-        for (int n = lane % G; n < SUSN + spln; n += G) tab[n] = q[n];
-        if (n_jump > 0 && lane < kMaxJumps) jt_tab[lane] = ka.jump_ts[lane];
+        for (int n = tlane; n < n_save; n += 64 * NW) ts_tab[n] = ka.save_ts[n];
+        for (int n = tlane % G; n < SUSN + spln; n += G) tab[n] = q[n];
+        if (n_jump > 0 && tlane < kMaxJumps) jt_tab[tlane] = ka.jump_ts[tlane];
         // replay: the (t_prev, t_next) pairs this trajectory must take, staged in LDS behind the tables (a global load
         // inside the stepping loop would wait for every store issued before it: the loads and stores share vmcnt)
         const bool replay = ka.sched_in != nullptr;
@@ -431,8 +728,10 @@ struct Seip {
             const int64_t lead = ka.sched_leader ? ka.sched_leader[traj] : traj;
             n_sch = ka.sched_n_in[lead];
             const T *src = ka.sched_in + lead * (int64_t)(2 * ka.sched_cap);
-            for (int n = lane % G; n < 2 * (n_sch > 0 ? n_sch : 0); n += G) sch[n] = src[n];
+            for (int n = tlane % G; n < 2 * (n_sch > 0 ? n_sch : 0); n += G) sch[n] = src[n];
         }
+        // the mailbox of a wave group follows the schedule (16-byte aligned by construction of the table sizes or not: 4-byte words)
+        S.xw = sch + (replay ? TPW * 2 * ka.sched_cap : 0);
         __syncthreads();
         S.sus = tab + j * (K1 * M1 * L);
         S.spl = tab + SUSN + aa * K1 * (4 + 2 * nk);
@@ -493,8 +792,9 @@ struct Seip {
 #pragma unroll
         for (int v = 0; v < NV; ++v) lane_ok = lane_ok && (M::abs(y[v]) < M::inf()) && (M::abs(k[0][v]) < M::inf());
         const unsigned long long bad_lanes = __ballot(!lane_ok);
-        const unsigned long long group_mask = (G == 64 ? ~0ull : ((1ull << G) - 1ull)) << (grp * G);
-        const bool start_ok = (bad_lanes & group_mask) == 0ull;
+        const unsigned long long group_mask = (G >= 64 ? ~0ull : ((1ull << (G & 63)) - 1ull)) << (grp * (G & 63));
+        bool start_ok = (bad_lanes & group_mask) == 0ull;
+        if constexpr (NW > 1) start_ok = !S.wg_any(!lane_ok);
 
         if (replay) {
             tnext = n_sch > 0 ? sch[1] : tprev;
@@ -509,7 +809,7 @@ struct Seip {
                 n0 += q0 * q0;
                 n1 += q1 * q1;
             }
-            const T d0 = M::sqrt(group_sum<G>(n0) / Dn), d1 = M::sqrt(group_sum<G>(n1) / Dn);
+            const T d0 = M::sqrt(S.traj_sum(n0) / Dn), d1 = M::sqrt(S.traj_sum(n1) / Dn);
             const bool small = (d0 < T(1e-5)) || (d1 < T(1e-5));
             const T h0 = small ? T(1e-6) : T(0.01) * (d0 / d1);
 #pragma unroll
@@ -522,7 +822,7 @@ struct Seip {
                 const T q2 = (k[1][v] - k[0][v]) / sc;
                 s2 += q2 * q2;
             }
-            const T d2 = M::sqrt(group_sum<G>(s2) / Dn) / h0;
+            const T d2 = M::sqrt(S.traj_sum(s2) / Dn) / h0;
             const T max_d = M::max(d1, d2);
             tnext = tprev + M::min(T(100) * h0, Control<T>::initial_h1(max_d, h0));
         }
@@ -572,12 +872,13 @@ struct Seip {
                     const T r = (dt * e) * M::rcp_fast(atol + ym * rtol);
                     ss += r * r;
                 }
-                Control<T>::decide(M::sqrt(group_sum<G>(ss) / Dn), tprev, dt, keep, finite, factor);
+                Control<T>::decide(M::sqrt(S.traj_sum(ss) / Dn), tprev, dt, keep, finite, factor);
             } else {
                 bool ok = true;
 #pragma unroll
                 for (int v = 0; v < NV; ++v) ok = ok && (M::abs(yt[v]) < M::inf());
-                finite = ((__ballot(!ok) & group_mask) == 0ull);
+                if constexpr (NW > 1) finite = !S.wg_any(!ok);
+                else finite = ((__ballot(!ok) & group_mask) == 0ull);
             }
             const bool act = !done;
             steps += act ? 1 : 0;
@@ -732,15 +1033,25 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     Seip<T, METHOD, GA, L, K1, M1, KT>::run(ka);
 }
 
-template <typename T, int METHOD, int GA, int L, int K1, int M1, int KT = 1>
+// wave groups: one trajectory per workgroup of NW waves (lane groups of 128 or 256)
+template <typename T, int METHOD, int GA, int L, int K1, int M1, int KT, int NW>
+__global__ void __launch_bounds__(64 * NW) seip_kernel_wave_group(const KArgs<T> ka) {
+    Seip<T, METHOD, GA, L, K1, M1, KT, NW>::run(ka);
+}
+
+template <typename T, int METHOD, int GA, int L, int K1, int M1, int KT = 1, int NW = 1>
 hipError_t launch_seip(const KArgs<T> &ka, hipStream_t stream) {
-    constexpr int TPW = 64 / ((GA << L) * KT);
+    using Shape = Seip<T, METHOD, GA, L, K1, M1, KT, NW>;
+    constexpr int TPW = Shape::TPW;
     const int64_t blocks = (ka.B + TPW - 1) / TPW;
     if (blocks <= 0) return hipSuccess;
     const size_t per_traj = (size_t)(1 << L) * K1 * M1 * L + (size_t)ka.A * K1 * (4 + 2 * ka.n_vax_knots);
     const size_t lds = ((size_t)ka.n_save + (ka.n_jump > 0 ? kMaxJumps : 0) + TPW * per_traj +
-                        (ka.sched_in != nullptr ? (size_t)TPW * 2 * ka.sched_cap : 0)) * sizeof(T);
-    if constexpr (sizeof(T) == 4 && Seip<T, METHOD, GA, L, K1, M1, KT>::NV <= 20)
+                        (ka.sched_in != nullptr ? (size_t)TPW * 2 * ka.sched_cap : 0) +
+                        (NW > 1 ? (size_t)2 * NW * Shape::NSLOT * 64 : 0)) * sizeof(T);
+    if constexpr (NW > 1)
+        hipLaunchKernelGGL((seip_kernel_wave_group<T, METHOD, GA, L, K1, M1, KT, NW>), dim3((unsigned)blocks), dim3(64 * NW), lds, stream, ka);
+    else if constexpr (sizeof(T) == 4 && Shape::NV <= 20)
         hipLaunchKernelGGL((seip_kernel_two_waves<T, METHOD, GA, L, K1, M1, KT>), dim3((unsigned)blocks), dim3(64), lds, stream, ka);
     else
         hipLaunchKernelGGL((seip_kernel<T, METHOD, GA, L, K1, M1, KT>), dim3((unsigned)blocks), dim3(64), lds, stream, ka);

@@ -237,7 +237,8 @@ def schedule_capacity(model: ModelDesc, dtype, n_save: int) -> int:
     tpw = max(1, int(L.dyn_trajectories_per_wave(ctypes.byref(model.c()))))
     A, nL, H, K1, M1, nk = model.seip_dims
     per_traj = H * K1 * M1 * nL + A * K1 * (4 + 2 * nk)
-    words = 65536 // (8 if dtype == torch.float64 else 4) - n_save - 16 - tpw * per_traj
+    mailbox = 2 * 4 * 64 * (3 * nL + 8 + M1) if (1 << nL) * A >= 33 else 0     # wave groups (csrc/seip_kernel.hpp): upper bound
+    words = 65536 // (8 if dtype == torch.float64 else 4) - n_save - 16 - tpw * per_traj - mailbox
     return int(max(8, min(SCHEDULE_CAP, words // (2 * tpw))))
 
 

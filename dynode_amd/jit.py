@@ -143,6 +143,9 @@ def ensure_kernel(model: _abi.ModelDesc, dtype=torch.float32, method: str = "tsi
             else L.dyn_is_supported(ctypes.byref(mc), ctypes.byref(opts)))
     if have:
         return False
+    if model.family == 1 and _group_width(model.n_age) << model.n_strain > 64:
+        raise RuntimeError(f"{model}: a SEIP lane group beyond one wavefront runs as a wave group, and those shapes are compiled in: "
+                           "add a YW(...) line to csrc/seip_instances.def and rebuild")
     spl = choose_spl(model, n_dir)
     name = _name(model, dtype, mid, n_dir, spl)
     with _LOCK:

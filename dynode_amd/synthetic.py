@@ -202,5 +202,8 @@ WORKLOADS = {
     "cfg3d136": lambda B=16384, seed=1: seirs_multi_strain(B, seed),
     "seip": lambda B=4096, seed=7: seip(B, seed),
     "seip3": lambda B=4096, seed=7: seip(B, seed, A=4, L=3),      # three strains: tiers dealt over two lanes
+    # the north star's age x strain x immune-history sizes: lane groups of 128 / 256 = workgroups of 2 / 4 waves per trajectory
+    "seip83": lambda B=4096, seed=7: seip(B, seed, A=8, L=3),     # 8 ages x 3 strains (8 histories): D = 2496
+    "seip84": lambda B=2048, seed=7: seip(B, seed, A=8, L=4),     # 8 ages x 4 strains (16 histories): D = 6144
     "cfg5": lambda B=8192, seed=5: seirs_multi_strain(B, seed, seasonal=True),
 }

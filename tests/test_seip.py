@@ -153,9 +153,21 @@ def test_protection_table_follows_ode_model_md():
 
 
 # ------------------------------------------------------------------------------------------- GPU
+# wave groups (csrc/seip_kernel.hpp, NW > 1): lane groups beyond a wavefront, one trajectory per workgroup of 2 or 4 waves
+WAVE_GROUP_SHAPES = [
+    dict(A=8, L=3, K1=2, M1=2, n_knots=1, seasonal=True),                       # 8 x 8 histories x 2 tier lanes = 128 lanes (float64 twin)
+    dict(A=8, L=3, K1=3, M1=4, n_knots=2, seasonal_vax=True, intro=True),       # D = 2496, the 8-age x 3-strain model
+    dict(A=7, L=4, K1=1, M1=2, n_knots=0, intro=True),                          # 16 histories across two waves, no tier lanes
+    dict(A=8, L=4, K1=2, M1=2, n_knots=1, seasonal_vax=True),                   # four waves: histories and tier lanes across waves
+    dict(A=8, L=4, K1=3, M1=4, n_knots=2, seasonal=True, seasonal_vax=True),    # D = 6144, the 8-age x 4-strain model
+    dict(A=6, L=4, K1=2, M1=4, n_knots=1, seasonal_vax=True),                   # two waves, both tiers in one lane (float32)
+]
+
 GPU_CASES = [(SHAPES[0], "f64", "tsit5"), (SHAPES[1], "f64", "tsit5"), (SHAPES[1], "f64", "dopri5"), (SHAPES[4], "f64", "tsit5"),
              (SHAPES[0], "f32", "tsit5"), (SHAPES[1], "f32", "dopri5"), (SHAPES[2], "f32", "tsit5"), (SHAPES[3], "f32", "tsit5"),
-             (SHAPES[3], "f32", "dopri5"), (SHAPES[4], "f32", "tsit5"), (SHAPES[5], "f64", "tsit5"), (SHAPES[6], "f32", "tsit5")]
+             (SHAPES[3], "f32", "dopri5"), (SHAPES[4], "f32", "tsit5"), (SHAPES[5], "f64", "tsit5"), (SHAPES[6], "f32", "tsit5"),
+             (WAVE_GROUP_SHAPES[0], "f64", "tsit5"), (WAVE_GROUP_SHAPES[1], "f32", "tsit5"), (WAVE_GROUP_SHAPES[2], "f64", "tsit5"),
+             (WAVE_GROUP_SHAPES[3], "f64", "tsit5"), (WAVE_GROUP_SHAPES[4], "f32", "tsit5"), (WAVE_GROUP_SHAPES[5], "f32", "tsit5")]
 
 
 @pytest.mark.gpu
@@ -508,3 +520,32 @@ def test_tier_lanes_shape_built_on_demand():
     r = solve_batch(wl.model, wl.y0, wl.params, wl.contact, 90.0, ts, dtype=torch.float64, constant_dt=0.5)
     want, st, _, _ = O.solve(H.omodel(wl.model), wl.y0, wl.params, wl.contact, 90.0, ts, dtype=np.float64, n_threads=8, constant_dt=0.5)
     assert int(r.status.max()) == 0 and np.abs(r.ys.cpu().numpy() - want).max() / 1000.0 < 1e-11
+
+
+@pytest.mark.gpu
+def test_wave_groups_dispatch_sub_save_jumps_and_replay():
+    """Trajectories owned by a workgroup of several waves: the instance that runs, batch-position invariance, sub-save
+    masks, discontinuity points and recorded / replayed step sequences behave as for one-wave lane groups."""
+    import torch
+    from dynode_amd import _abi
+    from dynode_amd.engine import solve_batch
+
+    wl = synthetic.seip(B=11, seed=9, t1=120.0, **WAVE_GROUP_SHAPES[0])
+    m, ts = wl.model, synthetic.save_grid(120.0, 4)
+    full = solve_batch(m, wl.y0, wl.params, wl.contact, 120.0, ts, dtype=torch.float64, jump_ts=(31.5, 60.0), record_steps=512)
+    assert _abi.lib().dyn_last_kernel_name().decode().startswith("dyn::seip_kernel_wave_group<double, 0, 8, 3, 2, 2, 2, 2>")
+    want, st, na, nr = O.solve(H.omodel(m), wl.y0, wl.params, wl.contact, 120.0, ts, dtype=np.float64, n_threads=8, jump_ts=(31.5, 60.0))
+    got = full.ys.cpu().numpy()
+    assert int(full.status.max()) == 0 and st.max() == 0 and np.abs(got - want).max() / 1000.0 < 5e-5
+    assert np.abs((full.n_accept + full.n_reject).cpu().numpy() - (na + nr)).max() <= 8
+    perm = np.random.default_rng(0).permutation(11)
+    again = solve_batch(m, wl.y0[perm], wl.params[perm], wl.contact, 120.0, ts, dtype=torch.float64, jump_ts=(31.5, 60.0))
+    assert torch.equal(again.ys, full.ys[torch.as_tensor(perm, device="cuda")])                 # a trajectory's bits do not depend on its block
+    mask = np.array([1, 0, 0, 1], dtype=np.uint8)
+    sub = solve_batch(m, wl.y0, wl.params, wl.contact, 120.0, ts, dtype=torch.float64, jump_ts=(31.5, 60.0), save_mask=mask)
+    sizes = m.compartment_sizes
+    cols = np.concatenate([np.arange(sizes[0]), sum(sizes[:3]) + np.arange(sizes[3])])
+    assert np.array_equal(sub.ys.cpu().numpy(), got[:, :, cols])
+    steps, count = full.schedule
+    rep = solve_batch(m, wl.y0, wl.params, wl.contact, 120.0, ts, dtype=torch.float64, replay=(steps, count, None))
+    assert torch.equal(rep.ys, full.ys) and torch.equal(rep.n_accept, full.n_accept)           # the jumps are part of the recording

@@ -48,7 +48,7 @@ workload, batch = "cfg3", None
 for i, a in enumerate(extra):
     if a == "--workload": workload = extra[i + 1]
     if a == "--batch": batch = int(extra[i + 1])
-defaults = {"cfg2": 4096, "cfg3": 16384, "cfg3d136": 16384, "cfg5": 8192, "seip": 4096, "seip3": 4096}
+defaults = {"cfg2": 4096, "cfg3": 16384, "cfg3d136": 16384, "cfg5": 8192, "seip": 4096, "seip3": 4096, "seip83": 4096, "seip84": 2048}
 batch = batch or defaults[workload]
 
 kernel = instance_name(stats["Name"]) if stats else None
