@@ -524,8 +524,9 @@ static int solve_impl(const dyn_model_desc *m, const dyn_solver_opts *o, const v
         const int nw = dyn::entry_waves(e), kl = (dyn::seip_tiers(m) + ((e->FEAT & dyn::kSeipTierLanes) ? 1 : 0)) / ((e->FEAT & dyn::kSeipTierLanes) ? 2 : 1);
         const size_t mailbox = nw > 1 ? (size_t)2 * nw * 64 * (m->n_strain + kl * 4 + m->n_wane + 2 * m->n_strain) : 0; /* >= 2 NW NSLOT 64 */
         const size_t bytes = ((size_t)n_save + dyn::kMaxJumps + (64 / dyn::entry_lanes(e)) * per_traj + mailbox) * (o->dtype == DYN_F64 ? 8 : 4);
-        if (bytes > 64 * 1024) {
-            snprintf(dyn::tl_error, sizeof(dyn::tl_error), "SEIP tables need %zu bytes of LDS per wave (limit 65536)", bytes);
+        const size_t limit = nw > 1 ? 160 * 1024 : 64 * 1024; /* a wave group is alone (or two) on its CU */
+        if (bytes > limit) {
+            snprintf(dyn::tl_error, sizeof(dyn::tl_error), "SEIP tables need %zu bytes of LDS per workgroup (limit %zu)", bytes, limit);
             return DYN_ERR_UNSUPPORTED;
         }
     }

@@ -1049,8 +1049,16 @@ hipError_t launch_seip(const KArgs<T> &ka, hipStream_t stream) {
     const size_t lds = ((size_t)ka.n_save + (ka.n_jump > 0 ? kMaxJumps : 0) + TPW * per_traj +
                         (ka.sched_in != nullptr ? (size_t)TPW * 2 * ka.sched_cap : 0) +
                         (NW > 1 ? (size_t)2 * NW * Shape::NSLOT * 64 : 0)) * sizeof(T);
-    if constexpr (NW > 1)
+    if constexpr (NW > 1) {
+        // one or two workgroups per CU (one wave per SIMD at ~400 registers): beyond the default 64 KB of dynamic LDS the
+        // kernel attribute has to allow it (160 KB per CU)
+        if (lds > 65536) {
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&seip_kernel_wave_group<T, METHOD, GA, L, K1, M1, KT, NW>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+        }
         hipLaunchKernelGGL((seip_kernel_wave_group<T, METHOD, GA, L, K1, M1, KT, NW>), dim3((unsigned)blocks), dim3(64 * NW), lds, stream, ka);
+    }
     else if constexpr (sizeof(T) == 4 && Shape::NV <= 20)
         hipLaunchKernelGGL((seip_kernel_two_waves<T, METHOD, GA, L, K1, M1, KT>), dim3((unsigned)blocks), dim3(64), lds, stream, ka);
     else

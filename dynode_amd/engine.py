@@ -233,12 +233,13 @@ SCHEDULE_CAP = 2048      # accepted steps recorded per trajectory (the adaptive 
 def schedule_capacity(model: ModelDesc, dtype, n_save: int) -> int:
     """Steps per trajectory a replayed schedule may hold: the kernel stages it in LDS next to the save grid and the
     model's tables (64 KB per wave in all), at most `SCHEDULE_CAP`."""
-    L = _abi.lib()
-    tpw = max(1, int(L.dyn_trajectories_per_wave(ctypes.byref(model.c()))))
     A, nL, H, K1, M1, nk = model.seip_dims
+    ga = 1
+    while ga < A:
+        ga <<= 1
+    tpw = max(1, 64 // (ga * H))            # the most trajectories any lane mapping puts in a wave (one lane per age x history)
     per_traj = H * K1 * M1 * nL + A * K1 * (4 + 2 * nk)
-    mailbox = 2 * 4 * 64 * (3 * nL + 8 + M1) if (1 << nL) * A >= 33 else 0     # wave groups (csrc/seip_kernel.hpp): upper bound
-    words = 65536 // (8 if dtype == torch.float64 else 4) - n_save - 16 - tpw * per_traj - mailbox
+    words = 65536 // (8 if dtype == torch.float64 else 4) - n_save - 16 - tpw * per_traj      # wave groups: their mailbox has LDS of its own
     return int(max(8, min(SCHEDULE_CAP, words // (2 * tpw))))
 
 

@@ -32,7 +32,8 @@ def run(name, B=None, nchk=64, reps=20, method="tsit5"):
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
     frac = wl.bytes_per_trajectory(4) * wl.B / (ms * 1e-3) / 8e12
-    print(f"{name:9s} {method} B={wl.B:6d} D={m.state_dim:4d} ms={ms:8.4f} traj/s={wl.B/ms*1e3:12.0f} hbm_frac={frac:.4f} "
+    att = (r.n_accept + r.n_reject).float()
+    print(f"{name:9s} {method} B={wl.B:6d} D={m.state_dim:4d} ms={ms:8.4f} traj/s={wl.B/ms*1e3:12.0f} hbm_frac={frac:.4f} attempts mean={float(att.mean()):.1f} max={float(att.max()):.0f} "
           f"status_ok={int(r.status.max())==0} err/scale={err:.3e} mixed(1e-6,1e-5)={mixed:.3f} finite={bool(np.isfinite(got).all())} | {kern}", flush=True)
 
 if __name__ == "__main__":
