@@ -20,3 +20,7 @@ for C in "FETCH_SIZE" "WRITE_SIZE" \
   rocprofv3 --pmc $C --output-format csv -d "$OUT/pmc_$i" -- python3 "$ROOT/bench.py" $PARGS > "$OUT/pmc_$i.log" 2>&1 || { echo "pmc pass $i ($C) failed"; tail -5 "$OUT/pmc_$i.log"; }
 done
 python3 "$ROOT/tools/summarize_prof.py" "$OUT" "$TAG" "$@"
+# the GPU box's repo copy is scratch: hand the summary, the kernel stats and the traffic table back through gpurun_out/
+mkdir -p "$ROOT/gpurun_out/profiles_out"
+cp "$ROOT/profiles/${TAG}_rocprof_summary.md" "$ROOT/profiles/traffic.json" "$ROOT/gpurun_out/profiles_out/" 2>/dev/null
+find "$OUT/trace" -name "*kernel_stats.csv" -exec cp {} "$ROOT/gpurun_out/profiles_out/${TAG}_kernel_stats.csv" \;
