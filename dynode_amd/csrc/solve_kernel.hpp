@@ -364,7 +364,9 @@ struct Solver {
     static constexpr int NE = HAS_E ? S : 0;
     static constexpr int NCU = HAS_C ? S : 0;
     static constexpr int NV = 1 + NE + S + S * W + NCU;
-    static constexpr int IE = 1, II = 1 + NE, IR = II + S, IC = IR + S * W;
+    // per-lane element order: e | i | r | c | s -- the strain blocks first, so that they start on even indices (pairs for
+    // the packed stepper arithmetic, whole 16-byte runs for the stores), the lone s last (next to the pad when NV is odd)
+    static constexpr int IE = 0, II = NE, IR = II + S, IC = IR + S * W, IS = IC + NCU;
     static constexpr int TPW = 64 / G;
     static constexpr int NC = 1 + ND;          // planes
     // Small states are latency-bound by the serial save rounds: interpolate SU save times per
@@ -373,6 +375,36 @@ struct Solver {
     static constexpr int NDA = ND > 0 ? ND : 1; // array extent for tangent-only data
     using M = Mth<T>;
     using TB = Tab<METHOD>;
+
+    // One plane of the per-lane state (or of a stage derivative): NV values kept as NP two-element vectors, so that the
+    // register allocator holds them in aligned register pairs from the start and the linear algebra of the stepper -- the
+    // stage combinations, the embedded error, the dense output -- runs on v_pk_fma_f32 without the pair-packing moves
+    // the vectoriser otherwise inserts (12 % of the vector instructions of the D = 360 kernel).  operator[] gives the
+    // right-hand side element access; an odd NV leaves one pad element, which stays 0.
+    static constexpr int NP = (NV + 1) / 2;
+    typedef T V2 __attribute__((ext_vector_type(2)));
+    struct State {
+        V2 p[NP];
+        struct Ref {
+            V2 &v;
+            int i;
+            __device__ __forceinline__ operator T() const { return v[i]; }
+            __device__ __forceinline__ Ref &operator=(T x) {
+                v[i] = x;
+                return *this;
+            }
+            __device__ __forceinline__ Ref &operator=(const Ref &o) {
+                v[i] = (T)o;
+                return *this;
+            }
+            __device__ __forceinline__ Ref &operator+=(T x) {
+                v[i] += x;
+                return *this;
+            }
+        };
+        __device__ __forceinline__ T operator[](int e) const { return p[e >> 1][e & 1]; }
+        __device__ __forceinline__ Ref operator[](int e) { return Ref{p[e >> 1], e & 1}; }
+    };
 
     // per-lane model data
     T beta[S], gamma[S], sigma[S], omega[S];
@@ -422,8 +454,8 @@ struct Solver {
 
     // f(t, y) for this lane's age bin (plane 0) and its JVP (planes 1..ND);
     // reference RHS: see include/dynode_hip.h
-    __device__ __forceinline__ void rhs(T t, const T (&y)[NC][NV], T (&dy)[NC][NV]) const {
-        const T(&y0)[NV] = y[0];
+    __device__ __forceinline__ void rhs(T t, const State (&y)[NC], State (&dy)[NC]) const {
+        const State &y0 = y[0];
         T se = 0, si = 0, sr = 0;
 #pragma unroll
         for (int l = 0; l < S; ++l) {
@@ -432,7 +464,7 @@ struct Solver {
 #pragma unroll
             for (int w = 0; w < W; ++w) sr += y0[IR + l * W + w];
         }
-        const T N = y0[0] + strain_sum((se + si) + sr);
+        const T N = y0[IS] + strain_sum((se + si) + sr);
         T invN = T(1);
         if (normalize) invN = pad ? T(0) : M::recip(N);
         T season = T(1), sin_arg = T(0), cos_arg = T(0);
@@ -463,7 +495,7 @@ struct Solver {
         for (int l = 0; l < S; ++l) {
             foi[l] = (beta[l] * season) * acc[l];
             if constexpr (KV > 0) foi[l] *= sus[l];
-            const T flux = foi[l] * y0[0];
+            const T flux = foi[l] * y0[IS];
             const T g_i = gamma[l] * y0[II + l];
             out_s += flux;
             if constexpr (HAS_E) {
@@ -490,7 +522,7 @@ struct Solver {
             }
             if constexpr (HAS_C) dy[0][IC + l] = flux;
         }
-        dy[0][0] = strain_sum(back_s - out_s);
+        dy[0][IS] = strain_sum(back_s - out_s);
         T v_rate = T(0), v_nage = T(0);       // max(nu, 0) and the age's population, reused by the tangents
         bool v_nu_pos = false, v_capped = false, v_has_s = false;
         if constexpr (KV > 0) {
@@ -505,23 +537,23 @@ struct Solver {
             T n_age = N + xchg_xor<1>(N);
             if constexpr (KV == 4) n_age += xchg_xor<2>(n_age);
             const T doses = M::max(nu, T(0)) * n_age;
-            const T leave = vax_top ? T(0) : M::min(doses, M::max(y0[0], T(0)));
+            const T leave = vax_top ? T(0) : M::min(doses, M::max(y0[IS], T(0)));
             v_rate = M::max(nu, T(0));
             v_nage = n_age;
             v_nu_pos = nu > T(0);
-            v_has_s = y0[0] > T(0);
-            v_capped = !(doses < M::max(y0[0], T(0))); // the tier runs empty: everyone left is vaccinated
+            v_has_s = y0[IS] > T(0);
+            v_capped = !(doses < M::max(y0[IS], T(0))); // the tier runs empty: everyone left is vaccinated
             // lane of tier k receives what tier k - 1 of the same age gives up
             const T from_below = KV == 2 ? xchg_xor<1>(leave) : dpp_mov<0x90>(leave); // quad_perm [0,0,1,2]
-            dy[0][0] += (vax_first ? T(0) : from_below) - leave;
+            dy[0][IS] += (vax_first ? T(0) : from_below) - leave;
         }
 
         // ---- JVP planes: the same expression tree, linearised
         if constexpr (ND > 0) {
 #pragma unroll
             for (int j = 0; j < ND; ++j) {
-                const T(&u)[NV] = y[1 + j];
-                T(&du)[NV] = dy[1 + j];
+                const State &u = y[1 + j];
+                State &du = dy[1 + j];
                 T dse = 0, dsi = 0, dsr = 0;
 #pragma unroll
                 for (int l = 0; l < S; ++l) {
@@ -530,7 +562,7 @@ struct Solver {
 #pragma unroll
                     for (int w = 0; w < W; ++w) dsr += u[IR + l * W + w];
                 }
-                const T dN = u[0] + strain_sum((dse + dsi) + dsr);
+                const T dN = u[IS] + strain_sum((dse + dsi) + dsr);
                 const T dinvN = normalize ? -(invN * invN) * dN : T(0); // pad: invN == 0
                 T dseason = T(0);
                 if (seasonal)
@@ -557,7 +589,7 @@ struct Solver {
                     const T dbs = dbeta[j][l] * season + beta[l] * dseason;
                     T dfoi = dbs * acc[l] + bs * dacc[l];
                     if constexpr (KV > 0) dfoi = dfoi * sus[l] + (bs * acc[l]) * dsus[j][l];
-                    const T dflux = dfoi * y0[0] + foi[l] * u[0];
+                    const T dflux = dfoi * y0[IS] + foi[l] * u[IS];
                     const T dg_i = dgamma[j][l] * y0[II + l] + gamma[l] * u[II + l];
                     dout_s += dflux;
                     if constexpr (HAS_E) {
@@ -584,7 +616,7 @@ struct Solver {
                     }
                     if constexpr (HAS_C) du[IC + l] = dflux;
                 }
-                du[0] = strain_sum(dback_s - dout_s);
+                du[IS] = strain_sum(dback_s - dout_s);
                 if constexpr (KV > 0) {
                     // d min(max(nu, 0) * P_a, max(s, 0)): doses while they last, else the remaining susceptibles
                     T dnu = dvbase[j][0] + t * (dvbase[j][1] + t * (dvbase[j][2] + t * dvbase[j][3]));
@@ -597,9 +629,9 @@ struct Solver {
                     T dn_age = dN + xchg_xor<1>(dN);
                     if constexpr (KV == 4) dn_age += xchg_xor<2>(dn_age);
                     const T ddoses = (v_nu_pos ? dnu : T(0)) * v_nage + v_rate * dn_age;
-                    const T dleave = vax_top ? T(0) : (v_capped ? (v_has_s ? u[0] : T(0)) : ddoses);
+                    const T dleave = vax_top ? T(0) : (v_capped ? (v_has_s ? u[IS] : T(0)) : ddoses);
                     const T dfrom_below = KV == 2 ? xchg_xor<1>(dleave) : dpp_mov<0x90>(dleave);
-                    du[0] += (vax_first ? T(0) : dfrom_below) - dleave;
+                    du[IS] += (vax_first ? T(0) : dfrom_below) - dleave;
                 }
             }
         }
@@ -625,52 +657,62 @@ struct Solver {
         if constexpr ((BASE + 1) * 4 < GA) gather_base<BASE + 1>(x, acc);
     }
 
-    // dense output at theta in [0,1] for the accepted step (y -> y1), k = stage derivatives
+    // dense output at theta in [0,1] for the accepted step (y -> y1), k = stage derivatives.  The Tsit5 weights b_i(theta) are
+    // kept splatted over a register pair each: the packed form multiplies whole pairs by them, and a scalar weight read
+    // back from the struct and splatted at the use is widened by instcombine into overlapping two-float loads that pin the
+    // struct in scratch memory.
     struct Dense {
-        T b[7]; // Tsit5: b_i(theta)
+        V2 b0, b1, b2, b3, b4, b5, b6;
         T theta;
     };
     __device__ __forceinline__ static void dense_prepare(T th, Dense &d) {
         d.theta = th;
         if constexpr (METHOD == 0) {
             const T t2 = th * th;
-            d.b[0] = T(-1.0530884977290216) * th * (th - T(1.3299890189751412)) *
-                     (t2 - T(1.4364028541716351) * th + T(0.7139816917074209));
-            d.b[1] = T(0.1017) * t2 * (t2 - T(2.1966568338249754) * th + T(1.2949852507374631));
-            d.b[2] = T(2.490627285651252793) * t2 *
-                     (t2 - T(2.38535645472061657) * th + T(1.57803468208092486));
-            d.b[3] = T(-16.54810288924490272) * (th - T(1.21712927295533244)) *
-                     (th - T(0.61620406037800089)) * t2;
-            d.b[4] = T(47.37952196281928122) * (th - T(1.203071208372362603)) *
-                     (th - T(0.658047292653547382)) * t2;
-            d.b[5] = T(-34.87065786149660974) * (th - T(1.2)) * (th - T(0.666666666666666667)) * t2;
-            d.b[6] = T(2.5) * (th - T(1.0)) * (th - T(0.6)) * t2;
+            const T w0 = T(-1.0530884977290216) * th * (th - T(1.3299890189751412)) *
+                         (t2 - T(1.4364028541716351) * th + T(0.7139816917074209));
+            const T w1 = T(0.1017) * t2 * (t2 - T(2.1966568338249754) * th + T(1.2949852507374631));
+            const T w2 = T(2.490627285651252793) * t2 * (t2 - T(2.38535645472061657) * th + T(1.57803468208092486));
+            const T w3 = T(-16.54810288924490272) * (th - T(1.21712927295533244)) * (th - T(0.61620406037800089)) * t2;
+            const T w4 = T(47.37952196281928122) * (th - T(1.203071208372362603)) * (th - T(0.658047292653547382)) * t2;
+            const T w5 = T(-34.87065786149660974) * (th - T(1.2)) * (th - T(0.666666666666666667)) * t2;
+            const T w6 = T(2.5) * (th - T(1.0)) * (th - T(0.6)) * t2;
+            d.b0 = V2{w0, w0};
+            d.b1 = V2{w1, w1};
+            d.b2 = V2{w2, w2};
+            d.b3 = V2{w3, w3};
+            d.b4 = V2{w4, w4};
+            d.b5 = V2{w5, w5};
+            d.b6 = V2{w6, w6};
         }
     }
-    __device__ __forceinline__ static T dense_eval(const Dense &d, T dt, T y0v, T y1v, T k0, T k1,
-                                                   T k2, T k3, T k4, T k5, T k6) {
+    __device__ __forceinline__ static T wt(const V2 &w, T) { return w[0]; }
+    __device__ __forceinline__ static V2 wt(const V2 &w, V2) { return w; }
+    template <typename U>   // U = T (one value) or V2 (a register pair of the packed state)
+    __device__ __forceinline__ static U dense_eval(const Dense &d, T dt, U y0v, U y1v, U k0, U k1,
+                                                   U k2, U k3, U k4, U k5, U k6) {
         if constexpr (METHOD == 0) {
-            T a = d.b[0] * k0;
-            a += d.b[1] * k1;
-            a += d.b[2] * k2;
-            a += d.b[3] * k3;
-            a += d.b[4] * k4;
-            a += d.b[5] * k5;
-            a += d.b[6] * k6;
+            U a = wt(d.b0, U()) * k0;
+            a += wt(d.b1, U()) * k1;
+            a += wt(d.b2, U()) * k2;
+            a += wt(d.b3, U()) * k3;
+            a += wt(d.b4, U()) * k4;
+            a += wt(d.b5, U()) * k5;
+            a += wt(d.b6, U()) * k6;
             return y0v + dt * a;
         } else {
             // quartic through y0, y1, ymid, f0, f1 (Shampine midpoint weights)
-            T mid = T(TB::cmid[0]) * k0;
+            U mid = T(TB::cmid[0]) * k0;
             mid += T(TB::cmid[2]) * k2;
             mid += T(TB::cmid[3]) * k3;
             mid += T(TB::cmid[4]) * k4;
             mid += T(TB::cmid[5]) * k5;
             mid += T(TB::cmid[6]) * k6;
-            const T ymid = y0v + dt * mid;
-            const T f0 = dt * k0, f1 = dt * k6;
-            const T ca = T(2) * (f1 - f0) - T(8) * (y1v + y0v) + T(16) * ymid;
-            const T cb = T(5) * f0 - T(3) * f1 + T(18) * y0v + T(14) * y1v - T(32) * ymid;
-            const T cc = f1 - T(4) * f0 - T(11) * y0v - T(5) * y1v + T(16) * ymid;
+            const U ymid = y0v + dt * mid;
+            const U f0 = dt * k0, f1 = dt * k6;
+            const U ca = T(2) * (f1 - f0) - T(8) * (y1v + y0v) + T(16) * ymid;
+            const U cb = T(5) * f0 - T(3) * f1 + T(18) * y0v + T(14) * y1v - T(32) * ymid;
+            const U cc = f1 - T(4) * f0 - T(11) * y0v - T(5) * y1v + T(16) * ymid;
             const T th = d.theta;
             return (((ca * th + cb) * th + cc) * th + f0) * th + y0v;
         }
@@ -678,21 +720,52 @@ struct Solver {
 
     // interpolate + store one compartment block [FIRST, FIRST+CNT) of one plane of this lane
     template <int FIRST, int CNT>
-    __device__ __forceinline__ static void save_block(const Dense &d, T dt, const T (&y)[NV],
-                                                      const T (&y1)[NV], const T (&k)[7][NC][NV],
+    __device__ __forceinline__ static void save_block(const Dense &d, T dt, const State &y,
+                                                      const State &y1, const State (&k)[7][NC],
                                                       int plane, T *dst, bool vec_ok) {
-        T v[CNT];
+        if constexpr (FIRST % 2 == 0 && CNT % 2 == 0) { // whole register pairs: packed arithmetic, stored as they come
+            V2 o[CNT / 2];
 #pragma unroll
-        for (int q = 0; q < CNT; ++q) {
-            const int j = FIRST + q;
+            for (int q = 0; q < CNT / 2; ++q) {
+                const int j = FIRST / 2 + q;
 #ifdef DYN_DIAG_NOINTERP   // diagnostic builds (tools/probes): what does the save loop cost without its arithmetic / stores?
-            v[q] = y[j] + d.b[q % 7];
+                o[q] = y.p[j] + d.b0;
 #else
-            v[q] = dense_eval(d, dt, y[j], y1[j], k[0][plane][j], k[1][plane][j], k[2][plane][j],
-                              k[3][plane][j], k[4][plane][j], k[5][plane][j], k[6][plane][j]);
+                o[q] = dense_eval<V2>(d, dt, y.p[j], y1.p[j], k[0][plane].p[j], k[1][plane].p[j], k[2][plane].p[j],
+                                      k[3][plane].p[j], k[4][plane].p[j], k[5][plane].p[j], k[6][plane].p[j]);
 #endif
+            }
+            if (vec_ok) {
+                if constexpr (sizeof(T) == 4 && CNT % 4 == 0) {
+                    typedef T V4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+                    for (int q = 0; q < CNT / 4; ++q)
+                        *reinterpret_cast<V4 *>(dst + 4 * q) = V4{o[2 * q][0], o[2 * q][1], o[2 * q + 1][0], o[2 * q + 1][1]};
+                } else {
+#pragma unroll
+                    for (int q = 0; q < CNT / 2; ++q) *reinterpret_cast<V2 *>(dst + 2 * q) = o[q];
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < CNT / 2; ++q) {
+                    dst[2 * q] = o[q][0];
+                    dst[2 * q + 1] = o[q][1];
+                }
+            }
+        } else {
+            T v[CNT];
+#pragma unroll
+            for (int q = 0; q < CNT; ++q) {
+                const int j = FIRST + q;
+#ifdef DYN_DIAG_NOINTERP
+                v[q] = y[j] + d.b0[0];
+#else
+                v[q] = dense_eval<T>(d, dt, y[j], y1[j], k[0][plane][j], k[1][plane][j], k[2][plane][j],
+                                     k[3][plane][j], k[4][plane][j], k[5][plane][j], k[6][plane][j]);
+#endif
+            }
+            store_run<T, CNT>(dst, v, vec_ok);
         }
-        store_run<T, CNT>(dst, v, vec_ok);
     }
 
     // ---- fused observation likelihood (Poisson log-likelihood of the reference's model(),
@@ -716,8 +789,8 @@ struct Solver {
         for (int c = 1; c < NC; ++c) ll.dacc[c] += coef * (double)inc[c];
     }
     template <int FIRST, int CNT>
-    __device__ __forceinline__ static void ll_block(const KArgs<T> &ka, const Dense &d, T dt, const T (&y)[NC][NV],
-                                                    const T (&yt)[NC][NV], const T (&k)[7][NC][NV], LL &ll,
+    __device__ __forceinline__ static void ll_block(const KArgs<T> &ka, const Dense &d, T dt, const State (&y)[NC],
+                                                    const State (&yt)[NC], const State (&k)[7][NC], LL &ll,
                                                     int j, int off, T *tab_row) {
         const bool have = ka.ll_mode == 0 || j > 0;
         const T *orow = ka.obs + (int64_t)(ka.ll_mode == 0 ? j : (j > 0 ? j - 1 : 0)) * ka.ll_row + off;
@@ -727,8 +800,8 @@ struct Solver {
             T v[NC];
 #pragma unroll
             for (int c = 0; c < NC; ++c)
-                v[c] = dense_eval(d, dt, y[c][e], yt[c][e], k[0][c][e], k[1][c][e], k[2][c][e], k[3][c][e],
-                                  k[4][c][e], k[5][c][e], k[6][c][e]);
+                v[c] = dense_eval<T>(d, dt, y[c][e], yt[c][e], k[0][c][e], k[1][c][e], k[2][c][e], k[3][c][e],
+                                     k[4][c][e], k[5][c][e], k[6][c][e]);
             if (tab_row != nullptr) {
 #pragma unroll
                 for (int c = 0; c < NC; ++c) tab_row[q * NC + c] = v[c];
@@ -744,12 +817,12 @@ struct Solver {
             }
         }
     }
-    __device__ __forceinline__ static void ll_row(const KArgs<T> &ka, const Dense &d, T dt, const T (&y)[NC][NV],
-                                                  const T (&yt)[NC][NV], const T (&k)[7][NC][NV], LL &ll, int j,
+    __device__ __forceinline__ static void ll_row(const KArgs<T> &ka, const Dense &d, T dt, const State (&y)[NC],
+                                                  const State (&yt)[NC], const State (&k)[7][NC], LL &ll, int j,
                                                   int a, int as, bool lead, T *tab_row) {
         switch (ka.ll_slot) {
         case 0:
-            if (lead) ll_block<0, 1>(ka, d, dt, y, yt, k, ll, j, a, tab_row);
+            if (lead) ll_block<IS, 1>(ka, d, dt, y, yt, k, ll, j, a, tab_row);
             break;
         case 1:
             if constexpr (HAS_E) ll_block<IE, S>(ka, d, dt, y, yt, k, ll, j, as, tab_row);
@@ -790,12 +863,12 @@ struct Solver {
     // `as` = a * ST + h * SPL: position of this lane's first strain inside an [A, ST] block
     template <int PLANE>
     __device__ __forceinline__ static void save_row(const KArgs<T> &ka, const Dense &dn, T dt,
-                                                    const T (&y)[NC][NV], const T (&yt)[NC][NV],
-                                                    const T (&k)[7][NC][NV], T *row, int a, int as,
+                                                    const State (&y)[NC], const State (&yt)[NC],
+                                                    const State (&k)[7][NC], T *row, int a, int as,
                                                     bool lead, bool vec_ok) {
         if constexpr (SAVE_ALL) vec_ok = true;
         if ((SAVE_ALL || ka.save_off[0] >= 0) && lead)
-            save_block<0, 1>(dn, dt, y[PLANE], yt[PLANE], k, PLANE, row + ka.save_off[0] + a, false);
+            save_block<IS, 1>(dn, dt, y[PLANE], yt[PLANE], k, PLANE, row + ka.save_off[0] + a, false);
         if constexpr (HAS_E)
             if (SAVE_ALL || ka.save_off[1] >= 0)
                 save_block<IE, S>(dn, dt, y[PLANE], yt[PLANE], k, PLANE, row + ka.save_off[1] + as,
@@ -829,9 +902,9 @@ struct Solver {
 
     template <int PLANE>
     __device__ __forceinline__ static void save_tangents(const KArgs<T> &ka, const Dense &dn, T dt,
-                                                         const T (&y)[NC][NV],
-                                                         const T (&yt)[NC][NV],
-                                                         const T (&k)[7][NC][NV], T *drow, int a,
+                                                         const State (&y)[NC],
+                                                         const State (&yt)[NC],
+                                                         const State (&k)[7][NC], T *drow, int a,
                                                          int as, bool lead, bool vec_ok) {
         if constexpr (PLANE < NC) {
             save_row<PLANE>(ka, dn, dt, y, yt, k, drow + (int64_t)(PLANE - 1) * ka.d_saved, a, as,
@@ -976,7 +1049,16 @@ struct Solver {
         }
 
         // ---- initial state (plane 0) and its seeds (planes 1..ND)
-        T y[NC][NV], yt[NC][NV], k[7][NC][NV];
+        State y[NC], yt[NC], k[7][NC];
+        if constexpr (NV % 2 == 1) { // the pad element of every plane: zero for good (nothing but the pairwise stepper touches it)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                y[c].p[NP - 1][1] = T(0);
+                yt[c].p[NP - 1][1] = T(0);
+#pragma unroll
+                for (int q = 0; q < 7; ++q) k[q][c].p[NP - 1][1] = T(0);
+            }
+        }
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             const T *src;
@@ -987,7 +1069,7 @@ struct Solver {
                 zero = zero || ka.dy0 == nullptr;
                 src = ka.dy0 + ((ka.dy0_batched ? traj * ND : 0) + (c - 1)) * (int64_t)D;
             }
-            y[c][0] = zero ? T(0) : src[aa];
+            y[c][IS] = zero ? T(0) : src[aa];
 #pragma unroll
             for (int l = 0; l < S; ++l) {
                 const int sg = aa * ST + s0 + l; // (age, global strain)
@@ -1024,8 +1106,8 @@ struct Solver {
             for (int v = 0; v < NV; ++v) {
                 const T sc = atol + M::abs(y[0][v]) * rtol;
                 const T q0 = y[0][v] / sc, q1 = k[0][0][v] / sc;
-                n0 += (v == 0 ? w_s : T(1)) * (q0 * q0);
-                n1 += (v == 0 ? w_s : T(1)) * (q1 * q1);
+                n0 += (v == IS ? w_s : T(1)) * (q0 * q0);
+                n1 += (v == IS ? w_s : T(1)) * (q1 * q1);
             }
             const T d0 = M::sqrt(group_sum<G>(n0) / Dn), d1 = M::sqrt(group_sum<G>(n1) / Dn);
             const bool small = (d0 < T(1e-5)) || (d1 < T(1e-5));
@@ -1033,14 +1115,14 @@ struct Solver {
 #pragma unroll
             for (int c = 0; c < NC; ++c)
 #pragma unroll
-                for (int v = 0; v < NV; ++v) yt[c][v] = y[c][v] + h0 * k[0][c][v];
+                for (int pp = 0; pp < NP; ++pp) yt[c].p[pp] = y[c].p[pp] + h0 * k[0][c].p[pp];
             L.rhs(tprev + h0, yt, k[1]);
             T s2 = 0;
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
                 const T sc = atol + M::abs(y[0][v]) * rtol;
                 const T q2 = (k[1][0][v] - k[0][0][v]) / sc;
-                s2 += (v == 0 ? w_s : T(1)) * (q2 * q2);
+                s2 += (v == IS ? w_s : T(1)) * (q2 * q2);
             }
             const T d2 = M::sqrt(group_sum<G>(s2) / Dn) / h0;
             const T max_d = M::max(d1, d2);
@@ -1122,12 +1204,12 @@ struct Solver {
 #pragma unroll
                 for (int c = 0; c < NC; ++c)
 #pragma unroll
-                    for (int v = 0; v < NV; ++v) {
-                        T acc = T(TB::a[sg][0]) * k[0][c][v];
+                    for (int pp = 0; pp < NP; ++pp) { // register pairs: v_pk_fma_f32
+                        V2 acc = T(TB::a[sg][0]) * k[0][c].p[pp];
 #pragma unroll
                         for (int q = 1; q < sg; ++q)
-                            if (TB::a[sg][q] != 0.0) acc += T(TB::a[sg][q]) * k[q][c][v];
-                        yt[c][v] = y[c][v] + dt * acc;
+                            if (TB::a[sg][q] != 0.0) acc += T(TB::a[sg][q]) * k[q][c].p[pp];
+                        yt[c].p[pp] = y[c].p[pp] + dt * acc;
                     }
                 L.rhs(tprev + T(TB::c[sg]) * dt, yt, k[sg]);
             }
@@ -1138,15 +1220,21 @@ struct Solver {
             T factor = T(1);
             if (!constant) {
                 T ss = 0;
+                State err;
 #pragma unroll
-                for (int v = 0; v < NV; ++v) {
-                    T e = T(TB::berr[0]) * k[0][0][v];
+                for (int pp = 0; pp < NP; ++pp) {
+                    V2 e2 = T(TB::berr[0]) * k[0][0].p[pp];
 #pragma unroll
                     for (int q = 1; q < 7; ++q)
-                        if (TB::berr[q] != 0.0) e += T(TB::berr[q]) * k[q][0][v];
+                        if (TB::berr[q] != 0.0) e2 += T(TB::berr[q]) * k[q][0].p[pp];
+                    err.p[pp] = e2;
+                }
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    const T e = err[v];
                     const T ym = M::max(M::abs(y[0][v]), M::abs(yt[0][v]));
                     const T r = (dt * e) * M::rcp_fast(atol + ym * rtol);
-                    if (GS > 1 && v == 0)
+                    if (GS > 1 && v == IS)
                         ss += L.lead ? r * r : T(0);
                     else
                         ss += r * r;
@@ -1155,7 +1243,7 @@ struct Solver {
             } else {
                 T chk = 0;
 #pragma unroll
-                for (int v = 0; v < NV; ++v) chk += yt[0][v] - yt[0][v];
+                for (int v = 0; v < NV; ++v) chk += (T)yt[0][v] - (T)yt[0][v];
                 chk = group_sum<G>(chk);
                 finite = (chk == T(0));
             }
@@ -1244,9 +1332,9 @@ struct Solver {
 #pragma unroll
                 for (int c = 0; c < NC; ++c)
 #pragma unroll
-                    for (int v = 0; v < NV; ++v) {
-                        y[c][v] = yt[c][v];
-                        k[0][c][v] = k[6][c][v];
+                    for (int pp = 0; pp < NP; ++pp) {
+                        y[c].p[pp] = yt[c].p[pp];
+                        k[0][c].p[pp] = k[6][c].p[pp];
                     }
                 ++n_acc;
             } else if (act && finite) {
@@ -1269,7 +1357,7 @@ struct Solver {
 #pragma unroll
                         for (int c = 0; c < NC; ++c)
 #pragma unroll
-                            for (int v = 0; v < NV; ++v) k[0][c][v] = k[1][c][v];
+                            for (int pp = 0; pp < NP; ++pp) k[0][c].p[pp] = k[1][c].p[pp];
                     }
                 }
                 if (act) at_jump = false;

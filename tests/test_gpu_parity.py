@@ -606,7 +606,7 @@ def test_vaccination_tiers_match_oracle_and_move_people_up(ages, m, dtype):
     want, st, na, nr = O.solve(H.omodel(m), y0, p, C, t1, ts, dtype=NP[dtype], n_threads=8)
     got = r.ys.cpu().numpy()
     assert int(r.status.max()) == 0 and int(st.max()) == 0
-    assert np.abs(got - want).max() / 1000.0 < 5e-5
+    assert np.abs(got - want).max() / 1000.0 < (5e-5 if dtype == F64 else 2e-4)    # a few solver tolerances (the SEIP family's bars)
     assert np.abs((r.n_accept + r.n_reject).cpu().numpy() - (na + nr)).max() <= max(12, 0.25 * (na + nr).max())
     KV, G, S = m.vax_lanes, m.n_age, m.n_strain
     n_pop = m.state_dim - (G * S if m.has_c else 0)
