@@ -230,6 +230,20 @@ __device__ __forceinline__ void fma_quad_pair(float &acc_a, float &acc_b, float 
         : "+v"(acc_a), "+v"(acc_b)
         : "v"(xa), "v"(xb), "v"(c0), "v"(c1), "v"(c2), "v"(c3));
 }
+// the same with acc_a = c0 * xa, acc_b = c0 * xb as the first term (base 0 of the gather: no zero-initialised accumulator)
+__device__ __forceinline__ void mul_quad_pair(float &acc_a, float &acc_b, float xa, float xb,
+                                              float c0, float c1, float c2, float c3) {
+    asm("v_mul_f32_e32 %0, %2, %4\n\t"
+        "v_mul_f32_e32 %1, %3, %4\n\t"
+        "v_fmac_f32_dpp %0, %2, %5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %1, %3, %5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %0, %2, %6 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %1, %3, %6 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %0, %2, %7 quad_perm:[3,2,1,0] row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %1, %3, %7 quad_perm:[3,2,1,0] row_mask:0xf bank_mask:0xf"
+        : "=&v"(acc_a), "=&v"(acc_b)
+        : "v"(xa), "v"(xb), "v"(c0), "v"(c1), "v"(c2), "v"(c3));
+}
 __device__ __forceinline__ void fma_quad_one(float &acc, float x, float c0, float c1, float c2,
                                              float c3) {
     asm("v_fmac_f32_e32 %0, %1, %2\n\t"
@@ -253,6 +267,13 @@ __device__ __forceinline__ void fma_quad_pair(T &acc_a, T &acc_b, T xa, T xb, T 
                                               T c3) {
     fma_quad_one<T>(acc_a, xa, c0, c1, c2, c3);
     fma_quad_one<T>(acc_b, xb, c0, c1, c2, c3);
+}
+
+template <typename T>
+__device__ __forceinline__ void mul_quad_pair(T &acc_a, T &acc_b, T xa, T xb, T c0, T c1, T c2, T c3) {
+    acc_a = T(0);
+    acc_b = T(0);
+    fma_quad_pair<T>(acc_a, acc_b, xa, xb, c0, c1, c2, c3);
 }
 
 template <int G, typename T>
@@ -408,6 +429,10 @@ struct Solver {
 
     // per-lane model data
     T beta[S], gamma[S], sigma[S], omega[S];
+    // the same rates as register pairs over the strains (rhs_strain_pairs; an instantiation keeps whichever form it reads)
+    static constexpr bool PAIRED_RHS = sizeof(T) == 4 && S % 2 == 0 && W == 1 && ND == 0 && KV == 0 && !INTRO;
+    static constexpr int SP = PAIRED_RHS ? S / 2 : 1;
+    V2 beta2[SP], gamma2[SP], sigma2[SP], omega2[SP];
     T Cx[GA]; // Cx[k] = contact[a][a ^ k] (0 outside the matrix)
     T amp, phase, w_season;
     // external introductions (INTRO): peak day, 1 / scale, percentage / (scale sqrt(2 pi)) * [age receives it]
@@ -454,7 +479,64 @@ struct Solver {
 
     // f(t, y) for this lane's age bin (plane 0) and its JVP (planes 1..ND);
     // reference RHS: see include/dynode_hip.h
+    // f(t, y) written on register pairs over the strains (plain multi-strain shapes in float32: the 8 age x 4 strain models).
+    // The same expression tree as rhs() strain by strain; only the sums over the strains of a lane -- the population and the
+    // net flow of s -- are formed pairwise first and across the pair last (a different, equally valid summation order).
+    __device__ __forceinline__ void rhs_strain_pairs(T t, const State &y0, State &dy) const {
+        constexpr int PE = IE / 2, PI = II / 2, PR = IR / 2, PC = IC / 2;
+        V2 tot = y0.p[PI];
+#pragma unroll
+        for (int q = 1; q < SP; ++q) tot += y0.p[PI + q];
+#pragma unroll
+        for (int q = 0; q < SP; ++q) {
+            if constexpr (HAS_E) tot += y0.p[PE + q];
+            tot += y0.p[PR + q];
+        }
+        const T s = y0[IS];
+        const T N = s + strain_sum(tot[0] + tot[1]);
+        T invN = T(1);
+        if (normalize) invN = pad ? T(0) : M::recip(N);
+        T season = T(1);
+        if (__builtin_expect(seasonal, 0)) season = T(1) + amp * M::sin(w_season * t + phase);
+        T x[S], acc[S];
+#pragma unroll
+        for (int q = 0; q < SP; ++q) {
+            const V2 xq = y0.p[PI + q] * invN;
+            x[2 * q] = xq[0];
+            x[2 * q + 1] = xq[1];
+        }
+        contract(x, acc);
+        V2 net = V2{T(0), T(0)};   // what returns to s minus what leaves it, per strain pair
+#pragma unroll
+        for (int q = 0; q < SP; ++q) {
+            const V2 foi = (beta2[q] * season) * V2{acc[2 * q], acc[2 * q + 1]};
+            const V2 flux = foi * s;
+            const V2 g_i = gamma2[q] * y0.p[PI + q];
+            net -= flux;
+            if constexpr (HAS_E) {
+                const V2 s_e = sigma2[q] * y0.p[PE + q];
+                dy.p[PE + q] = flux - s_e;
+                dy.p[PI + q] = s_e - g_i;
+            } else {
+                dy.p[PI + q] = flux - g_i;
+            }
+            if constexpr (HAS_WANE) {
+                const V2 o = omega2[q] * y0.p[PR + q];
+                dy.p[PR + q] = g_i - o;
+                net += o;
+            } else {
+                dy.p[PR + q] = g_i;
+            }
+            if constexpr (HAS_C) dy.p[PC + q] = flux;
+        }
+        dy[IS] = strain_sum(net[0] + net[1]);
+    }
+
     __device__ __forceinline__ void rhs(T t, const State (&y)[NC], State (&dy)[NC]) const {
+        if constexpr (PAIRED_RHS) {
+            rhs_strain_pairs(t, y[0], dy[0]);
+            return;
+        }
         const State &y0 = y[0];
         T se = 0, si = 0, sr = 0;
 #pragma unroll
@@ -649,9 +731,12 @@ struct Solver {
 #pragma unroll
         for (int l = 0; l < S; ++l) xb[l] = xchg_xor<off>(x[l]);
 #pragma unroll
-        for (int l = 0; l + 1 < S; l += 2)
-            fma_quad_pair(acc[l], acc[l + 1], xb[l], xb[l + 1], Cx[off], Cx[off ^ 1], Cx[off ^ 2],
-                          Cx[off ^ 3]);
+        for (int l = 0; l + 1 < S; l += 2) {
+            if constexpr (BASE == 0)
+                mul_quad_pair(acc[l], acc[l + 1], xb[l], xb[l + 1], Cx[off], Cx[off ^ 1], Cx[off ^ 2], Cx[off ^ 3]);
+            else
+                fma_quad_pair(acc[l], acc[l + 1], xb[l], xb[l + 1], Cx[off], Cx[off ^ 1], Cx[off ^ 2], Cx[off ^ 3]);
+        }
         if constexpr (S % 2 == 1)
             fma_quad_one(acc[S - 1], xb[S - 1], Cx[off], Cx[off ^ 1], Cx[off ^ 2], Cx[off ^ 3]);
         if constexpr ((BASE + 1) * 4 < GA) gather_base<BASE + 1>(x, acc);
@@ -950,6 +1035,15 @@ struct Solver {
                 L.gamma[l] = p[ST + s0 + l];
                 L.sigma[l] = HAS_E ? p[oS * ST + s0 + l] : T(0);
                 L.omega[l] = HAS_WANE ? p[oW * ST + s0 + l] : T(0);
+            }
+            if constexpr (PAIRED_RHS) {
+#pragma unroll
+                for (int q = 0; q < SP; ++q) {
+                    L.beta2[q] = V2{L.beta[2 * q], L.beta[2 * q + 1]};
+                    L.gamma2[q] = V2{L.gamma[2 * q], L.gamma[2 * q + 1]};
+                    L.sigma2[q] = V2{L.sigma[2 * q], L.sigma[2 * q + 1]};
+                    L.omega2[q] = V2{L.omega[2 * q], L.omega[2 * q + 1]};
+                }
             }
             if constexpr (INTRO) {
 #pragma unroll

@@ -85,9 +85,10 @@ def test_nuts_posterior_matches_grid_quadrature(data, sampler, adaptation):
         thin = post[name][:, ::10].reshape(-1).cpu().numpy()          # 48 x 25 nearly independent draws
         ks = stats.kstest(thin, lambda x: np.interp(x, grid, cdf))
         assert ks.pvalue > 1e-3, (name, ks)
-        # the data were generated at r0 = 2, T_inf = 7
-        truth = 2.0 if name.endswith("r0") else 7.0
-        assert abs(np.median(thin) - truth) < 4 * np.std(thin) / np.sqrt(thin.size) + 0.02 * truth
+        # the sample median against the posterior's own (quadrature) median -- not against the generating values
+        # r0 = 2, T_inf = 7, which the priors pull away from: the posterior median of T_inf is 7.2
+        q_median = float(np.interp(0.5, cdf, grid))
+        assert abs(np.median(thin) - q_median) < 5 * 1.2533 * np.std(thin) / np.sqrt(thin.size), (name, np.median(thin), q_median)
         print(name, "posterior mean %.4f sd %.4f KS p=%.3f" % (thin.mean(), thin.std(), ks.pvalue))
     print("mean leapfrogs/transition %.2f, gradient-solves %d" % (float(mcmc.nuts.num_steps.double().mean()), mcmc.nuts.potential_evals))
 
