@@ -546,8 +546,8 @@ def marginal_cdfs_by_quadrature(potential: Potential, z_grids: list) -> list:
 def ks_against_quadrature(potential: Potential, draws: dict, z_grids: list, thin: int = 20) -> dict:
     """Kolmogorov-Smirnov test of every latent site's draws (``[chains, draws]``, thinned by ``thin`` along the draws
     axis to decorrelate them) against the marginal CDF from :func:`marginal_cdfs_by_quadrature`, with the moments of
-    both: ``{site: {"ks_p", "ks_stat", "n", "mean", "sd", "quad_mean", "quad_sd", "mean_z"}}`` where ``mean_z`` is
-    the error of the sample mean in Monte-Carlo standard errors (sd / sqrt(effective sample size))."""
+    both: ``{site: {"ks_p", "ks_stat", "n", "mean", "sd", "quad_mean", "quad_sd", "mean_z", "sd_z"}}`` where ``mean_z`` /
+    ``sd_z`` are the errors of the sample mean / standard deviation in their Monte-Carlo standard errors."""
     import numpy as np
     from scipy import stats
 
@@ -561,9 +561,14 @@ def ks_against_quadrature(potential: Potential, draws: dict, z_grids: list, thin
         qm = float((grid * pmf).sum())
         qs = float(np.sqrt((((grid - qm) ** 2) * pmf).sum()))
         ess = effective_sample_size(x)
+        # the standard deviation's own Monte-Carlo error: delta method on the squared deviations, with THEIR effective sample size
+        d2 = (x - qm) ** 2
+        ess2 = effective_sample_size(d2)
+        sd_se = float(np.sqrt(d2.var() / max(ess2, 1.0)) / (2.0 * qs))
         out[name] = {"ks_p": float(res.pvalue), "ks_stat": float(res.statistic), "n": int(thinned.size), "mean": float(x.mean()),
-                     "sd": float(x.std()), "quad_mean": qm, "quad_sd": qs, "ess": float(ess),
-                     "mean_z": float((x.mean() - qm) / (qs / np.sqrt(max(ess, 1.0))))}
+                     "sd": float(x.std()), "quad_mean": qm, "quad_sd": qs, "ess": float(ess), "ess_sq": float(ess2),
+                     "mean_z": float((x.mean() - qm) / (qs / np.sqrt(max(ess, 1.0)))),
+                     "sd_z": float((np.sqrt(d2.mean()) - qs) / sd_se)}
     return out
 
 

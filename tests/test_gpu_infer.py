@@ -95,12 +95,12 @@ def test_nuts_posterior_matches_grid_quadrature(data, sampler, adaptation):
 
 def test_nuts_posterior_high_power_ks_and_moments(data):
     """cfg 4 at one GPU's share (128 chains), default per-chain adaptation as in numpyro, 12,800 thinned draws per
-    site: KS p > 0.01 against the quadrature CDF, sample mean within 3 Monte-Carlo standard errors and standard
-    deviation within 3 of its standard errors of the quadrature moments."""
+    site (1000 + 1000 transitions, BASELINE cfg 4): KS p > 0.01 against the quadrature CDF, sample mean and standard
+    deviation within 3 of their Monte-Carlo standard errors of the quadrature moments."""
     from dynode_amd.infer.inference import ks_against_quadrature
 
     kw = dict(config=ex.get_config(), tf=100, obs_data=data)
-    process = MCMCProcess(numpyro_model=ex.model_fused, num_warmup=500, num_samples=1000, num_chains=128,
+    process = MCMCProcess(numpyro_model=ex.model_fused, num_warmup=1000, num_samples=1000, num_chains=128,
                           nuts_max_tree_depth=10, progress_bar=False)
     process.infer(**kw)
     post = process.get_samples(group_by_chain=True)
@@ -114,8 +114,7 @@ def test_nuts_posterior_high_power_ks_and_moments(data):
     for name, r in rep.items():
         print(name, {k: (round(v, 5) if isinstance(v, float) else v) for k, v in r.items()})
         assert r["n"] >= 10_000 and r["ks_p"] > 0.01, (name, r)
-        assert abs(r["mean_z"]) < 3.0, (name, r)
-        assert abs(r["sd"] / r["quad_sd"] - 1.0) < 3.0 / np.sqrt(2.0 * r["ess"]) + 2e-3, (name, r)
+        assert abs(r["mean_z"]) < 3.0 and abs(r["sd_z"]) < 3.0, (name, r)
 
 
 def test_get_samples_before_infer_raises():
