@@ -944,6 +944,17 @@ struct Solver {
         }
     }
 
+    // CNT consecutive elements of an interpolated plane to aligned memory (SAVE_ALL rows)
+    template <int FIRST, int CNT>
+    __device__ __forceinline__ static void store_elements(const State &o, T *dst) {
+        if constexpr (CNT > 0) {
+            T v[CNT];
+#pragma unroll
+            for (int q = 0; q < CNT; ++q) v[q] = o[FIRST + q];
+            store_run<T, CNT>(dst, v, true);
+        }
+    }
+
     // one saved row of one plane
     // `as` = a * ST + h * SPL: position of this lane's first strain inside an [A, ST] block
     template <int PLANE>
@@ -951,6 +962,21 @@ struct Solver {
                                                     const State (&y)[NC], const State (&yt)[NC],
                                                     const State (&k)[7][NC], T *row, int a, int as,
                                                     bool lead, bool vec_ok) {
+        if constexpr (SAVE_ALL && sizeof(T) == 4 && S % 2 == 1) {
+            // every compartment is saved and the strain blocks are single elements (the strain-split shapes): interpolate
+            // ALL register pairs at once -- e and i, c and s share pairs -- and store the elements from the result
+            State o;
+#pragma unroll
+            for (int j = 0; j < NP; ++j)
+                o.p[j] = dense_eval<V2>(dn, dt, y[PLANE].p[j], yt[PLANE].p[j], k[0][PLANE].p[j], k[1][PLANE].p[j], k[2][PLANE].p[j],
+                                        k[3][PLANE].p[j], k[4][PLANE].p[j], k[5][PLANE].p[j], k[6][PLANE].p[j]);
+            if (lead) row[ka.save_off[0] + a] = o[IS];
+            store_elements<IE, NE>(o, row + ka.save_off[1] + as);
+            store_elements<II, S>(o, row + ka.save_off[2] + as);
+            store_elements<IR, S * W>(o, row + ka.save_off[3] + as * W);
+            store_elements<IC, NCU>(o, row + ka.save_off[4] + as);
+            return;
+        }
         if constexpr (SAVE_ALL) vec_ok = true;
         if ((SAVE_ALL || ka.save_off[0] >= 0) && lead)
             save_block<IS, 1>(dn, dt, y[PLANE], yt[PLANE], k, PLANE, row + ka.save_off[0] + a, false);
@@ -1313,26 +1339,23 @@ struct Solver {
             bool keep = true, finite = true;
             T factor = T(1);
             if (!constant) {
-                T ss = 0;
-                State err;
+                // scaled error per element, pair by pair: only |.|, max and the reciprocal are one-element instructions
+                V2 ssq[2] = {V2{T(0), T(0)}, V2{T(0), T(0)}};   // two partial sums: no dependent packed FMAs back to back
 #pragma unroll
                 for (int pp = 0; pp < NP; ++pp) {
                     V2 e2 = T(TB::berr[0]) * k[0][0].p[pp];
 #pragma unroll
                     for (int q = 1; q < 7; ++q)
                         if (TB::berr[q] != 0.0) e2 += T(TB::berr[q]) * k[q][0].p[pp];
-                    err.p[pp] = e2;
+                    const V2 ym = V2{M::max(M::abs(y[0].p[pp][0]), M::abs(yt[0].p[pp][0])),
+                                     M::max(M::abs(y[0].p[pp][1]), M::abs(yt[0].p[pp][1]))};
+                    const V2 sc = ym * rtol + atol;
+                    V2 r = (dt * e2) * V2{M::rcp_fast(sc[0]), M::rcp_fast(sc[1])};
+                    if (GS > 1 && pp == IS / 2) r[IS % 2] = L.lead ? r[IS % 2] : T(0); // the replicated s counts once
+                    ssq[pp & 1] += r * r;       // (the pad element of an odd NV carries e = 0)
                 }
-#pragma unroll
-                for (int v = 0; v < NV; ++v) {
-                    const T e = err[v];
-                    const T ym = M::max(M::abs(y[0][v]), M::abs(yt[0][v]));
-                    const T r = (dt * e) * M::rcp_fast(atol + ym * rtol);
-                    if (GS > 1 && v == IS)
-                        ss += L.lead ? r * r : T(0);
-                    else
-                        ss += r * r;
-                }
+                const V2 ss2 = ssq[0] + ssq[1];
+                const T ss = ss2[0] + ss2[1];
                 Control<T>::decide(M::sqrt(group_sum<G>(ss) / Dn), tprev, dt, keep, finite, factor);
             } else {
                 T chk = 0;
