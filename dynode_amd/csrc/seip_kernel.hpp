@@ -17,6 +17,9 @@
 #pragma once
 #include "solve_kernel.hpp"
 
+#ifndef DYN_SEIP_CACHE_SUS
+#define DYN_SEIP_CACHE_SUS 0
+#endif
 namespace dyn {
 
 // KT = 2 ("tier lanes"): the vaccination tiers of an (age, history) pair are dealt over two lanes -- lane bit above the
@@ -41,6 +44,11 @@ struct Seip {
     // the age contraction and the dense output are the ones of the s/e/i/r/c kernels
     using Lanes = Solver<T, METHOD, GA, L, true, true, true, 1, 0, L>;
     using Dense = typename Lanes::Dense;
+    // the state, the stage state and the seven stage derivatives in register pairs (solve_kernel.hpp: PairState); the
+    // stepper's linear algebra runs on the pairs, the right-hand side below indexes elements
+    using PS = PairState<T, NV>;
+    typedef T V2 __attribute__((ext_vector_type(2)));
+    static constexpr int NP = PS::NP;
     // ---- wave groups: which lane bits of the trajectory lie above the wavefront
     static constexpr int LOGA = GA == 1 ? 0 : GA == 2 ? 1 : GA == 4 ? 2 : GA == 8 ? 3 : GA == 16 ? 4 : GA == 32 ? 5 : 6;
     static constexpr int HB_IN = (6 - LOGA) < L ? (6 - LOGA) : L;   // immune-history bits inside a wave
@@ -89,6 +97,15 @@ struct Seip {
     T itime[L], iinv[L], iamp[L]; // external introductions: day, 1 / scale, pct / (scale sqrt(2 pi)) * pop * [age receives it]
     T pop;             // population of this lane's age (doses per day = nu * pop)
     const T *sus;      // LDS: sus[K1][M1][L] of this lane's history
+    // ... and a copy in registers of the rows this lane multiplies by in EVERY right-hand side (its tiers x waning states x
+    // strains), where the register file has the room: the LDS reads sit behind the mailbox writes of a wave group (nothing
+    // hoists them), and with one wave per SIMD nobody hides their latency
+    static constexpr bool CACHE_SUS = DYN_SEIP_CACHE_SUS && !(sizeof(T) == 4 && NV <= 20) && (9 * NV + KL * M1 * L + 70) * (int)(sizeof(T) / 4) <= 500;
+    T susr[CACHE_SUS ? KL * M1 * L : 1];
+    __device__ __forceinline__ T sus_at(int slot, int kc, int m, int l) const {
+        if constexpr (CACHE_SUS) return susr[(slot * M1 + m) * L + l];
+        else return sus[(kc * M1 + m) * L + l];
+    }
     const T *spl;      // LDS: spline[K1][4 + 2 nk] of this lane's age
     int nk, hist, tl; // tl: tier lane (KT = 2), 0 otherwise
     bool pad, seasonal, seasonal_vax, intro;
@@ -104,7 +121,7 @@ struct Seip {
 
     // recovery of strain l: gamma_l i_{a,j,k,l} enters s_{a, j | 2^l, k, 0}
     template <int l>
-    __device__ __forceinline__ void recover(const T (&y)[NV], T (&dy)[NV]) const {
+    __device__ __forceinline__ void recover(const PS &y, PS &dy) const {
         if constexpr (l < L) {
             const bool has = (hist >> l) & 1;
 #pragma unroll
@@ -117,14 +134,14 @@ struct Seip {
         }
     }
 
-    __device__ __forceinline__ void rhs(T t, const T (&y)[NV], T (&dy)[NV]) const {
+    __device__ __forceinline__ void rhs(T t, const PS &y, PS &dy) const {
         if constexpr (NW > 1) rhs_wave_group(t, y, dy);
         else if constexpr (KT == 2) rhs_tier_lanes(t, y, dy);
         else rhs_one_lane(t, y, dy);
     }
 
     // every tier of an (age, history) pair in one lane (KT = 1, NW = 1)
-    __device__ __forceinline__ void rhs_one_lane(T t, const T (&y)[NV], T (&dy)[NV]) const {
+    __device__ __forceinline__ void rhs_one_lane(T t, const PS &y, PS &dy) const {
         T x[L], lam[L];
 #pragma unroll
         for (int l = 0; l < L; ++l) {
@@ -185,11 +202,10 @@ struct Seip {
 #pragma unroll
             for (int m = 0; m < M1; ++m) {
                 const T S = y[k * M1 + m];
-                const T *su = sus + (k * M1 + m) * L;
                 T out = T(0);
 #pragma unroll
                 for (int l = 0; l < L; ++l) {
-                    const T f = (lam[l] * su[l]) * S;
+                    const T f = (lam[l] * sus_at(k, k, m, l)) * S;
                     inflow[l] += f;
                     out += f;
                 }
@@ -233,7 +249,7 @@ struct Seip {
     }
 
     // ---- the same right-hand side with the tiers dealt over two lanes (KT = 2): slot s of this lane is tier 2 s + tl
-    __device__ __forceinline__ void rhs_tier_lanes(T t, const T (&y)[NV], T (&dy)[NV]) const {
+    __device__ __forceinline__ void rhs_tier_lanes(T t, const PS &y, PS &dy) const {
         constexpr int TB_ = GA * H; // lane distance to the tier partner
         T x[L], lam[L];
 #pragma unroll
@@ -292,11 +308,10 @@ struct Seip {
 #pragma unroll
             for (int m = 0; m < M1; ++m) {
                 const T S = y[sl * M1 + m];
-                const T *su = sus + (kc * M1 + m) * L;
                 T out = T(0);
 #pragma unroll
                 for (int l = 0; l < L; ++l) {
-                    const T f = (lam[l] * su[l]) * S;
+                    const T f = (lam[l] * sus_at(sl, kc, m, l)) * S;
                     inflow[l] += f;
                     out += f;
                 }
@@ -358,7 +373,7 @@ struct Seip {
     // tier totals (when histories cross waves), the recovery flows of the strains whose history bit selects the wave, the
     // seasonal fall-back of the top tier, and -- when the tier totals are complete inside a wave -- the vaccination flow
     // to the tier partner; otherwise that flow goes in a second round once the totals are known.
-    __device__ __forceinline__ void rhs_wave_group(T t, const T (&y)[NV], T (&dy)[NV]) const {
+    __device__ __forceinline__ void rhs_wave_group(T t, const PS &y, PS &dy) const {
         constexpr int S_TOT = L, S_REC = L + KL, S_SEND = L + KL * (1 + HB_X), S_SV = S_SEND + KL;
         constexpr int sK = K / KT, tK = K % KT, sD = K > 0 ? (K - 1) / KT : 0;   // slot / tier lane of the top tier, slot below it
         const int b = xbuf;
@@ -505,11 +520,10 @@ struct Seip {
 #pragma unroll
             for (int m = 0; m < M1; ++m) {
                 const T S = y[sl * M1 + m];
-                const T *su = sus + (kc * M1 + m) * L;
                 T out = T(0);
 #pragma unroll
                 for (int l = 0; l < L; ++l) {
-                    const T f = (lam[l] * su[l]) * S;
+                    const T f = (lam[l] * sus_at(sl, kc, m, l)) * S;
                     inflow[l] += f;
                     out += f;
                 }
@@ -597,7 +611,7 @@ struct Seip {
 
     // recovery for the KL local slots (the same exchange over the history bits as recover<>)
     template <int l>
-    __device__ __forceinline__ void recover_slots(const T (&y)[NV], T (&dy)[NV]) const {
+    __device__ __forceinline__ void recover_slots(const PS &y, PS &dy) const {
         if constexpr (l < HB_IN) {   // (= L unless a wave group splits the history bits: rhs_wave_group serves the rest)
             const bool has = (hist >> l) & 1;
 #pragma unroll
@@ -612,47 +626,50 @@ struct Seip {
 
     // stages SG..6 of the step (k[0] is FSAL); compile-time stage index: every k[q][v] is a named register
     template <int SG>
-    __device__ __forceinline__ void stages(T tprev, T dt, const T (&y)[NV], T (&yt)[NV], T (&k)[7][NV]) const {
+    __device__ __forceinline__ void stages(T tprev, T dt, const PS &y, PS &yt, PS (&k)[7]) const {
         if constexpr (SG < 7) {
 #pragma unroll
-            for (int v = 0; v < NV; ++v) {
-                T acc = T(TB::a[SG][0]) * k[0][v];
+            for (int pp = 0; pp < NP; ++pp) { // register pairs: v_pk_fma_f32
+                V2 acc = T(TB::a[SG][0]) * k[0].p[pp];
 #pragma unroll
                 for (int r = 1; r < SG; ++r)
-                    if (TB::a[SG][r] != 0.0) acc += T(TB::a[SG][r]) * k[r][v];
-                yt[v] = y[v] + dt * acc;
+                    if (TB::a[SG][r] != 0.0) acc += T(TB::a[SG][r]) * k[r].p[pp];
+                yt.p[pp] = y.p[pp] + dt * acc;
             }
             rhs(tprev + T(TB::c[SG]) * dt, yt, k[SG]);
             stages<SG + 1>(tprev, dt, y, yt, k);
         }
     }
 
+    // dense output of every element of the lane at one save time (all register pairs at once)
+    __device__ __forceinline__ static void interpolate(const Dense &d, T dt, const PS &y, const PS &y1, const PS (&k)[7], PS &o) {
+#pragma unroll
+        for (int j = 0; j < NP; ++j)
+            o.p[j] = Lanes::template dense_eval<V2>(d, dt, y.p[j], y1.p[j], k[0].p[j], k[1].p[j], k[2].p[j], k[3].p[j], k[4].p[j],
+                                                    k[5].p[j], k[6].p[j]);
+    }
+
     template <int FIRST, int CNT>
-    __device__ __forceinline__ static void save_block(const Dense &d, T dt, const T (&y)[NV], const T (&y1)[NV],
-                                                      const T (&k)[7][NV], T *dst, bool vec_ok) {
+    __device__ __forceinline__ static void save_block(const PS &o, T *dst, bool vec_ok) {
         T v[CNT];
 #pragma unroll
-        for (int q = 0; q < CNT; ++q) {
-            const int j = FIRST + q;
-            v[q] = Lanes::dense_eval(d, dt, y[j], y1[j], k[0][j], k[1][j], k[2][j], k[3][j], k[4][j], k[5][j], k[6][j]);
-        }
+        for (int q = 0; q < CNT; ++q) v[q] = o[FIRST + q];
         store_run<T, CNT>(dst, v, vec_ok);
     }
 
     // KT = 2: one block per live tier slot and compartment
     template <int SL>
-    __device__ __forceinline__ static void save_slots(const KArgs<T> &ka, const Dense &d, T dt, const T (&y)[NV], const T (&y1)[NV],
-                                                      const T (&k)[7][NV], T *row, int g, int tl, bool vec_ok) {
+    __device__ __forceinline__ static void save_slots(const KArgs<T> &ka, const PS &o, T *row, int g, int tl, bool vec_ok) {
         if constexpr (SL < KL) {
             const int kt = SL * KT + tl;
             if (kt < K1) {
                 const int gk = g * K1 + kt;
-                if (ka.save_off[0] >= 0) save_block<SL * M1, M1>(d, dt, y, y1, k, row + ka.save_off[0] + gk * M1, vec_ok);
-                if (ka.save_off[1] >= 0) save_block<IE + SL * L, L>(d, dt, y, y1, k, row + ka.save_off[1] + gk * L, vec_ok);
-                if (ka.save_off[2] >= 0) save_block<II + SL * L, L>(d, dt, y, y1, k, row + ka.save_off[2] + gk * L, vec_ok);
-                if (ka.save_off[4] >= 0) save_block<IC + SL * L, L>(d, dt, y, y1, k, row + ka.save_off[4] + gk * L, vec_ok);
+                if (ka.save_off[0] >= 0) save_block<SL * M1, M1>(o, row + ka.save_off[0] + gk * M1, vec_ok);
+                if (ka.save_off[1] >= 0) save_block<IE + SL * L, L>(o, row + ka.save_off[1] + gk * L, vec_ok);
+                if (ka.save_off[2] >= 0) save_block<II + SL * L, L>(o, row + ka.save_off[2] + gk * L, vec_ok);
+                if (ka.save_off[4] >= 0) save_block<IC + SL * L, L>(o, row + ka.save_off[4] + gk * L, vec_ok);
             }
-            save_slots<SL + 1>(ka, d, dt, y, y1, k, row, g, tl, vec_ok);
+            save_slots<SL + 1>(ka, o, row, g, tl, vec_ok);
         }
     }
 
@@ -735,6 +752,14 @@ struct Seip {
         __syncthreads();
         S.sus = tab + j * (K1 * M1 * L);
         S.spl = tab + SUSN + aa * K1 * (4 + 2 * nk);
+        if constexpr (CACHE_SUS) {
+#pragma unroll
+            for (int sl = 0; sl < KL; ++sl) {
+                const int kt = sl * KT + tl, kc = kt < K1 ? kt : K;   // padded slots hold nobody: any valid row will do
+#pragma unroll
+                for (int q = 0; q < M1 * L; ++q) S.susr[sl * M1 * L + q] = S.sus[kc * M1 * L + q];
+            }
+        }
 #pragma unroll
         for (int l = 0; l < L; ++l) {
             S.beta[l] = p[l];
@@ -754,7 +779,11 @@ struct Seip {
         // memory layout: every (age, history) group holds K1 tiers; a lane holds them all (KT = 1) or tiers tl, tl + 2 (KT = 2)
         const int offE = A * H * K1 * M1, nE = A * H * K1 * L;
         const int D = offE + 3 * nE;
-        T y[NV], yt[NV], k[7][NV];
+        PS y, yt, k[7];
+        y.clear_pad();
+        yt.clear_pad();
+#pragma unroll
+        for (int q = 0; q < 7; ++q) k[q].clear_pad();
         {
             const T *src = ka.y0 + (ka.y0_batched ? traj * D : 0);
             if constexpr (KT == 1) { // a lane's tiers are contiguous in memory
@@ -813,7 +842,7 @@ struct Seip {
             const bool small = (d0 < T(1e-5)) || (d1 < T(1e-5));
             const T h0 = small ? T(1e-6) : T(0.01) * (d0 / d1);
 #pragma unroll
-            for (int v = 0; v < NV; ++v) yt[v] = y[v] + h0 * k[0][v];
+            for (int pp = 0; pp < NP; ++pp) yt.p[pp] = y.p[pp] + h0 * k[0].p[pp];
             S.rhs(tprev + h0, yt, k[1]);
             T s2 = 0;
 #pragma unroll
@@ -861,17 +890,20 @@ struct Seip {
             bool keep = true, finite = true;
             T factor = T(1);
             if (!fixed) {
-                T ss = 0;
+                V2 ssq[2] = {V2{T(0), T(0)}, V2{T(0), T(0)}};
 #pragma unroll
-                for (int v = 0; v < NV; ++v) {
-                    T e = T(TB::berr[0]) * k[0][v];
+                for (int pp = 0; pp < NP; ++pp) {
+                    V2 e2 = T(TB::berr[0]) * k[0].p[pp];
 #pragma unroll
                     for (int r = 1; r < 7; ++r)
-                        if (TB::berr[r] != 0.0) e += T(TB::berr[r]) * k[r][v];
-                    const T ym = M::max(M::abs(y[v]), M::abs(yt[v]));
-                    const T r = (dt * e) * M::rcp_fast(atol + ym * rtol);
-                    ss += r * r;
+                        if (TB::berr[r] != 0.0) e2 += T(TB::berr[r]) * k[r].p[pp];
+                    const V2 ym = V2{M::max(M::abs(y.p[pp][0]), M::abs(yt.p[pp][0])), M::max(M::abs(y.p[pp][1]), M::abs(yt.p[pp][1]))};
+                    const V2 sc = ym * rtol + atol;
+                    const V2 r2 = (dt * e2) * V2{M::rcp_fast(sc[0]), M::rcp_fast(sc[1])};
+                    ssq[pp & 1] += r2 * r2;   // (the pad element of an odd NV carries e = 0)
                 }
+                const V2 ss2 = ssq[0] + ssq[1];
+                const T ss = ss2[0] + ss2[1];
                 Control<T>::decide(M::sqrt(S.traj_sum(ss) / Dn), tprev, dt, keep, finite, factor);
             } else {
                 bool ok = true;
@@ -896,13 +928,15 @@ struct Seip {
                     Lanes::dense_prepare((ts_next - tprev) * inv_dt, dn);
                     if (writer) {
                         T *row = out_traj + (int64_t)save_idx * ka.d_saved;
+                        PS o;
+                        interpolate(dn, dt, y, yt, k, o);
                         if constexpr (KT == 1) {
-                            if (ka.save_off[0] >= 0) save_block<0, NS>(dn, dt, y, yt, k, row + ka.save_off[0] + g * NS, vec_ok);
-                            if (ka.save_off[1] >= 0) save_block<IE, NE>(dn, dt, y, yt, k, row + ka.save_off[1] + g * NE, vec_ok);
-                            if (ka.save_off[2] >= 0) save_block<II, NE>(dn, dt, y, yt, k, row + ka.save_off[2] + g * NE, vec_ok);
-                            if (ka.save_off[4] >= 0) save_block<IC, NE>(dn, dt, y, yt, k, row + ka.save_off[4] + g * NE, vec_ok);
+                            if (ka.save_off[0] >= 0) save_block<0, NS>(o, row + ka.save_off[0] + g * NS, vec_ok);
+                            if (ka.save_off[1] >= 0) save_block<IE, NE>(o, row + ka.save_off[1] + g * NE, vec_ok);
+                            if (ka.save_off[2] >= 0) save_block<II, NE>(o, row + ka.save_off[2] + g * NE, vec_ok);
+                            if (ka.save_off[4] >= 0) save_block<IC, NE>(o, row + ka.save_off[4] + g * NE, vec_ok);
                         } else {
-                            save_slots<0>(ka, dn, dt, y, yt, k, row, g, tl, vec_ok);
+                            save_slots<0>(ka, o, row, g, tl, vec_ok);
                         }
                     }
                     ++save_idx;
@@ -913,9 +947,9 @@ struct Seip {
 
             if (accept) {
 #pragma unroll
-                for (int v = 0; v < NV; ++v) {
-                    y[v] = yt[v];
-                    k[0][v] = k[6][v];
+                for (int pp = 0; pp < NP; ++pp) {
+                    y.p[pp] = yt.p[pp];
+                    k[0].p[pp] = k[6].p[pp];
                 }
                 if (ka.sched_out != nullptr && writer && a == 0 && j == 0 && tl == 0 && n_acc < ka.sched_cap) {
                     T *rec = ka.sched_out + (traj * (int64_t)ka.sched_cap + n_acc) * 2;
@@ -938,7 +972,7 @@ struct Seip {
                     S.rhs(next_t0, y, k[1]);
                     if (gap) {
 #pragma unroll
-                        for (int v = 0; v < NV; ++v) k[0][v] = k[1][v];
+                        for (int pp = 0; pp < NP; ++pp) k[0].p[pp] = k[1].p[pp];
                     }
                 }
                 if (act && finite) {
@@ -963,7 +997,7 @@ struct Seip {
                     S.rhs(next_t0, y, k[1]);
                     if (landed) {
 #pragma unroll
-                        for (int v = 0; v < NV; ++v) k[0][v] = k[1][v];
+                        for (int pp = 0; pp < NP; ++pp) k[0].p[pp] = k[1].p[pp];
                     }
                 }
                 if (act) at_jump = false;

@@ -353,6 +353,45 @@ struct Control {
     }
 };
 
+// ---------------------------------------------------------------- per-lane state in register pairs
+// One plane of the per-lane state (or of a stage derivative): N values kept as ceil(N / 2) two-element vectors, so that the
+// register allocator holds them in aligned register pairs from the start and the linear algebra of the stepper -- the
+// stage combinations, the embedded error, the dense output -- runs on v_pk_fma_f32 without the pair-packing moves the
+// vectoriser otherwise inserts (12 % of the vector instructions of the D = 360 kernel).  operator[] gives the right-hand
+// side element access; an odd N leaves one pad element, which stays 0.
+template <typename T, int N>
+struct PairState {
+    static constexpr int NP = (N + 1) / 2;
+    typedef T V2 __attribute__((ext_vector_type(2)));
+    V2 p[NP];
+    struct Ref {
+        V2 &v;
+        int i;
+        __device__ __forceinline__ operator T() const { return v[i]; }
+        __device__ __forceinline__ Ref &operator=(T x) {
+            v[i] = x;
+            return *this;
+        }
+        __device__ __forceinline__ Ref &operator=(const Ref &o) {
+            v[i] = (T)o;
+            return *this;
+        }
+        __device__ __forceinline__ Ref &operator+=(T x) {
+            v[i] += x;
+            return *this;
+        }
+        __device__ __forceinline__ Ref &operator-=(T x) {
+            v[i] -= x;
+            return *this;
+        }
+    };
+    __device__ __forceinline__ T operator[](int e) const { return p[e >> 1][e & 1]; }
+    __device__ __forceinline__ Ref operator[](int e) { return Ref{p[e >> 1], e & 1}; }
+    __device__ __forceinline__ void clear_pad() {
+        if constexpr (N % 2 == 1) p[NP - 1][1] = T(0);
+    }
+};
+
 // ---------------------------------------------------------------- the kernel
 // ND > 0 adds forward-mode tangents: NC = 1 + ND "planes" of every state array, plane 0 the
 // primal.  RK stages, FSAL and the dense output are linear in (y, k), so they are applied
@@ -397,35 +436,10 @@ struct Solver {
     using M = Mth<T>;
     using TB = Tab<METHOD>;
 
-    // One plane of the per-lane state (or of a stage derivative): NV values kept as NP two-element vectors, so that the
-    // register allocator holds them in aligned register pairs from the start and the linear algebra of the stepper -- the
-    // stage combinations, the embedded error, the dense output -- runs on v_pk_fma_f32 without the pair-packing moves
-    // the vectoriser otherwise inserts (12 % of the vector instructions of the D = 360 kernel).  operator[] gives the
-    // right-hand side element access; an odd NV leaves one pad element, which stays 0.
+    // the per-lane state, the stage state and the stage derivatives live in register pairs (PairState above)
     static constexpr int NP = (NV + 1) / 2;
     typedef T V2 __attribute__((ext_vector_type(2)));
-    struct State {
-        V2 p[NP];
-        struct Ref {
-            V2 &v;
-            int i;
-            __device__ __forceinline__ operator T() const { return v[i]; }
-            __device__ __forceinline__ Ref &operator=(T x) {
-                v[i] = x;
-                return *this;
-            }
-            __device__ __forceinline__ Ref &operator=(const Ref &o) {
-                v[i] = (T)o;
-                return *this;
-            }
-            __device__ __forceinline__ Ref &operator+=(T x) {
-                v[i] += x;
-                return *this;
-            }
-        };
-        __device__ __forceinline__ T operator[](int e) const { return p[e >> 1][e & 1]; }
-        __device__ __forceinline__ Ref operator[](int e) { return Ref{p[e >> 1], e & 1}; }
-    };
+    using State = PairState<T, NV>;
 
     // per-lane model data
     T beta[S], gamma[S], sigma[S], omega[S];

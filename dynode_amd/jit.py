@@ -171,7 +171,7 @@ def ensure_kernel(model: _abi.ModelDesc, dtype=torch.float32, method: str = "tsi
                             f.write(_source(model, dtype, mid, n_dir, spl))
                         print(f"[dynode_amd] building the kernel for {name} (one-off, ~15 s) ...", file=sys.stderr, flush=True)
                         try:
-                            flags = [] if model.family == 1 else ["-fno-slp-vectorize"]      # as csrc/Makefile (SOLVE_FLAGS)
+                            flags = ["-fno-slp-vectorize"]      # as csrc/Makefile (SOLVE_FLAGS, SEIP_FLAGS)
                             subprocess.run([HIPCC, "-O3", "-std=c++17", "-fPIC", "-shared", "--offload-arch=gfx950", *flags, src, "-o", tmp],
                                            check=True)
                             probe = ctypes.CDLL(tmp)           # refuse to publish a library without its entry point
