@@ -18,7 +18,7 @@
 #include "solve_kernel.hpp"
 
 #ifndef DYN_SEIP_CACHE_SUS
-#define DYN_SEIP_CACHE_SUS 0
+#define DYN_SEIP_CACHE_SUS 1
 #endif
 namespace dyn {
 
@@ -100,8 +100,33 @@ struct Seip {
     // ... and a copy in registers of the rows this lane multiplies by in EVERY right-hand side (its tiers x waning states x
     // strains), where the register file has the room: the LDS reads sit behind the mailbox writes of a wave group (nothing
     // hoists them), and with one wave per SIMD nobody hides their latency
-    static constexpr bool CACHE_SUS = DYN_SEIP_CACHE_SUS && !(sizeof(T) == 4 && NV <= 20) && (9 * NV + KL * M1 * L + 70) * (int)(sizeof(T) / 4) <= 500;
+    static constexpr bool CACHE_SUS = DYN_SEIP_CACHE_SUS && NW == 2 && (9 * NV + KL * (M1 * L + 12) + 70) * (int)(sizeof(T) / 4) <= 500;
     T susr[CACHE_SUS ? KL * M1 * L : 1];
+    T splr[CACHE_SUS ? KL * 12 : 1];   // per slot: the cubic's 4 coefficients, 4 knots, 4 knot coefficients (0 beyond nk)
+    // nu(t) of one dose tier: cubic + truncated-power terms (reference utils/splines.py:10-109 conditional_knots), from the LDS
+    // table row `c` or from this lane's register copy of its slot
+    __device__ __forceinline__ T dose_rate_at(int slot, const T *c, T t) const {
+        T nu;
+        if constexpr (CACHE_SUS) {
+            const T *r = splr + slot * 12;
+            nu = r[0] + t * (r[1] + t * (r[2] + t * r[3]));
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const T lag = M::max(t - r[4 + n], T(0));
+                nu += r[8 + n] * (lag * lag * lag);
+            }
+        } else {
+            nu = c[0] + t * (c[1] + t * (c[2] + t * c[3]));
+#pragma unroll
+            for (int n = 0; n < 4; ++n) { // branch-free: knots beyond nk (wave-uniform) contribute coef = 0
+                const bool on = n < nk;
+                const T knot = c[on ? 4 + n : 0], coef = on ? c[on ? 4 + nk + n : 0] : T(0);
+                const T lag = M::max(t - knot, T(0));
+                nu += coef * (lag * lag * lag);
+            }
+        }
+        return nu;
+    }
     __device__ __forceinline__ T sus_at(int slot, int kc, int m, int l) const {
         if constexpr (CACHE_SUS) return susr[(slot * M1 + m) * L + l];
         else return sus[(kc * M1 + m) * L + l];
@@ -174,15 +199,7 @@ struct Seip {
         T rate[K1];
 #pragma unroll
         for (int k = 0; k < K1; ++k) {
-            const T *c = spl + k * (4 + 2 * nk);
-            T nu = c[0] + t * (c[1] + t * (c[2] + t * c[3]));
-#pragma unroll
-            for (int n = 0; n < 4; ++n) { // branch-free: knots beyond nk (wave-uniform) contribute coef = 0
-                const bool on = n < nk;
-                const T knot = c[on ? 4 + n : 0], coef = on ? c[on ? 4 + nk + n : 0] : T(0);
-                const T lag = M::max(t - knot, T(0));
-                nu += coef * (lag * lag * lag);
-            }
+            const T nu = dose_rate_at(k, spl + k * (4 + 2 * nk), t);
             T tot = y[k * M1];
 #pragma unroll
             for (int m = 1; m < M1; ++m) tot += y[k * M1 + m];
@@ -286,15 +303,7 @@ struct Seip {
             const int k = sl * 2 + tl;          // this slot's tier
             const bool live = k < K1, top = k == K;
             const int kc = live ? k : K;        // padded slots hold nobody: any valid table row will do
-            const T *c = spl + kc * (4 + 2 * nk);
-            T nu = c[0] + t * (c[1] + t * (c[2] + t * c[3]));
-#pragma unroll
-            for (int n = 0; n < 4; ++n) {
-                const bool on = n < nk;
-                const T knot = c[on ? 4 + n : 0], coef = on ? c[on ? 4 + nk + n : 0] : T(0);
-                const T lag = M::max(t - knot, T(0));
-                nu += coef * (lag * lag * lag);
-            }
+            const T nu = dose_rate_at(sl, spl + kc * (4 + 2 * nk), t);
             T tot = y[sl * M1];
 #pragma unroll
             for (int m = 1; m < M1; ++m) tot += y[sl * M1 + m];
@@ -403,15 +412,7 @@ struct Seip {
         for (int sl = 0; sl < KL; ++sl) {
             const int k = sl * KT + tl;
             const int kc = k < K1 ? k : K;
-            const T *c = spl + kc * (4 + 2 * nk);
-            T nu = c[0] + t * (c[1] + t * (c[2] + t * c[3]));
-#pragma unroll
-            for (int n = 0; n < 4; ++n) {
-                const bool on = n < nk;
-                const T knot = c[on ? 4 + n : 0], coef = on ? c[on ? 4 + nk + n : 0] : T(0);
-                const T lag = M::max(t - knot, T(0));
-                nu += coef * (lag * lag * lag);
-            }
+            const T nu = dose_rate_at(sl, spl + kc * (4 + 2 * nk), t);
             dose[sl] = M::max(nu, T(0)) * pop;
             T tt = y[sl * M1];
 #pragma unroll
@@ -758,6 +759,14 @@ struct Seip {
                 const int kt = sl * KT + tl, kc = kt < K1 ? kt : K;   // padded slots hold nobody: any valid row will do
 #pragma unroll
                 for (int q = 0; q < M1 * L; ++q) S.susr[sl * M1 * L + q] = S.sus[kc * M1 * L + q];
+                const T *c = S.spl + kc * (4 + 2 * nk);
+#pragma unroll
+                for (int n = 0; n < 4; ++n) {
+                    const bool on = n < nk;
+                    S.splr[sl * 12 + n] = c[n];
+                    S.splr[sl * 12 + 4 + n] = c[on ? 4 + n : 0];
+                    S.splr[sl * 12 + 8 + n] = on ? c[on ? 4 + nk + n : 0] : T(0);
+                }
             }
         }
 #pragma unroll
