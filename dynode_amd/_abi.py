@@ -30,7 +30,7 @@ EXPORTED_SYMBOLS = (
     "dyn_last_error", "dyn_solve_batch", "dyn_solve_batch_jvp", "dyn_is_supported_jvp",
     "dyn_nuts_advance", "dyn_nuts_state_size", "dyn_philox4x32_10", "dyn_latent_sites",
     "dyn_solve_batch_loglik", "dyn_register_instance", "dyn_last_kernel_name", "dyn_solve_batch_record",
-    "dyn_solve_batch_replay",
+    "dyn_solve_batch_replay", "dyn_latent_param_map", "dyn_potential_combine",
 )
 
 MAX_SITES = 8
@@ -222,5 +222,12 @@ def lib() -> ctypes.CDLL:
         L.dyn_philox4x32_10.argtypes = [ctypes.POINTER(ctypes.c_uint32)] * 3
         L.dyn_latent_sites.restype = ctypes.c_int
         L.dyn_latent_sites.argtypes = [ctypes.POINTER(SiteDescC), ctypes.c_int32, ctypes.c_int64] + [ctypes.c_void_p] * 6
+        L.dyn_latent_param_map.restype = ctypes.c_int
+        L.dyn_latent_param_map.argtypes = ([ctypes.POINTER(SiteDescC), ctypes.c_int32, ctypes.c_int64] + [ctypes.c_void_p] * 4
+                                           + [ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32]
+                                           + [ctypes.c_void_p] * 3)
+        L.dyn_potential_combine.restype = ctypes.c_int
+        L.dyn_potential_combine.argtypes = ([ctypes.c_int64, ctypes.c_int32] + [ctypes.c_void_p] * 4 + [ctypes.c_double]
+                                            + [ctypes.c_void_p] * 3)
         _lib = L
     return _lib

@@ -21,6 +21,56 @@ struct SiteTable {
 
 __device__ inline double log_sigmoid(double z) { return z < 0 ? z - log1p(exp(z)) : -log1p(exp(-z)); }
 
+// one scalar site of one chain: bijection onto the support, log density, and their derivatives in z
+struct SiteValue {
+    double x, dx;      // constrained value, d x / d z
+    double lp, dlp;    // log prior(x) + log |dx/dz|, and its derivative in z
+};
+
+__device__ inline SiteValue eval_site(const dyn_site_desc &d, double zi) {
+    // ---- bijection onto the support [lo, hi] (numpyro biject_to: identity / sigmoid / exp)
+    double x, dx, ladj, dladj;
+    const bool lo_inf = isinf(d.lo), hi_inf = isinf(d.hi);
+    if (lo_inf && hi_inf) {
+        x = zi; dx = 1.0; ladj = 0.0; dladj = 0.0;
+    } else if (!lo_inf && !hi_inf) {
+        const double s = 1.0 / (1.0 + exp(-zi)), w = d.hi - d.lo;
+        x = d.lo + w * s; dx = w * s * (1.0 - s);
+        ladj = log(w) + log_sigmoid(zi) + log_sigmoid(-zi); dladj = 1.0 - 2.0 * s;
+    } else if (hi_inf) {
+        const double e = exp(zi);
+        x = d.lo + e; dx = e; ladj = zi; dladj = 1.0;
+    } else {
+        const double e = exp(zi);
+        x = d.hi - e; dx = -e; ladj = zi; dladj = 1.0;
+    }
+    // ---- log density of y = aff_loc + aff_scale * base at x, and its derivative in x
+    const double xb = (x - d.aff_loc) / d.aff_scale;
+    double lp, dlp;
+    switch (d.dist) {
+    case DYN_DIST_NORMAL: {
+        const double u = (xb - d.p[0]) / d.p[1];
+        lp = -0.5 * u * u - log(d.p[1]) - 0.91893853320467274178; dlp = -u / d.p[1];
+    } break;
+    case DYN_DIST_UNIFORM: {
+        const bool in = xb >= d.p[0] && xb <= d.p[1];
+        lp = in ? -log(d.p[1] - d.p[0]) : -INFINITY; dlp = 0.0;
+    } break;
+    case DYN_DIST_BETA: {   // p = {a, b, log B(a, b)}
+        lp = (d.p[0] - 1.0) * log(xb) + (d.p[1] - 1.0) * log1p(-xb) - d.p[2];
+        dlp = (d.p[0] - 1.0) / xb - (d.p[1] - 1.0) / (1.0 - xb);
+    } break;
+    default: {              // DYN_DIST_TRUNCNORMAL: p = {loc, scale, log Z, unused}; support = [lo, hi] of the base
+        const double u = (xb - d.p[0]) / d.p[1];
+        const bool in = xb >= d.base_lo && xb <= d.base_hi;
+        lp = in ? -0.5 * u * u - 0.91893853320467274178 - log(d.p[1]) - d.p[2] : -INFINITY; dlp = -u / d.p[1];
+    } break;
+    }
+    lp -= log(fabs(d.aff_scale));
+    dlp /= d.aff_scale;
+    return {x, dx, lp + ladj, dlp * dx + dladj};
+}
+
 __global__ void __launch_bounds__(64) latent_sites(const SiteTable tab, int64_t C, const double *__restrict__ z,
                                                    double *__restrict__ x_out, double *__restrict__ lp_out,
                                                    double *__restrict__ dx_dz, double *__restrict__ dlp_dz) {
@@ -29,63 +79,67 @@ __global__ void __launch_bounds__(64) latent_sites(const SiteTable tab, int64_t 
     const int n = tab.n;
     double total = 0.0;
     for (int i = 0; i < n; ++i) {
-        const dyn_site_desc &d = tab.s[i];
-        const double zi = z[c * n + i];
-        // ---- bijection onto the support [lo, hi] (numpyro biject_to: identity / sigmoid / exp)
-        double x, dx, ladj, dladj;
-        const bool lo_inf = isinf(d.lo), hi_inf = isinf(d.hi);
-        if (lo_inf && hi_inf) {
-            x = zi; dx = 1.0; ladj = 0.0; dladj = 0.0;
-        } else if (!lo_inf && !hi_inf) {
-            const double s = 1.0 / (1.0 + exp(-zi)), w = d.hi - d.lo;
-            x = d.lo + w * s; dx = w * s * (1.0 - s);
-            ladj = log(w) + log_sigmoid(zi) + log_sigmoid(-zi); dladj = 1.0 - 2.0 * s;
-        } else if (hi_inf) {
-            const double e = exp(zi);
-            x = d.lo + e; dx = e; ladj = zi; dladj = 1.0;
-        } else {
-            const double e = exp(zi);
-            x = d.hi - e; dx = -e; ladj = zi; dladj = 1.0;
-        }
-        // ---- log density of y = aff_loc + aff_scale * base at x, and its derivative in x
-        const double xb = (x - d.aff_loc) / d.aff_scale;
-        double lp, dlp;
-        switch (d.dist) {
-        case DYN_DIST_NORMAL: {
-            const double u = (xb - d.p[0]) / d.p[1];
-            lp = -0.5 * u * u - log(d.p[1]) - 0.91893853320467274178; dlp = -u / d.p[1];
-        } break;
-        case DYN_DIST_UNIFORM: {
-            const bool in = xb >= d.p[0] && xb <= d.p[1];
-            lp = in ? -log(d.p[1] - d.p[0]) : -INFINITY; dlp = 0.0;
-        } break;
-        case DYN_DIST_BETA: {   // p = {a, b, log B(a, b)}
-            lp = (d.p[0] - 1.0) * log(xb) + (d.p[1] - 1.0) * log1p(-xb) - d.p[2];
-            dlp = (d.p[0] - 1.0) / xb - (d.p[1] - 1.0) / (1.0 - xb);
-        } break;
-        default: {              // DYN_DIST_TRUNCNORMAL: p = {loc, scale, log Z, unused}; support = [lo, hi] of the base
-            const double u = (xb - d.p[0]) / d.p[1];
-            const bool in = xb >= d.base_lo && xb <= d.base_hi;
-            lp = in ? -0.5 * u * u - 0.91893853320467274178 - log(d.p[1]) - d.p[2] : -INFINITY; dlp = -u / d.p[1];
-        } break;
-        }
-        lp -= log(fabs(d.aff_scale));
-        dlp /= d.aff_scale;
-        total += lp + ladj;
-        x_out[c * n + i] = x;
-        dx_dz[c * n + i] = dx;
-        dlp_dz[c * n + i] = dlp * dx + dladj;
+        const SiteValue v = eval_site(tab.s[i], z[c * n + i]);
+        total += v.lp;
+        x_out[c * n + i] = v.x;
+        dx_dz[c * n + i] = v.dx;
+        dlp_dz[c * n + i] = v.dlp;
     }
     lp_out[c] = total;
 }
 
+// The same with the model's parameter map behind it, for models whose ODE parameter row is a monomial in the site values:
+// p_j = coef_j * prod_i x_i^expo[j][i] (the reference's get_odeparams family, SURVEY rows A6: beta = r0 / T_inf,
+// gamma = 1 / T_inf, sigma = 1 / T_lat, omega = 1 / T_wane).  Writes the parameter rows and the tangent seeds
+// d p_j / d z_i = expo[j][i] p_j / x_i * dx_i/dz_i in the solve's dtype: what `dyn_solve_batch_loglik` reads next.
+template <typename T>
+__global__ void __launch_bounds__(64) latent_param_map(const SiteTable tab, int64_t C, const double *__restrict__ z,
+                                                       double *__restrict__ x_out, double *__restrict__ lp_out,
+                                                       double *__restrict__ dlp_dz, int P, const double *__restrict__ coef,
+                                                       const double *__restrict__ expo, T *__restrict__ params,
+                                                       T *__restrict__ seeds) {
+    const int64_t c = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (c >= C) return;
+    const int n = tab.n;
+    double total = 0.0, x[DYN_MAX_SITES], rel[DYN_MAX_SITES];   // rel_i = (dx_i/dz_i) / x_i
+    for (int i = 0; i < n; ++i) {
+        const SiteValue v = eval_site(tab.s[i], z[c * n + i]);
+        total += v.lp;
+        x[i] = v.x;
+        rel[i] = v.dx / v.x;
+        x_out[c * n + i] = v.x;
+        dlp_dz[c * n + i] = v.dlp;
+    }
+    lp_out[c] = total;
+    for (int j = 0; j < P; ++j) {
+        double p = coef[j];
+        for (int i = 0; i < n; ++i) {
+            const double e = expo[j * n + i];
+            if (e == 1.0) p *= x[i];
+            else if (e == -1.0) p /= x[i];
+            else if (e != 0.0) p *= pow(x[i], e);
+        }
+        params[c * P + j] = (T)p;
+        for (int i = 0; i < n; ++i) seeds[(c * n + i) * P + j] = (T)(expo[j * n + i] * p * rel[i]);
+    }
+}
+
+// u = -(lp + ll + offset), g = -(dlp_dz + dll): the potential and its gradient from the prior side and the solve's
+// log-likelihood (one thread per chain)
+__global__ void __launch_bounds__(64) potential_combine(int64_t C, int n, const double *__restrict__ lp,
+                                                        const double *__restrict__ dlp_dz, const double *__restrict__ ll,
+                                                        const double *__restrict__ dll, double offset, double *__restrict__ u,
+                                                        double *__restrict__ g) {
+    const int64_t c = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (c >= C) return;
+    u[c] = -(lp[c] + ll[c] + offset);
+    for (int i = 0; i < n; ++i) g[c * n + i] = -(dlp_dz[c * n + i] + dll[c * n + i]);
+}
+
 } // namespace dynlat
 
-extern "C" int dyn_latent_sites(const dyn_site_desc *sites, int32_t n_sites, int64_t C, const double *z, double *x,
-                                double *lp, double *dx_dz, double *dlp_dz, void *stream) {
-    if (!sites || (C > 0 && (!z || !x || !lp || !dx_dz || !dlp_dz))) return DYN_ERR_NULL;
-    if (n_sites < 1 || n_sites > DYN_MAX_SITES || C < 0) return DYN_ERR_SIZE;
-    dynlat::SiteTable tab;
+static int fill_table(dynlat::SiteTable &tab, const dyn_site_desc *sites, int32_t n_sites) {
+    if (n_sites < 1 || n_sites > DYN_MAX_SITES) return DYN_ERR_SIZE;
     tab.n = n_sites;
     for (int i = 0; i < n_sites; ++i) {
         const dyn_site_desc &d = sites[i];
@@ -93,8 +147,46 @@ extern "C" int dyn_latent_sites(const dyn_site_desc *sites, int32_t n_sites, int
             return DYN_ERR_OPTS;
         tab.s[i] = d;
     }
+    return 0;
+}
+
+extern "C" int dyn_latent_sites(const dyn_site_desc *sites, int32_t n_sites, int64_t C, const double *z, double *x,
+                                double *lp, double *dx_dz, double *dlp_dz, void *stream) {
+    if (!sites || (C > 0 && (!z || !x || !lp || !dx_dz || !dlp_dz))) return DYN_ERR_NULL;
+    if (C < 0) return DYN_ERR_SIZE;
+    dynlat::SiteTable tab;
+    if (int rc = fill_table(tab, sites, n_sites)) return rc;
     if (C == 0) return 0;
     hipLaunchKernelGGL(dynlat::latent_sites, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, (hipStream_t)stream, tab, C,
                        z, x, lp, dx_dz, dlp_dz);
+    return hipGetLastError() == hipSuccess ? 0 : DYN_ERR_LAUNCH;
+}
+
+extern "C" int dyn_latent_param_map(const dyn_site_desc *sites, int32_t n_sites, int64_t C, const double *z, double *x,
+                                    double *lp, double *dlp_dz, int32_t P, const double *coef, const double *expo,
+                                    int32_t dtype, void *params, void *seeds, void *stream) {
+    if (!sites || !coef || !expo || (C > 0 && (!z || !x || !lp || !dlp_dz || !params || !seeds))) return DYN_ERR_NULL;
+    if (C < 0 || P < 1) return DYN_ERR_SIZE;
+    if (dtype != DYN_F32 && dtype != DYN_F64) return DYN_ERR_OPTS;
+    dynlat::SiteTable tab;
+    if (int rc = fill_table(tab, sites, n_sites)) return rc;
+    if (C == 0) return 0;
+    const dim3 grid((unsigned)((C + 63) / 64)), block(64);
+    if (dtype == DYN_F32)
+        hipLaunchKernelGGL(dynlat::latent_param_map<float>, grid, block, 0, (hipStream_t)stream, tab, C, z, x, lp, dlp_dz,
+                           (int)P, coef, expo, (float *)params, (float *)seeds);
+    else
+        hipLaunchKernelGGL(dynlat::latent_param_map<double>, grid, block, 0, (hipStream_t)stream, tab, C, z, x, lp, dlp_dz,
+                           (int)P, coef, expo, (double *)params, (double *)seeds);
+    return hipGetLastError() == hipSuccess ? 0 : DYN_ERR_LAUNCH;
+}
+
+extern "C" int dyn_potential_combine(int64_t C, int32_t n, const double *lp, const double *dlp_dz, const double *ll,
+                                     const double *dll, double offset, double *u, double *g, void *stream) {
+    if (C > 0 && (!lp || !dlp_dz || !ll || !dll || !u || !g)) return DYN_ERR_NULL;
+    if (C < 0 || n < 1 || n > DYN_MAX_SITES) return DYN_ERR_SIZE;
+    if (C == 0) return 0;
+    hipLaunchKernelGGL(dynlat::potential_combine, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, (hipStream_t)stream, C,
+                       (int)n, lp, dlp_dz, ll, dll, offset, u, g);
     return hipGetLastError() == hipSuccess ? 0 : DYN_ERR_LAUNCH;
 }

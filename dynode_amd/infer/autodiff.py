@@ -273,12 +273,19 @@ class _DiffLogLik(torch.autograd.Function):
 def solve_loglik_diff(model, y0, params: torch.Tensor, contact, t1, save_ts, obs, obs_compartment: int, *,
                       increments: bool = True, floor: float = 1e-6, **kw):
     """``(logp [B], status, n_accept, n_reject)``, differentiable with respect to ``params``."""
+    from . import folded
+
+    seen = dict(model=model, y0=y0, params=params, contact=contact, t1=t1, save_ts=save_ts, obs=obs, comp=int(obs_compartment),
+                increments=bool(increments), floor=float(floor), kw=dict(kw))
     params = _joined(params, y0)
     y0 = y0.detach() if isinstance(y0, torch.Tensor) else y0
     leaf = _rowwise_leaf(params)
     if leaf is not None:
         seeds = _latent_seeds(params, leaf, kw.get("dtype", torch.float32))
-        return _DiffLogLikLatent.apply(leaf, params.detach(), seeds, model, y0, contact, t1, save_ts, obs,
-                                       int(obs_compartment), bool(increments), float(floor), kw)
-    return _DiffLogLik.apply(params, model, y0, contact, t1, save_ts, obs, int(obs_compartment), bool(increments),
-                             float(floor), kw)
+        out = _DiffLogLikLatent.apply(leaf, params.detach(), seeds, model, y0, contact, t1, save_ts, obs,
+                                      int(obs_compartment), bool(increments), float(floor), kw)
+    else:
+        out = _DiffLogLik.apply(params, model, y0, contact, t1, save_ts, obs, int(obs_compartment), bool(increments),
+                                float(floor), kw)
+    folded.note(dict(seen, result=out[0]))      # only inside `folded.recording()` (structure discovery of a sampler's potential)
+    return out

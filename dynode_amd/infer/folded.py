@@ -1,0 +1,188 @@
+"""The sampler's potential in three launches: sites + parameter map, tangent solve with the likelihood, combine.
+
+A numpyro model such as the reference's ``model(config, tf, obs_data)`` (examples/sir_infer_parameters.py:21-39) is, between
+its sample sites and ``diffeqsolve``, a small program: ``get_odeparams`` turns the sampled ``r0`` / ``infectious_period`` into
+``beta = r0 / T``, ``gamma = 1 / T`` (examples/sir.py:87-92 and the rest of SURVEY row A6), packs them, and the likelihood
+adds a constant.  XLA fuses that program into the solve; run op by op it is ~26 launches of 2-5 us around an 80 us solve
+(`profiles/r01_fused_nuts_iteration.md`).  Every member of the reference's ``get_odeparams`` family is a MONOMIAL map of the
+site values, ``p_j = c_j * prod_i x_i ** e_ji``.  `discover` recognises that structure numerically -- one batched evaluation
+of the model on a handful of probe rows, a log-linear fit, and an exact check on the rows the fit did not need -- and then
+the potential and its gradient are
+
+    dyn_latent_param_map   z -> x, log prior + log|dx/dz| (+ derivative), parameter rows, seeds d params / d z
+    dyn_solve_batch_loglik parameters + seeds -> log-likelihood and its derivative along z
+    dyn_potential_combine  u = -(lp + ll + offset), g = -(dlp + dll)
+
+written straight into the sampler kernel's input buffers (`KernelNUTS`: 4 launches per iteration with `dyn_nuts_advance`).
+A model that does not have the structure (a second solve, a parameter that is a sum of sites, a sampled initial state, a
+likelihood outside the solve, sites outside the fused families) is NOT folded: `discover` returns None and the sampler keeps
+the general torch-autograd potential -- the same GPU kernels, more launches.  Nothing here guesses: the folded potential is
+compared with the general one on the probe rows before it is used.
+"""
+
+from __future__ import annotations
+
+import contextlib
+import ctypes
+import threading
+from typing import Optional
+
+import torch
+
+from .. import _abi
+
+_STATE = threading.local()
+
+
+@contextlib.contextmanager
+def recording():
+    """Collect the arguments (and result) of every ``autodiff.solve_loglik_diff`` call made inside the block."""
+    calls: list = []
+    prev = getattr(_STATE, "calls", None)
+    _STATE.calls = calls
+    try:
+        yield calls
+    finally:
+        _STATE.calls = prev
+
+
+def note(call: dict) -> None:
+    calls = getattr(_STATE, "calls", None)
+    if calls is not None:
+        calls.append(call)
+
+
+def _fit_monomials(x: torch.Tensor, params: torch.Tensor):
+    """(coef [P], expo [P, n]) with params[:, j] == coef[j] * prod_i x[:, i] ** expo[j, i] on EVERY probe row, or None."""
+    R, n = x.shape
+    P = params.shape[1]
+    usable = [i for i in range(n) if bool((x[:, i] > 0).all())]          # a site that can be <= 0 cannot carry a power
+    A = torch.cat([torch.ones(R, 1, dtype=torch.float64), torch.log(x[:, usable])], dim=1) if usable else torch.ones(R, 1, dtype=torch.float64)
+    coef, expo = torch.zeros(P, dtype=torch.float64), torch.zeros(P, n, dtype=torch.float64)
+    for j in range(P):
+        v = params[:, j]
+        if bool((v == v[0]).all()):                 # a constant (also zero or negative ones)
+            coef[j] = v[0]
+            continue
+        if not (bool((v > 0).all()) or bool((v < 0).all())):
+            return None
+        sign = 1.0 if float(v[0]) > 0 else -1.0
+        sol = torch.linalg.lstsq(A, torch.log(v.abs())[:, None]).solution[:, 0]
+        e = sol[1:]
+        snapped = torch.round(e * 2.0) / 2.0        # the family's exponents are +-1; allow halves, keep anything else as fitted
+        e = torch.where((e - snapped).abs() < 1e-8, snapped, e)
+        logc = (torch.log(v.abs()) - torch.log(x[:, usable]) @ e).mean()
+        coef[j] = sign * torch.exp(logc)
+        for col, i in enumerate(usable):
+            expo[j, i] = e[col]
+    logx = torch.log(x.clamp_min(1e-300))           # columns with a zero exponent contribute 0 whatever their sign
+    pred = coef[None, :] * torch.exp((expo[None] * logx[:, None, :]).sum(-1))
+    if not bool(((pred - params).abs() <= 1e-11 * params.abs() + 1e-300).all()):
+        return None
+    return coef, expo
+
+
+class FoldedPotential:
+    """``into(z, u_out, g_out)``: potential and gradient of ``pot`` for a fixed number of chains, three launches."""
+
+    def __init__(self, pot, call: dict, coef: torch.Tensor, expo: torch.Tensor, offset: float):
+        self.pot, self.call, self.offset = pot, call, float(offset)
+        dev = pot.device
+        self.coef, self.expo = coef.to(dev).contiguous(), expo.to(dev).contiguous()
+        self.n, self.P = pot.dim, int(coef.shape[0])
+        self.dtype = call["kw"].get("dtype", torch.float32)
+        self._buf: dict = {}
+
+    def _buffers(self, C: int):
+        b = self._buf.get(C)
+        if b is None:
+            dev, f64 = self.pot.device, torch.float64
+            b = self._buf[C] = dict(x=torch.empty((C, self.n), dtype=f64, device=dev), lp=torch.empty(C, dtype=f64, device=dev),
+                                    dlp=torch.empty((C, self.n), dtype=f64, device=dev),
+                                    params=torch.empty((C, self.P), dtype=self.dtype, device=dev),
+                                    seeds=torch.empty((C, self.n, self.P), dtype=self.dtype, device=dev))
+        return b
+
+    def into(self, z: torch.Tensor, u_out: torch.Tensor, g_out: torch.Tensor) -> None:
+        from ..engine import _DTYPES, solve_batch_loglik
+        from .autodiff import direction_chunks
+
+        C = z.shape[0]
+        for t in (z, u_out, g_out):
+            if not (t.is_cuda and t.dtype == torch.float64 and t.is_contiguous()):
+                raise ValueError("FoldedPotential.into needs contiguous float64 device tensors")
+        if tuple(z.shape) != (C, self.n) or tuple(g_out.shape) != (C, self.n) or tuple(u_out.shape) != (C,):
+            raise ValueError(f"shapes: z, g [C, {self.n}], u [C]")
+        L, b, c = _abi.lib(), self._buffers(C), self.call
+        arr, n = self.pot.site_table
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        rc = L.dyn_latent_param_map(arr, n, C, z.data_ptr(), b["x"].data_ptr(), b["lp"].data_ptr(), b["dlp"].data_ptr(), self.P,
+                                    self.coef.data_ptr(), self.expo.data_ptr(), _DTYPES[self.dtype],
+                                    b["params"].data_ptr(), b["seeds"].data_ptr(), stream)
+        if rc:
+            raise RuntimeError(f"dyn_latent_param_map: {_abi.ERR_NAMES.get(rc, rc)}")
+        method = c["kw"].get("method", "tsit5")
+        ll, grads, start = None, [], 0
+        for nd in direction_chunks(c["model"], method, self.dtype, self.n):
+            seeds = b["seeds"] if nd == self.n else b["seeds"][:, start:start + nd].contiguous()
+            lp_, dlp_, *_ = solve_batch_loglik(c["model"], c["y0"], b["params"], c["contact"], c["t1"], c["save_ts"], c["obs"],
+                                               c["comp"], dparams=seeds, increments=c["increments"], floor=c["floor"], **c["kw"])
+            ll = lp_ if ll is None else ll
+            grads.append(dlp_)
+            start += nd
+        dll = grads[0] if len(grads) == 1 else torch.cat(grads, dim=1)
+        rc = L.dyn_potential_combine(C, self.n, b["lp"].data_ptr(), b["dlp"].data_ptr(), ll.data_ptr(), dll.data_ptr(),
+                                     self.offset, u_out.data_ptr(), g_out.data_ptr(), stream)
+        if rc:
+            raise RuntimeError(f"dyn_potential_combine: {_abi.ERR_NAMES.get(rc, rc)}")
+
+    def __call__(self, z: torch.Tensor):
+        """The ``potential_and_grad`` signature (fresh outputs), for the samplers that are not `KernelNUTS`."""
+        z = z.detach().to(torch.float64).contiguous()
+        u = torch.empty(z.shape[0], dtype=torch.float64, device=z.device)
+        g = torch.empty_like(z)
+        self.into(z, u, g)
+        return u, g
+
+
+def discover(pot, seed: int = 0, verbose: bool = False) -> Optional[FoldedPotential]:
+    """`FoldedPotential` of ``pot`` (an `inference.Potential`) if the model has the structure, else None."""
+    why = lambda msg: (print(f"[dynode_amd] potential not folded: {msg}") if verbose else None)  # noqa: E731
+    if pot.site_table is None or torch.device(pot.device).type != "cuda":
+        return why("latent sites outside the fused families, or no GPU")
+    n = pot.dim
+    R = 2 * n + 6
+    gen = torch.Generator().manual_seed(1234 + seed)
+    z = (0.8 * torch.randn((R, n), generator=gen, dtype=torch.float64)).to(pot.device)
+    with recording() as calls:
+        u_ref, g_ref = pot.potential_and_grad(z)
+    if len(calls) != 1:
+        return why(f"{len(calls)} fused-likelihood solves per evaluation (need exactly one)")
+    call = calls[0]
+    params, y0 = call.pop("params"), call["y0"]
+    if isinstance(y0, torch.Tensor) and (y0.requires_grad or y0.dim() != 1):
+        return why("the initial state depends on the batch or on a latent site")
+    if not (isinstance(params, torch.Tensor) and params.dim() == 2 and params.shape[0] == R):
+        return why("parameter matrix is not [chains, P]")
+    if not bool(torch.isfinite(u_ref).all()):
+        return why("non-finite potential on the probe rows")
+    from .fused_sites import LatentSites
+
+    x, lp_sites = LatentSites.apply(z, pot.site_table)
+    fit = _fit_monomials(x.cpu(), params.detach().to(torch.float64).cpu())
+    if fit is None:
+        return why("the parameter rows are not monomials of the site values")
+    # everything else in the log joint must be a constant: log joint - log prior - log-likelihood of the solve
+    rest = (-u_ref) - lp_sites - call.pop("result").detach()
+    offset = float(rest.mean())
+    if not bool(((rest - offset).abs() <= 1e-9 * (1.0 + u_ref.abs())).all()):
+        return why("the log joint has terms besides the priors and the solve's likelihood")
+    folded = FoldedPotential(pot, call, fit[0], fit[1], offset)
+    u, g = folded(z)
+    # same kernels on (up to the last bit of a float64 product) the same parameter rows: agreement far inside the
+    # sampler's own float32 solve noise, and a loud refusal otherwise
+    scale_u, scale_g = 1.0 + u_ref.abs(), 1.0 + g_ref.abs()
+    if not (bool(((u - u_ref).abs() <= 1e-5 * scale_u).all()) and bool(((g - g_ref).abs() <= 1e-4 * scale_g).all())):
+        return why(f"folded and general potential differ on the probe rows (max |du| {float((u - u_ref).abs().max()):.3g}, "
+                   f"max |dg| {float((g - g_ref).abs().max()):.3g})")
+    return folded

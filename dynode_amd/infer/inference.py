@@ -269,6 +269,7 @@ class InferenceProcess(BaseModel):
     _inferer: Optional[Any] = PrivateAttr(default=None)
     _inference_state: Optional[Any] = PrivateAttr(default=None)
     _inferer_kwargs: Optional[dict] = PrivateAttr(default_factory=dict)
+    _folded_potential: bool = PrivateAttr(default=False)
 
     def infer(self, **kwargs):
         raise NotImplementedError("Inference process not implemented, please use a subclass.")
@@ -344,6 +345,10 @@ class MCMCProcess(InferenceProcess):
                                     this GPU -- shorter warm-up tails for many chains, not what numpyro does)
                      ``gradient``   ``"autograd"`` (default: tangent kernels + autograd) or ``"finite_difference"``
                                     (``fd_step``; for models without tangent kernels, with a constant solver step)
+                     ``fold``       ``True`` (default) / ``False`` / ``"verbose"``: a model whose ODE parameters are monomials
+                                    of its sampled sites and whose only likelihood is the solve's (``infer/folded.py``: the
+                                    reference's own inference example is one) is evaluated in three launches per gradient
+                                    instead of ~26; any other model silently keeps the general potential (``"verbose"`` says why)
     """
 
     num_samples: PositiveInt
@@ -357,7 +362,7 @@ class MCMCProcess(InferenceProcess):
 
     _NUTS_FIXED = {"adapt_step_size": True, "adapt_mass_matrix": True, "regularize_mass_matrix": True,
                    "find_heuristic_step_size": False}
-    _MCMC_OWN = ("sampler", "adaptation", "gradient", "fd_step", "stretch", "thin", "hip_graph")
+    _MCMC_OWN = ("sampler", "adaptation", "gradient", "fd_step", "stretch", "thin", "hip_graph", "fold")
 
     def _check_kwargs(self) -> int:
         """Every key of ``nuts_kwargs`` / ``mcmc_kwargs`` is honoured or refused; returns the thinning factor."""
@@ -445,6 +450,13 @@ class MCMCProcess(InferenceProcess):
             pg = lambda z: pot.potential_and_grad_fd(z, fd_step)  # noqa: E731
             if kind == "kernel":
                 extra["use_graph"] = False          # the model usually syncs with the host (numpy-built parameter tables)
+        elif kind == "kernel" and self.mcmc_kwargs.get("fold", True):
+            from .folded import discover
+
+            folded = discover(pot, seed=self.inference_prngkey, verbose=self.mcmc_kwargs.get("fold") == "verbose")
+            if folded is not None:
+                pg = folded
+        self._folded_potential = hasattr(pg, "into")
         sampler = cls(pg, max_tree_depth=self.nuts_max_tree_depth,
                       target_accept=self.nuts_kwargs.get("target_accept_prob", 0.8),
                       seed=self.inference_prngkey + 7919 * rank, **extra)

@@ -856,10 +856,15 @@ class KernelNUTS(LockstepNUTS):
             assert t.dtype == want and t.is_contiguous() and t.device == dev, name
             setattr(st, name, t.data_ptr())
 
+        into = getattr(self.pg, "into", None)      # a folded potential writes the kernel's inputs itself (infer/folded.py)
+
         def iteration():
-            u_, g_ = self.pg(S["z_eval"])
-            S["u_new"].copy_(u_)
-            S["g_new"].copy_(g_)
+            if into is not None:
+                into(S["z_eval"], S["u_new"], S["g_new"])
+            else:
+                u_, g_ = self.pg(S["z_eval"])
+                S["u_new"].copy_(u_)
+                S["g_new"].copy_(g_)
             rc = L.dyn_nuts_advance(ctypes.byref(st), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
             if rc:
                 raise RuntimeError(f"dyn_nuts_advance: {_abi.ERR_NAMES.get(rc, rc)}")

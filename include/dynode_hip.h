@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define DYN_ABI_VERSION 5
+#define DYN_ABI_VERSION 6
 /* the save grid is staged in LDS: n_save * sizeof(real) must not exceed this */
 #define DYN_MAX_SAVE_BYTES 49152
 
@@ -343,6 +343,25 @@ typedef struct dyn_site_desc {
 } dyn_site_desc;
 int dyn_latent_sites(const dyn_site_desc *sites, int32_t n_sites, int64_t C, const double *z, double *x,
                      double *lp, double *dx_dz, double *dlp_dz, void *stream);
+
+/*
+ * The sampler's potential folded into three launches (dyn_latent_param_map -> dyn_solve_batch_loglik ->
+ * dyn_potential_combine), for models whose ODE parameter row is a monomial in the site values:
+ *     params[c][j] = coef[j] * prod_i x[c][i] ^ expo[j][i]
+ * which is what the reference's get_odeparams family computes (examples/sir.py:87-92, sir_age_stratified.py:112-124,
+ * seirs.py:98-104, seirs_multi_strain_age_stratified.py:187-209: beta = r0 / infectious_period, gamma = 1 / infectious_period,
+ * sigma = 1 / latent_period, omega = 1 / waning_period).  Replaces the small program numpyro / XLA would trace between the
+ * sample sites and diffeqsolve (examples/sir_infer_parameters.py:21-39).
+ *   dyn_latent_param_map: dyn_latent_sites + the map.  coef [P], expo [P][n_sites]: DEVICE float64.
+ *     params [C][P] and seeds [C][n_sites][P] (= d params / d z, the dparams argument of dyn_solve_batch_loglik) are
+ *     written in `dtype` (DYN_F32 / DYN_F64); x, lp, dlp_dz as in dyn_latent_sites.
+ *   dyn_potential_combine: u[c] = -(lp[c] + ll[c] + offset), g[c][i] = -(dlp_dz[c][i] + dll[c][i]); all float64, device.
+ */
+int dyn_latent_param_map(const dyn_site_desc *sites, int32_t n_sites, int64_t C, const double *z, double *x, double *lp,
+                         double *dlp_dz, int32_t P, const double *coef, const double *expo, int32_t dtype, void *params,
+                         void *seeds, void *stream);
+int dyn_potential_combine(int64_t C, int32_t n, const double *lp, const double *dlp_dz, const double *ll,
+                          const double *dll, double offset, double *u, double *g, void *stream);
 
 #ifdef __cplusplus
 }

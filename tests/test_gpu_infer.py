@@ -365,6 +365,75 @@ def test_nuts_with_fused_likelihood_matches_grid_quadrature(data):
         assert stats.kstest(thin, lambda x: np.interp(x, grid, cdf)).pvalue > 1e-3
 
 
+def test_folded_potential_equals_the_general_one(data):
+    """infer/folded.py: sites + parameter map, tangent solve with the likelihood, combine -- three launches instead of the
+    model's torch program.  The map of the reference's example (beta = r0 / T, gamma = 1 / T: examples/sir.py:87-92) is found
+    from probe rows; values and gradients equal the general autograd potential."""
+    from dynode_amd.infer import folded
+
+    kw = dict(config=ex.get_config(), tf=100, obs_data=data)
+    dev = torch.device("cuda")
+    pot = Potential(ex.model_fused, kw, 0, dev)
+    f = folded.discover(pot)
+    assert f is not None
+    assert torch.equal(f.expo.cpu(), torch.tensor([[1.0, -1.0], [0.0, -1.0]], dtype=torch.float64))      # beta = r0 / T, gamma = 1 / T
+    assert torch.allclose(f.coef.cpu(), torch.ones(2, dtype=torch.float64), rtol=1e-12, atol=0)
+    z = pot.initial(64, init_to_median, 0) + 0.5 * torch.randn(64, 2, dtype=torch.float64, generator=torch.Generator().manual_seed(5)).cuda()
+    u0, g0 = pot.potential_and_grad(z)
+    u1, g1 = f(z)
+    # the same float32 kernel on parameter rows that agree to the last bit of a float64 product
+    assert torch.allclose(u1, u0, rtol=1e-7, atol=1e-4), float((u1 - u0).abs().max())
+    assert torch.allclose(g1, g0, rtol=1e-5, atol=1e-5 * float(g0.abs().max())), float((g1 - g0).abs().max())
+    # writes into the sampler's buffers; refuses anything but contiguous float64 device tensors of the right shape
+    u2, g2 = torch.empty_like(u0), torch.empty_like(g0)
+    f.into(z.contiguous(), u2, g2)
+    assert torch.equal(u2, u1) and torch.equal(g2, g1)
+    with pytest.raises(ValueError):
+        f.into(z.float(), u2, g2)
+    with pytest.raises(ValueError):
+        f.into(z.contiguous(), u2[:-1], g2)
+    # float64 end to end: rounding-level agreement
+    odes.enable_x64(True)
+    try:
+        pot64 = Potential(ex.model_fused, kw, 0, dev)
+        f64 = folded.discover(pot64)
+        assert f64 is not None and f64.dtype == torch.float64
+        ua, ga = pot64.potential_and_grad(z)
+        ub, gb = f64(z)
+    finally:
+        odes.enable_x64(False)
+    assert torch.allclose(ua, ub, rtol=1e-12, atol=1e-8) and torch.allclose(ga, gb, rtol=1e-9, atol=1e-7)
+
+
+def test_models_without_the_structure_keep_the_general_potential(data, capsys):
+    from dynode_amd.infer import folded
+
+    kw = dict(config=ex.get_config(), tf=100, obs_data=data)
+    dev = torch.device("cuda")
+    # the reference-shaped model scores the observations in torch, outside the solve: nothing to fold
+    assert folded.discover(Potential(ex.model, kw, 0, dev), verbose=True) is None
+    assert "0 fused-likelihood solves" in capsys.readouterr().out
+
+    def extra_term(config, tf, obs_data):
+        sol = ex.model_fused(config, tf, obs_data)
+        handlers.factor("penalty", -1e-3 * sol.log_likelihood.abs())          # a second, non-constant term of the log joint
+
+    assert folded.discover(Potential(extra_term, kw, 0, dev), verbose=True) is None
+    assert "terms besides" in capsys.readouterr().out
+
+    # the sampler runs either way, and says which potential it used
+    process = MCMCProcess(numpyro_model=extra_term, num_warmup=20, num_samples=10, num_chains=8, nuts_max_tree_depth=6, progress_bar=False)
+    process.infer(**kw)
+    assert process._folded_potential is False
+    process = MCMCProcess(numpyro_model=ex.model_fused, num_warmup=20, num_samples=10, num_chains=8, nuts_max_tree_depth=6, progress_bar=False)
+    process.infer(**kw)
+    assert process._folded_potential is True
+    process = MCMCProcess(numpyro_model=ex.model_fused, num_warmup=20, num_samples=10, num_chains=8, nuts_max_tree_depth=6, progress_bar=False,
+                          mcmc_kwargs={"fold": False})
+    process.infer(**kw)
+    assert process._folded_potential is False
+
+
 def test_tangents_are_seeded_along_the_latent_coordinates():
     """14 ODE parameters, 2 sampled: the gradient-solve runs 2 tangent directions (one launch), not 14
     (seven launches), and gives the same potential and gradient (examples/infer_introduction_time.py)."""

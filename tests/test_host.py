@@ -333,3 +333,28 @@ def test_numpyro_kwargs_at_supported_values_pass():
               mcmc_kwargs={"chain_method": "vectorized", "thinning": 4, "jit_model_args": True, "adaptation": "pooled"})
     assert p._check_kwargs() == 4
     assert _proc()._check_kwargs() == 1
+
+
+def test_monomial_parameter_maps_are_recognised_exactly_or_not_at_all():
+    """infer/folded.py: the structure test behind the three-launch potential.  The reference's get_odeparams family
+    (examples/sir.py:87-92, seirs_multi_strain_age_stratified.py:187-209) is monomial in the sampled values."""
+    from dynode_amd.infer.folded import _fit_monomials
+
+    g = torch.Generator().manual_seed(0)
+    x = torch.rand((12, 3), generator=g, dtype=torch.float64) * 4.0 + 0.5
+    r0, t_inf, t_wane = x.unbind(1)
+    params = torch.stack([r0 / t_inf, 1.0 / t_inf, 1.0 / t_wane, torch.full_like(r0, 0.25), torch.full_like(r0, -2.0),
+                          3.0 * torch.sqrt(r0) * t_wane, torch.zeros_like(r0)], dim=1)
+    coef, expo = _fit_monomials(x, params)
+    want = torch.tensor([[1, -1, 0], [0, -1, 0], [0, 0, -1], [0, 0, 0], [0, 0, 0], [0.5, 0, 1], [0, 0, 0]], dtype=torch.float64)
+    assert torch.equal(expo, want)
+    assert torch.allclose(coef, torch.tensor([1, 1, 1, 0.25, -2.0, 3.0, 0.0], dtype=torch.float64), rtol=1e-12, atol=0)
+    # sums, shifted powers and sign changes are refused, not approximated
+    assert _fit_monomials(x, torch.stack([r0 + t_inf, 1.0 / t_inf], dim=1)) is None
+    assert _fit_monomials(x, torch.stack([1.0 / (t_inf + 1.0)], dim=1)) is None
+    assert _fit_monomials(x, torch.stack([r0 - 2.0], dim=1)) is None
+    # a site that takes non-positive values cannot carry a power; constants next to it still fit
+    xn = x.clone()
+    xn[:, 2] -= 3.0
+    assert _fit_monomials(xn, torch.stack([r0 / t_inf, torch.full_like(r0, 7.0)], dim=1)) is not None
+    assert _fit_monomials(xn, torch.stack([xn[:, 2] * r0], dim=1)) is None

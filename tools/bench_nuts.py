@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--adaptation", default="pooled", choices=["per_chain", "pooled"])
     ap.add_argument("--target-accept", type=float, default=0.8)
     ap.add_argument("--fused-likelihood", action="store_true", help="score the observations inside the solve kernel (examples model_fused)")
+    ap.add_argument("--no-fold", action="store_true", help="keep the general torch-autograd potential (infer/folded.py off)")
     args = ap.parse_args()
     import numpy as np, torch, torch.distributed as dist
     from scipy import stats
@@ -39,7 +40,7 @@ def main():
     data = ex.synthetic_incidence(100)
     proc = MCMCProcess(numpyro_model=ex.model_fused if args.fused_likelihood else ex.model, num_warmup=args.warmup, num_samples=args.samples, num_chains=args.chains,
                        nuts_max_tree_depth=args.depth, progress_bar=(rank == 0),
-                       mcmc_kwargs={"sampler": args.sampler, "adaptation": args.adaptation},
+                       mcmc_kwargs={"sampler": args.sampler, "adaptation": args.adaptation, "fold": not args.no_fold},
                        nuts_kwargs={"target_accept_prob": args.target_accept})
     torch.cuda.synchronize()
     if world > 1: dist.barrier()
