@@ -449,6 +449,27 @@ struct Seip {
                 }
             }
         }
+        // ---- everything that needs no other wave goes here, between the mailbox writes and the barrier: it runs while the
+        // writes land and the other waves arrive (one wave per SIMD: nobody else hides that wait)
+#pragma unroll
+        for (int v = 0; v < NS; ++v) dy[v] = T(0);
+#pragma unroll
+        for (int sl = 0; sl < KL; ++sl) {
+#pragma unroll
+            for (int m = 0; m + 1 < M1; ++m) {
+                const T wn = omega[m] * y[sl * M1 + m];
+                dy[sl * M1 + m] -= wn;
+                dy[sl * M1 + m + 1] += wn;
+            }
+#pragma unroll
+            for (int l = 0; l < L; ++l) {
+                const int q = sl * L + l;
+                const T s_e = sigma[l] * y[IE + q], g_i = gamma[l] * y[II + q];
+                dy[IE + q] = -s_e;
+                dy[II + q] = s_e - g_i;
+            }
+        }
+        recover_slots<0>(y, dy);   // recovery eta(j, l) = j | 2^l over the in-wave history bits (xor exchange)
         __syncthreads();
         // ---- collect
 #pragma unroll
@@ -509,8 +530,6 @@ struct Seip {
 #pragma unroll
         for (int l = 0; l < L; ++l) lam[l] = (beta[l] * season) * lam[l];
 #pragma unroll
-        for (int v = 0; v < NS; ++v) dy[v] = T(0);
-#pragma unroll
         for (int sl = 0; sl < KL; ++sl) {
             const int k = sl * KT + tl;
             const bool top = k == K;
@@ -529,11 +548,6 @@ struct Seip {
                     out += f;
                 }
                 dy[sl * M1 + m] -= out;
-                if (m + 1 < M1) {
-                    const T wn = omega[m] * S;
-                    dy[sl * M1 + m] -= wn;
-                    dy[sl * M1 + m + 1] += wn;
-                }
                 const T v = (top && m == 0) ? T(0) : rate[sl] * S; // the freshest state of the top tier stays
                 dy[sl * M1 + m] -= v;
                 moved += v;
@@ -542,14 +556,11 @@ struct Seip {
 #pragma unroll
             for (int l = 0; l < L; ++l) {
                 const int q = sl * L + l;
-                const T s_e = sigma[l] * y[IE + q], g_i = gamma[l] * y[II + q];
-                dy[IE + q] = inflow[l] - s_e;
-                dy[II + q] = s_e - g_i;
+                dy[IE + q] += inflow[l];
                 dy[IC + q] = inflow[l];
             }
         }
-        // ---- recovery eta(j, l) = j | 2^l: in-wave history bits by xor exchange, the others from the mailbox
-        recover_slots<0>(y, dy);
+        // ---- recovery over the history bits that live in other waves: partners' gamma I from the mailbox
 #pragma unroll
         for (int q = 0; q < HB_X; ++q) {
             const bool has = (hist >> (HB_IN + q)) & 1;

@@ -9,6 +9,6 @@ rm -rf "$OUT"; mkdir -p "$OUT" "$ROOT/gpurun_out"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -- python3 "$ROOT/tools/bench_nuts.py" --chains 128 --warmup 300 --samples 300 "$@" \
   > "$ROOT/gpurun_out/prof_nuts_$TAG.log" 2>&1 || { echo "trace failed"; tail -5 "$ROOT/gpurun_out/prof_nuts_$TAG.log"; exit 1; }
-python3 "$ROOT/tools/summarize_nuts_prof.py" "$OUT" "$TAG" "$ROOT/gpurun_out/prof_nuts_$TAG.log"
+python3 "$ROOT/tools/summarize_nuts_prof.py" "$OUT" "$TAG" "$ROOT/gpurun_out/prof_nuts_$TAG.log" "$@"
 mkdir -p "$ROOT/gpurun_out/profiles_out"
 cp "$ROOT/profiles/${TAG}_nuts_kernel_stats.csv" "$ROOT/profiles/${TAG}_nuts_iteration.md" "$ROOT/gpurun_out/profiles_out/" 2>/dev/null

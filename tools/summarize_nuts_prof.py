@@ -42,15 +42,16 @@ for line in open(log):
         bench = json.loads(line)
 with open(os.path.join(root, "profiles", f"{tag}_nuts_iteration.md"), "w") as f:
     f.write(f"# cfg 4 sampler iteration under rocprofv3 --kernel-trace ({tag})\n\n")
-    f.write("Command: `rocprofv3 --kernel-trace --stats -- python3 tools/bench_nuts.py --chains 128 --warmup 300 --samples 300`\n")
-    f.write("(kernel-trace inflates every tiny launch to about 4.4 us; untraced the same graph replays in about 0.45 ms).\n\n")
+    f.write("Command: `rocprofv3 --kernel-trace --stats -- python3 tools/bench_nuts.py --chains 128 --warmup 300 --samples 300 "
+            + " ".join(sys.argv[4:]) + "` (`tools/profile_nuts.sh`)\n")
+    f.write("(kernel-trace inflates every tiny launch to about 4.4 us).\n\n")
     f.write(f"- sampler iterations (`dyn_nuts_advance` launches): {len(idx)}\n")
     f.write(f"- kernels per iteration (steady state): {mean(per_iter):.1f}; iteration span under trace {mean(span):.1f} us\n")
     if sk:
         f.write(f"- gradient-solve kernel `{short(sk['Name'])}`: {sk['Calls']} calls, avg {float(sk['AverageNs']) / 1e3:.1f} us ({sk['Percentage']} % of GPU time)\n")
     if na:
         f.write(f"- `dynnuts::nuts_advance`: {na['Calls']} calls, avg {float(na['AverageNs']) / 1e3:.1f} us, min {float(na['MinNs']) / 1e3:.1f}, max {float(na['MaxNs']) / 1e3:.1f} ({na['Percentage']} %); steady state {mean(adv):.1f} us\n")
-    f.write(f"- total GPU kernel time {total / 1e9:.2f} s; everything else is the model's torch program (constrain, priors, likelihood, autograd)\n")
+    f.write(f"- total GPU kernel time {total / 1e9:.2f} s; kernels not named above belong to the model's torch program (none when the potential is folded, infer/folded.py)\n")
     if bench:
         f.write(f"- traced run: {bench.get('seconds', 0):.2f} s, {bench.get('transitions_per_s', 0):.0f} transitions/s, KS p {bench.get('ks_pvalues_vs_quadrature')}\n")
     a, b = sel[len(sel) // 2], sel[len(sel) // 2 + 1]
