@@ -30,8 +30,10 @@ EXPORTED_SYMBOLS = (
     "dyn_last_error", "dyn_solve_batch", "dyn_solve_batch_jvp", "dyn_is_supported_jvp",
     "dyn_nuts_advance", "dyn_nuts_state_size", "dyn_philox4x32_10", "dyn_latent_sites",
     "dyn_solve_batch_loglik", "dyn_register_instance", "dyn_last_kernel_name", "dyn_solve_batch_record",
-    "dyn_solve_batch_replay", "dyn_latent_param_map", "dyn_potential_combine",
+    "dyn_solve_batch_replay", "dyn_latent_param_map", "dyn_potential_combine", "dyn_solve_batch_ordered", "dyn_cost_order",
 )
+
+MAX_COST_FEATURES = 32
 
 MAX_SITES = 8
 DIST_NORMAL, DIST_UNIFORM, DIST_BETA, DIST_TRUNCNORMAL = 0, 1, 2, 3
@@ -196,6 +198,12 @@ def lib() -> ctypes.CDLL:
         L.dyn_solve_batch_record.argtypes = base + [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p]
         L.dyn_solve_batch_replay.restype = ctypes.c_int
         L.dyn_solve_batch_replay.argtypes = base + [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p]
+        L.dyn_solve_batch_ordered.restype = ctypes.c_int
+        L.dyn_solve_batch_ordered.argtypes = base + [ctypes.c_void_p, ctypes.c_void_p]
+        L.dyn_cost_order.restype = ctypes.c_int
+        L.dyn_cost_order.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p,
+                                     ctypes.c_void_p, ctypes.c_double, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,
+                                     ctypes.c_void_p]
         L.dyn_is_supported_jvp.argtypes = [pm, po, ctypes.c_int32]
         L.dyn_is_supported_jvp.restype = ctypes.c_int32
         L.dyn_solve_batch_jvp.restype = ctypes.c_int

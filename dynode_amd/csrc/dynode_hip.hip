@@ -260,8 +260,9 @@ static int enqueue(const Entry *e, const dyn_model_desc *m, const dyn_solver_opt
                    const uint8_t *save_mask, void *ys_out, int32_t *status, int32_t *n_accept,
                    int32_t *n_reject, hipStream_t stream, const void *dparams = nullptr,
                    const void *dy0 = nullptr, int32_t dy0_is_batched = 0, void *dys_out = nullptr,
-                   const LLArgs *ll = nullptr, const SchedArgs *sc = nullptr) {
+                   const LLArgs *ll = nullptr, const SchedArgs *sc = nullptr, const int32_t *order = nullptr) {
     KArgs<T> ka;
+    ka.order = order;
     ka.sched_out = sc ? (T *)sc->out : nullptr;
     ka.sched_n_out = sc ? sc->n_out : nullptr;
     ka.sched_in = sc ? (const T *)sc->in : nullptr;
@@ -469,7 +470,7 @@ static int solve_impl(const dyn_model_desc *m, const dyn_solver_opts *o, const v
                       const uint8_t *save_mask, void *ys_out, int32_t *status, int32_t *n_accept,
                       int32_t *n_reject, void *stream, int32_t n_dir, const void *dparams,
                       const void *dy0, int32_t dy0_is_batched, void *dys_out,
-                      const dyn::LLArgs *ll = nullptr, const dyn::SchedArgs *sc = nullptr) {
+                      const dyn::LLArgs *ll = nullptr, const dyn::SchedArgs *sc = nullptr, const int32_t *order = nullptr) {
     dyn::tl_error[0] = 0;
     int rc = dyn::check_model(m);
     if (rc) return rc;
@@ -547,10 +548,10 @@ static int solve_impl(const dyn_model_desc *m, const dyn_solver_opts *o, const v
     if (o->dtype == DYN_F64)
         return dyn::enqueue<double>(e, m, o, y0, y0_is_batched, params, contact, B, t0, t1,
                                     save_ts, n_save, save_mask, ys_out, status, n_accept, n_reject,
-                                    (hipStream_t)stream, dparams, dy0, dy0_is_batched, dys_out, ll, sc);
+                                    (hipStream_t)stream, dparams, dy0, dy0_is_batched, dys_out, ll, sc, order);
     return dyn::enqueue<float>(e, m, o, y0, y0_is_batched, params, contact, B, t0, t1, save_ts,
                                n_save, save_mask, ys_out, status, n_accept, n_reject,
-                               (hipStream_t)stream, dparams, dy0, dy0_is_batched, dys_out, ll, sc);
+                               (hipStream_t)stream, dparams, dy0, dy0_is_batched, dys_out, ll, sc, order);
 }
 
 int dyn_solve_batch(const dyn_model_desc *m, const dyn_solver_opts *o, const void *y0,
@@ -561,6 +562,15 @@ int dyn_solve_batch(const dyn_model_desc *m, const dyn_solver_opts *o, const voi
     return solve_impl(m, o, y0, y0_is_batched, params, contact, B, t0, t1, save_ts, n_save,
                       save_mask, ys_out, status, n_accept, n_reject, stream, 0, nullptr, nullptr, 0,
                       nullptr);
+}
+
+int dyn_solve_batch_ordered(const dyn_model_desc *m, const dyn_solver_opts *o, const void *y0, int32_t y0_is_batched,
+                            const void *params, const void *contact, int64_t B, double t0, double t1, const void *save_ts,
+                            int32_t n_save, const uint8_t *save_mask, void *ys_out, int32_t *status, int32_t *n_accept,
+                            int32_t *n_reject, const int32_t *order, void *stream) {
+    if (order && B > 0x7fffffffLL) return DYN_ERR_SIZE;
+    return solve_impl(m, o, y0, y0_is_batched, params, contact, B, t0, t1, save_ts, n_save, save_mask, ys_out, status,
+                      n_accept, n_reject, stream, 0, nullptr, nullptr, 0, nullptr, nullptr, nullptr, order);
 }
 
 int dyn_solve_batch_record(const dyn_model_desc *m, const dyn_solver_opts *o, const void *y0, int32_t y0_is_batched,

@@ -1,0 +1,131 @@
+// order_kernel.hip -- dispatch order of a batch from a cost model (dyn_cost_order).
+//
+// The solve kernels integrate the 2..32 trajectories of a wave in lock-step (an iteration lasts until the slowest group
+// has stepped, a save round until the group with the most rows is done) and the hardware hands waves to SIMDs in index
+// order.  Which trajectories share a wave and which waves start last therefore changes the launch time by 10-15 % (measured:
+// DESIGN.md section 9) although it cannot change a single output bit.  diffrax under vmap has the same property on a CPU and
+// nobody orders the batch there; here it is two tiny launches in front of the solve:
+//   cost_keys        every trajectory: predicted number of step attempts = a quadratic form in the standardised logarithms
+//                    of its (varying, positive) parameters -- coefficients fitted by the host from step counts the solve
+//                    kernels returned on earlier batches (dynode_amd/schedule.py) -- quantised to a bucket, most expensive first
+//   order_from_keys  one workgroup: counting sort of the buckets (histogram in LDS, scan, scatter)
+// The order of equal keys is whatever the LDS atomics produce; the outputs of the solve do not depend on it.
+#include "../../include/dynode_hip.h"
+
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+namespace dynord {
+
+constexpr int kBuckets = 4096;
+constexpr int kMaxFeat = DYN_MAX_COST_FEATURES;
+
+// Exchangeable strains (n_sym = S > 1): the first sym_blocks * S parameters are blocks [quantity][strain] of a model that
+// treats its strains alike (beta, gamma, sigma, omega of dyn_model_desc family 0), so the step count is a symmetric function
+// of the strains and the forecast is much sharper on a canonical labelling: strains sorted by block 0 / block 1 (= r0),
+// largest first.  Parameter c < sym_blocks * S is then read at [c / S][rank (c % S)].
+constexpr int kMaxSym = 8;
+
+template <typename T>
+__global__ void __launch_bounds__(256) cost_keys(const T *__restrict__ params, int64_t B, int P, int n,
+                                                 const int32_t *__restrict__ cols, const float *__restrict__ coef,
+                                                 float key_scale, int n_sym, int sym_blocks, int32_t *__restrict__ keys) {
+    __shared__ float c[1 + 3 * kMaxFeat + kMaxFeat * (kMaxFeat + 1) / 2];
+    __shared__ int32_t col[kMaxFeat];
+    const int nq = 1 + n + n * (n + 1) / 2, nc = nq + 2 * n;     // quadratic form, then centre and 1 / spread of every log
+    for (int i = threadIdx.x; i < nc; i += 256) c[i] = coef[i];
+    for (int i = threadIdx.x; i < n; i += 256) col[i] = cols[i];
+    __syncthreads();
+    const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    float l[kMaxFeat];
+    const T *p = params + b * P;
+    int rank[kMaxSym];
+    if (n_sym > 1) { // insertion sort of the strains by block 0 / block 1, descending, stable
+        float key[kMaxSym];
+        for (int sI = 0; sI < n_sym; ++sI) {
+            const float k = (float)p[sI] / (float)p[n_sym + sI];
+            int at = sI;
+            while (at > 0 && key[at - 1] < k) {
+                key[at] = key[at - 1];
+                rank[at] = rank[at - 1];
+                --at;
+            }
+            key[at] = k;
+            rank[at] = sI;
+        }
+    }
+    for (int i = 0; i < n; ++i) { // column c >= 0: the logarithm of parameter c; c < 0: parameter -(c + 1) itself
+        const int cc = col[i];
+        int src = cc < 0 ? -(cc + 1) : cc;
+        if (n_sym > 1 && src < sym_blocks * n_sym) src = (src / n_sym) * n_sym + rank[src % n_sym];
+        const float v = (float)p[src];
+        l[i] = ((cc < 0 ? v : __logf(fmaxf(v, 1e-30f))) - c[nq + i]) * c[nq + n + i];
+    }
+    float pred = c[0];
+    const float *q = c + 1 + n;
+    for (int i = 0; i < n; ++i) {
+        float row = c[1 + i];                  // a_i + sum_{j >= i} q_ij l_j
+        for (int j = i; j < n; ++j) row = fmaf(*q++, l[j], row);
+        pred = fmaf(row, l[i], pred);
+    }
+    // non-finite predictions (NaN parameters) go last: they fail at once
+    int bucket = (pred == pred) ? (int)fminf(fmaxf(pred * key_scale, 0.0f), (float)(kBuckets - 1)) : 0;
+    keys[b] = kBuckets - 1 - bucket;           // ascending key = descending cost
+}
+
+__global__ void __launch_bounds__(1024) order_from_keys(const int32_t *__restrict__ keys, int64_t B, int32_t *__restrict__ order) {
+    __shared__ int32_t hist[kBuckets];
+    __shared__ int32_t part[1024];
+    const int t = threadIdx.x;
+    for (int i = t; i < kBuckets; i += 1024) hist[i] = 0;
+    __syncthreads();
+    for (int64_t b = t; b < B; b += 1024) atomicAdd(&hist[keys[b]], 1);
+    __syncthreads();
+    // exclusive scan of 4096 buckets: 4 per thread, then the 1024 partial sums
+    constexpr int PER = kBuckets / 1024;
+    int32_t v[PER], sum = 0;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        v[i] = hist[t * PER + i];
+        sum += v[i];
+    }
+    part[t] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int32_t add = t >= off ? part[t - off] : 0;
+        __syncthreads();
+        part[t] += add;
+        __syncthreads();
+    }
+    int32_t base = part[t] - sum;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        hist[t * PER + i] = base;
+        base += v[i];
+    }
+    __syncthreads();
+    for (int64_t b = t; b < B; b += 1024) order[atomicAdd(&hist[keys[b]], 1)] = (int32_t)b;
+}
+
+} // namespace dynord
+
+extern "C" int dyn_cost_order(const void *params, int32_t dtype, int64_t B, int32_t P, int32_t n_feat, const int32_t *cols,
+                              const float *coef, double key_scale, int32_t n_sym, int32_t sym_blocks, int32_t *keys_ws,
+                              int32_t *order, void *stream) {
+    if (B > 0 && (!params || !cols || !coef || !keys_ws || !order)) return DYN_ERR_NULL;
+    if (B < 0 || B > 0x7fffffffLL || P < 1 || n_feat < 0 || n_feat > DYN_MAX_COST_FEATURES) return DYN_ERR_SIZE;
+    if (n_sym < 0 || n_sym > dynord::kMaxSym || sym_blocks < 0 || (n_sym > 1 && (sym_blocks < 2 || sym_blocks * n_sym > P)))
+        return DYN_ERR_SIZE;
+    if ((dtype != DYN_F32 && dtype != DYN_F64) || !(key_scale > 0.0)) return DYN_ERR_OPTS;
+    if (B == 0) return 0;
+    const dim3 grid((unsigned)((B + 255) / 256));
+    if (dtype == DYN_F32)
+        hipLaunchKernelGGL(dynord::cost_keys<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float *)params, B, (int)P,
+                           (int)n_feat, cols, coef, (float)key_scale, (int)n_sym, (int)sym_blocks, keys_ws);
+    else
+        hipLaunchKernelGGL(dynord::cost_keys<double>, grid, dim3(256), 0, (hipStream_t)stream, (const double *)params, B, (int)P,
+                           (int)n_feat, cols, coef, (float)key_scale, (int)n_sym, (int)sym_blocks, keys_ws);
+    hipLaunchKernelGGL(dynord::order_from_keys, dim3(1), dim3(1024), 0, (hipStream_t)stream, keys_ws, B, order);
+    return hipGetLastError() == hipSuccess ? 0 : DYN_ERR_LAUNCH;
+}

@@ -691,8 +691,15 @@ struct Seip {
         const int tlane = NW > 1 ? (int)threadIdx.x : lane;
         const int a = tlane % GA, j = (tlane / GA) % H, tl = (tlane / (GA * H)) % KT, grp = NW > 1 ? 0 : lane / G;
         int64_t traj = (int64_t)blockIdx.x * TPW + grp;
-        const bool valid_traj = traj < ka.B;
+        bool valid_traj = traj < ka.B;
         if (!valid_traj) traj = ka.B - 1;
+        if (ka.order) { // dispatch order (KArgs::order)
+            traj = ka.order[traj];
+            if ((uint64_t)traj >= (uint64_t)ka.B) {
+                valid_traj = false;
+                traj = ka.B - 1;
+            }
+        }
         const int A = ka.A, nk = ka.n_vax_knots;
         Seip S;
         S.wv = NW > 1 ? (int)(threadIdx.x >> 6) : 0;

@@ -106,7 +106,8 @@ def solve_batch(model: ModelDesc, y0, params, contact, t1: float, save_ts, *, t0
                 jump_ts: Sequence[float] = (), save_mask: Optional[Sequence[bool]] = None,
                 out: Optional[torch.Tensor] = None, stats_out: Optional[tuple] = None,
                 stream: Optional[torch.cuda.Stream] = None, dparams=None, dy0=None,
-                dout: Optional[torch.Tensor] = None, record_steps: int = 0, replay: Optional[tuple] = None) -> BatchResult:
+                dout: Optional[torch.Tensor] = None, record_steps: int = 0, replay: Optional[tuple] = None,
+                order="auto") -> BatchResult:
     """Integrate B parameter samples of ``model`` over [t0, t1] on the current GPU.
 
     Replaces the per-sample ``diffeqsolve`` call of dynode.simulation.simulate
@@ -121,6 +122,11 @@ def solve_batch(model: ModelDesc, y0, params, contact, t1: float, save_ts, *, t0
     (``BatchResult.schedule``); ``replay=(steps, count, leader)`` makes every trajectory take the recorded steps of row
     ``leader[b]`` of ``steps`` (``leader=None``: row b) instead of controlling its own.  For this family ``dparams`` is
     served by `_replayed_tangents`: central differences of replayed solves on the primal's step sequence.
+
+    ``order``: dispatch order of the batch (``dyn_solve_batch_ordered``; never changes a result, see `schedule.py`).
+    ``"auto"`` (default): plain adaptive solves of at least `schedule.MIN_BATCH` trajectories are ordered by a step-count
+    forecast learned from earlier launches of the same model and settings; ``None``: the given order; an int32 device
+    tensor [B]: that permutation.
     """
     device = require_gpu()
     L = _abi.lib()
@@ -191,10 +197,32 @@ def solve_batch(model: ModelDesc, y0, params, contact, t1: float, save_ts, *, t0
         elif sched.shape[0] != B:
             raise ValueError("replay without a leader index needs one schedule row per trajectory")
 
+    plain = n_dir == 0 and not record_steps and replay is None
+    order_t, cost = None, None
+    if isinstance(order, torch.Tensor):
+        if not plain:
+            raise ValueError("a dispatch order goes with the plain solve (no tangents, no step schedules)")
+        if order.dtype != torch.int32 or tuple(order.shape) != (B,) or not order.is_contiguous() or order.device != params_t.device:
+            raise ValueError(f"order must be a contiguous int32 device tensor of shape ({B},)")
+        order_t = order
+    elif order == "auto":
+        from . import schedule
+
+        if (plain and B >= schedule.MIN_BATCH and not constant_dt > 0.0 and schedule.enabled()
+                and not torch.cuda.is_current_stream_capturing()):
+            key = (model, dtype, method, float(rtol), float(atol), float(t0), float(t1), n_save > 0, str(device))
+            cost = schedule.model_for(key, P, device, schedule.strain_symmetry(model))
+            if cost.ready:
+                order_t = cost.order(params_t, s)
+    elif order is not None:
+        raise ValueError('order must be "auto", None or an int32 tensor')
+
     def call():
         common = (ctypes.byref(model.c()), ctypes.byref(opts), y0_t.data_ptr(), int(batched),
                   params_t.data_ptr(), contact_t.data_ptr(), B, float(t0), float(t1), ts_t.data_ptr(),
                   n_save, mask_c, out.data_ptr(), status.data_ptr(), n_acc.data_ptr(), n_rej.data_ptr())
+        if order_t is not None:
+            return L.dyn_solve_batch_ordered(*common, order_t.data_ptr(), ctypes.c_void_p(s.cuda_stream))
         if record_steps:
             return L.dyn_solve_batch_record(*common, sched.data_ptr(), sched_n.data_ptr(), int(record_steps), ctypes.c_void_p(s.cuda_stream))
         if replay is not None:
@@ -219,9 +247,12 @@ def solve_batch(model: ModelDesc, y0, params, contact, t1: float, save_ts, *, t0
     if rc != 0:
         raise SolveError(rc, L.dyn_last_error().decode())
     # keep inputs alive until the stream has consumed them
-    for t in (y0_t, params_t, contact_t, ts_t, dparams_t, dy0_t, sched, sched_n, leader_t):
+    for t in (y0_t, params_t, contact_t, ts_t, dparams_t, dy0_t, sched, sched_n, leader_t, order_t):
         if t is not None:
             t.record_stream(s)
+    if cost is not None and cost.training:      # learn the step-count forecast from what this launch returns (schedule.py)
+        with torch.cuda.stream(s):
+            cost.observe(params_t, n_acc + n_rej, status)
     return BatchResult(out, status, n_acc, n_rej, saved, sizes, dout, (sched, sched_n) if record_steps else None)
 
 

@@ -363,6 +363,34 @@ int dyn_latent_param_map(const dyn_site_desc *sites, int32_t n_sites, int64_t C,
 int dyn_potential_combine(int64_t C, int32_t n, const double *lp, const double *dlp_dz, const double *ll,
                           const double *dll, double offset, double *u, double *g, void *stream);
 
+/*
+ * Dispatch order.  dyn_solve_batch_ordered is dyn_solve_batch with one more argument: grid slot i integrates trajectory
+ * order[i] (DEVICE int32 [B], a permutation of 0..B-1; NULL = identity; an entry outside 0..B-1 makes its slot idle, rows that
+ * no entry names stay unwritten).  Outputs are bit-identical for every permutation -- each trajectory is computed from its
+ * own inputs and written to its own rows -- but the lane groups of a wave step in lock-step and waves start in index order, so
+ * putting trajectories with similar step counts next to each other, the expensive ones first, shortens the launch by 10-15 %
+ * (diffrax under vmap / pmap has no counterpart: XLA:CPU runs the samples one after another).
+ * dyn_cost_order makes such an order from a cost model: predicted step attempts of trajectory b =
+ *     coef[0] + sum_i coef[1 + i] l_i + sum_{i <= j} coef[1 + n + k(i, j)] l_i l_j,
+ *     l_i = (f(params[b][c]) - coef[nq + i]) * coef[nq + n + i],   nq = 1 + n + n (n + 1) / 2,
+ *     f = log and c = cols[i] if cols[i] >= 0, f = identity and c = -(cols[i] + 1) otherwise
+ * (k runs over the upper triangle row by row), quantised to key_scale buckets per attempt, most expensive first.  The host fits
+ * coef from the n_accept + n_reject the solve returned on earlier batches (dynode_amd/schedule.py).
+ *   params [B][P] in dtype; cols [n_feat], coef [nq + 2 n] (float32), keys_ws [B], order [B]: DEVICE memory.
+ * n_sym = S > 1: the first sym_blocks * S parameters are [quantity][strain] blocks of a model that treats its strains alike
+ * (family 0: beta, gamma, sigma, omega); they are read in a canonical labelling -- strains sorted by block 0 / block 1 (r0),
+ * largest first -- which makes the forecast a symmetric function of the strains.  n_sym <= 1: parameters are read as they are.
+ */
+#define DYN_MAX_COST_FEATURES 32
+int dyn_solve_batch_ordered(const dyn_model_desc *model, const dyn_solver_opts *opts, const void *y0, int32_t y0_is_batched,
+                            const void *params, const void *contact, int64_t B, double t0, double t1, const void *save_ts,
+                            int32_t n_save, const uint8_t *save_mask, void *ys_out, int32_t *status, int32_t *n_accept,
+                            int32_t *n_reject, const int32_t *order, void *stream);
+int dyn_cost_order(const void *params, int32_t dtype, int64_t B, int32_t P, int32_t n_feat, const int32_t *cols,
+                   const float *coef, double key_scale, int32_t n_sym, int32_t sym_blocks, int32_t *keys_ws, int32_t *order,
+                   void *stream);
+
+
 #ifdef __cplusplus
 }
 #endif

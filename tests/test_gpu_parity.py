@@ -12,6 +12,8 @@ At BASELINE.json's full sizes the oracle is too slow, so size-independent proper
 mass conservation, exact first row, batch-position invariance, bitwise determinism.
 """
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -193,6 +195,87 @@ def test_output_offsets_beyond_2_to_the_31():
         assert float((total - 1000.0).abs().max()) < 5e-3
     del r
     torch.cuda.empty_cache()
+
+
+# ------------------------------------------------------------------ dispatch order (dyn_solve_batch_ordered, dynode_amd/schedule.py)
+@pytest.mark.parametrize("wl", [synthetic.seirs_multi_strain(1536, seed=11, W=8), synthetic.sir_age_stratified(1100, seed=12),
+                                synthetic.seirs_multi_strain(1030, seed=13, seasonal=True), synthetic.seip(96, seed=14)],
+                         ids=["cfg3_D360", "cfg2_replicated", "cfg5_ragged", "seip"])
+def test_dispatch_order_never_changes_a_result(wl):
+    """Grid slot i integrates trajectory order[i]: any permutation gives the bits of the given order, in float32 with
+    adaptive steps (accept / reject decisions included)."""
+    m = wl.model
+    args = (m, wl.y0, wl.params, wl.contact, wl.t1, wl.save_ts)
+    base = solve_batch(*args, dtype=F32, order=None)
+    g = torch.Generator().manual_seed(1)
+    orders = [torch.randperm(wl.B, generator=g), torch.arange(wl.B - 1, -1, -1),
+              torch.argsort((base.n_accept + base.n_reject).cpu(), descending=True, stable=True)]
+    for o in orders:
+        r = solve_batch(*args, dtype=F32, order=o.to(torch.int32).cuda())
+        for a, b in ((r.ys, base.ys), (r.status, base.status), (r.n_accept, base.n_accept), (r.n_reject, base.n_reject)):
+            assert torch.equal(a, b)
+    assert int(base.status.max()) == 0
+    # entries outside 0..B-1 leave their slot idle and rows nobody names unwritten -- and nothing else is touched
+    sentinel = torch.full_like(base.ys, -7.0)
+    stats = torch.full((3, wl.B), -5, dtype=torch.int32, device="cuda")
+    bad = torch.arange(wl.B, dtype=torch.int32)
+    bad[3], bad[wl.B - 2] = -1, wl.B + 5
+    solve_batch(*args, dtype=F32, order=bad.cuda(), out=sentinel, stats_out=(stats[0], stats[1], stats[2]))
+    torch.cuda.synchronize()
+    skipped = torch.zeros(wl.B, dtype=torch.bool, device="cuda")
+    skipped[3] = skipped[wl.B - 2] = True
+    assert torch.equal(sentinel[~skipped], base.ys[~skipped]) and bool((sentinel[skipped] == -7.0).all())
+    assert bool((stats[:, skipped] == -5).all()) and torch.equal(stats[0, ~skipped], base.status[~skipped])
+    with pytest.raises(ValueError):
+        solve_batch(*args, dtype=F32, order=torch.arange(wl.B).cuda())                      # int64
+    with pytest.raises(ValueError):
+        solve_batch(*args, dtype=F32, order=torch.arange(wl.B - 1, dtype=torch.int32).cuda())
+    with pytest.raises(ValueError):
+        solve_batch(*args, dtype=F32, order="sorted")
+
+
+def test_learned_dispatch_order():
+    """schedule.py: the step-count forecast is learned from what the kernels return, `dyn_cost_order` turns it into a
+    permutation (most expensive first), and `order="auto"` uses it from the second launch on without changing a bit."""
+    from dynode_amd import schedule
+
+    schedule.reset()
+    big = synthetic.seirs_multi_strain(8192, seed=21)
+    m, half = big.model, 4096
+    train = (m, big.y0[:half], big.params[:half], big.contact, big.t1, big.save_ts[::73])
+    test = (m, big.y0[half:], big.params[half:], big.contact, big.t1, big.save_ts[::73])
+    first = solve_batch(*train, dtype=F32)                      # trains (4096 rows >= 12 per coefficient)
+    (cm,) = schedule._MODELS.values()
+    assert cm.ready and int(cm.cols.numel()) == 16 and bool((cm.cols >= 0).all())      # 16 rates, all as logarithms
+    assert cm.best.sym == (4, 4)                                # exchangeable strains: the canonical labelling forecasts better
+    plain = solve_batch(*test, dtype=F32, order=None)
+    att = (plain.n_accept + plain.n_reject).double()
+    p_test = torch.as_tensor(big.params[half:], dtype=F32, device="cuda")
+    forecast = cm.forecast(p_test)
+    corr = float(torch.corrcoef(torch.stack([forecast, att]))[0, 1])
+    print(f"[dispatch order] forecast vs step attempts on unseen draws: correlation {corr:.3f}")
+    assert corr > 0.85
+    order = cm.order(p_test, torch.cuda.current_stream())
+    torch.cuda.synchronize()
+    assert torch.equal(torch.sort(order.long()).values, torch.arange(half, device="cuda"))       # a permutation
+    f_sorted = forecast[order.long()]
+    assert float((f_sorted[1:] - f_sorted[:-1]).max()) <= 1.0 / schedule.KEY_SCALE + 1e-3        # descending up to one bucket
+    auto = solve_batch(*test, dtype=F32)                        # ordered by the forecast
+    for a, b in ((auto.ys, plain.ys), (auto.n_accept, plain.n_accept), (auto.n_reject, plain.n_reject), (auto.status, plain.status)):
+        assert torch.equal(a, b)
+    assert torch.equal(first.status, torch.zeros_like(first.status))
+    # constant steps: every trajectory costs the same, nothing is learned or ordered
+    schedule.reset()
+    solve_batch(*test, dtype=F32, constant_dt=0.5)
+    assert not schedule._MODELS
+    # and it can be switched off
+    os.environ["DYNODE_ORDER"] = "0"
+    try:
+        solve_batch(*test, dtype=F32)
+        assert not schedule._MODELS
+    finally:
+        del os.environ["DYNODE_ORDER"]
+    schedule.reset()
 
 
 # ------------------------------------------------------------------ edge cases of the boundary
