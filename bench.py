@@ -186,7 +186,7 @@ def other_draws(gen, wl, seed):
     return big
 
 
-def measure(wl, dev, steps: int, warmup: int, fence, train_on=None):
+def measure(wl, dev, steps: int, warmup: int, fence, train_on=None, given_order_too=True):
     """Resident inputs, `warmup` untimed launches, then `steps` launches with a HIP event pair around each.
     ``train_on``: a workload of other draws of the same prior -- solved first (untimed) so that the step-count forecast behind
     the dispatch order has never seen the timed batch."""
@@ -221,7 +221,7 @@ def measure(wl, dev, steps: int, warmup: int, fence, train_on=None):
         torch.cuda.synchronize()
         cm = next(iter(schedule._MODELS.values()), None)
         if cm is not None and cm.ready:
-            given = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
+            given = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5 if given_order_too else 0)]
             for e0, e1 in given:
                 e0.record()
                 step(order=None)
@@ -231,7 +231,7 @@ def measure(wl, dev, steps: int, warmup: int, fence, train_on=None):
             order_info = {"kind": "step-count forecast learned from earlier launches (dynode_amd/schedule.py), forecast + sort inside the timed region",
                           "trained_on": (f"{cm.rows} other draws of the same prior" if train_on is not None else "the warm-up launches of this batch"),
                           "forecast_correlation_on_this_batch": float(torch.corrcoef(torch.stack([cm.forecast(params), att]))[0, 1]),
-                          "given_order_ms_per_launch": float(np.mean([e0.elapsed_time(e1) for e0, e1 in given]))}
+                          "given_order_ms_per_launch": float(np.mean([e0.elapsed_time(e1) for e0, e1 in given])) if given else None}
     else:
         for _ in range(warmup):
             step()
@@ -340,7 +340,7 @@ def main():
             big.y0 = big.y0[n:n + B]
         return big
 
-    res = measure(wl, dev, args.steps, args.warmup, fence, train_on=held_out(rank))
+    res = measure(wl, dev, args.steps, args.warmup, fence, train_on=held_out(rank), given_order_too=not args.no_extra)
     elapsed, kern_ms = res["elapsed"], res["kernel_ms"]
     ok = int(res["stats"][0].max()) == 0
     steps_mean = float((res["stats"][1] + res["stats"][2]).float().mean())

@@ -12,11 +12,13 @@ extra = sys.argv[3:]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KERNEL = "seip_kernel" if any(a.startswith("seip") for a in extra) else "solve_kernel"
 
-stats = None
+stats, side = None, []
 for f in glob.glob(os.path.join(out_dir, "trace", "**", "*kernel_stats.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
         if KERNEL in r["Name"]:
             stats = r
+        elif "dynord::" in r["Name"]:      # dispatch order: forecast + counting sort in front of every ordered launch
+            side.append(r)
 counters = collections.defaultdict(list)
 meta = {}
 for f in glob.glob(os.path.join(out_dir, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
@@ -55,9 +57,13 @@ kernel = instance_name(stats["Name"]) if stats else None
 lines = [f"# rocprofv3 summary `{tag}` -- bench.py --workload {workload} (B={batch} per GPU)", "",
          f"- source revision: `{build_rev()}`", f"- dispatched instance: `{kernel}`", ""]
 if stats:
-    lines += ["## kernel-trace --stats (50 timed + 5 warm-up launches, the default bench.py command)", "",
+    lines += ["## kernel-trace --stats (bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extra: 50 timed + 5 warm-up launches in the "
+              "learned dispatch order, plus the untimed launches on other draws that train its forecast)", "",
               "| kernel | calls | avg ns | min ns | max ns | % of GPU time |", "|---|---|---|---|---|---|",
-              f"| `{stats['Name'][:120]}` | {stats['Calls']} | {float(stats['AverageNs']):.0f} | {stats['MinNs']} | {stats['MaxNs']} | {stats['Percentage']} |", ""]
+              f"| `{stats['Name'][:120]}` | {stats['Calls']} | {float(stats['AverageNs']):.0f} | {stats['MinNs']} | {stats['MaxNs']} | {stats['Percentage']} |"]
+    for r in side:
+        lines.append(f"| `{r['Name'][:120]}` | {r['Calls']} | {float(r['AverageNs']):.0f} | {r['MinNs']} | {r['MaxNs']} | {r['Percentage']} |")
+    lines.append("")
 if meta:
     lines += ["## dispatch", "", "| " + " | ".join(meta) + " |", "|" + "---|" * len(meta), "| " + " | ".join(meta.values()) + " |", ""]
 if mean:
