@@ -18,7 +18,6 @@
 namespace dynord {
 
 constexpr int kBuckets = 4096;
-constexpr int kMaxFeat = DYN_MAX_COST_FEATURES;
 
 // Exchangeable strains (n_sym = S > 1): the first sym_blocks * S parameters are blocks [quantity][strain] of a model that
 // treats its strains alike (beta, gamma, sigma, omega of dyn_model_desc family 0), so the step count is a symmetric function
@@ -26,47 +25,64 @@ constexpr int kMaxFeat = DYN_MAX_COST_FEATURES;
 // largest first.  Parameter c < sym_blocks * S is then read at [c / S][rank (c % S)].
 constexpr int kMaxSym = 8;
 
-template <typename T>
-__global__ void __launch_bounds__(256) cost_keys(const T *__restrict__ params, int64_t B, int P, int n,
+// NF = compiled feature capacity (the host pads the coefficient arrays of a smaller model with zeros): with the loops
+// unrolled the features stay in registers and the coefficients -- wave-uniform addresses -- arrive through scalar loads, so a
+// trajectory costs its NF logarithms and NF (NF + 3) / 2 FMAs.
+template <typename T, int NF>
+__global__ void __launch_bounds__(256) cost_keys(const T *__restrict__ params, int64_t B, int P,
                                                  const int32_t *__restrict__ cols, const float *__restrict__ coef,
                                                  float key_scale, int n_sym, int sym_blocks, int32_t *__restrict__ keys) {
-    __shared__ float c[1 + 3 * kMaxFeat + kMaxFeat * (kMaxFeat + 1) / 2];
-    __shared__ int32_t col[kMaxFeat];
-    const int nq = 1 + n + n * (n + 1) / 2, nc = nq + 2 * n;     // quadratic form, then centre and 1 / spread of every log
-    for (int i = threadIdx.x; i < nc; i += 256) c[i] = coef[i];
-    for (int i = threadIdx.x; i < n; i += 256) col[i] = cols[i];
-    __syncthreads();
+    constexpr int NQ = 1 + NF + NF * (NF + 1) / 2;      // quadratic form, then centre and 1 / spread of every feature
     const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (b >= B) return;
-    float l[kMaxFeat];
     const T *p = params + b * P;
     int rank[kMaxSym];
     if (n_sym > 1) { // insertion sort of the strains by block 0 / block 1, descending, stable
         float key[kMaxSym];
-        for (int sI = 0; sI < n_sym; ++sI) {
-            const float k = (float)p[sI] / (float)p[n_sym + sI];
-            int at = sI;
-            while (at > 0 && key[at - 1] < k) {
-                key[at] = key[at - 1];
-                rank[at] = rank[at - 1];
-                --at;
+#pragma unroll
+        for (int sI = 0; sI < kMaxSym; ++sI) {
+            if (sI < n_sym) {
+                const float k = (float)p[sI] / (float)p[n_sym + sI];
+                int at = sI;
+#pragma unroll
+                for (int back = kMaxSym - 1; back > 0; --back) {      // (unrolled: `key` and `rank` stay in registers)
+                    if (back <= sI && at == back && key[back - 1] < k) {
+                        key[back] = key[back - 1];
+                        rank[back] = rank[back - 1];
+                        at = back - 1;
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < kMaxSym; ++q)
+                    if (q == at) {
+                        key[q] = k;
+                        rank[q] = sI;
+                    }
             }
-            key[at] = k;
-            rank[at] = sI;
         }
     }
-    for (int i = 0; i < n; ++i) { // column c >= 0: the logarithm of parameter c; c < 0: parameter -(c + 1) itself
-        const int cc = col[i];
+    float l[NF];
+#pragma unroll
+    for (int i = 0; i < NF; ++i) { // column c >= 0: the logarithm of parameter c; c < 0: parameter -(c + 1) itself
+        const int cc = cols[i];
         int src = cc < 0 ? -(cc + 1) : cc;
-        if (n_sym > 1 && src < sym_blocks * n_sym) src = (src / n_sym) * n_sym + rank[src % n_sym];
+        if (n_sym > 1 && src < sym_blocks * n_sym) {
+            const int sI = src % n_sym;
+            int r = 0;
+#pragma unroll
+            for (int q = 0; q < kMaxSym; ++q) r = q == sI ? rank[q] : r;
+            src = (src / n_sym) * n_sym + r;
+        }
         const float v = (float)p[src];
-        l[i] = ((cc < 0 ? v : __logf(fmaxf(v, 1e-30f))) - c[nq + i]) * c[nq + n + i];
+        l[i] = ((cc < 0 ? v : __logf(fmaxf(v, 1e-30f))) - coef[NQ + i]) * coef[NQ + NF + i];
     }
-    float pred = c[0];
-    const float *q = c + 1 + n;
-    for (int i = 0; i < n; ++i) {
-        float row = c[1 + i];                  // a_i + sum_{j >= i} q_ij l_j
-        for (int j = i; j < n; ++j) row = fmaf(*q++, l[j], row);
+    float pred = coef[0];
+    int q = 1 + NF;
+#pragma unroll
+    for (int i = 0; i < NF; ++i) {
+        float row = coef[1 + i];                  // a_i + sum_{j >= i} q_ij l_j
+#pragma unroll
+        for (int j = i; j < NF; ++j) row = fmaf(coef[q++], l[j], row);
         pred = fmaf(row, l[i], pred);
     }
     // non-finite predictions (NaN parameters) go last: they fail at once
@@ -74,13 +90,25 @@ __global__ void __launch_bounds__(256) cost_keys(const T *__restrict__ params, i
     keys[b] = kBuckets - 1 - bucket;           // ascending key = descending cost
 }
 
+// One workgroup: counting sort of the bucket keys (histogram in LDS, scan, scatter).  A thread keeps up to PER_THREAD of its
+// keys in registers between the two passes; longer batches read them again.
 __global__ void __launch_bounds__(1024) order_from_keys(const int32_t *__restrict__ keys, int64_t B, int32_t *__restrict__ order) {
     __shared__ int32_t hist[kBuckets];
     __shared__ int32_t part[1024];
+    constexpr int PER_THREAD = 16;
     const int t = threadIdx.x;
     for (int i = t; i < kBuckets; i += 1024) hist[i] = 0;
+    int32_t mine[PER_THREAD];
+#pragma unroll
+    for (int i = 0; i < PER_THREAD; ++i) {
+        const int64_t b = t + (int64_t)i * 1024;
+        mine[i] = b < B ? keys[b] : -1;
+    }
     __syncthreads();
-    for (int64_t b = t; b < B; b += 1024) atomicAdd(&hist[keys[b]], 1);
+#pragma unroll
+    for (int i = 0; i < PER_THREAD; ++i)
+        if (mine[i] >= 0) atomicAdd(&hist[mine[i]], 1);
+    for (int64_t b = t + (int64_t)PER_THREAD * 1024; b < B; b += 1024) atomicAdd(&hist[keys[b]], 1);
     __syncthreads();
     // exclusive scan of 4096 buckets: 4 per thread, then the 1024 partial sums
     constexpr int PER = kBuckets / 1024;
@@ -105,27 +133,47 @@ __global__ void __launch_bounds__(1024) order_from_keys(const int32_t *__restric
         base += v[i];
     }
     __syncthreads();
-    for (int64_t b = t; b < B; b += 1024) order[atomicAdd(&hist[keys[b]], 1)] = (int32_t)b;
+#pragma unroll
+    for (int i = 0; i < PER_THREAD; ++i)
+        if (mine[i] >= 0) order[atomicAdd(&hist[mine[i]], 1)] = (int32_t)(t + i * 1024);
+    for (int64_t b = t + (int64_t)PER_THREAD * 1024; b < B; b += 1024) order[atomicAdd(&hist[keys[b]], 1)] = (int32_t)b;
 }
 
 } // namespace dynord
+
+template <typename T>
+static void launch_keys(int nf, dim3 grid, hipStream_t st, const T *params, int64_t B, int P, const int32_t *cols, const float *coef,
+                        float key_scale, int n_sym, int sym_blocks, int32_t *keys) {
+#define DYN_KEYS(NF) hipLaunchKernelGGL((dynord::cost_keys<T, NF>), grid, dim3(256), 0, st, params, B, P, cols, coef, key_scale, n_sym, sym_blocks, keys)
+    if (nf <= 4) DYN_KEYS(4);
+    else if (nf <= 8) DYN_KEYS(8);
+    else if (nf <= 16) DYN_KEYS(16);
+    else if (nf <= 24) DYN_KEYS(24);
+    else DYN_KEYS(32);
+#undef DYN_KEYS
+}
+
+extern "C" int32_t dyn_cost_order_capacity(int32_t n_feat) {
+    return n_feat <= 4 ? 4 : n_feat <= 8 ? 8 : n_feat <= 16 ? 16 : n_feat <= 24 ? 24 : n_feat <= DYN_MAX_COST_FEATURES ? 32 : -1;
+}
 
 extern "C" int dyn_cost_order(const void *params, int32_t dtype, int64_t B, int32_t P, int32_t n_feat, const int32_t *cols,
                               const float *coef, double key_scale, int32_t n_sym, int32_t sym_blocks, int32_t *keys_ws,
                               int32_t *order, void *stream) {
     if (B > 0 && (!params || !cols || !coef || !keys_ws || !order)) return DYN_ERR_NULL;
-    if (B < 0 || B > 0x7fffffffLL || P < 1 || n_feat < 0 || n_feat > DYN_MAX_COST_FEATURES) return DYN_ERR_SIZE;
+    if (B < 0 || B > 0x7fffffffLL || P < 1 || n_feat < 1 || n_feat > DYN_MAX_COST_FEATURES) return DYN_ERR_SIZE;
+    if (n_feat != dyn_cost_order_capacity(n_feat)) return DYN_ERR_SIZE;   // pad with zero coefficients (dyn_cost_order_capacity)
     if (n_sym < 0 || n_sym > dynord::kMaxSym || sym_blocks < 0 || (n_sym > 1 && (sym_blocks < 2 || sym_blocks * n_sym > P)))
         return DYN_ERR_SIZE;
     if ((dtype != DYN_F32 && dtype != DYN_F64) || !(key_scale > 0.0)) return DYN_ERR_OPTS;
     if (B == 0) return 0;
     const dim3 grid((unsigned)((B + 255) / 256));
     if (dtype == DYN_F32)
-        hipLaunchKernelGGL(dynord::cost_keys<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float *)params, B, (int)P,
-                           (int)n_feat, cols, coef, (float)key_scale, (int)n_sym, (int)sym_blocks, keys_ws);
+        launch_keys<float>(n_feat, grid, (hipStream_t)stream, (const float *)params, B, (int)P, cols, coef, (float)key_scale,
+                           (int)n_sym, (int)sym_blocks, keys_ws);
     else
-        hipLaunchKernelGGL(dynord::cost_keys<double>, grid, dim3(256), 0, (hipStream_t)stream, (const double *)params, B, (int)P,
-                           (int)n_feat, cols, coef, (float)key_scale, (int)n_sym, (int)sym_blocks, keys_ws);
+        launch_keys<double>(n_feat, grid, (hipStream_t)stream, (const double *)params, B, (int)P, cols, coef, (float)key_scale,
+                            (int)n_sym, (int)sym_blocks, keys_ws);
     hipLaunchKernelGGL(dynord::order_from_keys, dim3(1), dim3(1024), 0, (hipStream_t)stream, keys_ws, B, order);
     return hipGetLastError() == hipSuccess ? 0 : DYN_ERR_LAUNCH;
 }

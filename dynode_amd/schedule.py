@@ -38,6 +38,11 @@ RIDGE = 1e-4
 MIN_R2 = 0.5                # a forecast that explains less of the step-count variance than this is not used (given order)
 
 
+def capacity(n: int) -> int:
+    """Compiled feature capacity of `dyn_cost_order` for n features (``dyn_cost_order_capacity``)."""
+    return next(c for c in (4, 8, 16, 24, 32) if n <= c)
+
+
 def enabled() -> bool:
     return os.environ.get("DYNODE_ORDER", "1") != "0"
 
@@ -49,7 +54,7 @@ class _Regression:
     def __init__(self, P: int, device, sym):
         self.P, self.device, self.sym = int(P), device, sym
         self.cols = None            # int32 [n]: dyn_cost_order's encoding of the feature columns
-        self.coef = None            # float32 [nq + 2 n]
+        self.coef = None            # float32: dyn_cost_order's coefficient array at the compiled feature capacity
         self.rss = float("inf")     # in-sample residual variance of the last fit
         self.variance = 0.0         # ... and the variance of the step count itself
 
@@ -103,25 +108,34 @@ class _Regression:
         return torch.cat([torch.ones(z.shape[0], 1, dtype=torch.float64, device=z.device), z, z[:, self._iu[0]] * z[:, self._iu[1]]], dim=1)
 
     def add(self, params, attempts, weight) -> None:
-        Q = self.features(params)
+        keep = weight[:, None] > 0
+        Q = torch.where(keep, self.features(params), torch.zeros((), dtype=torch.float64, device=params.device))   # (failed rows may hold NaN)
         Qw = Q * weight[:, None]
-        y = attempts.double()
+        y = attempts.double() * weight
         self.G += Qw.T @ Q
         self.r += Qw.T @ y
-        self.yy += (weight * y * y).sum()
+        self.yy += (y * y).sum()
         self.wsum += weight.sum()
 
     def fit(self) -> None:
         ridge = RIDGE * torch.diagonal(self.G).clamp_min(1e-12)
         ridge[0] = 0.0
         w = torch.linalg.solve(self.G + torch.diag(ridge), self.r)
-        self.coef = torch.cat([w, self.centre, self.inv_spread]).float().contiguous()
+        self.w = w
+        # dyn_cost_order's layout at the compiled feature capacity NF >= n: features beyond n have zero coefficients and spread
+        n, NF = int(self._idx.numel()), capacity(int(self._idx.numel()))
+        quad = torch.zeros((NF, NF), dtype=torch.float64, device=self.device)
+        quad[self._iu[0], self._iu[1]] = w[1 + n:]
+        iu = torch.triu_indices(NF, NF, device=self.device)
+        pad = torch.zeros(NF - n, dtype=torch.float64, device=self.device)
+        self.coef = torch.cat([w[:1 + n], pad, quad[iu[0], iu[1]], self.centre, pad, self.inv_spread, pad]).float().contiguous()
+        self.cols_padded = torch.cat([self.cols, self.cols[:1].expand(NF - n)]).contiguous()
         n = self.wsum.clamp_min(1.0)
         self.rss = float((self.yy - 2.0 * (w @ self.r) + w @ (self.G @ w)) / n)
         self.variance = float(self.yy / n - (self.r[0] / n) ** 2)          # (feature 0 is the constant: r[0] = sum of y)
 
     def forecast(self, params: torch.Tensor) -> torch.Tensor:
-        return self.features(params) @ self.coef[:self.G.shape[0]].double()
+        return self.features(params) @ self.w
 
 
 class CostModel:
@@ -158,7 +172,8 @@ class CostModel:
         params, attempts, status = params[:MAX_FIT_ROWS], attempts[:MAX_FIT_ROWS], status[:MAX_FIT_ROWS]
         if not self._picked:                   # the one look at the data from the host (first training launch only)
             self._picked = True
-            self.variants = [v for v in self.variants if v.pick_columns(params, attempts)]
+            good = status == 0                 # (rows of failed solves may hold anything, NaN included)
+            self.variants = [v for v in self.variants if v.pick_columns(params[good], attempts[good])] if bool(good.any()) else []
             if not self.variants:
                 self.unusable = True
         if self.unusable:
@@ -184,12 +199,12 @@ class CostModel:
         keys = torch.empty(B, dtype=torch.int32, device=params_t.device)
         order = torch.empty(B, dtype=torch.int32, device=params_t.device)
         S, F = v.sym if v.sym is not None else (0, 0)
-        rc = _abi.lib().dyn_cost_order(params_t.data_ptr(), _DTYPES[params_t.dtype], B, self.P, int(v.cols.numel()),
-                                       v.cols.data_ptr(), v.coef.data_ptr(), KEY_SCALE, int(S), int(F), keys.data_ptr(),
+        rc = _abi.lib().dyn_cost_order(params_t.data_ptr(), _DTYPES[params_t.dtype], B, self.P, int(v.cols_padded.numel()),
+                                       v.cols_padded.data_ptr(), v.coef.data_ptr(), KEY_SCALE, int(S), int(F), keys.data_ptr(),
                                        order.data_ptr(), ctypes.c_void_p(stream.cuda_stream))
         if rc:
             raise RuntimeError(f"dyn_cost_order: {_abi.ERR_NAMES.get(rc, rc)}")
-        for t in (keys, order, v.cols, v.coef):
+        for t in (keys, order, v.cols_padded, v.coef):
             t.record_stream(stream)
         return order
 

@@ -382,6 +382,9 @@ int dyn_potential_combine(int64_t C, int32_t n, const double *lp, const double *
  * largest first -- which makes the forecast a symmetric function of the strains.  n_sym <= 1: parameters are read as they are.
  */
 #define DYN_MAX_COST_FEATURES 32
+/* compiled feature capacities: n_feat must be one of 4, 8, 16, 24, 32 -- pad a smaller model with repeated columns and zero
+ * coefficients / spreads (dyn_cost_order_capacity(n) = the capacity to pad n features to, -1 beyond the maximum) */
+int32_t dyn_cost_order_capacity(int32_t n_feat);
 int dyn_solve_batch_ordered(const dyn_model_desc *model, const dyn_solver_opts *opts, const void *y0, int32_t y0_is_batched,
                             const void *params, const void *contact, int64_t B, double t0, double t1, const void *save_ts,
                             int32_t n_save, const uint8_t *save_mask, void *ys_out, int32_t *status, int32_t *n_accept,

@@ -378,6 +378,7 @@ def test_step_count_forecast_features_and_fit():
     assert cm.training and not cm.ready
     cm.observe(params[:3000], steps[:3000], torch.zeros(3000, dtype=torch.int32))
     assert cm.ready and cm.cols.tolist() == [0, 1, 2, -4]                    # dyn_cost_order's encoding: -(3 + 1) = column 3, linear
+    assert cm.best.coef.numel() == (1 + 4 + 10) + 2 * 4 and cm.best.cols_padded.numel() == 4 and schedule.capacity(5) == 8
     pred = cm.forecast(params[3000:])
     assert float((pred - steps[3000:]).abs().max()) < 0.05
     # failed solves carry no weight
