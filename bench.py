@@ -208,7 +208,7 @@ def measure(wl, dev, steps: int, warmup: int, fence, train_on=None, given_order_
         return solve_batch(m, y0, params, contact, wl.t1, ts, dtype=f32, out=out, stats_out=(stats[0], stats[1], stats[2]), order=order)
 
     order_info = {"kind": "given order"}
-    if schedule.enabled() and wl.B >= schedule.MIN_BATCH:
+    if schedule.enabled() and wl.B >= schedule.MIN_BATCH and wl.B * m.state_dim >= schedule.MIN_WORK:
         schedule.reset()
         if train_on is not None:
             ty0 = torch.as_tensor(train_on.y0, dtype=f32, device=dev)
@@ -221,17 +221,8 @@ def measure(wl, dev, steps: int, warmup: int, fence, train_on=None, given_order_
         torch.cuda.synchronize()
         cm = next(iter(schedule._MODELS.values()), None)
         if cm is not None and cm.ready:
-            given = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5 if given_order_too else 0)]
-            for e0, e1 in given:
-                e0.record()
-                step(order=None)
-                e1.record()
-            torch.cuda.synchronize()
-            att = (stats[1] + stats[2]).double()
             order_info = {"kind": "step-count forecast learned from earlier launches (dynode_amd/schedule.py), forecast + sort inside the timed region",
-                          "trained_on": (f"{cm.rows} other draws of the same prior" if train_on is not None else "the warm-up launches of this batch"),
-                          "forecast_correlation_on_this_batch": float(torch.corrcoef(torch.stack([cm.forecast(params), att]))[0, 1]),
-                          "given_order_ms_per_launch": float(np.mean([e0.elapsed_time(e1) for e0, e1 in given])) if given else None}
+                          "trained_on": (f"{cm.rows} other draws of the same prior" if train_on is not None else "the warm-up launches of this batch")}
     else:
         for _ in range(warmup):
             step()
@@ -245,6 +236,18 @@ def measure(wl, dev, steps: int, warmup: int, fence, train_on=None, given_order_
     fence()
     elapsed = time.perf_counter() - t0
     kern_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev]))
+    if "trained_on" in order_info:
+        # beside it, after the timed region (clocks as warm as they were for it): the same batch in its given order
+        att = (stats[1] + stats[2]).double()
+        order_info["forecast_correlation_on_this_batch"] = float(torch.corrcoef(torch.stack([cm.forecast(params), att]))[0, 1])
+        if given_order_too:
+            given = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(min(steps, 20))]
+            for e0, e1 in given:
+                e0.record()
+                step(order=None)
+                e1.record()
+            torch.cuda.synchronize()
+            order_info["given_order_ms_per_launch"] = float(np.mean([e0.elapsed_time(e1) for e0, e1 in given]))
     return {"elapsed": elapsed, "kernel_ms": kern_ms, "out": out, "stats": stats, "kernel": kernel_name(), "dispatch_order": order_info}
 
 

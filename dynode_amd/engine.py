@@ -208,7 +208,7 @@ def solve_batch(model: ModelDesc, y0, params, contact, t1: float, save_ts, *, t0
     elif order == "auto":
         from . import schedule
 
-        if (plain and B >= schedule.MIN_BATCH and not constant_dt > 0.0 and schedule.enabled()
+        if (plain and B >= schedule.MIN_BATCH and B * D >= schedule.MIN_WORK and not constant_dt > 0.0 and schedule.enabled()
                 and not torch.cuda.is_current_stream_capturing()):
             key = (model, dtype, method, float(rtol), float(atol), float(t0), float(t1), n_save > 0, str(device))
             cost = schedule.model_for(key, P, device, schedule.strain_symmetry(model))
