@@ -32,8 +32,9 @@ from . import _abi
 TRAIN_ROWS = 32768          # trajectories observed per (model, settings) before the forecast is frozen
 MIN_ROWS_PER_FEATURE = 12   # first fit once this many rows per regression coefficient were seen
 MIN_BATCH = 1024            # smaller batches are launched in the given order ...
-MIN_WORK = 1 << 20          # ... and so are launches below this many state values (B x D): cfg 2 (4096 x 24, 0.2 ms) gains
-                            # 7 % in an isolated A/B and loses as much to the two extra launches inside a host loop
+MIN_WORK = 1 << 21          # ... and so are launches below this many state values (B x D): the two extra launches cost
+                            # ~20 us; cfg 2 (4096 x 24, 0.2 ms) and cfg 5's share (8192 x 136, 0.65 ms, one wave per SIMD)
+                            # gain less than that inside a host loop
 MAX_FIT_ROWS = 65536        # rows of one launch that enter the normal equations
 KEY_SCALE = 4.0             # buckets per predicted step attempt (4096 buckets: up to 1024 attempts)
 RIDGE = 1e-4

@@ -240,11 +240,11 @@ def test_learned_dispatch_order():
     from dynode_amd import schedule
 
     schedule.reset()
-    big = synthetic.seirs_multi_strain(16384, seed=21)
-    m, half = big.model, 8192            # 8192 x 136 state values: above schedule.MIN_WORK
+    big = synthetic.seirs_multi_strain(32768, seed=21)
+    m, half = big.model, 16384           # 16384 x 136 state values: above schedule.MIN_WORK
     train = (m, big.y0[:half], big.params[:half], big.contact, big.t1, big.save_ts[::73])
     test = (m, big.y0[half:], big.params[half:], big.contact, big.t1, big.save_ts[::73])
-    first = solve_batch(*train, dtype=F32)                      # trains (8192 rows >= 12 per coefficient)
+    first = solve_batch(*train, dtype=F32)                      # trains (16384 rows >= 12 per coefficient)
     (cm,) = schedule._MODELS.values()
     assert cm.ready and int(cm.cols.numel()) == 16 and bool((cm.cols >= 0).all())      # 16 rates, all as logarithms
     assert cm.best.sym == (4, 4)                                # exchangeable strains: the canonical labelling forecasts better
