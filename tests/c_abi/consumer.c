@@ -6,6 +6,7 @@
  *        -L<repo>/dynode_amd/lib -ldynode_hip -L/opt/rocm/lib -lamdhip64 -o consumer */
 #include <hip/hip_runtime_api.h>
 #include <stdio.h>
+#include <string.h>
 #include <stdlib.h>
 
 #include "dynode_hip.h"
@@ -49,6 +50,23 @@ int main(void) {
     for (int b = 0; b < B; ++b) {
         printf("traj %d status %d accepted %d rejected %d\n", b, stat[0][b], stat[1][b], stat[2][b]);
         for (int j = 0; j < NSAVE; j += 10) printf("%d %d %.17g %.17g %.17g\n", b, j, out[b][j][0], out[b][j][1], out[b][j][2]);
+    }
+    /* the same batch dispatched in reverse order (dyn_solve_batch_ordered): every byte of the output must be the same */
+    {
+        int32_t order[B], *d_order;
+        void *d_out2;
+        static double out2[B][NSAVE][D];
+        for (int b = 0; b < B; ++b) order[b] = B - 1 - b;
+        CHECK(hipMalloc((void **)&d_order, sizeof order));
+        CHECK(hipMalloc(&d_out2, sizeof out2));
+        CHECK(hipMemcpy(d_order, order, sizeof order, hipMemcpyHostToDevice));
+        rc = dyn_solve_batch_ordered(&m, &o, d_y0, 0, d_p, d_c, B, 0.0, 50.0, d_ts, NSAVE, NULL, d_out2, d_stat, d_stat + B,
+                                     d_stat + 2 * B, d_order, NULL);
+        if (rc) { fprintf(stderr, "dyn_solve_batch_ordered: %d (%s)\n", rc, dyn_last_error()); return 6; }
+        CHECK(hipDeviceSynchronize());
+        CHECK(hipMemcpy(out2, d_out2, sizeof out2, hipMemcpyDeviceToHost));
+        if (memcmp(out, out2, sizeof out) != 0) { fprintf(stderr, "ordered dispatch changed the output\n"); return 7; }
+        printf("ordered dispatch identical\n");
     }
     /* an unsupported request comes back as an error code and a message, never as a crash */
     m.n_strain = 7;

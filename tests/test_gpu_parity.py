@@ -260,6 +260,11 @@ def test_learned_dispatch_order():
     assert torch.equal(torch.sort(order.long()).values, torch.arange(half, device="cuda"))       # a permutation
     f_sorted = forecast[order.long()]
     assert float((f_sorted[1:] - f_sorted[:-1]).max()) <= 1.0 / schedule.KEY_SCALE + 1e-3        # descending up to one bucket
+    order64 = cm.order(p_test.double(), torch.cuda.current_stream())       # float64 parameter rows take the same kernel
+    torch.cuda.synchronize()
+    assert torch.equal(torch.sort(order64.long()).values, torch.arange(half, device="cuda"))
+    f64_sorted = forecast[order64.long()]
+    assert float((f64_sorted[1:] - f64_sorted[:-1]).max()) <= 1.0 / schedule.KEY_SCALE + 1e-3
     auto = solve_batch(*test, dtype=F32)                        # ordered by the forecast
     for a, b in ((auto.ys, plain.ys), (auto.n_accept, plain.n_accept), (auto.n_reject, plain.n_reject), (auto.status, plain.status)):
         assert torch.equal(a, b)
@@ -607,7 +612,8 @@ def test_c_consumer_of_the_abi(tmp_path):
     run = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert run.returncode == 0, run.stderr
     lines = run.stdout.strip().splitlines()
-    assert lines[-1] == "unsupported rc -7"
+    assert lines[-1] == "unsupported rc -7" and lines[-2] == "ordered dispatch identical"       # dyn_solve_batch_ordered, reversed batch
+    lines = lines[:-1]
     B, ts = 5, np.arange(51.0)
     p = np.array([[(2.0 + 0.1 * b) / 7.0, 1.0 / 7.0] for b in range(B)])
     want, st, na, nr = O.solve(H.omodel(ModelDesc(n_age=1)), np.array([0.9, 0.1, 0.0]), p, np.ones((1, 1)), 50.0, ts, dtype=np.float64)
