@@ -55,6 +55,7 @@ struct Entry {
 constexpr int kSeip = 0x100;
 constexpr int kSeipTierLanes = 0x20; // SEIP entry with the tiers dealt over two lanes (seip_kernel.hpp, KT = 2)
 constexpr int kSeipWaves2 = 0x40, kSeipWaves4 = 0x80; // ... whose trajectory is owned by a workgroup of 2 / 4 waves (NW)
+constexpr int kSeipTierWaves = 0x200; // ... or one tier per tier lane with whole waves as tier lanes: KT = K1, NW = K1 x (lanes / 64)
 // FEAT bit 14 (solve_kernel.hpp SAVE_ALL): variant without the per-round save-offset / store-width tests, picked by
 // enqueue when every compartment is saved into 16-byte aligned rows
 constexpr int kSaveAll = 0x4000;
@@ -84,7 +85,7 @@ static const Entry kEntries[] = {
      (void *)(hipError_t(*)(const KArgs<T> &, hipStream_t)) & launch_seip<T, METHOD, GA, L, K1, M1, 2>},
 #define YW(T, METHOD, GA, L, K1, M1, KT, NW)                                                                     \
     {DType<T>::id, METHOD, GA, L, 1, 1, 1, M1, 0, 1,                                                             \
-     kSeip | (KT == 2 ? kSeipTierLanes : 0) | (NW == 2 ? kSeipWaves2 : kSeipWaves4) | K1,                        \
+     kSeip | (KT > 2 ? kSeipTierWaves : ((KT == 2 ? kSeipTierLanes : 0) | (NW == 2 ? kSeipWaves2 : kSeipWaves4))) | K1, \
      (void *)(hipError_t(*)(const KArgs<T> &, hipStream_t)) & launch_seip<T, METHOD, GA, L, K1, M1, KT, NW>},
 #include "seip_instances.def"
 #undef YW
@@ -115,7 +116,12 @@ static int model_features(const dyn_model_desc *m) {
     return (m->has_intro ? 1 : 0) | (vax_lanes(m) << 1);
 }
 // lanes one trajectory occupies in a wave
-static int entry_waves(const Entry *e) { return (e->FEAT & kSeip) ? ((e->FEAT & kSeipWaves4) ? 4 : (e->FEAT & kSeipWaves2) ? 2 : 1) : 1; }
+static int entry_waves(const Entry *e) {
+    if (!(e->FEAT & kSeip)) return 1;
+    if (e->FEAT & kSeipTierWaves) return (e->FEAT & 0x1f) * (((e->G << e->S) + 63) / 64);
+    return (e->FEAT & kSeipWaves4) ? 4 : (e->FEAT & kSeipWaves2) ? 2 : 1;
+}
+static int entry_tier_lanes(const Entry *e) { return (e->FEAT & kSeipTierWaves) ? (e->FEAT & 0x1f) : (e->FEAT & kSeipTierLanes) ? 2 : 1; }
 // lanes of a WAVE one trajectory occupies (a wave group owns whole waves: 64)
 static int entry_lanes(const Entry *e) {
     if ((e->FEAT & kSeip) && entry_waves(e) > 1) return 64;
@@ -174,6 +180,13 @@ static const Entry *select_seip_entry(const dyn_model_desc *m, int dtype, int me
     const int k1 = seip_tiers(m), lanes = group_width(m->n_age) << m->n_strain;
     const int per_tier = m->n_wane + 3 * m->n_strain, per_lane = k1 * per_tier;
     const char *force = getenv("DYNODE_HIP_SEIP_TIER_LANES"); // tuning aid: 0 / 1
+    // one tier per wave (K1 >= 3 tiers, a wavefront or more per tier): a third to a half of the state per lane, no padded tier
+    // slot, two to three waves per SIMD instead of one -- measured on D = 2496: see DESIGN.md
+    const char *tw_env = getenv("DYNODE_HIP_SEIP_TIER_WAVES"); // tuning aid: 0 switches the mapping off
+    if (lanes >= 64 && !(tw_env && atoi(tw_env) == 0)) {
+        const Entry *tw = find_variant(&probe, kSeip | kSeipTierWaves | k1);
+        if (tw) return tw;
+    }
     if (lanes > 64) { // histories across waves: tier lanes on top (four waves) for big per-lane states, else two waves
         const Entry *w2 = find_variant(&probe, kSeip | kSeipWaves2 | k1);
         const Entry *w4 = find_variant(&probe, kSeip | kSeipTierLanes | kSeipWaves4 | k1);
@@ -201,7 +214,7 @@ static thread_local char tl_kernel[160] = "";
 static void note_kernel(const Entry *e) {
     const char *t = e->dtype == DYN_F64 ? "double" : "float";
     if (e->FEAT & kSeip) {
-        const int k1 = e->FEAT & 0x1f, kt = (e->FEAT & kSeipTierLanes) ? 2 : 1;
+        const int k1 = e->FEAT & 0x1f, kt = entry_tier_lanes(e);
         const int nv = ((k1 + kt - 1) / kt) * (e->W + 3 * e->S);
         if (entry_waves(e) > 1)
             snprintf(tl_kernel, sizeof(tl_kernel), "dyn::seip_kernel_wave_group<%s, %d, %d, %d, %d, %d, %d, %d>", t, e->method, e->G,
@@ -522,7 +535,7 @@ static int solve_impl(const dyn_model_desc *m, const dyn_solver_opts *o, const v
         const size_t per_traj = (size_t)(1 << m->n_strain) * dyn::seip_tiers(m) * m->n_wane * m->n_strain +
                                 (size_t)m->n_age * dyn::seip_tiers(m) * (4 + 2 * m->n_vax_knots) +
                                 (sc && sc->in ? (size_t)2 * sc->cap : 0); /* replayed schedule */
-        const int nw = dyn::entry_waves(e), kl = (dyn::seip_tiers(m) + ((e->FEAT & dyn::kSeipTierLanes) ? 1 : 0)) / ((e->FEAT & dyn::kSeipTierLanes) ? 2 : 1);
+        const int nw = dyn::entry_waves(e), ktl = dyn::entry_tier_lanes(e), kl = (dyn::seip_tiers(m) + ktl - 1) / ktl;
         const size_t mailbox = nw > 1 ? (size_t)2 * nw * 64 * (m->n_strain + kl * 4 + m->n_wane + 2 * m->n_strain) : 0; /* >= 2 NW NSLOT 64 */
         const size_t bytes = ((size_t)n_save + dyn::kMaxJumps + (64 / dyn::entry_lanes(e)) * per_traj + mailbox) * (o->dtype == DYN_F64 ? 8 : 4);
         const size_t limit = nw > 1 ? 160 * 1024 : 64 * 1024; /* a wave group is alone (or two) on its CU */

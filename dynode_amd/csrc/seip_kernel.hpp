@@ -17,6 +17,9 @@
 #pragma once
 #include "solve_kernel.hpp"
 
+#ifndef DYN_SEIP_CACHE_TW
+#define DYN_SEIP_CACHE_TW 1
+#endif
 #ifndef DYN_SEIP_CACHE_SUS
 #define DYN_SEIP_CACHE_SUS 1
 #endif
@@ -26,6 +29,9 @@ namespace dyn {
 // history bits, tier k on lane k % 2, slot k / 2 -- so a lane holds ceil(K1 / 2) * (M1 + 3 L) values instead of
 // K1 * (M1 + 3 L): three strains x three tiers no longer spill.  Every tier-to-tier flow (vaccination k -> k + 1, the
 // seasonal reset K -> K - 1) then crosses to the partner lane with one xor exchange.
+// KT = K1 = 3, 4 ("one tier per wave"): when an (age, history) plane already fills a wavefront (8 ages x 8 histories), every
+// tier gets its own wave(s) and a lane holds ONE tier: M1 + 3 L values (13 for the D = 2496 model against 26 with two tier
+// lanes), no padded tier slot, and 2 waves per SIMD instead of 1.  Measured on D = 2496: 21.2 -> 16.0 ms per 4096 trajectories.
 // NW > 1 ("wave groups"): a trajectory whose G = GA * H * KT lanes exceed a wavefront is owned by a WORKGROUP of NW = G / 64
 // waves (one trajectory per workgroup).  The lane bits above 64 -- the top immune-history bit(s) and / or the tier-lane
 // bit -- select the wave; what crossed lanes with an xor exchange crosses waves through a small LDS mailbox, with ONE
@@ -34,8 +40,10 @@ namespace dyn {
 template <typename T, int METHOD, int GA, int L, int K1, int M1, int KT = 1, int NW = 1>
 struct Seip {
     static constexpr int H = 1 << L, G = GA * H * KT, TPW = NW > 1 ? 1 : 64 / G, K = K1 - 1;
-    static_assert((NW == 1 ? G <= 64 : G == 64 * NW) && L >= 1 && L <= 4 && K1 >= 1 && K1 <= 4 && M1 >= 1 && (KT == 1 || KT == 2) &&
-                  (NW == 1 || NW == 2 || NW == 4), "SEIP lane group");
+    static_assert((NW == 1 ? G <= 64 : G == 64 * NW) && L >= 1 && L <= 4 && K1 >= 1 && K1 <= 4 && M1 >= 1 && KT >= 1 && KT <= 4 &&
+                  NW >= 1 && NW <= 8, "SEIP lane group");
+    // KT = 3, 4: one tier per tier lane (KT = K1), and the tier lanes are whole waves (below: TIER_X)
+    static_assert(KT <= 2 || (KT == K1 && GA * H >= 64 && NW > 1), "SEIP: more than two tier lanes only as one tier per wave");
     static constexpr int KL = (K1 + KT - 1) / KT; // tier slots per lane
     static constexpr int NS = KL * M1, NE = KL * L, NV = NS + 3 * NE;
     static constexpr int IE = NS, II = NS + NE, IC = NS + 2 * NE;
@@ -53,9 +61,9 @@ struct Seip {
     static constexpr int LOGA = GA == 1 ? 0 : GA == 2 ? 1 : GA == 4 ? 2 : GA == 8 ? 3 : GA == 16 ? 4 : GA == 32 ? 5 : 6;
     static constexpr int HB_IN = (6 - LOGA) < L ? (6 - LOGA) : L;   // immune-history bits inside a wave
     static constexpr int HB_X = L - HB_IN;                           // ... selecting the wave (low wave bits)
-    static constexpr bool TIER_X = KT == 2 && GA * H >= 64;          // the tier-lane bit selects the wave (the top wave bit)
+    static constexpr bool TIER_X = KT >= 2 && GA * H >= 64;          // the tier lane selects the wave (the top wave bits)
     static constexpr int NXH = 1 << HB_X;                            // waves that differ in history bits only
-    static_assert(NW == 1 || NW == NXH * (TIER_X ? 2 : 1), "SEIP wave group: NW = 2^(cross-wave history bits) * (cross-wave tier lane ? 2 : 1)");
+    static_assert(NW == 1 || NW == NXH * (TIER_X ? KT : 1), "SEIP wave group: NW = 2^(cross-wave history bits) * (tier lanes across waves)");
     // mailbox slots of one round: infectious sums [L], tier totals [KL], recovery partners [HB_X][KL], tier flow [KL],
     // seasonal fall-back of the top tier [M1 + 2 L]
     static constexpr int NSLOT = L + (K1 + KT - 1) / KT * (2 + HB_X) + M1 + 2 * L;
@@ -100,7 +108,7 @@ struct Seip {
     // ... and a copy in registers of the rows this lane multiplies by in EVERY right-hand side (its tiers x waning states x
     // strains), where the register file has the room: the LDS reads sit behind the mailbox writes of a wave group (nothing
     // hoists them), and with one wave per SIMD nobody hides their latency
-    static constexpr bool CACHE_SUS = DYN_SEIP_CACHE_SUS && NW == 2 && (9 * NV + KL * (M1 * L + 12) + 70) * (int)(sizeof(T) / 4) <= 500;
+    static constexpr bool CACHE_SUS = DYN_SEIP_CACHE_SUS && (NW == 2 || (KT > 2 && NW == 3 && DYN_SEIP_CACHE_TW)) && (9 * NV + KL * (M1 * L + 12) + 70) * (int)(sizeof(T) / 4) <= 500;
     T susr[CACHE_SUS ? KL * M1 * L : 1];
     T splr[CACHE_SUS ? KL * 12 : 1];   // per slot: the cubic's 4 coefficients, 4 knots, 4 knot coefficients (0 beyond nk)
     // nu(t) of one dose tier: cubic + truncated-power terms (reference utils/splines.py:10-109 conditional_knots), from the LDS
@@ -492,8 +500,10 @@ struct Seip {
         T up[KL];   // arrivals from the tier below, per slot
 #pragma unroll
         for (int sl = 0; sl < KL; ++sl) up[sl] = T(0);
-        if constexpr (KT == 2) {
+        if constexpr (KT >= 2) {
             T got[KL];
+            // the tier lane below this one (cyclically): its wave, same history waves
+            const int src_wave = TIER_X ? ((((tlw + KT - 1) % KT) << HB_X) | hw) : 0;
             if constexpr (TIER_X && HB_X > 0) { // second round: the flows could only be formed now
                 const int b2 = xbuf;
                 xbuf ^= 1;
@@ -501,15 +511,15 @@ struct Seip {
                 for (int sl = 0; sl < KL; ++sl) *xslot(b2, wv, 0 + sl) = (sl * KT + tl == K) ? T(0) : rate[sl] * totl[sl];
                 __syncthreads();
 #pragma unroll
-                for (int sl = 0; sl < KL; ++sl) got[sl] = *xslot(b2, wv ^ NXH, sl);
+                for (int sl = 0; sl < KL; ++sl) got[sl] = *xslot(b2, src_wave, sl);
             } else if constexpr (TIER_X) {
 #pragma unroll
-                for (int sl = 0; sl < KL; ++sl) got[sl] = *xslot(b, wv ^ NXH, S_SEND + sl);
+                for (int sl = 0; sl < KL; ++sl) got[sl] = *xslot(b, src_wave, S_SEND + sl);
             } else {
 #pragma unroll
                 for (int sl = 0; sl < KL; ++sl) got[sl] = xchg_xor<GA * H>((sl * KT + tl == K) ? T(0) : rate[sl] * totl[sl]);
             }
-            // tier 2 s (lane 0) -> 2 s + 1 (lane 1, same slot); tier 2 s + 1 (lane 1) -> 2 s + 2 (lane 0, next slot)
+            // tier s KT + tl - 1 (the lane below, same slot) -> s KT + tl; the last lane's tier -> lane 0 of the next slot
 #pragma unroll
             for (int sl = 0; sl < KL; ++sl) {
                 up[sl] += tl ? got[sl] : T(0);
@@ -590,15 +600,19 @@ struct Seip {
                         dy[II + (K - 1) * L + l] += fi;
                     }
                 } else {
-                    const bool holder = tl == tK;
+                    // the lane of tier K offers, the lane of tier K - 1 takes (with two tier lanes: the other one)
+                    constexpr int tR = (K - 1) % KT;
+                    const bool holder = tl == tK, taker = tl == tR;
+                    const int holder_wave = TIER_X ? ((tK << HB_X) | hw) : 0;
+                    (void)holder_wave;
 #pragma unroll
                     for (int m = 0; m < M1; ++m) {
                         const T f = holder ? phi * y[sK * M1 + m] : T(0);
                         dy[sK * M1 + m] -= f;
                         T got;
-                        if constexpr (TIER_X) got = *xslot(b, wv ^ NXH, S_SV + m);
+                        if constexpr (TIER_X) got = *xslot(b, holder_wave, S_SV + m);
                         else got = xchg_xor<GA * H>(f);
-                        dy[sD * M1 + m] += holder ? T(0) : got;
+                        dy[sD * M1 + m] += taker ? got : T(0);
                     }
 #pragma unroll
                     for (int l = 0; l < L; ++l) {
@@ -607,14 +621,14 @@ struct Seip {
                         dy[II + sK * L + l] -= fi;
                         T ge, gi;
                         if constexpr (TIER_X) {
-                            ge = *xslot(b, wv ^ NXH, S_SV + M1 + l);
-                            gi = *xslot(b, wv ^ NXH, S_SV + M1 + L + l);
+                            ge = *xslot(b, holder_wave, S_SV + M1 + l);
+                            gi = *xslot(b, holder_wave, S_SV + M1 + L + l);
                         } else {
                             ge = xchg_xor<GA * H>(fe);
                             gi = xchg_xor<GA * H>(fi);
                         }
-                        dy[IE + sD * L + l] += holder ? T(0) : ge;
-                        dy[II + sD * L + l] += holder ? T(0) : gi;
+                        dy[IE + sD * L + l] += taker ? ge : T(0);
+                        dy[II + sD * L + l] += taker ? gi : T(0);
                     }
                 }
             }

@@ -161,13 +161,16 @@ WAVE_GROUP_SHAPES = [
     dict(A=8, L=4, K1=2, M1=2, n_knots=1, seasonal_vax=True),                   # four waves: histories and tier lanes across waves
     dict(A=8, L=4, K1=3, M1=4, n_knots=2, seasonal=True, seasonal_vax=True),    # D = 6144, the 8-age x 4-strain model
     dict(A=6, L=4, K1=2, M1=4, n_knots=1, seasonal_vax=True),                   # two waves, both tiers in one lane (float32)
+    dict(A=8, L=3, K1=3, M1=2, n_knots=1, seasonal=True, seasonal_vax=True),    # one tier per wave: three waves (float64 twin)
+    dict(A=8, L=4, K1=3, M1=1, n_knots=1, seasonal_vax=True, intro=True),       # ... with 16 histories: six waves (float64 twin)
 ]
 
 GPU_CASES = [(SHAPES[0], "f64", "tsit5"), (SHAPES[1], "f64", "tsit5"), (SHAPES[1], "f64", "dopri5"), (SHAPES[4], "f64", "tsit5"),
              (SHAPES[0], "f32", "tsit5"), (SHAPES[1], "f32", "dopri5"), (SHAPES[2], "f32", "tsit5"), (SHAPES[3], "f32", "tsit5"),
              (SHAPES[3], "f32", "dopri5"), (SHAPES[4], "f32", "tsit5"), (SHAPES[5], "f64", "tsit5"), (SHAPES[6], "f32", "tsit5"),
              (WAVE_GROUP_SHAPES[0], "f64", "tsit5"), (WAVE_GROUP_SHAPES[1], "f32", "tsit5"), (WAVE_GROUP_SHAPES[2], "f64", "tsit5"),
-             (WAVE_GROUP_SHAPES[3], "f64", "tsit5"), (WAVE_GROUP_SHAPES[4], "f32", "tsit5"), (WAVE_GROUP_SHAPES[5], "f32", "tsit5")]
+             (WAVE_GROUP_SHAPES[3], "f64", "tsit5"), (WAVE_GROUP_SHAPES[4], "f32", "tsit5"), (WAVE_GROUP_SHAPES[5], "f32", "tsit5"),
+             (WAVE_GROUP_SHAPES[6], "f64", "tsit5"), (WAVE_GROUP_SHAPES[7], "f64", "tsit5")]
 
 
 @pytest.mark.gpu
@@ -549,3 +552,27 @@ def test_wave_groups_dispatch_sub_save_jumps_and_replay():
     steps, count = full.schedule
     rep = solve_batch(m, wl.y0, wl.params, wl.contact, 120.0, ts, dtype=torch.float64, replay=(steps, count, None))
     assert torch.equal(rep.ys, full.ys) and torch.equal(rep.n_accept, full.n_accept)           # the jumps are part of the recording
+
+
+@pytest.mark.gpu
+def test_one_tier_per_wave_and_tier_lanes_are_the_same_model(monkeypatch):
+    """8 ages x 3 strains x 3 tiers (D = 2496) has two lane mappings: two waves with the tiers dealt over two lanes and two
+    slots per lane (`KT = 2`), and three waves with one tier each (`KT = K1 = 3`, the default).  Same right-hand side: under a
+    constant step both agree with the oracle to float32 rounding, and adaptively with each other to the tolerance."""
+    import torch
+    from dynode_amd import _abi
+    from dynode_amd.engine import solve_batch
+
+    wl = synthetic.seip(B=6, seed=41, t1=120.0, **WAVE_GROUP_SHAPES[1])
+    m, ts = wl.model, synthetic.save_grid(120.0)
+    want, st, _, _ = O.solve(H.omodel(m), wl.y0, wl.params, wl.contact, 120.0, ts, dtype=np.float32, n_threads=8, constant_dt=0.5)
+    got = {}
+    for flag, name in (("1", "dyn::seip_kernel_wave_group<float, 0, 8, 3, 3, 4, 3, 3>"), ("0", "dyn::seip_kernel_wave_group<float, 0, 8, 3, 3, 4, 2, 2>")):
+        monkeypatch.setenv("DYNODE_HIP_SEIP_TIER_WAVES", flag)
+        rc = solve_batch(m, wl.y0, wl.params, wl.contact, 120.0, ts, constant_dt=0.5)
+        assert _abi.lib().dyn_last_kernel_name().decode() == name
+        assert int(rc.status.max()) == 0 and np.abs(rc.ys.cpu().numpy() - want).max() / 1000.0 < 2e-5
+        got[flag] = solve_batch(m, wl.y0, wl.params, wl.contact, 120.0, ts)
+        assert int(got[flag].status.max()) == 0
+    assert float((got["1"].ys - got["0"].ys).abs().max()) / 1000.0 < 2e-4
+    assert int((got["1"].n_accept + got["1"].n_reject - got["0"].n_accept - got["0"].n_reject).abs().max()) <= 8
