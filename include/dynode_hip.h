@@ -93,9 +93,13 @@ extern "C" {
  *         the m' = 0 term of ode_model.md's top-tier gain has no matching loss and is dropped, so people are conserved
  *     seasonal vaccination (seasonal_vax)   phi(t) = sin(2 pi (t + tau) / 730)^1000 moves s, e, i of tier K to K - 1
  *         (ode_model.md:70-84; applied at all times -- the power makes it vanish outside the yearly window)
- * Limits: group_width(n_age) * 2^n_strain <= 64 lanes (one trajectory must fit a wavefront), n_strain <= 4, tiers <= 4;
- * all solver options of dyn_solve_batch apply (both methods, constant steps, discontinuity points, sub-save masks);
- * dyn_solve_batch_jvp / _loglik return DYN_ERR_UNSUPPORTED for this family (no tangent planes yet).
+ * Limits: group_width(n_age) * 2^n_strain <= 128 lanes, n_strain <= 4, tiers <= 4.  A trajectory is one lane group of a
+ * wavefront when it fits (optionally with the tiers dealt over two lanes), else a workgroup of 2..6 waves with the cross-wave
+ * sums through LDS ("wave groups": 8 ages x 3 strains x 3 tiers = three waves of one tier each, D = 2496; 8 x 4 x 3 = six
+ * waves, D = 6144) -- which mapping runs is the library's choice among the compiled instances (dyn_last_kernel_name).
+ * All solver options of dyn_solve_batch apply (both methods, constant steps, discontinuity points, sub-save masks).
+ * dyn_solve_batch_jvp / _loglik return DYN_ERR_UNSUPPORTED for this family (its kernels carry no tangent planes): gradients
+ * come from dyn_solve_batch_record + dyn_solve_batch_replay (central differences on the recorded step sequence, below).
  */
 #define DYN_MAX_STRAINS 8
 typedef struct dyn_model_desc {
@@ -111,7 +115,7 @@ typedef struct dyn_model_desc {
     int32_t n_vax_tiers; /* ABI 3: 0/1 = no vaccination axis; 2..4 = tracked dose counts (see above) */
     uint64_t intro_age_mask[DYN_MAX_STRAINS]; /* per strain: bit a = age bin a receives introductions */
     int32_t n_vax_knots; /* knots of the vaccination-rate splines, 0..4 */
-    int32_t family;       /* ABI 4: 0 = the s/e/i/r/c family, 1 = SEIP (see above; n_strain <= 3, n_age * 2^n_strain <= 64) */
+    int32_t family;       /* ABI 4: 0 = the s/e/i/r/c family, 1 = SEIP (see above; n_strain <= 4, group_width(n_age) * 2^n_strain <= 128) */
     int32_t seasonal_vax; /* ABI 4, SEIP only */
     int32_t reserved;
 } dyn_model_desc;
