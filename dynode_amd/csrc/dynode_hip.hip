@@ -124,6 +124,7 @@ static int entry_waves(const Entry *e) {
 static int entry_tier_lanes(const Entry *e) { return (e->FEAT & kSeipTierWaves) ? (e->FEAT & 0x1f) : (e->FEAT & kSeipTierLanes) ? 2 : 1; }
 // lanes of a WAVE one trajectory occupies (a wave group owns whole waves: 64)
 static int entry_lanes(const Entry *e) {
+    if ((e->FEAT & kSeip) && (e->FEAT & kSeipTierWaves) && (e->G << e->S) < 64) return e->G << e->S; // packed: planes side by side
     if ((e->FEAT & kSeip) && entry_waves(e) > 1) return 64;
     return (e->FEAT & kSeip) ? (e->G << e->S) * ((e->FEAT & kSeipTierLanes) ? 2 : 1) : e->G * (e->S / e->SPL);
 }
@@ -183,7 +184,7 @@ static const Entry *select_seip_entry(const dyn_model_desc *m, int dtype, int me
     // one tier per wave (K1 >= 3 tiers, a wavefront or more per tier): a third to a half of the state per lane, no padded tier
     // slot, two to three waves per SIMD instead of one -- measured on D = 2496: see DESIGN.md
     const char *tw_env = getenv("DYNODE_HIP_SEIP_TIER_WAVES"); // tuning aid: 0 switches the mapping off
-    if (lanes >= 64 && !(tw_env && atoi(tw_env) == 0)) {
+    if (!(tw_env && atoi(tw_env) == 0)) {
         const Entry *tw = find_variant(&probe, kSeip | kSeipTierWaves | k1);
         if (tw) return tw;
     }

@@ -39,11 +39,16 @@ namespace dyn {
 // norm takes one more per step.  All waves of a trajectory see bit-identical norms, so their control flow is identical.
 template <typename T, int METHOD, int GA, int L, int K1, int M1, int KT = 1, int NW = 1>
 struct Seip {
-    static constexpr int H = 1 << L, G = GA * H * KT, TPW = NW > 1 ? 1 : 64 / G, K = K1 - 1;
-    static_assert((NW == 1 ? G <= 64 : G == 64 * NW) && L >= 1 && L <= 4 && K1 >= 1 && K1 <= 4 && M1 >= 1 && KT >= 1 && KT <= 4 &&
-                  NW >= 1 && NW <= 8, "SEIP lane group");
+    static constexpr int H = 1 << L, G = GA * H * KT, K = K1 - 1;
+    // one tier per wave with an (age, history) plane smaller than a wavefront: the planes of 64 / (GA H) trajectories sit side
+    // by side in every wave of the group ("packed": 4 ages x 8 histories = 32 lanes, two trajectories per group of three waves)
+    static constexpr bool PACKED = KT > 2 && GA * H < 64;
+    static constexpr int GWL = PACKED ? GA * H : (NW > 1 ? 64 : G);    // lanes of ONE wave that belong to one trajectory
+    static constexpr int TPW = PACKED ? 64 / GWL : (NW > 1 ? 1 : 64 / G);
+    static_assert((NW == 1 ? G <= 64 : (PACKED || G == 64 * NW)) && L >= 1 && L <= 4 && K1 >= 1 && K1 <= 4 && M1 >= 1 && KT >= 1 &&
+                  KT <= 4 && NW >= 1 && NW <= 8, "SEIP lane group");
     // KT = 3, 4: one tier per tier lane (KT = K1), and the tier lanes are whole waves (below: TIER_X)
-    static_assert(KT <= 2 || (KT == K1 && GA * H >= 64 && NW > 1), "SEIP: more than two tier lanes only as one tier per wave");
+    static_assert(KT <= 2 || (KT == K1 && NW > 1), "SEIP: more than two tier lanes only as one tier per wave");
     static constexpr int KL = (K1 + KT - 1) / KT; // tier slots per lane
     static constexpr int NS = KL * M1, NE = KL * L, NV = NS + 3 * NE;
     static constexpr int IE = NS, II = NS + NE, IC = NS + 2 * NE;
@@ -61,7 +66,7 @@ struct Seip {
     static constexpr int LOGA = GA == 1 ? 0 : GA == 2 ? 1 : GA == 4 ? 2 : GA == 8 ? 3 : GA == 16 ? 4 : GA == 32 ? 5 : 6;
     static constexpr int HB_IN = (6 - LOGA) < L ? (6 - LOGA) : L;   // immune-history bits inside a wave
     static constexpr int HB_X = L - HB_IN;                           // ... selecting the wave (low wave bits)
-    static constexpr bool TIER_X = KT >= 2 && GA * H >= 64;          // the tier lane selects the wave (the top wave bits)
+    static constexpr bool TIER_X = KT >= 2 && (GA * H >= 64 || PACKED); // the tier lane selects the wave (the top wave bits)
     static constexpr int NXH = 1 << HB_X;                            // waves that differ in history bits only
     static_assert(NW == 1 || NW == NXH * (TIER_X ? KT : 1), "SEIP wave group: NW = 2^(cross-wave history bits) * (tier lanes across waves)");
     // mailbox slots of one round: infectious sums [L], tier totals [KL], recovery partners [HB_X][KL], tier flow [KL],
@@ -89,14 +94,16 @@ struct Seip {
     }
     // any lane of any wave of the trajectory has `flag` set
     __device__ __forceinline__ bool wg_any(bool flag) const {
-        const bool mine = __any(flag);
+        const int grp_in_wave = GWL >= 64 ? 0 : (int)(threadIdx.x & 63) / GWL;
+        const unsigned long long mask = (GWL >= 64 ? ~0ull : ((1ull << (GWL & 63)) - 1ull)) << (grp_in_wave * (GWL & 63));
+        const bool mine = (__ballot(flag) & mask) != 0ull;   // this trajectory's lanes of this wave
         if constexpr (NW == 1) return mine;
         else return wg_sum(mine ? T(1) : T(0)) > T(0);
     }
     // sum over the lanes of a trajectory
     __device__ __forceinline__ T traj_sum(T v) const {
         if constexpr (NW == 1) return group_sum<G>(v);
-        else return wg_sum(group_sum<64>(v));
+        else return wg_sum(group_sum<GWL>(v));
     }
 
     T beta[L], gamma[L], sigma[L], omega[M1];
@@ -702,8 +709,11 @@ struct Seip {
     __device__ __forceinline__ static void run(const KArgs<T> &ka) {
         const int lane = threadIdx.x & 63;
         // position inside the trajectory's lane group: the lane itself, or (NW > 1) wave * 64 + lane of the workgroup
-        const int tlane = NW > 1 ? (int)threadIdx.x : lane;
-        const int a = tlane % GA, j = (tlane / GA) % H, tl = (tlane / (GA * H)) % KT, grp = NW > 1 ? 0 : lane / G;
+        const int wtid = NW > 1 ? (int)threadIdx.x : lane;          // index inside the workgroup (cooperative table loads)
+        const int tlane = PACKED ? lane : wtid;
+        const int a = tlane % GA, j = (tlane / GA) % H, tl = PACKED ? (int)(threadIdx.x >> 6) : (tlane / (GA * H)) % KT;
+        const int grp = PACKED ? lane / GWL : (NW > 1 ? 0 : lane / G);
+        const int tidx = PACKED ? tl * GWL + lane % GWL : tlane % G;   // index among the G lanes of this trajectory
         int64_t traj = (int64_t)blockIdx.x * TPW + grp;
         bool valid_traj = traj < ka.B;
         if (!valid_traj) traj = ka.B - 1;
@@ -766,22 +776,23 @@ struct Seip {
                 S.iamp[l] = here ? intro_p[2 * L + l] / (scale * T(2.5066282746310002)) * S.pop : T(0);
             }
         }
-        for (int n = tlane; n < n_save; n += 64 * NW) ts_tab[n] = ka.save_ts[n];
-        for (int n = tlane % G; n < SUSN + spln; n += G) tab[n] = q[n];
-        if (n_jump > 0 && tlane < kMaxJumps) jt_tab[tlane] = ka.jump_ts[tlane];
+        for (int n = wtid; n < n_save; n += 64 * NW) ts_tab[n] = ka.save_ts[n];
+        for (int n = tidx; n < SUSN + spln; n += G) tab[n] = q[n];
+        if (n_jump > 0 && wtid < kMaxJumps) jt_tab[wtid] = ka.jump_ts[wtid];
         // replay: the (t_prev, t_next) pairs this trajectory must take, staged in LDS behind the tables (a global load
         // inside the stepping loop would wait for every store issued before it: the loads and stores share vmcnt)
         const bool replay = ka.sched_in != nullptr;
-        T *const sch = jt_tab + (n_jump > 0 ? kMaxJumps : 0) + TPW * (SUSN + spln) + grp * (2 * ka.sched_cap);
+        T *const sch_base = jt_tab + (n_jump > 0 ? kMaxJumps : 0) + TPW * (SUSN + spln);
+        T *const sch = sch_base + grp * (2 * ka.sched_cap);
         int n_sch = 0;
         if (replay) {
             const int64_t lead = ka.sched_leader ? ka.sched_leader[traj] : traj;
             n_sch = ka.sched_n_in[lead];
             const T *src = ka.sched_in + lead * (int64_t)(2 * ka.sched_cap);
-            for (int n = tlane % G; n < 2 * (n_sch > 0 ? n_sch : 0); n += G) sch[n] = src[n];
+            for (int n = tidx; n < 2 * (n_sch > 0 ? n_sch : 0); n += G) sch[n] = src[n];
         }
         // the mailbox of a wave group follows the schedule (16-byte aligned by construction of the table sizes or not: 4-byte words)
-        S.xw = sch + (replay ? TPW * 2 * ka.sched_cap : 0);
+        S.xw = sch_base + (replay ? TPW * 2 * ka.sched_cap : 0);   // the mailbox of the wave group: behind every trajectory's schedule
         __syncthreads();
         S.sus = tab + j * (K1 * M1 * L);
         S.spl = tab + SUSN + aa * K1 * (4 + 2 * nk);
@@ -862,7 +873,7 @@ struct Seip {
 #pragma unroll
         for (int v = 0; v < NV; ++v) lane_ok = lane_ok && (M::abs(y[v]) < M::inf()) && (M::abs(k[0][v]) < M::inf());
         const unsigned long long bad_lanes = __ballot(!lane_ok);
-        const unsigned long long group_mask = (G >= 64 ? ~0ull : ((1ull << (G & 63)) - 1ull)) << (grp * (G & 63));
+        const unsigned long long group_mask = (GWL >= 64 ? ~0ull : ((1ull << (GWL & 63)) - 1ull)) << (grp * (GWL & 63));
         bool start_ok = (bad_lanes & group_mask) == 0ull;
         if constexpr (NW > 1) start_ok = !S.wg_any(!lane_ok);
 

@@ -158,7 +158,7 @@ int32_t dyn_n_compartments(const dyn_model_desc *m);
 int32_t dyn_compartment_offsets(const dyn_model_desc *m, int32_t *off);
 /* 1 if a kernel for (model shape, method, dtype) is compiled in, else 0 */
 int32_t dyn_is_supported(const dyn_model_desc *m, const dyn_solver_opts *o);
-/* trajectories integrated by one 64-lane wavefront for this model (lanes = age bins) */
+/* trajectories that share a 64-lane wavefront for this model (a wave group of the SEIP family: per workgroup of NW waves) */
 int32_t dyn_trajectories_per_wave(const dyn_model_desc *m);
 /* last launch-failure text of the calling thread ("" if none) */
 const char *dyn_last_error(void);

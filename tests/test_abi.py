@@ -180,10 +180,11 @@ def test_library_links_only_the_hip_runtime():
 
 def test_trajectories_per_wave_follows_the_seip_lane_mapping():
     """SEIP: 8 ages x 4 histories is 32 lanes (2 trajectories per wave) with all tiers on one lane; the float kernel
-    that is compiled in deals the tiers over two lanes (64 lanes, 1 per wave).  Three strains x 4 ages: 64 lanes."""
+    that is compiled in deals the tiers over two lanes (64 lanes, 1 per wave).  Three strains x 4 ages x 3 tiers runs one
+    tier per wave with the (age, history) planes of two trajectories side by side in each of the three waves."""
     lib = _abi.lib()
     seip = lambda **kw: ModelDesc(has_e=True, has_wane=True, has_c=True, normalize=False, family=1, **kw)
     assert lib.dyn_trajectories_per_wave(ctypes.byref(seip(n_age=8, n_strain=2, n_wane=4, n_vax_tiers=3).c())) == 1
     assert lib.dyn_trajectories_per_wave(ctypes.byref(seip(n_age=4, n_strain=2, n_wane=4, n_vax_tiers=3).c())) == 4
-    assert lib.dyn_trajectories_per_wave(ctypes.byref(seip(n_age=4, n_strain=3, n_wane=4, n_vax_tiers=3).c())) == 1
+    assert lib.dyn_trajectories_per_wave(ctypes.byref(seip(n_age=4, n_strain=3, n_wane=4, n_vax_tiers=3).c())) == 2
     assert lib.dyn_trajectories_per_wave(ctypes.byref(seip(n_age=2, n_strain=2, n_wane=2, n_vax_tiers=2).c())) == 8

@@ -163,6 +163,7 @@ WAVE_GROUP_SHAPES = [
     dict(A=6, L=4, K1=2, M1=4, n_knots=1, seasonal_vax=True),                   # two waves, both tiers in one lane (float32)
     dict(A=8, L=3, K1=3, M1=2, n_knots=1, seasonal=True, seasonal_vax=True),    # one tier per wave: three waves (float64 twin)
     dict(A=8, L=4, K1=3, M1=1, n_knots=1, seasonal_vax=True, intro=True),       # ... with 16 histories: six waves (float64 twin)
+    dict(A=3, L=3, K1=3, M1=2, n_knots=2, seasonal=True, seasonal_vax=True, intro=True),   # ... 4 age lanes x 8 histories: two trajectories per group of three waves (float64 twin)
 ]
 
 GPU_CASES = [(SHAPES[0], "f64", "tsit5"), (SHAPES[1], "f64", "tsit5"), (SHAPES[1], "f64", "dopri5"), (SHAPES[4], "f64", "tsit5"),
@@ -170,7 +171,7 @@ GPU_CASES = [(SHAPES[0], "f64", "tsit5"), (SHAPES[1], "f64", "tsit5"), (SHAPES[1
              (SHAPES[3], "f32", "dopri5"), (SHAPES[4], "f32", "tsit5"), (SHAPES[5], "f64", "tsit5"), (SHAPES[6], "f32", "tsit5"),
              (WAVE_GROUP_SHAPES[0], "f64", "tsit5"), (WAVE_GROUP_SHAPES[1], "f32", "tsit5"), (WAVE_GROUP_SHAPES[2], "f64", "tsit5"),
              (WAVE_GROUP_SHAPES[3], "f64", "tsit5"), (WAVE_GROUP_SHAPES[4], "f32", "tsit5"), (WAVE_GROUP_SHAPES[5], "f32", "tsit5"),
-             (WAVE_GROUP_SHAPES[6], "f64", "tsit5"), (WAVE_GROUP_SHAPES[7], "f64", "tsit5")]
+             (WAVE_GROUP_SHAPES[6], "f64", "tsit5"), (WAVE_GROUP_SHAPES[7], "f64", "tsit5"), (WAVE_GROUP_SHAPES[8], "f64", "tsit5")]
 
 
 @pytest.mark.gpu
@@ -576,3 +577,38 @@ def test_one_tier_per_wave_and_tier_lanes_are_the_same_model(monkeypatch):
         assert int(got[flag].status.max()) == 0
     assert float((got["1"].ys - got["0"].ys).abs().max()) / 1000.0 < 2e-4
     assert int((got["1"].n_accept + got["1"].n_reject - got["0"].n_accept - got["0"].n_reject).abs().max()) <= 8
+
+
+@pytest.mark.gpu
+def test_packed_tier_waves_two_trajectories_per_wave_group(monkeypatch):
+    """4 ages x 8 histories is half a wavefront: with one tier per wave the planes of TWO trajectories sit side by side in
+    each of the three waves (an odd batch leaves the last group half empty).  Against the oracle, against the tier-lane
+    mapping, and through record / replay (every trajectory of a group has its own schedule rows in LDS)."""
+    import torch
+    from dynode_amd import _abi
+    from dynode_amd.engine import solve_batch
+
+    wl = synthetic.seip(B=7, seed=43, t1=120.0, A=4, L=3, K1=3, M1=4, n_knots=2, seasonal_vax=True)
+    m, ts = wl.model, synthetic.save_grid(120.0)
+    want, st, _, _ = O.solve(H.omodel(m), wl.y0, wl.params, wl.contact, 120.0, ts, dtype=np.float32, n_threads=8, constant_dt=0.5)
+    got = {}
+    for flag, name in (("1", "dyn::seip_kernel_wave_group<float, 0, 4, 3, 3, 4, 3, 3>"), ("0", "dyn::seip_kernel<float, 0, 4, 3, 3, 4, 2>")):
+        monkeypatch.setenv("DYNODE_HIP_SEIP_TIER_WAVES", flag)
+        rc = solve_batch(m, wl.y0, wl.params, wl.contact, 120.0, ts, constant_dt=0.5)
+        assert _abi.lib().dyn_last_kernel_name().decode() == name
+        assert int(rc.status.max()) == 0 and np.abs(rc.ys.cpu().numpy() - want).max() / 1000.0 < 2e-5
+        got[flag] = solve_batch(m, wl.y0, wl.params, wl.contact, 120.0, ts, jump_ts=(40.25,))
+        assert int(got[flag].status.max()) == 0
+    assert float((got["1"].ys - got["0"].ys).abs().max()) / 1000.0 < 2e-4
+    monkeypatch.setenv("DYNODE_HIP_SEIP_TIER_WAVES", "1")
+    perm = np.random.default_rng(1).permutation(7)
+    again = solve_batch(m, wl.y0[perm], wl.params[perm], wl.contact, 120.0, ts, jump_ts=(40.25,))
+    assert torch.equal(again.ys, got["1"].ys[torch.as_tensor(perm, device="cuda")])          # bits do not depend on the neighbour in the wave
+    full = solve_batch(m, wl.y0, wl.params, wl.contact, 120.0, ts, jump_ts=(40.25,), record_steps=512)
+    assert torch.equal(full.ys, got["1"].ys)
+    steps, count = full.schedule
+    rep = solve_batch(m, wl.y0, wl.params, wl.contact, 120.0, ts, jump_ts=(40.25,), replay=(steps, count, None))
+    assert torch.equal(rep.ys, full.ys) and torch.equal(rep.n_accept, full.n_accept)
+    leader = np.array([0, 0, 2, 2, 4, 4, 6])                                                    # neighbours follow different leaders
+    led = solve_batch(m, wl.y0, wl.params, wl.contact, 120.0, ts, jump_ts=(40.25,), replay=(steps, count, leader))
+    assert torch.equal(led.ys[leader], full.ys[leader]) and torch.equal(led.n_accept, full.n_accept[leader])
