@@ -71,7 +71,8 @@ struct Seip {
     static_assert(NW == 1 || NW == NXH * (TIER_X ? KT : 1), "SEIP wave group: NW = 2^(cross-wave history bits) * (tier lanes across waves)");
     // mailbox slots of one round: infectious sums [L], tier totals [KL], recovery partners [HB_X][KL], tier flow [KL],
     // seasonal fall-back of the top tier [M1 + 2 L]
-    static constexpr int NSLOT = L + (K1 + KT - 1) / KT * (2 + HB_X) + M1 + 2 * L;
+    //   + the doses [KL] when the tier flow is formed by the RECEIVING wave (tiers and histories both across waves)
+    static constexpr int NSLOT = L + (K1 + KT - 1) / KT * (2 + HB_X) + M1 + 2 * L + ((TIER_X && HB_X > 0) ? (K1 + KT - 1) / KT : 0);
     T *xw;               // LDS mailbox [2][NW][NSLOT][64] (NW > 1)
     int wv;              // this wave's index inside the trajectory's workgroup
     mutable int xbuf;    // which half of the mailbox the next round writes
@@ -398,7 +399,8 @@ struct Seip {
     // seasonal fall-back of the top tier, and -- when the tier totals are complete inside a wave -- the vaccination flow
     // to the tier partner; otherwise that flow goes in a second round once the totals are known.
     __device__ __forceinline__ void rhs_wave_group(T t, const PS &y, PS &dy) const {
-        constexpr int S_TOT = L, S_REC = L + KL, S_SEND = L + KL * (1 + HB_X), S_SV = S_SEND + KL;
+        constexpr int S_TOT = L, S_REC = L + KL, S_SEND = L + KL * (1 + HB_X), S_SV = S_SEND + KL, S_DOSE = S_SV + M1 + 2 * L;
+        (void)S_DOSE;
         constexpr int sK = K / KT, tK = K % KT, sD = K > 0 ? (K - 1) / KT : 0;   // slot / tier lane of the top tier, slot below it
         const int b = xbuf;
         xbuf ^= 1;
@@ -435,6 +437,10 @@ struct Seip {
             totl[sl] = tt;
             tot[sl] = hist_sum(tt);
             if constexpr (HB_X > 0) *xslot(b, wv, S_TOT + sl) = tot[sl];
+            if constexpr (TIER_X && HB_X > 0) { // the tier above forms this slot's flow itself once the totals are in (below)
+                *xslot(b, wv, S_SEND + sl) = tt;
+                *xslot(b, wv, S_DOSE + sl) = dose[sl];
+            }
 #pragma unroll
             for (int q = 0; q < HB_X; ++q) *xslot(b, wv, S_REC + q * KL + sl) = gamma[HB_IN + q] * y[II + sl * L + HB_IN + q];
         }
@@ -511,14 +517,23 @@ struct Seip {
             T got[KL];
             // the tier lane below this one (cyclically): its wave, same history waves
             const int src_wave = TIER_X ? ((((tlw + KT - 1) % KT) << HB_X) | hw) : 0;
-            if constexpr (TIER_X && HB_X > 0) { // second round: the flows could only be formed now
-                const int b2 = xbuf;
-                xbuf ^= 1;
+            if constexpr (TIER_X && HB_X > 0) {
+                // the flow out of the tier below needs that tier's total over ALL histories, which its own waves only know
+                // after the barrier too: instead of a second mailbox round (one more barrier per right-hand side) this wave
+                // forms it from what the tier below posted in the first -- its dose, its lane's total and the per-wave
+                // totals -- with the same operations in the same order, so the bits are the ones the sender would have sent
+                const int tsrc = (tlw + KT - 1) % KT;
 #pragma unroll
-                for (int sl = 0; sl < KL; ++sl) *xslot(b2, wv, 0 + sl) = (sl * KT + tl == K) ? T(0) : rate[sl] * totl[sl];
-                __syncthreads();
+                for (int sl = 0; sl < KL; ++sl) {
+                    T tot_src = *xslot(b, tsrc << HB_X, S_TOT + sl);
 #pragma unroll
-                for (int sl = 0; sl < KL; ++sl) got[sl] = *xslot(b2, src_wave, sl);
+                    for (int h = 1; h < NXH; ++h) tot_src += *xslot(b, (tsrc << HB_X) | h, S_TOT + sl);
+                    const T dose_src = *xslot(b, src_wave, S_DOSE + sl), totl_src = *xslot(b, src_wave, S_SEND + sl);
+                    const int ksrc = sl * KT + tsrc;
+                    const T sh = dose_src * M::recip(tot_src > T(0) ? tot_src : T(1));
+                    const T rate_src = (ksrc < K1 && tot_src > T(0)) ? (dose_src < tot_src ? sh : T(1)) : T(0);
+                    got[sl] = (ksrc == K) ? T(0) : rate_src * totl_src;
+                }
             } else if constexpr (TIER_X) {
 #pragma unroll
                 for (int sl = 0; sl < KL; ++sl) got[sl] = *xslot(b, src_wave, S_SEND + sl);
