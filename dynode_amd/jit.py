@@ -54,10 +54,31 @@ def _seip_tier_lanes(model: _abi.ModelDesc, dtype=torch.float32) -> bool:
     return (K1 * per_tier > 32 or small) and K1 > 1 and _group_width(A) * H * 2 <= 64
 
 
+def _seip_wave_group(model: _abi.ModelDesc):
+    """(KT, NW) of the wave-group mapping a SEIP shape needs when its (age, history) plane fills a wavefront or more
+    (csrc/seip_kernel.hpp: `Seip<..., KT, NW>`; the same choices as `select_seip_entry` in csrc/dynode_hip.hip), else None:
+    one tier per wave from three tiers on, the two tiers on a wave each, a single tier's 128 lanes as two waves."""
+    A, L, H, K1, M1, _ = model.seip_dims
+    lanes = _group_width(A) * H
+    if lanes < 64 or (lanes == 64 and K1 == 1):
+        return None
+    if lanes > 128:
+        raise RuntimeError(f"{model}: {lanes} (age, immune history) lanes per tier; the SEIP wave groups go up to 128")
+    nxh = lanes // 64
+    return (K1, K1 * nxh) if K1 >= 2 else (1, nxh)
+
+
 def _features(model: _abi.ModelDesc, dtype=torch.float32) -> int:
     """The kernel template's FEAT word: bit 0 = externally introduced strains, the rest = vaccination-tier lanes."""
-    if model.family == 1:                                    # kSeip | tiers [| tier lanes] (csrc/dynode_hip.hip)
-        return 0x100 | max(int(model.n_vax_tiers), 1) | (0x20 if _seip_tier_lanes(model, dtype) else 0)
+    if model.family == 1:                                    # kSeip | tiers [| lane mapping] (csrc/dynode_hip.hip)
+        feat = 0x100 | max(int(model.n_vax_tiers), 1)
+        wg = _seip_wave_group(model)
+        if wg is None:
+            return feat | (0x20 if _seip_tier_lanes(model, dtype) else 0)
+        kt, nw = wg
+        if kt > 2:
+            return feat | 0x200                              # kSeipTierWaves: one tier per wave
+        return feat | (0x20 if kt == 2 else 0) | (0x40 if nw == 2 else 0x80)
     return int(model.has_intro) | (model.vax_lanes << 1)
 
 
@@ -119,7 +140,9 @@ def _source(model, dtype, method, n_dir, spl) -> str:
     b = lambda v: "true" if v else "false"
     if model.family == 1:
         A, L, _, K1, M1, _ = model.seip_dims
-        args = f"{t}, {method}, {_group_width(A)}, {L}, {K1}, {M1}" + (", 2" if _seip_tier_lanes(model, dtype) else "")
+        wg = _seip_wave_group(model)
+        args = f"{t}, {method}, {_group_width(A)}, {L}, {K1}, {M1}" + (
+            f", {wg[0]}, {wg[1]}" if wg is not None else (", 2" if _seip_tier_lanes(model, dtype) else ""))
         return (f'#include "{os.path.join(_CSRC, "seip_kernel.hpp")}"\n'
                 f"namespace dyn {{ template hipError_t launch_seip<{args}>(const KArgs<{t}> &, hipStream_t); }}\n"
                 f'extern "C" void *dyn_extra_launch(void) {{\n'
@@ -143,9 +166,6 @@ def ensure_kernel(model: _abi.ModelDesc, dtype=torch.float32, method: str = "tsi
             else L.dyn_is_supported(ctypes.byref(mc), ctypes.byref(opts)))
     if have:
         return False
-    if model.family == 1 and _group_width(model.n_age) << model.n_strain > 64:
-        raise RuntimeError(f"{model}: a SEIP lane group beyond one wavefront runs as a wave group, and those shapes are compiled in: "
-                           "add a YW(...) line to csrc/seip_instances.def and rebuild")
     spl = choose_spl(model, n_dir)
     name = _name(model, dtype, mid, n_dir, spl)
     with _LOCK:

@@ -527,6 +527,29 @@ def test_tier_lanes_shape_built_on_demand():
 
 
 @pytest.mark.gpu
+@pytest.mark.on_demand_build
+def test_wave_group_shapes_built_on_demand():
+    """Lane groups beyond a wavefront that are not compiled in: the on-demand build picks the wave-group mapping (one tier
+    per wave from three tiers on, each of two tiers on its own wave, 16 histories of a single tier across two waves) and
+    registers it under the feature word `select_seip_entry` looks for."""
+    import torch
+    from dynode_amd import _abi, jit
+    from dynode_amd.engine import solve_batch
+
+    cases = [(dict(A=8, L=3, K1=2, M1=3, n_knots=1, seasonal_vax=True), (2, 2), 0x100 | 0x20 | 0x40 | 2, "dyn::seip_kernel_wave_group<double, 0, 8, 3, 2, 3, 2, 2>"),
+             (dict(A=5, L=3, K1=4, M1=2, n_knots=1, intro=True), (4, 4), 0x100 | 0x200 | 4, "dyn::seip_kernel_wave_group<double, 0, 8, 3, 4, 2, 4, 4>"),
+             (dict(A=8, L=4, K1=1, M1=3, n_knots=0), (1, 2), 0x100 | 0x40 | 1, "dyn::seip_kernel_wave_group<double, 0, 8, 4, 1, 3, 1, 2>")]
+    for shape, wg, feat, name in cases:
+        wl = synthetic.seip(B=3, seed=27, t1=60.0, **shape)
+        assert jit._seip_wave_group(wl.model) == wg and jit._features(wl.model, torch.float64) == feat
+        ts = synthetic.save_grid(60.0)
+        r = solve_batch(wl.model, wl.y0, wl.params, wl.contact, 60.0, ts, dtype=torch.float64, constant_dt=0.5)
+        assert _abi.lib().dyn_last_kernel_name().decode() == name
+        want, st, _, _ = O.solve(H.omodel(wl.model), wl.y0, wl.params, wl.contact, 60.0, ts, dtype=np.float64, n_threads=8, constant_dt=0.5)
+        assert int(r.status.max()) == 0 and np.abs(r.ys.cpu().numpy() - want).max() / 1000.0 < 1e-11
+
+
+@pytest.mark.gpu
 def test_wave_groups_dispatch_sub_save_jumps_and_replay():
     """Trajectories owned by a workgroup of several waves: the instance that runs, batch-position invariance, sub-save
     masks, discontinuity points and recorded / replayed step sequences behave as for one-wave lane groups."""
