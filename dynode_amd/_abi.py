@@ -205,8 +205,8 @@ def lib() -> ctypes.CDLL:
         L.dyn_cost_order_capacity.argtypes = [ctypes.c_int32]
         L.dyn_cost_order.restype = ctypes.c_int
         L.dyn_cost_order.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p,
-                                     ctypes.c_void_p, ctypes.c_double, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,
-                                     ctypes.c_void_p]
+                                     ctypes.c_void_p, ctypes.c_double, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p,
+                                     ctypes.c_void_p, ctypes.c_void_p]
         L.dyn_is_supported_jvp.argtypes = [pm, po, ctypes.c_int32]
         L.dyn_is_supported_jvp.restype = ctypes.c_int32
         L.dyn_solve_batch_jvp.restype = ctypes.c_int

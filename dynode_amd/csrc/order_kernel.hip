@@ -92,7 +92,19 @@ __global__ void __launch_bounds__(256) cost_keys(const T *__restrict__ params, i
 
 // One workgroup: counting sort of the bucket keys (histogram in LDS, scan, scatter).  A thread keeps up to PER_THREAD of its
 // keys in registers between the two passes; longer batches read them again.
-__global__ void __launch_bounds__(1024) order_from_keys(const int32_t *__restrict__ keys, int64_t B, int32_t *__restrict__ order) {
+// `pair` > 0 (a launch whose waves all start at once: one residency round): the sorted list is cut into waves of `pair`
+// trajectories and the waves are dealt heavy, light, heavy, light ... (wave w of the descending order goes to slot 2 w in the
+// first half and 2 (n - 1 - w) + 1 in the second), so that the waves sharing a SIMD add up to about the same work.  With
+// several rounds the descending order itself (longest first) is the better one: measured, DESIGN.md section 9.
+__device__ inline int64_t dealt(int64_t pos, int64_t B, int pair) {
+    if (pair <= 0) return pos;
+    const int64_t n = B / pair, w = pos / pair, r = pos % pair;      // (B is a multiple of `pair`: checked by the host side)
+    const int64_t slot = w < (n + 1) / 2 ? 2 * w : 2 * (n - 1 - w) + 1;
+    return slot * pair + r;
+}
+
+__global__ void __launch_bounds__(1024) order_from_keys(const int32_t *__restrict__ keys, int64_t B, int32_t *__restrict__ order,
+                                                        int pair) {
     __shared__ int32_t hist[kBuckets];
     __shared__ int32_t part[1024];
     constexpr int PER_THREAD = 16;
@@ -135,8 +147,8 @@ __global__ void __launch_bounds__(1024) order_from_keys(const int32_t *__restric
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < PER_THREAD; ++i)
-        if (mine[i] >= 0) order[atomicAdd(&hist[mine[i]], 1)] = (int32_t)(t + i * 1024);
-    for (int64_t b = t + (int64_t)PER_THREAD * 1024; b < B; b += 1024) order[atomicAdd(&hist[keys[b]], 1)] = (int32_t)b;
+        if (mine[i] >= 0) order[dealt(atomicAdd(&hist[mine[i]], 1), B, pair)] = (int32_t)(t + i * 1024);
+    for (int64_t b = t + (int64_t)PER_THREAD * 1024; b < B; b += 1024) order[dealt(atomicAdd(&hist[keys[b]], 1), B, pair)] = (int32_t)b;
 }
 
 } // namespace dynord
@@ -158,14 +170,14 @@ extern "C" int32_t dyn_cost_order_capacity(int32_t n_feat) {
 }
 
 extern "C" int dyn_cost_order(const void *params, int32_t dtype, int64_t B, int32_t P, int32_t n_feat, const int32_t *cols,
-                              const float *coef, double key_scale, int32_t n_sym, int32_t sym_blocks, int32_t *keys_ws,
-                              int32_t *order, void *stream) {
+                              const float *coef, double key_scale, int32_t n_sym, int32_t sym_blocks, int32_t deal_waves_of,
+                              int32_t *keys_ws, int32_t *order, void *stream) {
     if (B > 0 && (!params || !cols || !coef || !keys_ws || !order)) return DYN_ERR_NULL;
     if (B < 0 || B > 0x7fffffffLL || P < 1 || n_feat < 1 || n_feat > DYN_MAX_COST_FEATURES) return DYN_ERR_SIZE;
     if (n_feat != dyn_cost_order_capacity(n_feat)) return DYN_ERR_SIZE;   // pad with zero coefficients (dyn_cost_order_capacity)
     if (n_sym < 0 || n_sym > dynord::kMaxSym || sym_blocks < 0 || (n_sym > 1 && (sym_blocks < 2 || sym_blocks * n_sym > P)))
         return DYN_ERR_SIZE;
-    if ((dtype != DYN_F32 && dtype != DYN_F64) || !(key_scale > 0.0)) return DYN_ERR_OPTS;
+    if ((dtype != DYN_F32 && dtype != DYN_F64) || !(key_scale > 0.0) || deal_waves_of < 0) return DYN_ERR_OPTS;
     if (B == 0) return 0;
     const dim3 grid((unsigned)((B + 255) / 256));
     if (dtype == DYN_F32)
@@ -174,6 +186,7 @@ extern "C" int dyn_cost_order(const void *params, int32_t dtype, int64_t B, int3
     else
         launch_keys<double>(n_feat, grid, (hipStream_t)stream, (const double *)params, B, (int)P, cols, coef, (float)key_scale,
                             (int)n_sym, (int)sym_blocks, keys_ws);
-    hipLaunchKernelGGL(dynord::order_from_keys, dim3(1), dim3(1024), 0, (hipStream_t)stream, keys_ws, B, order);
+    const int pair = (deal_waves_of > 0 && B % deal_waves_of == 0 && B / deal_waves_of >= 2) ? (int)deal_waves_of : 0;
+    hipLaunchKernelGGL(dynord::order_from_keys, dim3(1), dim3(1024), 0, (hipStream_t)stream, keys_ws, B, order, pair);
     return hipGetLastError() == hipSuccess ? 0 : DYN_ERR_LAUNCH;
 }

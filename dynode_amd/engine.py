@@ -213,7 +213,9 @@ def solve_batch(model: ModelDesc, y0, params, contact, t1: float, save_ts, *, t0
             key = (model, dtype, method, float(rtol), float(atol), float(t0), float(t1), n_save > 0, str(device))
             cost = schedule.model_for(key, P, device, schedule.strain_symmetry(model))
             if cost.ready:
-                order_t = cost.order(params_t, s)
+                tpw = int(L.dyn_trajectories_per_wave(ctypes.byref(model.c())))
+                one_round = tpw > 0 and B % tpw == 0 and B // tpw <= schedule.ONE_ROUND_WAVES
+                order_t = cost.order(params_t, s, tpw if one_round else 0)
     elif order is not None:
         raise ValueError('order must be "auto", None or an int32 tensor')
 

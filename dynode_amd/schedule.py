@@ -38,6 +38,7 @@ MIN_WORK = 1 << 21          # ... and so are launches below this many state valu
 MAX_FIT_ROWS = 65536        # rows of one launch that enter the normal equations
 KEY_SCALE = 4.0             # buckets per predicted step attempt (4096 buckets: up to 1024 attempts)
 RIDGE = 1e-4
+ONE_ROUND_WAVES = int(os.environ.get("DYNODE_ONE_ROUND", "1")) * 2048   # 1024 SIMDs x 2 resident waves of the <= 256-register kernels: up to here a launch is one round (DYNODE_ONE_ROUND=0: never deal)
 MIN_R2 = 0.5                # a forecast that explains less of the step-count variance than this is not used (given order)
 
 
@@ -193,8 +194,9 @@ class CostModel:
             self.best = best if best.rss <= (1.0 - MIN_R2) * best.variance else None
             self.fitted_rows = self.rows
 
-    def order(self, params_t: torch.Tensor, stream) -> torch.Tensor:
-        """int32 [B]: dispatch order of the rows of ``params_t`` ([B, P], float32 / float64, on the device)."""
+    def order(self, params_t: torch.Tensor, stream, deal_waves_of: int = 0) -> torch.Tensor:
+        """int32 [B]: dispatch order of the rows of ``params_t`` ([B, P], float32 / float64, on the device).
+        ``deal_waves_of`` = trajectories per wave when the launch is one residency round (see `dyn_cost_order`)."""
         from .engine import _DTYPES
 
         v = self.best
@@ -203,8 +205,8 @@ class CostModel:
         order = torch.empty(B, dtype=torch.int32, device=params_t.device)
         S, F = v.sym if v.sym is not None else (0, 0)
         rc = _abi.lib().dyn_cost_order(params_t.data_ptr(), _DTYPES[params_t.dtype], B, self.P, int(v.cols_padded.numel()),
-                                       v.cols_padded.data_ptr(), v.coef.data_ptr(), KEY_SCALE, int(S), int(F), keys.data_ptr(),
-                                       order.data_ptr(), ctypes.c_void_p(stream.cuda_stream))
+                                       v.cols_padded.data_ptr(), v.coef.data_ptr(), KEY_SCALE, int(S), int(F), int(deal_waves_of),
+                                       keys.data_ptr(), order.data_ptr(), ctypes.c_void_p(stream.cuda_stream))
         if rc:
             raise RuntimeError(f"dyn_cost_order: {_abi.ERR_NAMES.get(rc, rc)}")
         for t in (keys, order, v.cols_padded, v.coef):

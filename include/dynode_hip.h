@@ -384,6 +384,9 @@ int dyn_potential_combine(int64_t C, int32_t n, const double *lp, const double *
  * n_sym = S > 1: the first sym_blocks * S parameters are [quantity][strain] blocks of a model that treats its strains alike
  * (family 0: beta, gamma, sigma, omega); they are read in a canonical labelling -- strains sorted by block 0 / block 1 (r0),
  * largest first -- which makes the forecast a symmetric function of the strains.  n_sym <= 1: parameters are read as they are.
+ * deal_waves_of = t > 0 (t = dyn_trajectories_per_wave, B a multiple of it): the sorted list is cut into waves of t trajectories
+ * and the waves are dealt heavy, light, heavy, light ...: for launches whose waves all start at once (the waves sharing a SIMD
+ * then carry about the same work); 0 = most expensive first throughout (launches of several residency rounds).
  */
 #define DYN_MAX_COST_FEATURES 32
 /* compiled feature capacities: n_feat must be one of 4, 8, 16, 24, 32 -- pad a smaller model with repeated columns and zero
@@ -394,8 +397,8 @@ int dyn_solve_batch_ordered(const dyn_model_desc *model, const dyn_solver_opts *
                             int32_t n_save, const uint8_t *save_mask, void *ys_out, int32_t *status, int32_t *n_accept,
                             int32_t *n_reject, const int32_t *order, void *stream);
 int dyn_cost_order(const void *params, int32_t dtype, int64_t B, int32_t P, int32_t n_feat, const int32_t *cols,
-                   const float *coef, double key_scale, int32_t n_sym, int32_t sym_blocks, int32_t *keys_ws, int32_t *order,
-                   void *stream);
+                   const float *coef, double key_scale, int32_t n_sym, int32_t sym_blocks, int32_t deal_waves_of,
+                   int32_t *keys_ws, int32_t *order, void *stream);
 
 
 #ifdef __cplusplus

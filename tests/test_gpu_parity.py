@@ -260,6 +260,15 @@ def test_learned_dispatch_order():
     assert torch.equal(torch.sort(order.long()).values, torch.arange(half, device="cuda"))       # a permutation
     f_sorted = forecast[order.long()]
     assert float((f_sorted[1:] - f_sorted[:-1]).max()) <= 1.0 / schedule.KEY_SCALE + 1e-3        # descending up to one bucket
+    # one residency round: waves of 8 dealt heavy, light, heavy, light ... (wave w of the descending list in slot 2 w / 2 (n - 1 - w) + 1)
+    dealt = cm.order(p_test, torch.cuda.current_stream(), 8)
+    torch.cuda.synchronize()
+    assert torch.equal(torch.sort(dealt.long()).values, torch.arange(half, device="cuda"))
+    n = half // 8
+    wave_cost = forecast[dealt.long()].reshape(n, 8).mean(1)
+    desc_cost = f_sorted.reshape(n, 8).mean(1)
+    slot = torch.tensor([2 * w if w < (n + 1) // 2 else 2 * (n - 1 - w) + 1 for w in range(n)], device="cuda")
+    assert float((wave_cost[slot] - desc_cost).abs().max()) <= 1.0 / schedule.KEY_SCALE + 1e-3
     order64 = cm.order(p_test.double(), torch.cuda.current_stream())       # float64 parameter rows take the same kernel
     torch.cuda.synchronize()
     assert torch.equal(torch.sort(order64.long()).values, torch.arange(half, device="cuda"))
