@@ -359,7 +359,8 @@ static int enqueue(const Entry *e, const dyn_model_desc *m, const dyn_solver_opt
     }
     // Small, save-heavy batches leave most SIMDs idle and are bound by the serial latency of one
     // trajectory's dense output: replicate each trajectory over 2^r lane groups (<= 8) while the
-    // grid still fits in one resident round (~2 waves per SIMD on 1024 SIMDs).
+    // grid still fits in one resident round of 2 waves per SIMD on 1024 SIMDs (cfg 2, 512 trajectory-waves: 4 replicas
+    // 0.178 ms, 8 replicas 0.204 ms, 2 replicas 0.232 ms, none 0.39 ms -- every replica repeats the stepping).
     {
         const int tpw = 64 / entry_lanes(e);
         const int64_t waves = (B + tpw - 1) / tpw;
@@ -372,7 +373,7 @@ static int enqueue(const Entry *e, const dyn_model_desc *m, const dyn_solver_opt
             // (cfg 2: 0.37 -> 0.19 ms); register-heavy VALU-bound shapes do not (cfg 5: 0.72 -> 0.89 ms)
             const int nv = 1 + e->SPL * (e->E + 1 + e->W + e->C);
             if (nv <= 5 && !(e->FEAT & kSeip))
-                while (r < 3 && (waves << (r + 1)) <= 4096) ++r;
+                while (r < 3 && (waves << (r + 1)) <= 2048) ++r;
         }
         ka.rep_log2 = r < 0 ? 0 : (r > 3 ? 3 : r);
         if (ll) { // the replicas of a trajectory must share a wave (LDS table, lane reductions)
