@@ -635,3 +635,39 @@ def test_packed_tier_waves_two_trajectories_per_wave_group(monkeypatch):
     leader = np.array([0, 0, 2, 2, 4, 4, 6])                                                    # neighbours follow different leaders
     led = solve_batch(m, wl.y0, wl.params, wl.contact, 120.0, ts, jump_ts=(40.25,), replay=(steps, count, leader))
     assert torch.equal(led.ys[leader], full.ys[leader]) and torch.equal(led.n_accept, full.n_accept[leader])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,B", [("seip83", 768), ("seip84", 384), ("seip3", 1025)])
+def test_north_star_sizes_properties(name, B):
+    """The SEIP shapes `bench.py` measures (8 ages x 3 and x 4 strains as wave groups of one tier per wave; 4 ages x 3 strains
+    packed two to a group), 365 days, daily save, at sizes-independent properties: every solve succeeds, people are conserved
+    per age, cumulative infections never decrease, the first row is the initial state, the result does not depend on the
+    position in the batch nor on the run, and a sample of trajectories is the float32 oracle's to the tolerance."""
+    import torch
+    from dynode_amd.engine import solve_batch
+
+    wl = synthetic.WORKLOADS[name](B)
+    m = wl.model
+    A, L, Hh, K1, M1, _ = m.seip_dims
+    r = solve_batch(m, wl.y0, wl.params, wl.contact, wl.t1, wl.save_ts)
+    r2 = solve_batch(m, wl.y0, wl.params, wl.contact, wl.t1, wl.save_ts)
+    torch.cuda.synchronize()
+    assert int(r.status.max()) == 0 and r.ys.shape == (B, 366, m.state_dim) and bool(torch.isfinite(r.ys).all())
+    assert torch.equal(r.ys, r2.ys)
+    assert torch.equal(r.ys[:, 0, :], torch.as_tensor(wl.y0, dtype=torch.float32, device="cuda"))
+    sizes = m.compartment_sizes                                    # s, e, i, c
+    s_, e_, i_, c_ = torch.split(r.ys.double(), list(sizes), dim=2)
+    people = s_.reshape(B, 366, A, -1).sum(-1) + e_.reshape(B, 366, A, -1).sum(-1) + i_.reshape(B, 366, A, -1).sum(-1)
+    assert float((people - people[:, :1]).abs().max()) < 2e-2      # float32, 1000 people over thousands of cells and 365 days
+    assert float(r.ys.min()) > -5e-3 and float((c_[:, 1:] - c_[:, :-1]).min()) > -5e-3      # (undershoots of the order of the tolerance)
+    perm = np.random.default_rng(2).permutation(B)
+    rp = solve_batch(m, wl.y0[perm], wl.params[perm], wl.contact, wl.t1, wl.save_ts)
+    assert torch.equal(rp.ys, r.ys[torch.as_tensor(perm, device="cuda")])
+    idx = np.arange(0, B, max(B // 6, 1))[:6]
+    want, st, na, nr = O.solve(H.omodel(m), wl.y0[idx], wl.params[idx], wl.contact, wl.t1, wl.save_ts, dtype=np.float32, n_threads=8)
+    got = r.ys[torch.as_tensor(idx, device="cuda")].cpu().numpy()
+    assert st.max() == 0 and np.abs(got - want).max() / 1000.0 < 5e-4          # adaptive float32: step decisions differ near the dose-cap kinks
+    assert np.abs((r.n_accept + r.n_reject).cpu().numpy()[idx] - (na + nr)).max() <= 30
+    del r, r2, rp
+    torch.cuda.empty_cache()
