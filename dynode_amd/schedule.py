@@ -13,7 +13,9 @@ models: correlation 0.93 with the true count on unseen draws of the BASELINE cfg
 model, 0.98 when the strains are relabelled canonically first -- `CostModel`).  `solve_batch(order="auto")` (the default) trains on the launches
 it sees until `TRAIN_ROWS` trajectories of a (model, solver settings) pair have been observed, then orders every later batch
 with two small launches (`dyn_cost_order`: forecast + bucket, counting sort) in front of the solve.  Nothing synchronises
-with the host after the first training launch (which looks at the batch once to pick the varying parameters).
+with the host after the first training launch (which looks at the batch once to pick the varying parameters); a training launch
+costs a feature matrix and a 150 x 150 solve on the device next to it (a millisecond or two for 16384 rows), the first two or
+three launches of a (model, settings) pair only.
 
 The reference has no counterpart (diffrax under `vmap` on XLA:CPU runs the samples one after another); `order=None` or
 ``DYNODE_ORDER=0`` switches it off, `order=<int32 tensor>` dispatches in a caller-supplied order.
