@@ -235,10 +235,10 @@ def lib() -> ctypes.CDLL:
         L.dyn_latent_sites.argtypes = [ctypes.POINTER(SiteDescC), ctypes.c_int32, ctypes.c_int64] + [ctypes.c_void_p] * 6
         L.dyn_latent_param_map.restype = ctypes.c_int
         L.dyn_latent_param_map.argtypes = ([ctypes.POINTER(SiteDescC), ctypes.c_int32, ctypes.c_int64] + [ctypes.c_void_p] * 4
-                                           + [ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32]
+                                           + [ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32]
                                            + [ctypes.c_void_p] * 3)
         L.dyn_potential_combine.restype = ctypes.c_int
-        L.dyn_potential_combine.argtypes = ([ctypes.c_int64, ctypes.c_int32] + [ctypes.c_void_p] * 4 + [ctypes.c_double]
+        L.dyn_potential_combine.argtypes = ([ctypes.c_int64, ctypes.c_int32] + [ctypes.c_void_p] * 4 + [ctypes.c_double, ctypes.c_int32]
                                             + [ctypes.c_void_p] * 3)
         _lib = L
     return _lib

@@ -97,7 +97,7 @@ __global__ void __launch_bounds__(64) latent_param_map(const SiteTable tab, int6
                                                        double *__restrict__ x_out, double *__restrict__ lp_out,
                                                        double *__restrict__ dlp_dz, int P, const double *__restrict__ coef,
                                                        const double *__restrict__ expo, T *__restrict__ params,
-                                                       T *__restrict__ seeds) {
+                                                       T *__restrict__ seeds, int split) {
     const int64_t c = (int64_t)blockIdx.x * 64 + threadIdx.x;
     if (c >= C) return;
     const int n = tab.n;
@@ -119,8 +119,15 @@ __global__ void __launch_bounds__(64) latent_param_map(const SiteTable tab, int6
             else if (e == -1.0) p /= x[i];
             else if (e != 0.0) p *= pow(x[i], e);
         }
-        params[c * P + j] = (T)p;
-        for (int i = 0; i < n; ++i) seeds[(c * n + i) * P + j] = (T)(expo[j * n + i] * p * rel[i]);
+        if (split) { // one direction per trajectory: chain c becomes rows c, C + c, ... of an n C batch with one seed row each
+            for (int i = 0; i < n; ++i) {
+                params[(i * C + c) * P + j] = (T)p;
+                seeds[(i * C + c) * P + j] = (T)(expo[j * n + i] * p * rel[i]);
+            }
+        } else {
+            params[c * P + j] = (T)p;
+            for (int i = 0; i < n; ++i) seeds[(c * n + i) * P + j] = (T)(expo[j * n + i] * p * rel[i]);
+        }
     }
 }
 
@@ -128,12 +135,12 @@ __global__ void __launch_bounds__(64) latent_param_map(const SiteTable tab, int6
 // log-likelihood (one thread per chain)
 __global__ void __launch_bounds__(64) potential_combine(int64_t C, int n, const double *__restrict__ lp,
                                                         const double *__restrict__ dlp_dz, const double *__restrict__ ll,
-                                                        const double *__restrict__ dll, double offset, double *__restrict__ u,
-                                                        double *__restrict__ g) {
+                                                        const double *__restrict__ dll, double offset, int split,
+                                                        double *__restrict__ u, double *__restrict__ g) {
     const int64_t c = (int64_t)blockIdx.x * 64 + threadIdx.x;
     if (c >= C) return;
-    u[c] = -(lp[c] + ll[c] + offset);
-    for (int i = 0; i < n; ++i) g[c * n + i] = -(dlp_dz[c * n + i] + dll[c * n + i]);
+    u[c] = -(lp[c] + ll[c] + offset);      // (split: the n copies of a chain carry the same log-likelihood; the first is read)
+    for (int i = 0; i < n; ++i) g[c * n + i] = -(dlp_dz[c * n + i] + (split ? dll[i * C + c] : dll[c * n + i]));
 }
 
 } // namespace dynlat
@@ -164,7 +171,7 @@ extern "C" int dyn_latent_sites(const dyn_site_desc *sites, int32_t n_sites, int
 
 extern "C" int dyn_latent_param_map(const dyn_site_desc *sites, int32_t n_sites, int64_t C, const double *z, double *x,
                                     double *lp, double *dlp_dz, int32_t P, const double *coef, const double *expo,
-                                    int32_t dtype, void *params, void *seeds, void *stream) {
+                                    int32_t dtype, int32_t split_directions, void *params, void *seeds, void *stream) {
     if (!sites || !coef || !expo || (C > 0 && (!z || !x || !lp || !dlp_dz || !params || !seeds))) return DYN_ERR_NULL;
     if (C < 0 || P < 1) return DYN_ERR_SIZE;
     if (dtype != DYN_F32 && dtype != DYN_F64) return DYN_ERR_OPTS;
@@ -174,19 +181,19 @@ extern "C" int dyn_latent_param_map(const dyn_site_desc *sites, int32_t n_sites,
     const dim3 grid((unsigned)((C + 63) / 64)), block(64);
     if (dtype == DYN_F32)
         hipLaunchKernelGGL(dynlat::latent_param_map<float>, grid, block, 0, (hipStream_t)stream, tab, C, z, x, lp, dlp_dz,
-                           (int)P, coef, expo, (float *)params, (float *)seeds);
+                           (int)P, coef, expo, (float *)params, (float *)seeds, (int)(split_directions != 0));
     else
         hipLaunchKernelGGL(dynlat::latent_param_map<double>, grid, block, 0, (hipStream_t)stream, tab, C, z, x, lp, dlp_dz,
-                           (int)P, coef, expo, (double *)params, (double *)seeds);
+                           (int)P, coef, expo, (double *)params, (double *)seeds, (int)(split_directions != 0));
     return hipGetLastError() == hipSuccess ? 0 : DYN_ERR_LAUNCH;
 }
 
 extern "C" int dyn_potential_combine(int64_t C, int32_t n, const double *lp, const double *dlp_dz, const double *ll,
-                                     const double *dll, double offset, double *u, double *g, void *stream) {
+                                     const double *dll, double offset, int32_t split_directions, double *u, double *g, void *stream) {
     if (C > 0 && (!lp || !dlp_dz || !ll || !dll || !u || !g)) return DYN_ERR_NULL;
     if (C < 0 || n < 1 || n > DYN_MAX_SITES) return DYN_ERR_SIZE;
     if (C == 0) return 0;
     hipLaunchKernelGGL(dynlat::potential_combine, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, (hipStream_t)stream, C,
-                       (int)n, lp, dlp_dz, ll, dll, offset, u, g);
+                       (int)n, lp, dlp_dz, ll, dll, offset, (int)(split_directions != 0), u, g);
     return hipGetLastError() == hipSuccess ? 0 : DYN_ERR_LAUNCH;
 }

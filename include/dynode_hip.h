@@ -360,12 +360,16 @@ int dyn_latent_sites(const dyn_site_desc *sites, int32_t n_sites, int64_t C, con
  *     params [C][P] and seeds [C][n_sites][P] (= d params / d z, the dparams argument of dyn_solve_batch_loglik) are
  *     written in `dtype` (DYN_F32 / DYN_F64); x, lp, dlp_dz as in dyn_latent_sites.
  *   dyn_potential_combine: u[c] = -(lp[c] + ll[c] + offset), g[c][i] = -(dlp_dz[c][i] + dll[c][i]); all float64, device.
+ *   split_directions != 0 (few chains on an otherwise idle GPU): one tangent direction per trajectory instead of n_sites in
+ *     one -- params [n_sites][C][P] (chain c repeated), seeds [n_sites][C][1][P], to be solved as a batch of n_sites C rows
+ *     with n_dir = 1 (a third less work on the serial path of every trajectory at n_sites = 2; same bits); the combine then
+ *     reads ll [n_sites C] (the first C), dll [n_sites C][1] as [i][c].
  */
 int dyn_latent_param_map(const dyn_site_desc *sites, int32_t n_sites, int64_t C, const double *z, double *x, double *lp,
-                         double *dlp_dz, int32_t P, const double *coef, const double *expo, int32_t dtype, void *params,
-                         void *seeds, void *stream);
+                         double *dlp_dz, int32_t P, const double *coef, const double *expo, int32_t dtype,
+                         int32_t split_directions, void *params, void *seeds, void *stream);
 int dyn_potential_combine(int64_t C, int32_t n, const double *lp, const double *dlp_dz, const double *ll,
-                          const double *dll, double offset, double *u, double *g, void *stream);
+                          const double *dll, double offset, int32_t split_directions, double *u, double *g, void *stream);
 
 /*
  * Dispatch order.  dyn_solve_batch_ordered is dyn_solve_batch with one more argument: grid slot i integrates trajectory

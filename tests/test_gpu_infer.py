@@ -384,6 +384,18 @@ def test_folded_potential_equals_the_general_one(data):
     # the same float32 kernel on parameter rows that agree to the last bit of a float64 product
     assert torch.allclose(u1, u0, rtol=1e-7, atol=1e-4), float((u1 - u0).abs().max())
     assert torch.allclose(g1, g0, rtol=1e-5, atol=1e-5 * float(g0.abs().max())), float((g1 - g0).abs().max())
+    # few chains: one tangent direction per trajectory (2 x 64 rows, n_dir = 1); many: both directions in one trajectory
+    assert f.split_directions(64) and not f.split_directions(1200)
+    zb = pot.initial(1200, init_to_median, 1) + 0.5 * torch.randn(1200, 2, dtype=torch.float64, generator=torch.Generator().manual_seed(6)).cuda()
+    ub0, gb0 = pot.potential_and_grad(zb)
+    ub1, gb1 = f(zb)
+    assert torch.allclose(ub1, ub0, rtol=1e-7, atol=1e-4) and torch.allclose(gb1, gb0, rtol=1e-5, atol=1e-5 * float(gb0.abs().max()))
+    keep, f.SPLIT_MAX_ROWS = f.SPLIT_MAX_ROWS, 0            # the same 64 chains without the split: identical bits
+    f._split.clear(); f._buf.clear()
+    u1b, g1b = f(z)
+    f.SPLIT_MAX_ROWS = keep
+    f._split.clear(); f._buf.clear()
+    assert torch.equal(u1b, u1) and torch.equal(g1b, g1)
     # writes into the sampler's buffers; refuses anything but contiguous float64 device tensors of the right shape
     u2, g2 = torch.empty_like(u0), torch.empty_like(g0)
     f.into(z.contiguous(), u2, g2)
