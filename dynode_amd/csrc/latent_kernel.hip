@@ -119,10 +119,10 @@ __global__ void __launch_bounds__(64) latent_param_map(const SiteTable tab, int6
             else if (e == -1.0) p /= x[i];
             else if (e != 0.0) p *= pow(x[i], e);
         }
-        if (split) { // one direction per trajectory: chain c becomes rows c, C + c, ... of an n C batch with one seed row each
-            for (int i = 0; i < n; ++i) {
-                params[(i * C + c) * P + j] = (T)p;
-                seeds[(i * C + c) * P + j] = (T)(expo[j * n + i] * p * rel[i]);
+        if (split) { // one direction per trajectory: chain c becomes rows c n .. c n + n - 1 of an n C batch with one seed row each
+            for (int i = 0; i < n; ++i) {     // (neighbours: the copies of a chain take the same steps, so they share a wave for free)
+                params[(c * n + i) * P + j] = (T)p;
+                seeds[(c * n + i) * P + j] = (T)(expo[j * n + i] * p * rel[i]);
             }
         } else {
             params[c * P + j] = (T)p;
@@ -139,8 +139,8 @@ __global__ void __launch_bounds__(64) potential_combine(int64_t C, int n, const 
                                                         double *__restrict__ u, double *__restrict__ g) {
     const int64_t c = (int64_t)blockIdx.x * 64 + threadIdx.x;
     if (c >= C) return;
-    u[c] = -(lp[c] + ll[c] + offset);      // (split: the n copies of a chain carry the same log-likelihood; the first is read)
-    for (int i = 0; i < n; ++i) g[c * n + i] = -(dlp_dz[c * n + i] + (split ? dll[i * C + c] : dll[c * n + i]));
+    u[c] = -(lp[c] + ll[split ? c * n : c] + offset);   // (split: the n copies of a chain carry the same log-likelihood; the first is read)
+    for (int i = 0; i < n; ++i) g[c * n + i] = -(dlp_dz[c * n + i] + dll[c * n + i]);    // (split: row c n + i holds direction i)
 }
 
 } // namespace dynlat

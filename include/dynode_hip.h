@@ -361,9 +361,9 @@ int dyn_latent_sites(const dyn_site_desc *sites, int32_t n_sites, int64_t C, con
  *     written in `dtype` (DYN_F32 / DYN_F64); x, lp, dlp_dz as in dyn_latent_sites.
  *   dyn_potential_combine: u[c] = -(lp[c] + ll[c] + offset), g[c][i] = -(dlp_dz[c][i] + dll[c][i]); all float64, device.
  *   split_directions != 0 (few chains on an otherwise idle GPU): one tangent direction per trajectory instead of n_sites in
- *     one -- params [n_sites][C][P] (chain c repeated), seeds [n_sites][C][1][P], to be solved as a batch of n_sites C rows
- *     with n_dir = 1 (a third less work on the serial path of every trajectory at n_sites = 2; same bits); the combine then
- *     reads ll [n_sites C] (the first C), dll [n_sites C][1] as [i][c].
+ *     one -- params [C][n_sites][P] (chain c repeated n_sites times), seeds [C][n_sites][1][P], to be solved as a batch of
+ *     n_sites C rows with n_dir = 1 (a third less work on the serial path of every trajectory at n_sites = 2; same bits); the
+ *     combine then reads ll [C n_sites] at c n_sites and dll [C n_sites][1] as [c][i].
  */
 int dyn_latent_param_map(const dyn_site_desc *sites, int32_t n_sites, int64_t C, const double *z, double *x, double *lp,
                          double *dlp_dz, int32_t P, const double *coef, const double *expo, int32_t dtype,
