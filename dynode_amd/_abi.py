@@ -85,7 +85,9 @@ class NutsStateC(ctypes.Structure):
     _fields_ = ([(n, ctypes.c_int32) for n in ("n_chains", "dim", "max_depth", "num_warmup", "num_samples", "n_windows", "pooled")]
                 + [("w_start", ctypes.c_int32 * NUTS_MAX_WINDOWS), ("w_end", ctypes.c_int32 * NUTS_MAX_WINDOWS),
                    ("seed", ctypes.c_uint64), ("target_accept", ctypes.c_double), ("max_delta_energy", ctypes.c_double)]
-                + [(n, ctypes.c_void_p) for n in NUTS_POINTER_FIELDS])
+                + [(n, ctypes.c_void_p) for n in NUTS_POINTER_FIELDS]
+                + [(n, ctypes.c_void_p) for n in ("pot_lp", "pot_dlp", "pot_ll", "pot_dll")]
+                + [("pot_offset", ctypes.c_double), ("pot_ll_stride", ctypes.c_int32), ("pot_reserved", ctypes.c_int32)])
 
 
 @dataclass(frozen=True)

@@ -178,8 +178,16 @@ __global__ void __launch_bounds__(64) nuts_advance(const dyn_nuts_state st) {
     Philox rng{(uint32_t)st.seed, (uint32_t)(st.seed >> 32), (uint64_t)L_rng_ctr, (uint32_t)c};
 
     // ---- finish the leapfrog started by the previous launch: second momentum half step
-    const double un = st.u_new[c];
-    const double *gn = st.g_new + (int64_t)c * D;
+    // the potential at z_eval: handed over as (u, g), or -- folded potential, infer/folded.py -- as its parts, combined here
+    // instead of in a launch of their own: u = -(lp + ll + offset), g = -(dlp + dll)
+    double un, gn[D];
+    if (st.pot_lp != nullptr) {
+        un = -(st.pot_lp[c] + st.pot_ll[(int64_t)c * st.pot_ll_stride] + st.pot_offset);
+        for (int i = 0; i < D; ++i) gn[i] = -(st.pot_dlp[(int64_t)c * D + i] + st.pot_dll[(int64_t)c * D + i]);
+    } else {
+        un = st.u_new[c];
+        for (int i = 0; i < D; ++i) gn[i] = st.g_new[(int64_t)c * D + i];
+    }
     const double *zn = st.z_eval + (int64_t)c * D;
     double rn[D], tmp[D];
     bool bad = !isfinite(un);

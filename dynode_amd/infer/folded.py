@@ -122,15 +122,29 @@ class FoldedPotential:
         return b
 
     def into(self, z: torch.Tensor, u_out: torch.Tensor, g_out: torch.Tensor) -> None:
-        from ..engine import _DTYPES, solve_batch_loglik
-        from .autodiff import direction_chunks
-
         C = z.shape[0]
         for t in (z, u_out, g_out):
             if not (t.is_cuda and t.dtype == torch.float64 and t.is_contiguous()):
                 raise ValueError("FoldedPotential.into needs contiguous float64 device tensors")
         if tuple(z.shape) != (C, self.n) or tuple(g_out.shape) != (C, self.n) or tuple(u_out.shape) != (C,):
             raise ValueError(f"shapes: z, g [C, {self.n}], u [C]")
+        lp, dlp, ll, dll, stride = self.parts(z)
+        rc = _abi.lib().dyn_potential_combine(C, self.n, lp.data_ptr(), dlp.data_ptr(), ll.data_ptr(), dll.data_ptr(), self.offset,
+                                              int(stride > 1), u_out.data_ptr(), g_out.data_ptr(),
+                                              ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        if rc:
+            raise RuntimeError(f"dyn_potential_combine: {_abi.ERR_NAMES.get(rc, rc)}")
+
+    def parts(self, z: torch.Tensor):
+        """The two launches in front of the combine: ``(lp [C], dlp [C, n], ll, dll [C, n], ll_stride)`` with
+        ``u = -(lp + ll[::ll_stride] + offset)``, ``g = -(dlp + dll)`` -- `dyn_nuts_advance` forms these itself
+        (`dyn_nuts_state.pot_*`), so a sampler iteration of `KernelNUTS` is three launches."""
+        from ..engine import _DTYPES, solve_batch_loglik
+        from .autodiff import direction_chunks
+
+        C = z.shape[0]
+        if not (z.is_cuda and z.dtype == torch.float64 and z.is_contiguous() and tuple(z.shape) == (C, self.n)):
+            raise ValueError(f"FoldedPotential needs a contiguous float64 device tensor [C, {self.n}]")
         L, b, c = _abi.lib(), self._buffers(C), self.call
         arr, n = self.pot.site_table
         stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -154,10 +168,7 @@ class FoldedPotential:
                 grads.append(dlp_)
                 start += nd
             dll = grads[0] if len(grads) == 1 else torch.cat(grads, dim=1)
-        rc = L.dyn_potential_combine(C, self.n, b["lp"].data_ptr(), b["dlp"].data_ptr(), ll.data_ptr(), dll.data_ptr(),
-                                     self.offset, int(split), u_out.data_ptr(), g_out.data_ptr(), stream)
-        if rc:
-            raise RuntimeError(f"dyn_potential_combine: {_abi.ERR_NAMES.get(rc, rc)}")
+        return b["lp"], b["dlp"], ll, dll.reshape(C, self.n), (self.n if split else 1)
 
     def __call__(self, z: torch.Tensor):
         """The ``potential_and_grad`` signature (fresh outputs), for the samplers that are not `KernelNUTS`."""

@@ -856,11 +856,15 @@ class KernelNUTS(LockstepNUTS):
             assert t.dtype == want and t.is_contiguous() and t.device == dev, name
             setattr(st, name, t.data_ptr())
 
-        into = getattr(self.pg, "into", None)      # a folded potential writes the kernel's inputs itself (infer/folded.py)
+        parts = getattr(self.pg, "parts", None)    # a folded potential hands its parts to the kernel (infer/folded.py)
+        keep_alive = []
 
         def iteration():
-            if into is not None:
-                into(S["z_eval"], S["u_new"], S["g_new"])
+            if parts is not None:
+                lp_, dlp_, ll_, dll_, stride = parts(S["z_eval"])
+                keep_alive[:] = [lp_, dlp_, ll_, dll_]
+                st.pot_lp, st.pot_dlp, st.pot_ll, st.pot_dll = lp_.data_ptr(), dlp_.data_ptr(), ll_.data_ptr(), dll_.data_ptr()
+                st.pot_offset, st.pot_ll_stride = float(self.pg.offset), int(stride)
             else:
                 u_, g_ = self.pg(S["z_eval"])
                 S["u_new"].copy_(u_)

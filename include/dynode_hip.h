@@ -317,6 +317,12 @@ typedef struct dyn_nuts_state {
     /* post-warm-up draws */
     double *out_z, *out_acc;           /* [C][num_samples][D], [C][num_samples] */
     int32_t *out_n, *out_div;          /* [C][num_samples] leapfrogs per draw, divergence flag */
+    /* ABI 6, optional: the potential at z_eval in parts instead of (u_new, g_new) -- when pot_lp != NULL the kernel forms
+     * u = -(pot_lp[c] + pot_ll[c * pot_ll_stride] + pot_offset), g[c][i] = -(pot_dlp[c][i] + pot_dll[c][i]) itself
+     * (what dyn_potential_combine would write; saves that launch in every sampler iteration) */
+    const double *pot_lp, *pot_dlp, *pot_ll, *pot_dll;
+    double pot_offset;
+    int32_t pot_ll_stride, pot_reserved;
 } dyn_nuts_state;
 int dyn_nuts_advance(const dyn_nuts_state *st, void *stream);
 /* sizeof(dyn_nuts_state), for binding checks */

@@ -116,7 +116,7 @@ def test_sampler_state_struct_matches_the_header_and_rng_known_answers():
     ptrs = []
     for decl in re.findall(r"(?:const\s+)?(?:double|int32_t|int64_t)\s+(\*[^;]+);", body):
         ptrs += [n.strip().lstrip("*") for n in decl.split(",")]
-    assert tuple(ptrs) == _abi.NUTS_POINTER_FIELDS
+    assert tuple(ptrs) == _abi.NUTS_POINTER_FIELDS + ("pot_lp", "pot_dlp", "pot_ll", "pot_dll")     # (the optional potential parts come last)
     for name, val in (("DYN_NUTS_MAX_DIM", _abi.NUTS_MAX_DIM), ("DYN_NUTS_MAX_DEPTH", _abi.NUTS_MAX_DEPTH),
                       ("DYN_NUTS_MAX_WINDOWS", _abi.NUTS_MAX_WINDOWS)):
         assert int(re.search(rf"#define {name} (\d+)", text).group(1)) == val
