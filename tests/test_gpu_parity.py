@@ -547,7 +547,14 @@ def fuzz_compare(case, dtype=F64):
     step counts must be identical; float32: within the accept/reject flips rounding noise causes)."""
     m, y0, p, C, t1, ts, kw = case
     r = solve_batch(m, y0, p, C, t1, ts, dtype=dtype, **kw)
+    # the same case dispatched in a scrambled order (dyn_solve_batch_ordered): whatever the options (sub-save masks, jumps,
+    # constant steps, failures, +inf rows), not a bit may move
+    B = np.asarray(p).reshape(-1, m.param_dim).shape[0]
+    scr = torch.randperm(B, generator=torch.Generator().manual_seed(B)).to(torch.int32).cuda()
+    r_scr = solve_batch(m, y0, p, C, t1, ts, dtype=dtype, order=scr, **kw)
     torch.cuda.synchronize()
+    for a, b in ((r_scr.ys, r.ys), (r_scr.status, r.status), (r_scr.n_accept, r.n_accept), (r_scr.n_reject, r.n_reject)):
+        assert torch.equal(torch.nan_to_num(a, nan=-1.0), torch.nan_to_num(b, nan=-1.0)) if a.is_floating_point() else torch.equal(a, b)
     want, st, na, nr = O.solve(H.omodel(m), y0, p, C, t1, ts, dtype=NP[dtype], n_threads=8, **kw)
     if dtype == F32:
         got, fin = r.ys.cpu().numpy(), np.isfinite(want)
