@@ -31,7 +31,7 @@ EXPORTED_SYMBOLS = (
     "dyn_nuts_advance", "dyn_nuts_state_size", "dyn_philox4x32_10", "dyn_latent_sites",
     "dyn_solve_batch_loglik", "dyn_register_instance", "dyn_last_kernel_name", "dyn_solve_batch_record",
     "dyn_solve_batch_replay", "dyn_latent_param_map", "dyn_potential_combine", "dyn_solve_batch_ordered", "dyn_cost_order",
-    "dyn_cost_order_capacity",
+    "dyn_cost_order_capacity", "dyn_nuts_advance_mapped",
 )
 
 MAX_COST_FEATURES = 32
@@ -203,6 +203,9 @@ def lib() -> ctypes.CDLL:
         L.dyn_solve_batch_replay.argtypes = base + [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p]
         L.dyn_solve_batch_ordered.restype = ctypes.c_int
         L.dyn_solve_batch_ordered.argtypes = base + [ctypes.c_void_p, ctypes.c_void_p]
+        L.dyn_nuts_advance_mapped.restype = ctypes.c_int
+        L.dyn_nuts_advance_mapped.argtypes = ([ctypes.POINTER(NutsStateC), ctypes.POINTER(SiteDescC), ctypes.c_int32, ctypes.c_int32,
+                                               ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32] + [ctypes.c_void_p] * 6)
         L.dyn_cost_order_capacity.restype = ctypes.c_int32
         L.dyn_cost_order_capacity.argtypes = [ctypes.c_int32]
         L.dyn_cost_order.restype = ctypes.c_int

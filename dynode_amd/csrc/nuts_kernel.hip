@@ -11,7 +11,7 @@
 // next leapfrog -- is this single launch (about 400 tiny torch kernels before).  Randomness is
 // Philox4x32-10 keyed by (seed, chain) with a per-chain counter, so a chain's stream does not
 // depend on the other chains.
-#include "../../include/dynode_hip.h"
+#include "latent_device.hpp"
 
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -113,7 +113,7 @@ __device__ inline void mass_sqrt(const double *imm, double *out) {
 }
 
 template <int D>
-__global__ void __launch_bounds__(64) nuts_advance(const dyn_nuts_state st) {
+__global__ void __launch_bounds__(64) nuts_advance(const dyn_nuts_state st, const dynlat::MapArgs map) {
     const int c = blockIdx.x * 64 + threadIdx.x;
     const int C = st.n_chains, Dm = st.max_depth;
     if (c >= C) return;
@@ -407,9 +407,22 @@ __global__ void __launch_bounds__(64) nuts_advance(const dyn_nuts_state st) {
     double rh[D];
     for (int i = 0; i < D; ++i) rh[i] = rc[i] - 0.5 * es * gc[i];
     matvec<D>(imm, rh, tmp);
+    double ze[D];
     for (int i = 0; i < D; ++i) {
         p_r_half[i] = rh[i];
-        st.z_eval[(int64_t)c * D + i] = (it >= total) ? z[i] : zc[i] + es * tmp[i];
+        ze[i] = (it >= total) ? z[i] : zc[i] + es * tmp[i];
+        st.z_eval[(int64_t)c * D + i] = ze[i];
+    }
+    // dyn_nuts_advance_mapped: the prior side of the potential at that position and the parameter rows / tangent seeds of
+    // the solve that comes next -- what dyn_latent_param_map would do in a launch of its own (the potential parts read at the
+    // top of this call were consumed above, so their buffers can take the next position's values now)
+    if (map.enabled) {
+        if (map.f64)
+            dynlat::map_chain<double>(map.tab, st.n_chains, c, ze, map.x, map.lp, map.dlp_dz, map.P, map.coef, map.expo,
+                                      (double *)map.params, (double *)map.seeds, map.split);
+        else
+            dynlat::map_chain<float>(map.tab, st.n_chains, c, ze, map.x, map.lp, map.dlp_dz, map.P, map.coef, map.expo,
+                                     (float *)map.params, (float *)map.seeds, map.split);
     }
     st.rng_ctr[c] = (int64_t)rng.ctr;
     st.u[c] = L_u;
@@ -451,7 +464,7 @@ extern "C" void dyn_philox4x32_10(const uint32_t *ctr, const uint32_t *key, uint
     for (int i = 0; i < 4; ++i) out[i] = o[i];
 }
 
-extern "C" int dyn_nuts_advance(const dyn_nuts_state *st, void *stream) {
+static int advance(const dyn_nuts_state *st, const dynlat::MapArgs &map, void *stream) {
     if (!st) return DYN_ERR_NULL;
     if (st->n_chains < 0 || st->dim < 1 || st->dim > DYN_NUTS_MAX_DIM || st->max_depth < 1 ||
         st->max_depth > DYN_NUTS_MAX_DEPTH || st->n_windows < 0 || st->n_windows > DYN_NUTS_MAX_WINDOWS)
@@ -459,11 +472,11 @@ extern "C" int dyn_nuts_advance(const dyn_nuts_state *st, void *stream) {
     if (st->n_chains == 0) return 0;
     const unsigned blocks = (unsigned)((st->n_chains + 63) / 64);
     if (st->pooled && (!st->pool || !st->pool_ro || !st->pend)) return DYN_ERR_NULL;
-    using Kern = void (*)(const dyn_nuts_state);
+    using Kern = void (*)(const dyn_nuts_state, const dynlat::MapArgs);
     static const Kern kernels[DYN_NUTS_MAX_DIM] = {
         dynnuts::nuts_advance<1>, dynnuts::nuts_advance<2>, dynnuts::nuts_advance<3>, dynnuts::nuts_advance<4>,
         dynnuts::nuts_advance<5>, dynnuts::nuts_advance<6>, dynnuts::nuts_advance<7>, dynnuts::nuts_advance<8>};
-    hipLaunchKernelGGL(kernels[st->dim - 1], dim3(blocks), dim3(64), 0, (hipStream_t)stream, *st);
+    hipLaunchKernelGGL(kernels[st->dim - 1], dim3(blocks), dim3(64), 0, (hipStream_t)stream, *st, map);
     if (hipGetLastError() != hipSuccess) return DYN_ERR_LAUNCH;
     if (st->pooled) {
         // readers of the next launch see the pool as it stands now, never a half-updated one
@@ -472,4 +485,37 @@ extern "C" int dyn_nuts_advance(const dyn_nuts_state *st, void *stream) {
             return DYN_ERR_LAUNCH;
     }
     return 0;
+}
+
+extern "C" int dyn_nuts_advance(const dyn_nuts_state *st, void *stream) {
+    dynlat::MapArgs map;
+    map.enabled = 0;
+    return advance(st, map, stream);
+}
+
+extern "C" int dyn_nuts_advance_mapped(const dyn_nuts_state *st, const dyn_site_desc *sites, int32_t n_sites, int32_t P,
+                                       const double *coef, const double *expo, int32_t dtype, int32_t split_directions, double *x,
+                                       double *lp, double *dlp_dz, void *params, void *seeds, void *stream) {
+    if (!st || !sites || !coef || !expo || !x || !lp || !dlp_dz || !params || !seeds) return DYN_ERR_NULL;
+    if (n_sites != st->dim || n_sites < 1 || n_sites > DYN_MAX_SITES || P < 1) return DYN_ERR_SIZE;
+    if (dtype != DYN_F32 && dtype != DYN_F64) return DYN_ERR_OPTS;
+    dynlat::MapArgs map;
+    map.tab.n = n_sites;
+    for (int i = 0; i < n_sites; ++i) {
+        const dyn_site_desc &d = sites[i];
+        if (d.dist < DYN_DIST_NORMAL || d.dist > DYN_DIST_TRUNCNORMAL || d.aff_scale == 0.0 || !(d.lo < d.hi)) return DYN_ERR_OPTS;
+        map.tab.s[i] = d;
+    }
+    map.enabled = 1;
+    map.P = P;
+    map.f64 = dtype == DYN_F64;
+    map.split = split_directions != 0;
+    map.coef = coef;
+    map.expo = expo;
+    map.x = x;
+    map.lp = lp;
+    map.dlp_dz = dlp_dz;
+    map.params = params;
+    map.seeds = seeds;
+    return advance(st, map, stream);
 }

@@ -138,22 +138,45 @@ class FoldedPotential:
     def parts(self, z: torch.Tensor):
         """The two launches in front of the combine: ``(lp [C], dlp [C, n], ll, dll [C, n], ll_stride)`` with
         ``u = -(lp + ll[::ll_stride] + offset)``, ``g = -(dlp + dll)`` -- `dyn_nuts_advance` forms these itself
-        (`dyn_nuts_state.pot_*`), so a sampler iteration of `KernelNUTS` is three launches."""
-        from ..engine import _DTYPES, solve_batch_loglik
-        from .autodiff import direction_chunks
+        (`dyn_nuts_state.pot_*`)."""
+        self.map_now(z)
+        return self.solve_current(z.shape[0])
+
+    def map_now(self, z: torch.Tensor) -> None:
+        """`dyn_latent_param_map` at ``z``: fills this potential's buffers (x, lp, dlp, parameter rows, seeds)."""
+        from ..engine import _DTYPES
 
         C = z.shape[0]
         if not (z.is_cuda and z.dtype == torch.float64 and z.is_contiguous() and tuple(z.shape) == (C, self.n)):
             raise ValueError(f"FoldedPotential needs a contiguous float64 device tensor [C, {self.n}]")
-        L, b, c = _abi.lib(), self._buffers(C), self.call
+        b = self._buffers(C)
         arr, n = self.pot.site_table
-        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-        split = self.split_directions(C)
-        rc = L.dyn_latent_param_map(arr, n, C, z.data_ptr(), b["x"].data_ptr(), b["lp"].data_ptr(), b["dlp"].data_ptr(), self.P,
-                                    self.coef.data_ptr(), self.expo.data_ptr(), _DTYPES[self.dtype], int(split),
-                                    b["params"].data_ptr(), b["seeds"].data_ptr(), stream)
+        rc = _abi.lib().dyn_latent_param_map(arr, n, C, z.data_ptr(), b["x"].data_ptr(), b["lp"].data_ptr(), b["dlp"].data_ptr(),
+                                             self.P, self.coef.data_ptr(), self.expo.data_ptr(), _DTYPES[self.dtype],
+                                             int(self.split_directions(C)), b["params"].data_ptr(), b["seeds"].data_ptr(),
+                                             ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
         if rc:
             raise RuntimeError(f"dyn_latent_param_map: {_abi.ERR_NAMES.get(rc, rc)}")
+
+    def advance_mapped(self, st, C: int) -> int:
+        """`dyn_nuts_advance_mapped`: the sampler kernel also fills this potential's buffers for the position it hands out,
+        so the NEXT gradient is `solve_current` alone (a sampler iteration: two launches)."""
+        from ..engine import _DTYPES
+
+        b = self._buffers(C)
+        arr, n = self.pot.site_table
+        return _abi.lib().dyn_nuts_advance_mapped(ctypes.byref(st), arr, n, self.P, self.coef.data_ptr(), self.expo.data_ptr(),
+                                                  _DTYPES[self.dtype], int(self.split_directions(C)), b["x"].data_ptr(),
+                                                  b["lp"].data_ptr(), b["dlp"].data_ptr(), b["params"].data_ptr(),
+                                                  b["seeds"].data_ptr(), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+
+    def solve_current(self, C: int):
+        """The gradient-solve on the parameter rows and seeds the buffers hold: ``(lp, dlp, ll, dll, ll_stride)``."""
+        from ..engine import solve_batch_loglik
+        from .autodiff import direction_chunks
+
+        b, c = self._buffers(C), self.call
+        split = self.split_directions(C)
         method = c["kw"].get("method", "tsit5")
         if split:      # n C trajectories with one direction each: ll [n C], dll [n C, 1]
             ll, dll, *_ = solve_batch_loglik(c["model"], c["y0"], b["params"], c["contact"], c["t1"], c["save_ts"], c["obs"],

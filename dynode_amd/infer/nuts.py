@@ -856,20 +856,25 @@ class KernelNUTS(LockstepNUTS):
             assert t.dtype == want and t.is_contiguous() and t.device == dev, name
             setattr(st, name, t.data_ptr())
 
-        parts = getattr(self.pg, "parts", None)    # a folded potential hands its parts to the kernel (infer/folded.py)
+        # a folded potential (infer/folded.py) hands its parts to the kernel, and the kernel prepares the next position's
+        # prior side and parameter rows itself: an iteration is the gradient-solve and dyn_nuts_advance_mapped
+        folded = self.pg if hasattr(self.pg, "solve_current") else None
         keep_alive = []
+        if folded is not None:
+            folded.map_now(S["z_eval"])
 
         def iteration():
-            if parts is not None:
-                lp_, dlp_, ll_, dll_, stride = parts(S["z_eval"])
+            if folded is not None:
+                lp_, dlp_, ll_, dll_, stride = folded.solve_current(C)
                 keep_alive[:] = [lp_, dlp_, ll_, dll_]
                 st.pot_lp, st.pot_dlp, st.pot_ll, st.pot_dll = lp_.data_ptr(), dlp_.data_ptr(), ll_.data_ptr(), dll_.data_ptr()
-                st.pot_offset, st.pot_ll_stride = float(self.pg.offset), int(stride)
+                st.pot_offset, st.pot_ll_stride = float(folded.offset), int(stride)
+                rc = folded.advance_mapped(st, C)
             else:
                 u_, g_ = self.pg(S["z_eval"])
                 S["u_new"].copy_(u_)
                 S["g_new"].copy_(g_)
-            rc = L.dyn_nuts_advance(ctypes.byref(st), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+                rc = L.dyn_nuts_advance(ctypes.byref(st), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
             if rc:
                 raise RuntimeError(f"dyn_nuts_advance: {_abi.ERR_NAMES.get(rc, rc)}")
 

@@ -376,6 +376,13 @@ int dyn_latent_param_map(const dyn_site_desc *sites, int32_t n_sites, int64_t C,
                          int32_t split_directions, void *params, void *seeds, void *stream);
 int dyn_potential_combine(int64_t C, int32_t n, const double *lp, const double *dlp_dz, const double *ll,
                           const double *dll, double offset, int32_t split_directions, double *u, double *g, void *stream);
+/* dyn_nuts_advance that also does, for the position it hands out (z_eval), what dyn_latent_param_map (below) would do in a
+ * launch of its own: constrained values, log prior and its derivative, the parameter rows and tangent seeds of the solve that
+ * follows.  With st->pot_* set, a sampler iteration of the folded potential is TWO launches: dyn_solve_batch_loglik and this.
+ * n_sites must equal st->dim; the buffers are those of dyn_latent_param_map (lp = st->pot_lp, dlp_dz = st->pot_dlp of the next call). */
+int dyn_nuts_advance_mapped(const dyn_nuts_state *st, const dyn_site_desc *sites, int32_t n_sites, int32_t P, const double *coef,
+                            const double *expo, int32_t dtype, int32_t split_directions, double *x, double *lp, double *dlp_dz,
+                            void *params, void *seeds, void *stream);
 
 /*
  * Dispatch order.  dyn_solve_batch_ordered is dyn_solve_batch with one more argument: grid slot i integrates trajectory
