@@ -449,3 +449,30 @@ def test_a_forecast_that_explains_little_is_not_used():
     cm = schedule.CostModel(P=3, device=torch.device("cpu"))
     cm.observe(params, 100.0 + 2.0 * torch.log(params[:, 0]) + noise, torch.zeros(6000, dtype=torch.int32))
     assert cm.fitted_rows == 6000 and not cm.ready          # R^2 of a few per cent: the batch keeps its given order
+
+
+def test_on_demand_seip_lane_mappings_follow_the_dispatch_rules():
+    """jit._seip_wave_group / _features (host logic, no compiler): which SEIP lane mapping an on-demand build instantiates and
+    the feature word it registers -- the words `select_seip_entry` (csrc/dynode_hip.hip) looks for."""
+    from dynode_amd import jit, synthetic
+
+    def shape(**kw):
+        return synthetic.seip(B=1, seed=0, t1=5.0, **kw).model
+
+    cases = [
+        (dict(A=8, L=3, K1=3, M1=4), (3, 3), 0x100 | 0x200 | 3),        # 64 lanes per tier, three tiers: one tier per wave
+        (dict(A=8, L=4, K1=3, M1=4), (3, 6), 0x100 | 0x200 | 3),        # 128 lanes per tier: two waves per tier
+        (dict(A=8, L=3, K1=4, M1=2), (4, 4), 0x100 | 0x200 | 4),
+        (dict(A=8, L=3, K1=2, M1=3), (2, 2), 0x100 | 0x20 | 0x40 | 2),  # two tiers: a wave each
+        (dict(A=8, L=4, K1=2, M1=2), (2, 4), 0x100 | 0x20 | 0x80 | 2),
+        (dict(A=8, L=4, K1=1, M1=3), (1, 2), 0x100 | 0x40 | 1),         # one tier, 16 histories: two waves
+        (dict(A=8, L=3, K1=1, M1=3), None, 0x100 | 1),                  # fits a wavefront: no wave group
+        (dict(A=4, L=3, K1=3, M1=3), None, 0x100 | 0x20 | 3),           # half a wavefront: tier lanes inside the wave
+        (dict(A=2, L=2, K1=2, M1=2), None, 0x100 | 2),
+    ]
+    for kw, wg, feat in cases:
+        m = shape(n_knots=1, **kw)
+        assert jit._seip_wave_group(m) == wg, kw
+        assert jit._features(m, torch.float64) == feat, kw
+    src = jit._source(shape(A=8, L=4, K1=3, M1=4, n_knots=1), torch.float32, 0, 0, 1)
+    assert "launch_seip<float, 0, 8, 4, 3, 4, 3, 6>" in src
