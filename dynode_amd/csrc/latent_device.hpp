@@ -72,12 +72,12 @@ __device__ inline void map_chain(const SiteTable &tab, int64_t C, int64_t c, con
                                  double *__restrict__ lp_out, double *__restrict__ dlp_dz, int P, const double *__restrict__ coef,
                                  const double *__restrict__ expo, T *__restrict__ params, T *__restrict__ seeds, int split) {
     const int n = tab.n;
-    double total = 0.0, x[DYN_MAX_SITES], rel[DYN_MAX_SITES];   // rel_i = (dx_i/dz_i) / x_i
+    double total = 0.0, x[DYN_MAX_SITES], rel[DYN_MAX_SITES];   // rel_i = (dx_i/dz_i) / x_i (0 where x_i == 0: see the seeds below)
     for (int i = 0; i < n; ++i) {
         const SiteValue v = eval_site(tab.s[i], zrow[i]);
         total += v.lp;
         x[i] = v.x;
-        rel[i] = v.dx / v.x;
+        rel[i] = v.x != 0.0 ? v.dx / v.x : 0.0;
         x_out[c * n + i] = v.x;
         dlp_dz[c * n + i] = v.dlp;
     }
@@ -90,14 +90,30 @@ __device__ inline void map_chain(const SiteTable &tab, int64_t C, int64_t c, con
             else if (e == -1.0) p /= x[i];
             else if (e != 0.0) p *= pow(x[i], e);
         }
+        // seed d p_j / d z_i = expo_ji p_j (dx_i/dz_i) / x_i.  A parameter that does not depend on site i (expo == 0) gets an exact
+        // 0 whatever x_i is -- 0 * inf would be NaN when a site value underflows to 0 (a bounded site at its lower end, an
+        // identity site at 0) and would reach every gradient through the solve; at x_i == 0 itself the derivative of a power
+        // is 0 (e > 1), the coefficient (e == 1) or unbounded: the first two are formed from the product without x_i
+        auto seed = [&](int i) -> double {
+            const double e = expo[j * n + i];
+            if (e == 0.0) return 0.0;
+            if (x[i] != 0.0) return e * p * rel[i];
+            if (e < 1.0) return e * p * rel[i];      // unbounded derivative at the boundary: NaN / inf is the honest answer
+            double q = coef[j] * e;
+            for (int k = 0; k < n; ++k) {
+                const double ek = k == i ? e - 1.0 : expo[j * n + k];
+                if (ek != 0.0) q *= pow(x[k], ek);
+            }
+            return q * eval_site(tab.s[i], zrow[i]).dx;
+        };
         if (split) { // one direction per trajectory: chain c becomes rows c n .. c n + n - 1 of an n C batch with one seed row each
             for (int i = 0; i < n; ++i) {     // (neighbours: the copies of a chain take the same steps, so they share a wave for free)
                 params[(c * n + i) * P + j] = (T)p;
-                seeds[(c * n + i) * P + j] = (T)(expo[j * n + i] * p * rel[i]);
+                seeds[(c * n + i) * P + j] = (T)seed(i);
             }
         } else {
             params[c * P + j] = (T)p;
-            for (int i = 0; i < n; ++i) seeds[(c * n + i) * P + j] = (T)(expo[j * n + i] * p * rel[i]);
+            for (int i = 0; i < n; ++i) seeds[(c * n + i) * P + j] = (T)seed(i);
         }
     }
 }

@@ -303,33 +303,53 @@ def _replayed_tangents(model, y0, params, contact, t1, save_ts, dparams, dy0, *,
             dy = dy.unsqueeze(0).expand(B, n_dir, D)
         if tuple(dy.shape) != (B, n_dir, D):
             raise ValueError(f"dy0 must have shape {(n_dir, D)} or {(B, n_dir, D)}")
+    cap = schedule_capacity(model, dtype, len(save_ts))
+    cdt = float(kw.get("constant_dt", 0.0) or 0.0)
+    if cdt > 0.0:
+        need = int(np.ceil((float(t1) - float(kw.get("t0", 0.0))) / cdt)) + 1 + len(kw.get("jump_ts", ()) or ())
+        if need > cap:
+            raise ValueError(f"constant_step_size={cdt} takes {need} steps over the horizon, but a replayed step schedule of this "
+                             f"model holds at most {cap} (it is staged in LDS): use a larger step or split the horizon")
+    stream = kw.get("stream")
+    s = stream if stream is not None else torch.cuda.current_stream(device)
     base = solve_batch(model, y0_t, params_t, contact, t1, save_ts, dtype=dtype, out=out, stats_out=stats_out,
-                       record_steps=schedule_capacity(model, dtype, len(save_ts)), **kw)
-    # step along direction k: the largest |dp_i| / (|p_i| + floor) becomes _FD_REL_STEP
-    rel = (dp.abs() / (params_t.abs().unsqueeze(1) + 1e-3)).amax(dim=2)
-    if dy is not None:
-        y0b = y0_t if y0_t.dim() == 2 else y0_t.unsqueeze(0).expand(B, D)
-        rel = torch.maximum(rel, (dy.abs() / (y0b.abs().unsqueeze(1) + 1e-3)).amax(dim=2))
-    h = _FD_REL_STEP[dtype] / rel.clamp_min(1e-30)                                   # [B, n_dir]
-    h = torch.where(rel > 0, h, torch.ones_like(h))                                   # a zero direction: derivative 0
-    shift = (h.unsqueeze(-1) * dp).reshape(B * n_dir, P)
-    rows = params_t.repeat_interleave(n_dir, dim=0)
-    p_all = torch.cat([rows + shift, rows - shift], dim=0)                            # [2 n_dir B, P]
-    if dy is not None:
-        ys = (h.unsqueeze(-1) * dy).reshape(B * n_dir, D)
-        yrows = (y0_t if y0_t.dim() == 2 else y0_t.unsqueeze(0).expand(B, D)).repeat_interleave(n_dir, dim=0)
-        y_all = torch.cat([yrows + ys, yrows - ys], dim=0)
-    else:
-        y_all = y0_t.repeat_interleave(n_dir, dim=0).repeat(2, 1) if y0_t.dim() == 2 else y0_t
-    leader = torch.arange(B, device=device).repeat_interleave(n_dir).repeat(2)
+                       record_steps=cap, **kw)
+    with torch.cuda.stream(s):          # everything between the two launches runs on the stream the launches use
+        # step along direction k: the largest |dp_i| / (|p_i| + floor) becomes _FD_REL_STEP
+        rel = (dp.abs() / (params_t.abs().unsqueeze(1) + 1e-3)).amax(dim=2)
+        if dy is not None:
+            y0b = y0_t if y0_t.dim() == 2 else y0_t.unsqueeze(0).expand(B, D)
+            rel = torch.maximum(rel, (dy.abs() / (y0b.abs().unsqueeze(1) + 1e-3)).amax(dim=2))
+        h = _FD_REL_STEP[dtype] / rel.clamp_min(1e-30)                                   # [B, n_dir]
+        h = torch.where(rel > 0, h, torch.ones_like(h))                                   # a zero direction: derivative 0
+        shift = (h.unsqueeze(-1) * dp).reshape(B * n_dir, P)
+        rows = params_t.repeat_interleave(n_dir, dim=0)
+        p_all = torch.cat([rows + shift, rows - shift], dim=0)                            # [2 n_dir B, P]
+        if dy is not None:
+            ys = (h.unsqueeze(-1) * dy).reshape(B * n_dir, D)
+            yrows = (y0_t if y0_t.dim() == 2 else y0_t.unsqueeze(0).expand(B, D)).repeat_interleave(n_dir, dim=0)
+            y_all = torch.cat([yrows + ys, yrows - ys], dim=0)
+        else:
+            y_all = y0_t.repeat_interleave(n_dir, dim=0).repeat(2, 1) if y0_t.dim() == 2 else y0_t
+        leader = torch.arange(B, device=device).repeat_interleave(n_dir).repeat(2)
     kw.pop("constant_dt", None)                                                       # the recording already holds the steps
     pert = solve_batch(model, y_all, p_all, contact, t1, save_ts, dtype=dtype, replay=base.schedule + (leader,), **kw)
     n = B * n_dir
-    dys = (pert.ys[:n] - pert.ys[n:]).reshape(B, n_dir, pert.ys.shape[1], -1) / (2.0 * h).reshape(B, n_dir, 1, 1)
-    dys = dys.permute(0, 2, 1, 3).contiguous()
-    if dout is not None:
-        dout.copy_(dys)
-        dys = dout
+    with torch.cuda.stream(s):
+        # A primal that needed more accepted steps than the schedule holds (count -1) cannot be followed, and a perturbed
+        # row can fail by itself: such a trajectory reports a non-zero status (max_steps when the schedule overflowed, else
+        # the follower's code) and ZERO tangents -- never inf - inf = NaN behind an OK status.  On device, no sync.
+        follower = pert.status.reshape(2, B, n_dir).amax(dim=(0, 2))
+        overflow = base.schedule[1] < 0
+        status = torch.where(base.status != 0, base.status,
+                             torch.where(overflow, torch.ones_like(base.status), follower.to(base.status.dtype)))
+        base.status.copy_(status)
+        dys = (pert.ys[:n] - pert.ys[n:]).reshape(B, n_dir, pert.ys.shape[1], -1) / (2.0 * h).reshape(B, n_dir, 1, 1)
+        dys = torch.where((status != 0).reshape(B, 1, 1, 1), torch.zeros_like(dys), dys)
+        dys = dys.permute(0, 2, 1, 3).contiguous()
+        if dout is not None:
+            dout.copy_(dys)
+            dys = dout
     return BatchResult(base.ys, base.status, base.n_accept, base.n_reject, base.saved, base.sizes, dys, base.schedule)
 
 

@@ -466,8 +466,25 @@ class MCMCProcess(InferenceProcess):
             if self.progress_bar and rank == 0 and (it + 1) % max(1, total // 10) == 0:
                 print(f"[nuts] {'warmup' if warm else 'sample'} {it + 1}/{total} ({local} chains on this GPU)", flush=True)
 
-        res = sampler.run(z0, self.num_warmup, self.num_samples,
-                          init_step_size=self.nuts_kwargs.get("step_size", 1.0), progress=progress)
+        try:
+            res = sampler.run(z0, self.num_warmup, self.num_samples,
+                              init_step_size=self.nuts_kwargs.get("step_size", 1.0), progress=progress)
+        except Exception as err:
+            from .folded import FoldMismatch
+
+            if not isinstance(err, FoldMismatch):
+                raise
+            # the model's parameter map is not the monomial it looked like where the chains went: sample the model's own
+            # log joint instead (same kernels, more launches) -- never the extrapolated one
+            import sys
+
+            print(f"[dynode_amd] {err}; restarting with the general potential", file=sys.stderr, flush=True)
+            self._folded_potential = False
+            sampler = cls(pot.potential_and_grad, max_tree_depth=self.nuts_max_tree_depth,
+                          target_accept=self.nuts_kwargs.get("target_accept_prob", 0.8),
+                          seed=self.inference_prngkey + 7919 * rank, **extra)
+            res = sampler.run(z0, self.num_warmup, self.num_samples,
+                              init_step_size=self.nuts_kwargs.get("step_size", 1.0), progress=progress)
         if thinning > 1:   # numpyro keeps the draws whose (1-based) index is a multiple of `thinning`
             keep = slice(thinning - 1, None, thinning)
             res.samples, res.accept_prob = res.samples[:, keep].contiguous(), res.accept_prob[:, keep].contiguous()

@@ -795,6 +795,9 @@ class KernelNUTS(LockstepNUTS):
             raise ValueError("adaptation must be 'per_chain' or 'pooled'")
         self.block, self.use_graph, self.adaptation = int(block), bool(use_graph), adaptation
         self.monitor: Optional[Callable] = None     # diagnostics hook: called with the state dict every block
+        # a folded potential is re-checked against the model's own log joint at the chains' current positions after these
+        # blocks of warm-up (infer/folded.py: a parameter map that is piecewise far from the centre); a mismatch raises
+        self.recheck_blocks = (1, 3, 7)
 
     def run(self, z0: torch.Tensor, num_warmup: int, num_samples: int, init_step_size: float = 1.0,
             progress: Optional[Callable] = None) -> NUTSResult:
@@ -898,6 +901,11 @@ class KernelNUTS(LockstepNUTS):
                     iteration()
             self.evals += self.block
             blocks += 1
+            if folded is not None and blocks in self.recheck_blocks and hasattr(folded, "verify"):
+                if not folded.verify(S["z"].clone()):
+                    from .folded import FoldMismatch
+
+                    raise FoldMismatch(f"folded potential != model log joint at the chains' positions after {blocks * self.block} iterations")
             if self.monitor is not None:
                 self.monitor(S)
             if progress is not None:

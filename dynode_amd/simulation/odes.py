@@ -115,21 +115,26 @@ _OBS_CACHE: dict = {}
 
 
 def _observation_key(data):
-    """Cache key that changes when the observations do: a tensor's storage pointer and in-place version counter,
-    a numpy array's bytes (observation tables are small: time x groups)."""
+    """Cache key of an observation table.  A tensor is identified by the OBJECT (its id) and its in-place version counter;
+    the cache entry keeps a strong reference to it (`_observation_constants`), so the id -- and the storage behind it --
+    cannot be handed to another tensor while the entry lives (a freed tensor's address is routinely reused by the next one
+    of the same shape, with version 0 again).  No device-to-host copy: this runs at every potential evaluation of a
+    sampler.  A numpy array is identified by its bytes (observation tables are small: time x groups)."""
     if isinstance(data, torch.Tensor):
-        return ("t", data.data_ptr(), data._version, tuple(data.shape), str(data.dtype), str(data.device))
+        return ("t", id(data), data._version, tuple(data.shape), str(data.dtype), str(data.device))
     arr = np.ascontiguousarray(np.asarray(data))
     return ("n", arr.dtype.str, arr.shape, arr.tobytes())
 
 
 def _observation_constants(data, dtype, device, pad_tiers=None):
-    """(observations as a flat device tensor of the solve dtype, sum lgamma(data + 1)); cached by CONTENT (see
-    `_observation_key`), so a caller that refills one buffer with the next data set is scored on the new values.
-    ``pad_tiers`` = (tiers, slots): vaccinated models keep 2 or 4 tier slots per age on the kernel's contact axis
-    (axis 2 of the observation array, after time and age); the extra slots are filled with zeros."""
+    """(observations as a flat device tensor of the solve dtype, sum lgamma(data + 1)); cached per observation table
+    (see `_observation_key`), so a caller that refills one buffer in place, or passes the next data set, is scored on the
+    new values.  ``pad_tiers`` = (tiers, slots): vaccinated models keep 2 or 4 tier slots per age on the kernel's contact
+    axis (axis 2 of the observation array, after time and age); the extra slots are filled with zeros."""
     key = (_observation_key(data), dtype, str(device), pad_tiers)
     hit = _OBS_CACHE.get(key)
+    if hit is not None and isinstance(data, torch.Tensor) and hit[3] is not data:
+        hit = None                                  # an id that outlived its tensor (cannot happen while the entry holds it)
     if hit is None:
         if len(_OBS_CACHE) > 16:
             _OBS_CACHE.clear()
@@ -141,9 +146,10 @@ def _observation_constants(data, dtype, device, pad_tiers=None):
             extra = list(t64.shape)
             extra[2] = pad_tiers[1] - pad_tiers[0]
             t64 = torch.cat([t64, t64.new_zeros(extra)], dim=2)
-        hit = (t64.to(dtype).contiguous(), lg, shape)
+        # the last member pins a tensor argument: its id stays unique for as long as this entry can be hit
+        hit = (t64.to(dtype).contiguous(), lg, shape, data if isinstance(data, torch.Tensor) else None)
         _OBS_CACHE[key] = hit
-    return hit
+    return hit[:3]
 
 
 def _simulate_observed(ode, ode_parameters, packed, saveat, t1, kw, observe, differentiable, sp, n_comp, y0_arg=None):

@@ -476,3 +476,28 @@ def test_on_demand_seip_lane_mappings_follow_the_dispatch_rules():
         assert jit._features(m, torch.float64) == feat, kw
     src = jit._source(shape(A=8, L=4, K1=3, M1=4, n_knots=1), torch.float32, 0, 0, 1)
     assert "launch_seip<float, 0, 8, 4, 3, 4, 3, 6>" in src
+
+
+def test_observation_cache_never_scores_a_new_dataset_against_an_old_one():
+    """a freed observation tensor's address is reused by the next tensor of the same shape with version 0
+    again; the cache must tell the two apart (it pins the tensor it keyed) and must see in-place refills."""
+    from dynode_amd.simulation import odes
+
+    odes._OBS_CACHE.clear()
+    dev = torch.device("cpu")
+    seen = []
+    for scale in (1.0, 3.0, 7.0, 11.0):
+        data = torch.diff(torch.arange(0.0, 40.0).reshape(20, 2) ** 2 * scale, dim=0)   # same shape, freed every round
+        obs, lg, shape = odes._observation_constants(data, torch.float64, dev)
+        assert shape == (19, 2)
+        assert torch.equal(obs, data.to(torch.float64))
+        assert float(lg) == pytest.approx(float(torch.lgamma(data.double() + 1).sum()))
+        seen.append(float(lg))
+        del data
+    assert len(set(seen)) == 4
+    buf = torch.ones(5, 2)
+    a = odes._observation_constants(buf, torch.float64, dev)
+    assert odes._observation_constants(buf, torch.float64, dev)[0] is a[0]          # same object, same version: a hit
+    buf.mul_(4.0)                                                                   # refilled in place
+    b = odes._observation_constants(buf, torch.float64, dev)
+    assert torch.equal(b[0], torch.full((5, 2), 4.0, dtype=torch.float64))
