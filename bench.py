@@ -169,31 +169,14 @@ def profiled_traffic(workload: str, B: int, name: str):
     return None
 
 
-def other_draws(gen, wl, seed):
-    """B more parameter draws from the same generator with the same shared constants (age shares, contact matrix, save grid):
-    rows B..2B of the 2B-sample workload of the same seed.  The dispatch-order forecast (dynode_amd/schedule.py) is trained on
-    these, never on the batch that is timed.  None if the generator does not keep its constants across batch sizes."""
-    import numpy as np
-
-    big = gen(2 * wl.B, seed)
-    if not (np.array_equal(big.contact, wl.contact) and np.array_equal(big.save_ts, wl.save_ts) and big.model == wl.model):
-        return None
-    if big.y0.ndim == 2:
-        big.y0 = big.y0[wl.B:]
-    elif not np.array_equal(big.y0, wl.y0):
-        return None
-    big.params = big.params[wl.B:]
-    return big
-
-
-def measure(wl, dev, steps: int, warmup: int, fence, train_on=None, given_order_too=True):
-    """Resident inputs, `warmup` untimed launches, then `steps` launches with a HIP event pair around each.
-    ``train_on``: a workload of other draws of the same prior -- solved first (untimed) so that the step-count forecast behind
-    the dispatch order has never seen the timed batch."""
+def measure(wl, dev, steps: int, warmup: int, fence, order_hint_too=True):
+    """Resident inputs, `warmup` untimed launches, then `steps` launches with a HIP event pair around each -- the batch in its
+    GIVEN order, nothing learned or cached between launches (`solve_batch(order=None)`, the default).  ``order_hint_too``:
+    after the timed region, the same batch once more with a caller-supplied queue (most step attempts first, the exact counts
+    of the launches just timed): what `dyn_solve_batch_ordered` is worth to a caller who knows its batch.  Never the headline."""
     import numpy as np
     import torch
 
-    from dynode_amd import schedule
     from dynode_amd.engine import solve_batch
 
     m, f32 = wl.model, torch.float32
@@ -204,28 +187,11 @@ def measure(wl, dev, steps: int, warmup: int, fence, train_on=None, given_order_
     out = torch.empty((wl.B, wl.n_save, m.state_dim), dtype=f32, device=dev)
     stats = torch.empty((3, wl.B), dtype=torch.int32, device=dev)
 
-    def step(order="auto"):
+    def step(order=None):
         return solve_batch(m, y0, params, contact, wl.t1, ts, dtype=f32, out=out, stats_out=(stats[0], stats[1], stats[2]), order=order)
 
-    order_info = {"kind": "given order"}
-    if schedule.enabled() and wl.B >= schedule.MIN_BATCH and wl.B * m.state_dim >= schedule.MIN_WORK:
-        schedule.reset()
-        if train_on is not None:
-            ty0 = torch.as_tensor(train_on.y0, dtype=f32, device=dev)
-            tp = torch.as_tensor(train_on.params, dtype=f32, device=dev)
-            for _ in range(-(-schedule.TRAIN_ROWS // train_on.B)):
-                solve_batch(m, ty0, tp, contact, wl.t1, ts, dtype=f32, out=out, stats_out=(stats[0], stats[1], stats[2]))
-            del ty0, tp
-        for _ in range(warmup):
-            step()                  # (without `train_on` the forecast is fitted on these launches of the timed batch itself)
-        torch.cuda.synchronize()
-        cm = next(iter(schedule._MODELS.values()), None)
-        if cm is not None and cm.ready:
-            order_info = {"kind": "step-count forecast learned from earlier launches (dynode_amd/schedule.py), forecast + sort inside the timed region",
-                          "trained_on": (f"{cm.rows} other draws of the same prior" if train_on is not None else "the warm-up launches of this batch")}
-    else:
-        for _ in range(warmup):
-            step()
+    for _ in range(warmup):
+        step()
     fence()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
     t0 = time.perf_counter()
@@ -236,18 +202,17 @@ def measure(wl, dev, steps: int, warmup: int, fence, train_on=None, given_order_
     fence()
     elapsed = time.perf_counter() - t0
     kern_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev]))
-    if "trained_on" in order_info:
-        # beside it, after the timed region (clocks as warm as they were for it): the same batch in its given order
-        att = (stats[1] + stats[2]).double()
-        order_info["forecast_correlation_on_this_batch"] = float(torch.corrcoef(torch.stack([cm.forecast(params), att]))[0, 1])
-        if given_order_too:
-            given = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(min(steps, 20))]
-            for e0, e1 in given:
-                e0.record()
-                step(order=None)
-                e1.record()
-            torch.cuda.synchronize()
-            order_info["given_order_ms_per_launch"] = float(np.mean([e0.elapsed_time(e1) for e0, e1 in given]))
+    order_info = {"kind": "none: the batch in its given order, no forecast, nothing carried over from earlier launches"}
+    if order_hint_too:
+        hint = torch.argsort(stats[1] + stats[2], descending=True, stable=True).to(torch.int32)
+        given = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(min(steps, 10))]
+        for e0, e1 in given:
+            e0.record()
+            step(order=hint)
+            e1.record()
+        torch.cuda.synchronize()
+        order_info["with_caller_supplied_order_ms_per_launch"] = float(np.mean([e0.elapsed_time(e1) for e0, e1 in given]))
+        order_info["caller_supplied_order"] = "most step attempts first, exact counts of this batch (dyn_solve_batch_ordered): a side figure, not the headline"
     return {"elapsed": elapsed, "kernel_ms": kern_ms, "out": out, "stats": stats, "kernel": kernel_name(), "dispatch_order": order_info}
 
 
@@ -333,17 +298,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def held_out(r: int):
-        if args.scaling == "weak":
-            return other_draws(gen, wl, seed0 + 1000 * r)
-        big = gen(2 * (args.batch or 65536), seed0)      # strong: draws beyond the global batch, as many as this rank's shard
-        n = args.batch or 65536
-        big.params = big.params[n:n + B]
-        if big.y0.ndim == 2:
-            big.y0 = big.y0[n:n + B]
-        return big
-
-    res = measure(wl, dev, args.steps, args.warmup, fence, train_on=held_out(rank), given_order_too=not args.no_extra)
+    res = measure(wl, dev, args.steps, args.warmup, fence, order_hint_too=not args.no_extra and world == 1)
     elapsed, kern_ms = res["elapsed"], res["kernel_ms"]
     ok = int(res["stats"][0].max()) == 0
     steps_mean = float((res["stats"][1] + res["stats"][2]).float().mean())
@@ -366,7 +321,7 @@ def main():
                 shards_match = True
                 for r in range(1, world):
                     del res["out"]
-                    again = measure(shard_of(r), dev, 1, 0, torch.cuda.synchronize)
+                    again = measure(shard_of(r), dev, 1, 0, torch.cuda.synchronize, order_hint_too=False)
                     res["out"] = again["out"]
                     want = torch.tensor(checksums(again["out"], again["stats"]), dtype=torch.float64)
                     shards_match = shards_match and bool(torch.equal(want, every[r].cpu()))
@@ -404,7 +359,7 @@ def main():
             torch.cuda.empty_cache()
             # the same model without the bins axis, as a second full roofline block (20 launches, one event pair each)
             w2 = synthetic.WORKLOADS["cfg3d136"]()
-            r2 = measure(w2, dev, 20, 3, torch.cuda.synchronize, train_on=other_draws(synthetic.WORKLOADS["cfg3d136"], w2, SEEDS["cfg3d136"]))
+            r2 = measure(w2, dev, 20, 3, torch.cuda.synchronize)
             line["roofline_d136"] = dict(roofline_block(w2, "cfg3d136", r2), workload=describe(w2, "cfg3d136") + f", B={w2.B}",
                                          trajectories_per_s=w2.B / (r2["kernel_ms"] * 1e-3),
                                          all_status_ok=int(r2["stats"][0].max()) == 0)
@@ -414,14 +369,12 @@ def main():
             for name in ("cfg2", "cfg5", "seip", "seip3", "seip83", "seip84"):
                 torch.cuda.empty_cache()
                 w2 = synthetic.WORKLOADS[name]()
-                # (the SEIP forecasts stay below schedule.MIN_R2 and are not used: no point in generating other draws for them)
-                r2 = measure(w2, dev, 20, 3, torch.cuda.synchronize,
-                             train_on=other_draws(synthetic.WORKLOADS[name], w2, SEEDS[name]) if w2.model.family == 0 else None)
+                r2 = measure(w2, dev, 20, 3, torch.cuda.synchronize)
                 blk = roofline_block(w2, name, r2)
                 line["other_workloads"][name] = {
                     "workload": describe(w2, name) + f", B={w2.B}", "trajectories_per_s": w2.B / (r2["kernel_ms"] * 1e-3),
                     "ms_per_launch": r2["kernel_ms"], "hbm_frac": blk["frac"], "kernel": blk["kernel"],
-                    "given_order_ms_per_launch": r2["dispatch_order"].get("given_order_ms_per_launch"),
+                    "with_caller_supplied_order_ms_per_launch": r2["dispatch_order"].get("with_caller_supplied_order_ms_per_launch"),
                     "all_status_ok": int(r2["stats"][0].max()) == 0}
                 del r2
             torch.cuda.empty_cache()

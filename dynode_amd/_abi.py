@@ -72,6 +72,7 @@ class SolverOptsC(ctypes.Structure):
         ("constant_dt", ctypes.c_double),
         ("jump_ts", ctypes.POINTER(ctypes.c_double)),
         ("n_jump", ctypes.c_int32),
+        ("work_counter", ctypes.c_void_p),     # ABI 7: two zeroed int32 words on the device, or None (engine.work_counter)
     ]
 
 

@@ -277,6 +277,9 @@ static int enqueue(const Entry *e, const dyn_model_desc *m, const dyn_solver_opt
                    const LLArgs *ll = nullptr, const SchedArgs *sc = nullptr, const int32_t *order = nullptr) {
     KArgs<T> ka;
     ka.order = order;
+    // work pulling (dyn_solver_opts::work_counter): the s/e/i/r/c kernels; launch() keeps it only for grids beyond one
+    // resident round (the SEIP kernels have a static grid)
+    ka.work = (e->FEAT & kSeip) ? nullptr : o->work_counter;
     ka.sched_out = sc ? (T *)sc->out : nullptr;
     ka.sched_n_out = sc ? sc->n_out : nullptr;
     ka.sched_in = sc ? (const T *)sc->in : nullptr;

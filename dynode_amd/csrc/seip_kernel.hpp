@@ -753,7 +753,7 @@ struct Seip {
         const bool writer = valid_traj && !S.pad;
 
         // ---- LDS: save grid, then per trajectory slot the susceptibility table and the splines
-        extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
+        extern __shared__ __attribute__((aligned(32))) unsigned char dyn_smem[];
         T *const ts_tab = reinterpret_cast<T *>(dyn_smem);
         const int n_save = ka.n_save;
         constexpr int SUSN = H * K1 * M1 * L;
@@ -964,7 +964,7 @@ struct Seip {
 #pragma unroll
                     for (int r = 1; r < 7; ++r)
                         if (TB::berr[r] != 0.0) e2 += T(TB::berr[r]) * k[r].p[pp];
-                    const V2 ym = V2{M::max(M::abs(y.p[pp][0]), M::abs(yt.p[pp][0])), M::max(M::abs(y.p[pp][1]), M::abs(yt.p[pp][1]))};
+                    const V2 ym = V2{M::max_abs(y.p[pp][0], yt.p[pp][0]), M::max_abs(y.p[pp][1], yt.p[pp][1])};
                     const V2 sc = ym * rtol + atol;
                     const V2 r2 = (dt * e2) * V2{M::rcp_fast(sc[0]), M::rcp_fast(sc[1])};
                     ssq[pp & 1] += r2 * r2;   // (the pad element of an odd NV carries e = 0)

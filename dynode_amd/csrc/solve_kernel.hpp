@@ -18,6 +18,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 namespace dyn {
 
@@ -76,6 +77,10 @@ struct KArgs {
     // alone and written to its own rows); launch TIME does: the lane groups of a wave step in lock-step and waves are
     // dispatched in index order, so neighbours with similar step counts and the expensive ones first cost 10-15 % less.
     const int32_t *order;
+    // Work pulling (dyn_solver_opts::work_counter): two zeroed int32 words in device memory, or nullptr for a static launch.
+    // work[0] hands out queue entries beyond the first one of every slot, work[1] counts retired slots; the kernel leaves
+    // both at zero again (Solver::run).
+    int32_t *work;
 };
 constexpr int kMaxJumps = 16;
 
@@ -87,6 +92,13 @@ struct Mth<float> {
     static __device__ __forceinline__ float abs(float x) { return fabsf(x); }
     static __device__ __forceinline__ float max(float a, float b) { return fmaxf(a, b); }
     static __device__ __forceinline__ float min(float a, float b) { return fminf(a, b); }
+    // max(|a|, |b|) as ONE instruction: written with fmaxf / fabsf the compiler first quiets each operand (v_max x, x), three
+    // instructions per element of the error norm; v_max_f32 itself already returns the other operand for a NaN
+    static __device__ __forceinline__ float max_abs(float a, float b) {
+        float r;
+        asm("v_max_f32 %0, |%1|, |%2|" : "=v"(r) : "v"(a), "v"(b));
+        return r;
+    }
     static __device__ __forceinline__ float sqrt(float x) { return sqrtf(x); }
     static __device__ __forceinline__ float sin(float x) { return sinf(x); }
     static __device__ __forceinline__ float cos(float x) { return cosf(x); }
@@ -98,6 +110,9 @@ struct Mth<float> {
         return __builtin_fmaf(__builtin_fmaf(-x, r, 1.0f), r, r);
     }
     // x^e through v_log_f32 / v_exp_f32: only ever sets the next step size
+    // a / b for quantities that only steer the step-size controller (starting-step norms): multiply by the refined reciprocal
+    static __device__ __forceinline__ float div_ctl(float a, float r) { return a * r; }
+    static __device__ __forceinline__ float rcp_ctl(float b) { return recip(b); }
     static __device__ __forceinline__ float pow_fast(float x, float e) {
         return __builtin_amdgcn_exp2f(e * __builtin_amdgcn_logf(x));
     }
@@ -113,11 +128,18 @@ struct Mth<double> {
     static __device__ __forceinline__ double abs(double x) { return fabs(x); }
     static __device__ __forceinline__ double max(double a, double b) { return fmax(a, b); }
     static __device__ __forceinline__ double min(double a, double b) { return fmin(a, b); }
+    static __device__ __forceinline__ double max_abs(double a, double b) {
+        double r;
+        asm("v_max_f64 %0, |%1|, |%2|" : "=v"(r) : "v"(a), "v"(b));
+        return r;
+    }
     static __device__ __forceinline__ double sqrt(double x) { return ::sqrt(x); }
     static __device__ __forceinline__ double sin(double x) { return ::sin(x); }
     static __device__ __forceinline__ double cos(double x) { return ::cos(x); }
     static __device__ __forceinline__ double rcp_fast(double x) { return 1.0 / x; }
     static __device__ __forceinline__ double recip(double x) { return 1.0 / x; }
+    static __device__ __forceinline__ double div_ctl(double a, double r) { return a / r; }   // (float64: the oracle's division)
+    static __device__ __forceinline__ double rcp_ctl(double b) { return b; }
     static __device__ __forceinline__ double pow_fast(double x, double e) { return ::pow(x, e); }
     static __device__ __forceinline__ double exp(double x) { return ::exp(x); }
     static __device__ __forceinline__ double log(double x) { return ::log(x); }
@@ -148,6 +170,16 @@ struct Tab<0> { // Tsit5
                                        -0.007880878010261995,  0.1447110071732629,
                                        -0.5823571654525552,    0.45808210592918697,
                                        -0.015151515151515152};
+    // dense output: the weights b_i(theta) of Tsitouras' interpolant (the factored forms in Solver::dense_prepare) expanded
+    // in powers of theta; bp[i][m - 2] is the coefficient of theta^m, m = 2, 3, 4.  The theta^1 coefficient is 1 for i = 0
+    // (y'(t_prev) = f_0) and 0 for every other stage.  tests/test_tableau.py checks the expansion against the factored forms.
+    static constexpr double bp[7][3] = {{-2.763706197274826, 2.9132554618219126, -1.0530884977290216},
+                                        {0.13169999999999998, -0.2234, 0.1017},
+                                        {3.9302962368947516, -5.941033872131505, 2.490627285651253},
+                                        {-12.411077166933676, 30.33818863028232, -16.548102889244902},
+                                        {37.50931341651104, -88.1789048947664, 47.37952196281928},
+                                        {-27.896526289197286, 65.09189467479366, -34.87065786149661},
+                                        {1.5, -4.0, 2.5}};
 };
 template <>
 struct Tab<1> { // Dopri5
@@ -358,6 +390,19 @@ struct Control {
     }
 };
 
+// ---------------------------------------------------------------- kernel arguments of the cold paths
+// The stepping loop is entered thousands of times per launch, the prologue / write-off of a trajectory once per trajectory.
+// Arguments only those need (the input pointers, the batch size, the status arrays, ...) would otherwise sit in scalar
+// registers -- or in spilled ones, a v_readlane each -- through every iteration.  cold_args() hands back the kernel's argument
+// block (the KArgs struct is the kernel's only parameter, at offset 0 of the kernarg segment) through a pointer the compiler
+// cannot see through, so that those fields are re-read with scalar loads where they are used.
+template <typename T>
+__device__ __forceinline__ const KArgs<T> __attribute__((address_space(4))) *cold_args() {
+    auto p = (const KArgs<T> __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return p;
+}
+
 // ---------------------------------------------------------------- per-lane state in register pairs
 // One plane of the per-lane state (or of a stage derivative): N values kept as ceil(N / 2) two-element vectors, so that the
 // register allocator holds them in aligned register pairs from the start and the linear algebra of the stepper -- the
@@ -480,6 +525,47 @@ struct Solver {
         return v;
     }
 
+    // ---- step-scaled rates (PRESCALE).  Every term of the right-hand side is a rate times state values, so with the
+    // rates multiplied by the step size beforehand the right-hand side returns K = dt f directly: the stage combinations
+    // become y + sum a K (one packed FMA less per register pair and stage), the embedded error and the dense output lose
+    // their dt factors as well.  The rates as loaded are parked in LDS ([quad][lane] rows of four: conflict-free 16-byte
+    // reads) and re-scaled from there for every step attempt -- scaling the scaled copy by dt_new / dt_old instead would
+    // let rounding accumulate in the PARAMETERS over a hundred steps.  FSAL: k[0] carries the factor of the step it was
+    // computed in and is rescaled by dt_new / dt_old (Solver::run).  Every kernel without vaccination tiers (whose dose
+    // cap min(doses, s) is not linear in a rate).
+    static constexpr bool PRESCALE = KV == 0;
+    typedef T V4 __attribute__((ext_vector_type(4)));
+    // quads per lane: beta[S] | gamma[S] | sigma[S] | omega[S], then the same four blocks of every seed direction (the
+    // tangent of a rate-times-state term is d(rate) state + rate d(state): both carry the factor)
+    static constexpr int NRQ = S * (1 + ND);
+    __device__ __forceinline__ T &rate_ref(int i) {
+        const int plane = i / (4 * S), r = i % (4 * S), j = plane > 0 ? plane - 1 : 0;
+        if (plane == 0) return r < S ? beta[r] : (r < 2 * S ? gamma[r - S] : (r < 3 * S ? sigma[r - 2 * S] : omega[r - 3 * S]));
+        return r < S ? dbeta[j][r] : (r < 2 * S ? dgamma[j][r - S] : (r < 3 * S ? dsigma[j][r - 2 * S] : domega[j][r - 3 * S]));
+    }
+    __device__ __forceinline__ void park_rates(V4 *tab, int lane) {
+#pragma unroll
+        for (int q = 0; q < NRQ; ++q)
+            tab[q * 64 + lane] = V4{rate_ref(4 * q), rate_ref(4 * q + 1), rate_ref(4 * q + 2), rate_ref(4 * q + 3)};
+    }
+    __device__ __forceinline__ void scale_rates(const V4 *tab, int lane, T h) {
+#pragma unroll
+        for (int q = 0; q < NRQ; ++q) {
+            const V4 v = tab[q * 64 + lane] * h;
+#pragma unroll
+            for (int z = 0; z < 4; ++z) rate_ref(4 * q + z) = v[z];
+        }
+        if constexpr (PAIRED_RHS) {
+#pragma unroll
+            for (int q = 0; q < SP; ++q) {
+                beta2[q] = V2{beta[2 * q], beta[2 * q + 1]};
+                gamma2[q] = V2{gamma[2 * q], gamma[2 * q + 1]};
+                sigma2[q] = V2{sigma[2 * q], sigma[2 * q + 1]};
+                omega2[q] = V2{omega[2 * q], omega[2 * q + 1]};
+            }
+        }
+    }
+
     // acc_l = sum_k Cx[k] * x_l[lane ^ k]: all-gather over the lane group fused with the
     // pre-permuted contact row
     __device__ __forceinline__ void contract(const T (&x)[S], T (&acc)[S]) const {
@@ -557,15 +643,21 @@ struct Solver {
             return;
         }
         const State &y0 = y[0];
-        T se = 0, si = 0, sr = 0;
+        // everyone of this lane's strains who is not susceptible: the elements e | i | r sit in front of c and s (0 .. IC - 1);
+        // whole register pairs are added pairwise (packed adds), the two halves and an odd last element at the end
+        T others;
+        if constexpr (IC >= 4) {
+            V2 tot = y0.p[0];
 #pragma unroll
-        for (int l = 0; l < S; ++l) {
-            if constexpr (HAS_E) se += y0[IE + l];
-            si += y0[II + l];
+            for (int q = 1; q < IC / 2; ++q) tot += y0.p[q];
+            others = tot[0] + tot[1];
+            if constexpr (IC % 2 == 1) others += y0[IC - 1];
+        } else {
+            others = y0[0];
 #pragma unroll
-            for (int w = 0; w < W; ++w) sr += y0[IR + l * W + w];
+            for (int v = 1; v < IC; ++v) others += y0[v];
         }
-        const T N = y0[IS] + strain_sum((se + si) + sr);
+        const T N = y0[IS] + strain_sum(others);
         T invN = T(1);
         if (normalize) invN = pad ? T(0) : M::recip(N);
         T season = T(1), sin_arg = T(0), cos_arg = T(0);
@@ -822,22 +914,95 @@ struct Solver {
         }
     }
 
+    // ---- the same interpolant as a polynomial in theta, formed ONCE per accepted step (the s/e/i/r/c kernels; the SEIP
+    // kernels, which save about one row per step, keep the weight form above):
+    //     y(theta) = y + scale * (q1 + theta (q2 + theta (q3 + theta q4)))
+    // Tsit5: every weight b_i(theta) is a quartic without constant term and only b_1 has a theta^1 term (coefficient 1:
+    //     y'(t_prev) = f_1), so q1 = k[0], q_m = sum_i bp[i][m] k_i (Tab<0>::bp, 21 packed FMAs per register pair and step)
+    //     and scale = dt theta; a saved row then costs 4 packed FMAs per pair instead of 8 plus the 35 scalar operations of
+    //     the weights (at 3.3-5 rows per step: 9 % of the D = 360 kernel's instructions, more for D = 136).
+    // Dopri5: Shampine's quartic through y, y1, ymid, f0, f1 -- the coefficients the round-2 kernel formed per ROW, hoisted
+    //     (same operations, same order: bit-identical rows): q1 = dt k[0], q2 = cc, q3 = cb, q4 = ca, scale = theta.
+    // The coefficient planes overwrite stage derivatives that are dead once the error estimate exists:
+    //     k[1] <- q2, k[2] <- q3, k[3] <- q4 (Dopri5 also k[4] <- q1); k[0] and k[6] (FSAL) are never touched.
+    static constexpr int QP1 = (METHOD == 0 || PRESCALE) ? 0 : 4;   // (PRESCALE: k[] hold dt f already, q1 = k[0] for both methods)
+    struct Poly {
+        T theta, scale;
+    };
+    __device__ __forceinline__ static void poly_prepare(T th, T dt, Poly &d) {
+        d.theta = th;
+        d.scale = (METHOD == 0 && !PRESCALE) ? dt * th : th;
+    }
+    template <typename U>   // U = T (one value) or V2 (a register pair of the packed state)
+    __device__ __forceinline__ static U poly_eval(const Poly &d, U y0v, U q1, U q2, U q3, U q4) {
+        U a = q4 * d.theta + q3;
+        a = a * d.theta + q2;
+        a = a * d.theta + q1;
+        return a * d.scale + y0v;
+    }
+    __device__ __forceinline__ static void dense_coefficients(T dt, const State (&y)[NC], const State (&y1)[NC],
+                                                              State (&k)[7][NC]) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int pp = 0; pp < NP; ++pp) {
+                const V2 k0 = k[0][c].p[pp], k1 = k[1][c].p[pp], k2 = k[2][c].p[pp], k3 = k[3][c].p[pp],
+                         k4 = k[4][c].p[pp], k5 = k[5][c].p[pp], k6 = k[6][c].p[pp];
+                if constexpr (METHOD == 0) {
+                    V2 q[3];
+#pragma unroll
+                    for (int m = 0; m < 3; ++m) {
+                        V2 a = T(TB::bp[0][m]) * k0;
+                        a += T(TB::bp[1][m]) * k1;
+                        a += T(TB::bp[2][m]) * k2;
+                        a += T(TB::bp[3][m]) * k3;
+                        a += T(TB::bp[4][m]) * k4;
+                        a += T(TB::bp[5][m]) * k5;
+                        a += T(TB::bp[6][m]) * k6;
+                        q[m] = a;
+                    }
+                    k[1][c].p[pp] = q[0];
+                    k[2][c].p[pp] = q[1];
+                    k[3][c].p[pp] = q[2];
+                } else {
+                    const V2 y0v = y[c].p[pp], y1v = y1[c].p[pp];
+                    V2 mid = T(TB::cmid[0]) * k0;
+                    mid += T(TB::cmid[2]) * k2;
+                    mid += T(TB::cmid[3]) * k3;
+                    mid += T(TB::cmid[4]) * k4;
+                    mid += T(TB::cmid[5]) * k5;
+                    mid += T(TB::cmid[6]) * k6;
+                    V2 ymid, f0, f1;
+                    if constexpr (PRESCALE) {
+                        ymid = y0v + mid;
+                        f0 = k0;
+                        f1 = k6;
+                    } else {
+                        ymid = y0v + dt * mid;
+                        f0 = dt * k0;
+                        f1 = dt * k6;
+                    }
+                    const V2 ca = T(2) * (f1 - f0) - T(8) * (y1v + y0v) + T(16) * ymid;
+                    const V2 cb = T(5) * f0 - T(3) * f1 + T(18) * y0v + T(14) * y1v - T(32) * ymid;
+                    const V2 cc = f1 - T(4) * f0 - T(11) * y0v - T(5) * y1v + T(16) * ymid;
+                    k[1][c].p[pp] = cc;
+                    k[2][c].p[pp] = cb;
+                    k[3][c].p[pp] = ca;
+                    if constexpr (!PRESCALE) k[4][c].p[pp] = f0;
+                }
+            }
+    }
+
     // interpolate + store one compartment block [FIRST, FIRST+CNT) of one plane of this lane
     template <int FIRST, int CNT>
-    __device__ __forceinline__ static void save_block(const Dense &d, T dt, const State &y,
-                                                      const State &y1, const State (&k)[7][NC],
+    __device__ __forceinline__ static void save_block(const Poly &d, const State &y, const State (&k)[7][NC],
                                                       int plane, T *dst, bool vec_ok) {
         if constexpr (FIRST % 2 == 0 && CNT % 2 == 0) { // whole register pairs: packed arithmetic, stored as they come
             V2 o[CNT / 2];
 #pragma unroll
             for (int q = 0; q < CNT / 2; ++q) {
                 const int j = FIRST / 2 + q;
-#ifdef DYN_DIAG_NOINTERP   // diagnostic builds (tools/probes): what does the save loop cost without its arithmetic / stores?
-                o[q] = y.p[j] + d.b0;
-#else
-                o[q] = dense_eval<V2>(d, dt, y.p[j], y1.p[j], k[0][plane].p[j], k[1][plane].p[j], k[2][plane].p[j],
-                                      k[3][plane].p[j], k[4][plane].p[j], k[5][plane].p[j], k[6][plane].p[j]);
-#endif
+                o[q] = poly_eval<V2>(d, y.p[j], k[QP1][plane].p[j], k[1][plane].p[j], k[2][plane].p[j], k[3][plane].p[j]);
             }
             if (vec_ok) {
                 if constexpr (sizeof(T) == 4 && CNT % 4 == 0) {
@@ -861,12 +1026,7 @@ struct Solver {
 #pragma unroll
             for (int q = 0; q < CNT; ++q) {
                 const int j = FIRST + q;
-#ifdef DYN_DIAG_NOINTERP
-                v[q] = y[j] + d.b0[0];
-#else
-                v[q] = dense_eval<T>(d, dt, y[j], y1[j], k[0][plane][j], k[1][plane][j], k[2][plane][j],
-                                     k[3][plane][j], k[4][plane][j], k[5][plane][j], k[6][plane][j]);
-#endif
+                v[q] = poly_eval<T>(d, y[j], k[QP1][plane][j], k[1][plane][j], k[2][plane][j], k[3][plane][j]);
             }
             store_run<T, CNT>(dst, v, vec_ok);
         }
@@ -893,9 +1053,8 @@ struct Solver {
         for (int c = 1; c < NC; ++c) ll.dacc[c] += coef * (double)inc[c];
     }
     template <int FIRST, int CNT>
-    __device__ __forceinline__ static void ll_block(const KArgs<T> &ka, const Dense &d, T dt, const State (&y)[NC],
-                                                    const State (&yt)[NC], const State (&k)[7][NC], LL &ll,
-                                                    int j, int off, T *tab_row) {
+    __device__ __forceinline__ static void ll_block(const KArgs<T> &ka, const Poly &d, const State (&y)[NC],
+                                                    const State (&k)[7][NC], LL &ll, int j, int off, T *tab_row) {
         const bool have = ka.ll_mode == 0 || j > 0;
         const T *orow = ka.obs + (int64_t)(ka.ll_mode == 0 ? j : (j > 0 ? j - 1 : 0)) * ka.ll_row + off;
 #pragma unroll
@@ -904,8 +1063,7 @@ struct Solver {
             T v[NC];
 #pragma unroll
             for (int c = 0; c < NC; ++c)
-                v[c] = dense_eval<T>(d, dt, y[c][e], yt[c][e], k[0][c][e], k[1][c][e], k[2][c][e], k[3][c][e],
-                                     k[4][c][e], k[5][c][e], k[6][c][e]);
+                v[c] = poly_eval<T>(d, y[c][e], k[QP1][c][e], k[1][c][e], k[2][c][e], k[3][c][e]);
             if (tab_row != nullptr) {
 #pragma unroll
                 for (int c = 0; c < NC; ++c) tab_row[q * NC + c] = v[c];
@@ -921,24 +1079,24 @@ struct Solver {
             }
         }
     }
-    __device__ __forceinline__ static void ll_row(const KArgs<T> &ka, const Dense &d, T dt, const State (&y)[NC],
-                                                  const State (&yt)[NC], const State (&k)[7][NC], LL &ll, int j,
-                                                  int a, int as, bool lead, T *tab_row) {
+    __device__ __forceinline__ static void ll_row(const KArgs<T> &ka, const Poly &d, const State (&y)[NC],
+                                                  const State (&k)[7][NC], LL &ll, int j, int a, int as, bool lead,
+                                                  T *tab_row) {
         switch (ka.ll_slot) {
         case 0:
-            if (lead) ll_block<IS, 1>(ka, d, dt, y, yt, k, ll, j, a, tab_row);
+            if (lead) ll_block<IS, 1>(ka, d, y, k, ll, j, a, tab_row);
             break;
         case 1:
-            if constexpr (HAS_E) ll_block<IE, S>(ka, d, dt, y, yt, k, ll, j, as, tab_row);
+            if constexpr (HAS_E) ll_block<IE, S>(ka, d, y, k, ll, j, as, tab_row);
             break;
         case 2:
-            ll_block<II, S>(ka, d, dt, y, yt, k, ll, j, as, tab_row);
+            ll_block<II, S>(ka, d, y, k, ll, j, as, tab_row);
             break;
         case 3:
-            ll_block<IR, S * W>(ka, d, dt, y, yt, k, ll, j, as * W, tab_row);
+            ll_block<IR, S * W>(ka, d, y, k, ll, j, as * W, tab_row);
             break;
         default:
-            if constexpr (HAS_C) ll_block<IC, S>(ka, d, dt, y, yt, k, ll, j, as, tab_row);
+            if constexpr (HAS_C) ll_block<IC, S>(ka, d, y, k, ll, j, as, tab_row);
             break;
         }
     }
@@ -977,18 +1135,16 @@ struct Solver {
     // one saved row of one plane
     // `as` = a * ST + h * SPL: position of this lane's first strain inside an [A, ST] block
     template <int PLANE>
-    __device__ __forceinline__ static void save_row(const KArgs<T> &ka, const Dense &dn, T dt,
-                                                    const State (&y)[NC], const State (&yt)[NC],
-                                                    const State (&k)[7][NC], T *row, int a, int as,
-                                                    bool lead, bool vec_ok) {
+    __device__ __forceinline__ static void save_row(const KArgs<T> &ka, const Poly &dn, const State (&y)[NC],
+                                                    const State (&k)[7][NC], T *row, int a, int as, bool lead,
+                                                    bool vec_ok) {
         if constexpr (SAVE_ALL && sizeof(T) == 4 && S % 2 == 1) {
             // every compartment is saved and the strain blocks are single elements (the strain-split shapes): interpolate
             // ALL register pairs at once -- e and i, c and s share pairs -- and store the elements from the result
             State o;
 #pragma unroll
             for (int j = 0; j < NP; ++j)
-                o.p[j] = dense_eval<V2>(dn, dt, y[PLANE].p[j], yt[PLANE].p[j], k[0][PLANE].p[j], k[1][PLANE].p[j], k[2][PLANE].p[j],
-                                        k[3][PLANE].p[j], k[4][PLANE].p[j], k[5][PLANE].p[j], k[6][PLANE].p[j]);
+                o.p[j] = poly_eval<V2>(dn, y[PLANE].p[j], k[QP1][PLANE].p[j], k[1][PLANE].p[j], k[2][PLANE].p[j], k[3][PLANE].p[j]);
             if (lead) row[ka.save_off[0] + a] = o[IS];
             store_elements<IE, NE>(o, row + ka.save_off[1] + as);
             store_elements<II, S>(o, row + ka.save_off[2] + as);
@@ -998,21 +1154,17 @@ struct Solver {
         }
         if constexpr (SAVE_ALL) vec_ok = true;
         if ((SAVE_ALL || ka.save_off[0] >= 0) && lead)
-            save_block<IS, 1>(dn, dt, y[PLANE], yt[PLANE], k, PLANE, row + ka.save_off[0] + a, false);
+            save_block<IS, 1>(dn, y[PLANE], k, PLANE, row + ka.save_off[0] + a, false);
         if constexpr (HAS_E)
             if (SAVE_ALL || ka.save_off[1] >= 0)
-                save_block<IE, S>(dn, dt, y[PLANE], yt[PLANE], k, PLANE, row + ka.save_off[1] + as,
-                                  vec_ok);
+                save_block<IE, S>(dn, y[PLANE], k, PLANE, row + ka.save_off[1] + as, vec_ok);
         if (SAVE_ALL || ka.save_off[2] >= 0)
-            save_block<II, S>(dn, dt, y[PLANE], yt[PLANE], k, PLANE, row + ka.save_off[2] + as,
-                              vec_ok);
+            save_block<II, S>(dn, y[PLANE], k, PLANE, row + ka.save_off[2] + as, vec_ok);
         if (SAVE_ALL || ka.save_off[3] >= 0)
-            save_block<IR, S * W>(dn, dt, y[PLANE], yt[PLANE], k, PLANE,
-                                  row + ka.save_off[3] + as * W, vec_ok);
+            save_block<IR, S * W>(dn, y[PLANE], k, PLANE, row + ka.save_off[3] + as * W, vec_ok);
         if constexpr (HAS_C)
             if (SAVE_ALL || ka.save_off[4] >= 0)
-                save_block<IC, S>(dn, dt, y[PLANE], yt[PLANE], k, PLANE, row + ka.save_off[4] + as,
-                                  vec_ok);
+                save_block<IC, S>(dn, y[PLANE], k, PLANE, row + ka.save_off[4] + as, vec_ok);
     }
 
     __device__ __forceinline__ static void fill_row(const KArgs<T> &ka, T *row, int a, int as,
@@ -1031,36 +1183,149 @@ struct Solver {
     }
 
     template <int PLANE>
-    __device__ __forceinline__ static void save_tangents(const KArgs<T> &ka, const Dense &dn, T dt,
-                                                         const State (&y)[NC],
-                                                         const State (&yt)[NC],
-                                                         const State (&k)[7][NC], T *drow, int a,
-                                                         int as, bool lead, bool vec_ok) {
+    __device__ __forceinline__ static void save_tangents(const KArgs<T> &ka, const Poly &dn, const State (&y)[NC],
+                                                         const State (&k)[7][NC], T *drow, int a, int as, bool lead,
+                                                         bool vec_ok) {
         if constexpr (PLANE < NC) {
-            save_row<PLANE>(ka, dn, dt, y, yt, k, drow + (int64_t)(PLANE - 1) * ka.d_saved, a, as,
-                            lead, vec_ok);
-            save_tangents<PLANE + 1>(ka, dn, dt, y, yt, k, drow, a, as, lead, vec_ok);
+            save_row<PLANE>(ka, dn, y, k, drow + (int64_t)(PLANE - 1) * ka.d_saved, a, as, lead, vec_ok);
+            save_tangents<PLANE + 1>(ka, dn, y, k, drow, a, as, lead, vec_ok);
         }
     }
 
+    // everything of one trajectory that lives in this lane besides the state: rates, seasonal numbers, introductions,
+    // vaccination rows and their seed directions (KArgs::params row `traj`, broadcast loads inside the lane group)
+    template <typename KA>   // KA: KArgs<T> in whatever address space the caller reads it from (run(): cold_args)
+    __device__ __forceinline__ void load_parameters(const KA &ka, int64_t traj, int a, int aa, int s0) {
+        const int A = ka.A;
+        const T *p = ka.params + traj * ka.P;
+        constexpr int oS = 2, oW = 2 + (HAS_E ? 1 : 0), oI = 2 + (HAS_E ? 1 : 0) + (HAS_WANE ? 1 : 0),
+                      oSe = oI + (INTRO ? 3 : 0);
+#pragma unroll
+        for (int l = 0; l < S; ++l) {
+            beta[l] = p[s0 + l];
+            gamma[l] = p[ST + s0 + l];
+            sigma[l] = HAS_E ? p[oS * ST + s0 + l] : T(0);
+            omega[l] = HAS_WANE ? p[oW * ST + s0 + l] : T(0);
+        }
+        if constexpr (PAIRED_RHS) {
+#pragma unroll
+            for (int q = 0; q < SP; ++q) {
+                beta2[q] = V2{beta[2 * q], beta[2 * q + 1]};
+                gamma2[q] = V2{gamma[2 * q], gamma[2 * q + 1]};
+                sigma2[q] = V2{sigma[2 * q], sigma[2 * q + 1]};
+                omega2[q] = V2{omega[2 * q], omega[2 * q + 1]};
+            }
+        }
+        if constexpr (INTRO) {
+#pragma unroll
+            for (int l = 0; l < S; ++l) {
+                const T scale = p[(oI + 1) * ST + s0 + l];
+                const bool here = !pad && ((ka.intro_mask[s0 + l] >> aa) & 1ull);
+                itime[l] = p[oI * ST + s0 + l];
+                iinv[l] = T(1) / scale;
+                ibase[l] = here ? T(1) / (scale * T(2.5066282746310002)) : T(0);
+                iamp[l] = ibase[l] * p[(oI + 2) * ST + s0 + l];
+            }
+#pragma unroll
+            for (int j = 0; j < NDA; ++j)
+#pragma unroll
+                for (int l = 0; l < S; ++l) ditime[j][l] = discale[j][l] = dipct[j][l] = T(0);
+        }
+        if constexpr (KV > 0) {
+            // per-trajectory vaccination block after the seasonal numbers:
+            //   susceptibility [groups][ST], then per group: base[4], knot[n_knots], coef[n_knots]
+            const int nk = ka.n_vax_knots;
+            const T *vp = p + oSe * ST + (ka.seasonal ? 3 : 0);
+            const T *sp_ = vp + A * ST + aa * (4 + 2 * nk);
+            vnk = nk;
+#pragma unroll
+            for (int l = 0; l < S; ++l) sus[l] = pad ? T(0) : vp[aa * ST + s0 + l];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                vbase[q] = pad ? T(0) : sp_[q];
+                vknot[q] = (!pad && q < nk) ? sp_[4 + q] : T(0);
+                vcoef[q] = (!pad && q < nk) ? sp_[4 + nk + q] : T(0);
+            }
+            const int tier = a % KV;
+            vax_first = tier == 0;
+            vax_top = tier >= ka.n_vax_tiers - 1;
+        }
+        amp = T(0);
+        phase = T(0);
+        w_season = T(0);
+        T period = T(1);
+        if (seasonal) {
+            const T *sp = p + oSe * ST;
+            amp = sp[0];
+            phase = sp[1];
+            period = sp[2];
+            w_season = T(6.283185307179586476925286766559) / period;
+        }
+#pragma unroll
+        for (int j = 0; j < NDA; ++j) {
+#pragma unroll
+            for (int l = 0; l < S; ++l) dbeta[j][l] = dgamma[j][l] = dsigma[j][l] = domega[j][l] = T(0);
+            damp[j] = dphase[j] = dw_season[j] = T(0);
+        }
+        if constexpr (ND > 0) {
+#pragma unroll
+            for (int j = 0; j < ND; ++j) {
+                const T *dp = ka.dparams + (traj * ND + j) * ka.P;
+#pragma unroll
+                for (int l = 0; l < S; ++l) {
+                    dbeta[j][l] = dp[s0 + l];
+                    dgamma[j][l] = dp[ST + s0 + l];
+                    if constexpr (HAS_E) dsigma[j][l] = dp[oS * ST + s0 + l];
+                    if constexpr (HAS_WANE) domega[j][l] = dp[oW * ST + s0 + l];
+                    if constexpr (INTRO) {
+                        ditime[j][l] = dp[oI * ST + s0 + l];
+                        discale[j][l] = dp[(oI + 1) * ST + s0 + l];
+                        dipct[j][l] = dp[(oI + 2) * ST + s0 + l];
+                    }
+                }
+                if constexpr (KV > 0) {
+                    const int nk = ka.n_vax_knots;
+                    const T *dvp = dp + oSe * ST + (ka.seasonal ? 3 : 0);
+                    const T *dsp_ = dvp + A * ST + aa * (4 + 2 * nk);
+#pragma unroll
+                    for (int l = 0; l < S; ++l) dsus[j][l] = pad ? T(0) : dvp[aa * ST + s0 + l];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        dvbase[j][q] = pad ? T(0) : dsp_[q];
+                        dvknot[j][q] = (!pad && q < nk) ? dsp_[4 + q] : T(0);
+                        dvcoef[j][q] = (!pad && q < nk) ? dsp_[4 + nk + q] : T(0);
+                    }
+                }
+                if (seasonal) {
+                    const T *dsp = dp + oSe * ST;
+                    damp[j] = dsp[0];
+                    dphase[j] = dsp[1];
+                    dw_season[j] = -w_season / period * dsp[2]; // d(2 pi / period)
+                }
+            }
+        }
+    }
+
+    // ---- the solve.  A lane group is a SLOT that integrates one trajectory after the other:
+    //   static launches (KArgs::work == nullptr): grid = ceil(B 2^rep / TPW) waves, slot i takes trajectory i and stops;
+    //   work-pulling launches (KArgs::work != nullptr; the host sizes the grid to the waves the chip can hold at once):
+    //     slot i starts with trajectory i and, whenever its trajectory finishes, draws the next index from a device
+    //     counter (atomicAdd) and re-runs the prologue under its group's lanes while the other groups of the wave keep
+    //     stepping.  The lane groups of a wave still step in lock-step, but none of them waits for a finished partner for
+    //     longer than the rest of an iteration, and the launch ends when the queue is empty -- no max-over-groups of whole
+    //     trajectories, no round structure, nothing learned in advance.  With KArgs::order the queue is that permutation
+    //     (most expensive first, if the caller knows): tickets index it.
+    // Every trajectory is computed from its own inputs alone, with the same instructions whatever slot runs it, so the
+    // results do not depend on the assignment (tests/test_gpu_parity.py: dispatch order / batch position invariance).
     __device__ __forceinline__ static void run(const KArgs<T> &ka) {
         const int lane = threadIdx.x & 63;
         const int a = lane % GA;          // age lane
         const int h = (lane / GA) % GS;   // strain lane: strains h*SPL .. h*SPL+SPL-1
         const int grp = lane / G;
         const int64_t gslot = (int64_t)blockIdx.x * TPW + grp;
-        const int R = 1 << ka.rep_log2;                 // replicas per trajectory
+        const int R = 1 << ka.rep_log2;                 // replicas per trajectory (static launches only)
         const int rep = (int)(gslot & (R - 1));         // this group's replica number
-        int64_t traj = gslot >> ka.rep_log2;
-        bool valid_traj = traj < ka.B;
-        if (!valid_traj) traj = ka.B - 1; // duplicate a real trajectory, never store
-        if (ka.order) {
-            traj = ka.order[traj];
-            if ((uint64_t)traj >= (uint64_t)ka.B) { // not a permutation: never touch memory outside the batch
-                valid_traj = false;
-                traj = ka.B - 1;
-            }
-        }
+        const bool pull = ka.work != nullptr;
         const int A = ka.A;
         Solver L;
         L.pad = a >= A;
@@ -1068,215 +1333,21 @@ struct Solver {
         L.normalize = ka.normalize != 0;
         L.seasonal = ka.seasonal != 0;
         const int aa = L.pad ? 0 : a;
-        const bool writer = valid_traj && !L.pad;
+        const bool writer = !L.pad;
         const int s0 = h * SPL; // first global strain of this lane
 
-        // ---- flat-state offsets (compartment-major layout)
-        const int offE = A, offI = A + (HAS_E ? A * ST : 0), offR = offI + A * ST,
-                  offC = offR + A * ST * W;
-        const int D = offC + (HAS_C ? A * ST : 0);
+        const int D = A * (1 + ST * ((HAS_E ? 1 : 0) + 1 + W + (HAS_C ? 1 : 0)));   // state dimension (compartment-major layout)
 
-        // ---- per-trajectory parameters (broadcast loads inside the lane group)
-        {
-            const T *p = ka.params + traj * ka.P;
-            constexpr int oS = 2, oW = 2 + (HAS_E ? 1 : 0), oI = 2 + (HAS_E ? 1 : 0) + (HAS_WANE ? 1 : 0),
-                          oSe = oI + (INTRO ? 3 : 0);
-#pragma unroll
-            for (int l = 0; l < S; ++l) {
-                L.beta[l] = p[s0 + l];
-                L.gamma[l] = p[ST + s0 + l];
-                L.sigma[l] = HAS_E ? p[oS * ST + s0 + l] : T(0);
-                L.omega[l] = HAS_WANE ? p[oW * ST + s0 + l] : T(0);
-            }
-            if constexpr (PAIRED_RHS) {
-#pragma unroll
-                for (int q = 0; q < SP; ++q) {
-                    L.beta2[q] = V2{L.beta[2 * q], L.beta[2 * q + 1]};
-                    L.gamma2[q] = V2{L.gamma[2 * q], L.gamma[2 * q + 1]};
-                    L.sigma2[q] = V2{L.sigma[2 * q], L.sigma[2 * q + 1]};
-                    L.omega2[q] = V2{L.omega[2 * q], L.omega[2 * q + 1]};
-                }
-            }
-            if constexpr (INTRO) {
-#pragma unroll
-                for (int l = 0; l < S; ++l) {
-                    const T scale = p[(oI + 1) * ST + s0 + l];
-                    const bool here = !L.pad && ((ka.intro_mask[s0 + l] >> aa) & 1ull);
-                    L.itime[l] = p[oI * ST + s0 + l];
-                    L.iinv[l] = T(1) / scale;
-                    L.ibase[l] = here ? T(1) / (scale * T(2.5066282746310002)) : T(0);
-                    L.iamp[l] = L.ibase[l] * p[(oI + 2) * ST + s0 + l];
-                }
-#pragma unroll
-                for (int j = 0; j < NDA; ++j)
-#pragma unroll
-                    for (int l = 0; l < S; ++l) L.ditime[j][l] = L.discale[j][l] = L.dipct[j][l] = T(0);
-            }
-            if constexpr (KV > 0) {
-                // per-trajectory vaccination block after the seasonal numbers:
-                //   susceptibility [groups][ST], then per group: base[4], knot[n_knots], coef[n_knots]
-                const int nk = ka.n_vax_knots;
-                const T *vp = p + oSe * ST + (ka.seasonal ? 3 : 0);
-                const T *sp_ = vp + A * ST + aa * (4 + 2 * nk);
-                L.vnk = nk;
-#pragma unroll
-                for (int l = 0; l < S; ++l) L.sus[l] = L.pad ? T(0) : vp[aa * ST + s0 + l];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    L.vbase[q] = L.pad ? T(0) : sp_[q];
-                    L.vknot[q] = (!L.pad && q < nk) ? sp_[4 + q] : T(0);
-                    L.vcoef[q] = (!L.pad && q < nk) ? sp_[4 + nk + q] : T(0);
-                }
-                const int tier = a % KV;
-                L.vax_first = tier == 0;
-                L.vax_top = tier >= ka.n_vax_tiers - 1;
-            }
-            L.amp = T(0);
-            L.phase = T(0);
-            L.w_season = T(0);
-            T period = T(1);
-            if (L.seasonal) {
-                const T *sp = p + oSe * ST;
-                L.amp = sp[0];
-                L.phase = sp[1];
-                period = sp[2];
-                L.w_season = T(6.283185307179586476925286766559) / period;
-            }
-#pragma unroll
-            for (int j = 0; j < NDA; ++j) {
-#pragma unroll
-                for (int l = 0; l < S; ++l)
-                    L.dbeta[j][l] = L.dgamma[j][l] = L.dsigma[j][l] = L.domega[j][l] = T(0);
-                L.damp[j] = L.dphase[j] = L.dw_season[j] = T(0);
-            }
-            if constexpr (ND > 0) {
-#pragma unroll
-                for (int j = 0; j < ND; ++j) {
-                    const T *dp = ka.dparams + (traj * ND + j) * ka.P;
-#pragma unroll
-                    for (int l = 0; l < S; ++l) {
-                        L.dbeta[j][l] = dp[s0 + l];
-                        L.dgamma[j][l] = dp[ST + s0 + l];
-                        if constexpr (HAS_E) L.dsigma[j][l] = dp[oS * ST + s0 + l];
-                        if constexpr (HAS_WANE) L.domega[j][l] = dp[oW * ST + s0 + l];
-                        if constexpr (INTRO) {
-                            L.ditime[j][l] = dp[oI * ST + s0 + l];
-                            L.discale[j][l] = dp[(oI + 1) * ST + s0 + l];
-                            L.dipct[j][l] = dp[(oI + 2) * ST + s0 + l];
-                        }
-                    }
-                    if constexpr (KV > 0) {
-                        const int nk = ka.n_vax_knots;
-                        const T *dvp = dp + oSe * ST + (ka.seasonal ? 3 : 0);
-                        const T *dsp_ = dvp + A * ST + aa * (4 + 2 * nk);
-#pragma unroll
-                        for (int l = 0; l < S; ++l) L.dsus[j][l] = L.pad ? T(0) : dvp[aa * ST + s0 + l];
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            L.dvbase[j][q] = L.pad ? T(0) : dsp_[q];
-                            L.dvknot[j][q] = (!L.pad && q < nk) ? dsp_[4 + q] : T(0);
-                            L.dvcoef[j][q] = (!L.pad && q < nk) ? dsp_[4 + nk + q] : T(0);
-                        }
-                    }
-                    if (L.seasonal) {
-                        const T *dsp = dp + oSe * ST;
-                        L.damp[j] = dsp[0];
-                        L.dphase[j] = dsp[1];
-                        L.dw_season[j] = -L.w_season / period * dsp[2]; // d(2 pi / period)
-                    }
-                }
-            }
-        }
-        // ---- contact row, pre-permuted to the xor-exchange order
+        // ---- contact row, pre-permuted to the xor-exchange order (shared by every trajectory of the launch)
 #pragma unroll
         for (int k = 0; k < GA; ++k) {
             const int b = a ^ k;
             L.Cx[k] = (!L.pad && b < A) ? ka.contact[aa * A + b] : T(0);
         }
 
-        // ---- initial state (plane 0) and its seeds (planes 1..ND)
-        State y[NC], yt[NC], k[7][NC];
-        if constexpr (NV % 2 == 1) { // the pad element of every plane: zero for good (nothing but the pairwise stepper touches it)
-#pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                y[c].p[NP - 1][1] = T(0);
-                yt[c].p[NP - 1][1] = T(0);
-#pragma unroll
-                for (int q = 0; q < 7; ++q) k[q][c].p[NP - 1][1] = T(0);
-            }
-        }
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            const T *src;
-            bool zero = L.pad;
-            if (c == 0) {
-                src = ka.y0 + (ka.y0_batched ? traj * D : 0);
-            } else {
-                zero = zero || ka.dy0 == nullptr;
-                src = ka.dy0 + ((ka.dy0_batched ? traj * ND : 0) + (c - 1)) * (int64_t)D;
-            }
-            y[c][IS] = zero ? T(0) : src[aa];
-#pragma unroll
-            for (int l = 0; l < S; ++l) {
-                const int sg = aa * ST + s0 + l; // (age, global strain)
-                if constexpr (HAS_E) y[c][IE + l] = zero ? T(0) : src[offE + sg];
-                y[c][II + l] = zero ? T(0) : src[offI + sg];
-#pragma unroll
-                for (int w = 0; w < W; ++w) y[c][IR + l * W + w] = zero ? T(0) : src[offR + sg * W + w];
-                if constexpr (HAS_C) y[c][IC + l] = zero ? T(0) : src[offC + sg];
-            }
-        }
-
         const T rtol = ka.rtol, atol = ka.atol, t_end = ka.t1;
         const T Dn = T(D);
         const bool constant = ka.constant_dt > T(0);
-        T tprev = ka.t0, tnext;
-        L.rhs(tprev, y, k[0]);
-        // NaN / inf in the initial state or its derivative (e.g. NaN parameters): fail at once
-        bool lane_ok = true; // comparisons, not x - x: under -ffp-contract an expression minus itself need not be 0
-#pragma unroll
-        for (int v = 0; v < NV; ++v)
-            lane_ok = lane_ok && (M::abs(y[0][v]) < M::inf()) && (M::abs(k[0][0][v]) < M::inf());
-        const unsigned long long bad_lanes = __ballot(!lane_ok);
-        const unsigned long long group_mask = (G == 64 ? ~0ull : ((1ull << G) - 1ull)) << (grp * G);
-        const bool start_ok = (bad_lanes & group_mask) == 0ull;
-
-        if (constant) {
-            tnext = tprev + ka.constant_dt;
-        } else {
-            // Hairer-Norsett-Wanner II.4 starting step (diffrax _select_initial_step), primal only
-            // the replicated s (element 0) enters every norm once: only the lead strain lane counts it
-            const T w_s = L.lead ? T(1) : T(0);
-            T n0 = 0, n1 = 0;
-#pragma unroll
-            for (int v = 0; v < NV; ++v) {
-                const T sc = atol + M::abs(y[0][v]) * rtol;
-                const T q0 = y[0][v] / sc, q1 = k[0][0][v] / sc;
-                n0 += (v == IS ? w_s : T(1)) * (q0 * q0);
-                n1 += (v == IS ? w_s : T(1)) * (q1 * q1);
-            }
-            const T d0 = M::sqrt(group_sum<G>(n0) / Dn), d1 = M::sqrt(group_sum<G>(n1) / Dn);
-            const bool small = (d0 < T(1e-5)) || (d1 < T(1e-5));
-            const T h0 = small ? T(1e-6) : T(0.01) * (d0 / d1);
-#pragma unroll
-            for (int c = 0; c < NC; ++c)
-#pragma unroll
-                for (int pp = 0; pp < NP; ++pp) yt[c].p[pp] = y[c].p[pp] + h0 * k[0][c].p[pp];
-            L.rhs(tprev + h0, yt, k[1]);
-            T s2 = 0;
-#pragma unroll
-            for (int v = 0; v < NV; ++v) {
-                const T sc = atol + M::abs(y[0][v]) * rtol;
-                const T q2 = (k[1][0][v] - k[0][0][v]) / sc;
-                s2 += (v == IS ? w_s : T(1)) * (q2 * q2);
-            }
-            const T d2 = M::sqrt(group_sum<G>(s2) / Dn) / h0;
-            const T max_d = M::max(d1, d2);
-            tnext = tprev + M::min(T(100) * h0, Control<T>::initial_h1(max_d, h0));
-        }
-        tnext = M::min(tnext, t_end);
-
-        int save_idx = rep; // replica r owns save times r, r + R, r + 2R, ...
         const int n_save = ka.n_save;
         bool fused_ll = false, ll_table = false;
         if constexpr (ND > 0) {
@@ -1287,7 +1358,7 @@ struct Solver {
         // in-order vmcnt counter with the output stores, and waiting for it would drain every
         // store of the previous round (measured: the dominant stall of the save path).
         // LDS reads count on lgkmcnt, so stores stay fire-and-forget.
-        extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
+        extern __shared__ __attribute__((aligned(32))) unsigned char dyn_smem[];
         T *const ts_tab = reinterpret_cast<T *>(dyn_smem); // LDS address space: ds_read only
         for (int j = lane; j < n_save; j += 64) ts_tab[j] = ka.save_ts[j];
         // discontinuity points follow the save grid in LDS (per-group index into the table)
@@ -1297,49 +1368,229 @@ struct Solver {
         constexpr int LL_ROW = G * LLMAX * NC;
         T *const ll_tab = jt_tab + (n_jump > 0 ? kMaxJumps : 0);
         T *const ll_lane = ll_tab + ((int64_t)((lane / G) >> ka.rep_log2) * n_save * LL_ROW + (lane % G) * (LLMAX * NC));
+        // PRESCALE: the rates (and their seeds) as loaded, [quad][lane], 16-byte aligned behind the other tables
+        V4 *const rate_tab = reinterpret_cast<V4 *>(
+            ts_tab + (((n_save + (n_jump > 0 ? kMaxJumps : 0) + (ll_table ? (64 >> ka.rep_log2) * n_save * LLMAX * NC : 0)) + 3) & ~3));
         if (n_jump > 0 && lane == 0) {
 #pragma unroll
             for (int j = 0; j < kMaxJumps; ++j) jt_tab[j] = ka.jump_ts[j];
         }
         __syncthreads();
-        // jump bookkeeping (restates oracle/dynode_oracle_impl.inc): steps are clipped to land just
-        // before a jump, restart just after it with FSAL recomputed and the unclipped step size
-        int jidx = 0;
-        bool at_jump = false;
-        T dt_unclipped = T(0);
-        if (n_jump > 0) {
-            while (jidx < n_jump && jt_tab[jidx] <= tprev) ++jidx;
-            if (jidx < n_jump && jt_tab[jidx] < tnext) {
-                dt_unclipped = tnext - tprev;
-                tnext = M::next(jt_tab[jidx], -M::inf());
-                at_jump = true;
-            }
-        }
-        // next two save times kept in registers (the read of ts[idx+2] overlaps a whole round)
-        T ts_next = save_idx < n_save ? ts_tab[save_idx] : M::inf();
-        T ts_next2 = save_idx + R < n_save ? ts_tab[save_idx + R] : M::inf();
-        int64_t steps = 0;
-        int32_t n_acc = 0, n_rej = 0, st = start_ok ? ST_OK : ST_NONFINITE;
-        bool done = !(tprev < t_end) || !start_ok;
-        T *const out_traj = ka.out + traj * (int64_t)n_save * ka.d_saved;
-        T *const dout_traj = ND > 0 ? ka.dout + traj * (int64_t)n_save * ND * ka.d_saved : nullptr;
         const bool vec_ok = ka.vec_ok != 0;
         const int as = a * ST + s0;
-        LL ll;
-        if constexpr (ND > 0) {
-            ll.acc = 0.0;
+
+        // ---- the slot's trajectory: state, stage derivatives, step control
+        State y[NC], yt[NC], k[7][NC];
 #pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                ll.dacc[c] = 0.0;
+        for (int c = 0; c < NC; ++c) { // (also the pad element of every plane: zero for good -- nothing but the pairwise stepper touches it)
 #pragma unroll
-                for (int q = 0; q < LLMAX; ++q) ll.prev[c][q] = T(0);
+            for (int pp = 0; pp < NP; ++pp) {
+                y[c].p[pp] = V2{T(0), T(0)};
+                yt[c].p[pp] = V2{T(0), T(0)};
+#pragma unroll
+                for (int q = 0; q < 7; ++q) k[q][c].p[pp] = V2{T(0), T(0)};
             }
         }
-
+        int64_t traj = 0;
+        bool live = false, done = true;      // live: a trajectory is loaded and not yet written off; done: nothing to step
+        T tprev = ka.t0, tnext = ka.t0, ts_next = M::inf(), ts_next2 = M::inf(), dt_unclipped = T(0);
+        int save_idx = 0, jidx = 0, waited = 0;
+        bool at_jump = false;
+        int64_t steps = 0;
+        int32_t n_acc = 0, n_rej = 0, st = ST_OK;
+        T *out_traj = ka.out, *dout_traj = nullptr;
+        LL ll;
 #ifdef DYN_DIAG_ROUNDS
         int diag_iters = 0, diag_rounds = 0;
 #endif
-        while (__any(!done)) {
+        // first assignment: slot i takes entry i of the queue
+        bool need_load = false, want_ticket = false;
+        {
+            int64_t t = gslot >> ka.rep_log2;
+            if (t < ka.B) {
+                if (ka.order) t = ka.order[t];
+                // an order that is not a permutation never makes the kernel touch memory outside the batch: the entry is skipped
+                if ((uint64_t)t < (uint64_t)ka.B) {
+                    traj = t;
+                    need_load = true;
+                } else {
+                    want_ticket = pull;
+                }
+            }
+        }
+
+        for (;;) {
+            // A slot that needs work waits an iteration or two when another group of its wave is on the last step of ITS
+            // trajectory (tnext == t_end): one pass of the prologue then serves both (the pass costs the wave about a third of
+            // an iteration however many of its groups it loads).
+            bool draw = false;
+            if (__builtin_expect(__any(want_ticket), 0)) { // wave-uniform
+                const bool closing = __any(!done && !(tnext < t_end));
+                draw = want_ticket && !(closing && waited < 2);
+                waited += (want_ticket && !draw) ? 1 : 0;
+            }
+            if (__builtin_expect(draw, 0)) { // (lane-group uniform) draw the next entry of the queue
+                waited = 0;
+                const auto &kc = *cold_args<T>();
+                int32_t *const work = kc.work;
+                const int32_t *const order = kc.order;
+                const int64_t B = kc.B;
+                const int64_t n_slots = (int64_t)gridDim.x * TPW;
+                for (;;) {
+                    long long t = 0;
+                    if ((lane & (G - 1)) == 0) {
+                        t = n_slots + (long long)atomicAdd(work, 1);
+                        if (t >= B) {
+                            // this slot retires; the last one to retire re-arms the counters, so that the caller can hand
+                            // the same two words to its next launch on the stream without clearing them
+                            if (atomicAdd(work + 1, 1) == (int)(n_slots - 1)) {
+                                __atomic_store_n(work, 0, __ATOMIC_RELAXED);
+                                __atomic_store_n(work + 1, 0, __ATOMIC_RELAXED);
+                            }
+                        }
+                    }
+                    t = __shfl(t, lane & ~(G - 1), 64);
+                    if (t >= B) break;
+                    if (order) t = order[t];
+                    if ((uint64_t)t < (uint64_t)B) {
+                        traj = t;
+                        need_load = true;
+                        break;
+                    }
+                }
+                want_ticket = false;
+            }
+            if (__builtin_expect(need_load, 0)) { // ---- prologue of trajectory `traj`, under this group's lanes
+                need_load = false;
+                const auto &kc = *cold_args<T>();
+                // the lane's indices and the layout offsets are re-derived HERE from values the compiler cannot see through:
+                // hoisted out of the stepping loop, the address arithmetic of this block would hold a dozen registers through
+                // every iteration (the D = 136 kernel sits at the 256-register line)
+                int lane_c = lane;
+                asm volatile("" : "+v"(lane_c));
+                const int Ac = kc.A;
+                const int a_c = lane_c % GA, s0_c = ((lane_c / GA) % GS) * SPL, aa_c = a_c >= Ac ? 0 : a_c;
+                const int cE = Ac, cI = Ac + (HAS_E ? Ac * ST : 0), cR = cI + Ac * ST, cC = cR + Ac * ST * W;
+                const int Dc = cC + (HAS_C ? Ac * ST : 0);
+                L.load_parameters(kc, traj, a_c, aa_c, s0_c);
+                if constexpr (PRESCALE) L.park_rates(rate_tab, lane_c);
+                // initial state (plane 0) and its seeds (planes 1..ND)
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    const T *src;
+                    bool zero = L.pad;
+                    if (c == 0) {
+                        src = kc.y0 + (kc.y0_batched ? traj * Dc : 0);
+                    } else {
+                        const T *const dy0 = kc.dy0;
+                        zero = zero || dy0 == nullptr;
+                        src = dy0 + ((kc.dy0_batched ? traj * ND : 0) + (c - 1)) * (int64_t)Dc;
+                    }
+                    y[c][IS] = zero ? T(0) : src[aa_c];
+#pragma unroll
+                    for (int l = 0; l < S; ++l) {
+                        const int sg = aa_c * ST + s0_c + l; // (age, global strain)
+                        if constexpr (HAS_E) y[c][IE + l] = zero ? T(0) : src[cE + sg];
+                        y[c][II + l] = zero ? T(0) : src[cI + sg];
+#pragma unroll
+                        for (int w = 0; w < W; ++w) y[c][IR + l * W + w] = zero ? T(0) : src[cR + sg * W + w];
+                        if constexpr (HAS_C) y[c][IC + l] = zero ? T(0) : src[cC + sg];
+                    }
+                }
+                tprev = kc.t0;
+                L.rhs(tprev, y, k[0]);
+                // NaN / inf in the initial state or its derivative (e.g. NaN parameters): fail at once
+                bool lane_ok = true; // comparisons, not x - x: under -ffp-contract an expression minus itself need not be 0
+#pragma unroll
+                for (int v = 0; v < NV; ++v)
+                    lane_ok = lane_ok && (M::abs(y[0][v]) < M::inf()) && (M::abs(k[0][0][v]) < M::inf());
+                const unsigned long long bad_lanes = __ballot(!lane_ok);
+                const unsigned long long group_mask = (G == 64 ? ~0ull : ((1ull << G) - 1ull)) << ((lane_c / G) * G);
+                const bool start_ok = (bad_lanes & group_mask) == 0ull;
+
+                if (constant) {
+                    tnext = tprev + ka.constant_dt;
+                } else {
+                    // Hairer-Norsett-Wanner II.4 starting step (diffrax _select_initial_step), primal only
+                    // the replicated s (element 0) enters every norm once: only the lead strain lane counts it
+                    const T w_s = L.lead ? T(1) : T(0);
+                    T n0 = 0, n1 = 0;
+                    T rsc[NV];   // float32: 1 / scale (three divisions per element would be half of this block's instructions); float64: scale
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) {
+                        rsc[v] = M::rcp_ctl(atol + M::abs(y[0][v]) * rtol);
+                        const T q0 = M::div_ctl(y[0][v], rsc[v]), q1 = M::div_ctl(k[0][0][v], rsc[v]);
+                        n0 += (v == IS ? w_s : T(1)) * (q0 * q0);
+                        n1 += (v == IS ? w_s : T(1)) * (q1 * q1);
+                    }
+                    const T d0 = M::sqrt(group_sum<G>(n0) / Dn), d1 = M::sqrt(group_sum<G>(n1) / Dn);
+                    const bool small = (d0 < T(1e-5)) || (d1 < T(1e-5));
+                    const T h0 = small ? T(1e-6) : T(0.01) * (d0 / d1);
+#pragma unroll
+                    for (int c = 0; c < NC; ++c)
+#pragma unroll
+                        for (int pp = 0; pp < NP; ++pp) yt[c].p[pp] = y[c].p[pp] + h0 * k[0][c].p[pp];
+                    L.rhs(tprev + h0, yt, k[1]);
+                    T s2 = 0;
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) {
+                        const T q2 = M::div_ctl(k[1][0][v] - k[0][0][v], rsc[v]);
+                        s2 += (v == IS ? w_s : T(1)) * (q2 * q2);
+                    }
+                    const T d2 = M::sqrt(group_sum<G>(s2) / Dn) / h0;
+                    const T max_d = M::max(d1, d2);
+                    tnext = tprev + M::min(T(100) * h0, Control<T>::initial_h1(max_d, h0));
+                }
+                tnext = M::min(tnext, t_end);
+
+                save_idx = rep; // replica r owns save times r, r + R, r + 2R, ...
+                // jump bookkeeping (restates oracle/dynode_oracle_impl.inc): steps are clipped to land just
+                // before a jump, restart just after it with FSAL recomputed and the unclipped step size
+                jidx = 0;
+                at_jump = false;
+                dt_unclipped = T(0);
+                if (n_jump > 0) {
+                    while (jidx < n_jump && jt_tab[jidx] <= tprev) ++jidx;
+                    if (jidx < n_jump && jt_tab[jidx] < tnext) {
+                        dt_unclipped = tnext - tprev;
+                        tnext = M::next(jt_tab[jidx], -M::inf());
+                        at_jump = true;
+                    }
+                }
+                if constexpr (PRESCALE) { // from here on the rates and k[0] carry the factor of the step about to be tried
+                    const T dt0 = tnext - tprev;
+                    L.scale_rates(rate_tab, lane_c, dt0);
+#pragma unroll
+                    for (int c = 0; c < NC; ++c)
+#pragma unroll
+                        for (int pp = 0; pp < NP; ++pp) k[0][c].p[pp] = k[0][c].p[pp] * dt0;
+                }
+                // next two save times kept in registers (the read of ts[idx+2] overlaps a whole round)
+                ts_next = save_idx < n_save ? ts_tab[save_idx] : M::inf();
+                ts_next2 = save_idx + R < n_save ? ts_tab[save_idx + R] : M::inf();
+                steps = 0;
+                n_acc = 0;
+                n_rej = 0;
+                st = start_ok ? ST_OK : ST_NONFINITE;
+                done = !(tprev < t_end) || !start_ok;
+                live = true;
+                out_traj = kc.out + traj * (int64_t)n_save * ka.d_saved;
+                if constexpr (ND > 0) {
+                    dout_traj = kc.dout + traj * (int64_t)n_save * ND * ka.d_saved;
+                    ll.acc = 0.0;
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) {
+                        ll.dacc[c] = 0.0;
+#pragma unroll
+                        for (int q = 0; q < LLMAX; ++q) ll.prev[c][q] = T(0);
+                    }
+                }
+#ifdef DYN_DIAG_ROUNDS
+                diag_iters = diag_rounds = 0;
+#endif
+            }
+            if (!__any(live)) break;
+
 #ifdef DYN_DIAG_ROUNDS
             ++diag_iters;
 #endif
@@ -1351,11 +1602,19 @@ struct Solver {
                 for (int c = 0; c < NC; ++c)
 #pragma unroll
                     for (int pp = 0; pp < NP; ++pp) { // register pairs: v_pk_fma_f32
-                        V2 acc = T(TB::a[sg][0]) * k[0][c].p[pp];
+                        if constexpr (PRESCALE) {   // k[] hold dt f: y + sum a k, the chain starts on y
+                            V2 acc = T(TB::a[sg][0]) * k[0][c].p[pp] + y[c].p[pp];
 #pragma unroll
-                        for (int q = 1; q < sg; ++q)
-                            if (TB::a[sg][q] != 0.0) acc += T(TB::a[sg][q]) * k[q][c].p[pp];
-                        yt[c].p[pp] = y[c].p[pp] + dt * acc;
+                            for (int q = 1; q < sg; ++q)
+                                if (TB::a[sg][q] != 0.0) acc += T(TB::a[sg][q]) * k[q][c].p[pp];
+                            yt[c].p[pp] = acc;
+                        } else {
+                            V2 acc = T(TB::a[sg][0]) * k[0][c].p[pp];
+#pragma unroll
+                            for (int q = 1; q < sg; ++q)
+                                if (TB::a[sg][q] != 0.0) acc += T(TB::a[sg][q]) * k[q][c].p[pp];
+                            yt[c].p[pp] = y[c].p[pp] + dt * acc;
+                        }
                     }
                 L.rhs(tprev + T(TB::c[sg]) * dt, yt, k[sg]);
             }
@@ -1364,7 +1623,7 @@ struct Solver {
             // ---- embedded error, RMS norm over the whole (primal) state, I-controller
             bool keep = true, finite = true;
             T factor = T(1);
-            if (!constant) {
+            if (__builtin_expect(!constant, 1)) {
                 // scaled error per element, pair by pair: only |.|, max and the reciprocal are one-element instructions
                 V2 ssq[2] = {V2{T(0), T(0)}, V2{T(0), T(0)}};   // two partial sums: no dependent packed FMAs back to back
 #pragma unroll
@@ -1373,10 +1632,9 @@ struct Solver {
 #pragma unroll
                     for (int q = 1; q < 7; ++q)
                         if (TB::berr[q] != 0.0) e2 += T(TB::berr[q]) * k[q][0].p[pp];
-                    const V2 ym = V2{M::max(M::abs(y[0].p[pp][0]), M::abs(yt[0].p[pp][0])),
-                                     M::max(M::abs(y[0].p[pp][1]), M::abs(yt[0].p[pp][1]))};
+                    const V2 ym = V2{M::max_abs(y[0].p[pp][0], yt[0].p[pp][0]), M::max_abs(y[0].p[pp][1], yt[0].p[pp][1])};
                     const V2 sc = ym * rtol + atol;
-                    V2 r = (dt * e2) * V2{M::rcp_fast(sc[0]), M::rcp_fast(sc[1])};
+                    V2 r = (PRESCALE ? e2 : dt * e2) * V2{M::rcp_fast(sc[0]), M::rcp_fast(sc[1])};
                     if (GS > 1 && pp == IS / 2) r[IS % 2] = L.lead ? r[IS % 2] : T(0); // the replicated s counts once
                     ssq[pp & 1] += r * r;       // (the pad element of an odd NV carries e = 0)
                 }
@@ -1401,73 +1659,70 @@ struct Solver {
             // ---- SaveAt(ts): dense output at every save time in (tprev, tnext]
             bool pending = accept && (save_idx < n_save) && (ts_next <= tnext);
             const T inv_dt = M::recip(dt);
-            if constexpr (SU > 1) {
-                while (__any(pending)) {
-                    if (pending) {
-                        T tsu[SU];
-                        bool pu[SU];
-                        Dense dn[SU];
-                        tsu[0] = ts_next;
+            if (__any(pending)) {
+                // the step's interpolant as a polynomial in theta, once for all its rows (see dense_coefficients)
+                dense_coefficients(dt, y, yt, k);
+                if constexpr (SU > 1) {
+                    while (__any(pending)) {
+                        if (pending) {
+                            T tsu[SU];
+                            bool pu[SU];
+                            tsu[0] = ts_next;
 #pragma unroll
-                        for (int q = 1; q < SU; ++q)
-                            tsu[q] = save_idx + q * R < n_save ? ts_tab[save_idx + q * R] : M::inf();
-                        int cnt = 0;
+                            for (int q = 1; q < SU; ++q)
+                                tsu[q] = save_idx + q * R < n_save ? ts_tab[save_idx + q * R] : M::inf();
+                            int cnt = 0;
 #pragma unroll
-                        for (int q = 0; q < SU; ++q) {
-                            pu[q] = tsu[q] <= tnext; // increasing grid: the saved ones form a prefix
-                            cnt += pu[q] ? 1 : 0;
-                            dense_prepare(((pu[q] ? tsu[q] : tprev) - tprev) * inv_dt, dn[q]);
-                        }
-#pragma unroll
-                        for (int q = 0; q < SU; ++q) {
-                            if (ND > 0 && fused_ll) {
-                                if (pu[q] && writer)
-                                    ll_row(ka, dn[q], dt, y, yt, k, ll, save_idx + q * R, a, as, L.lead,
-                                           ll_table ? ll_lane + (int64_t)(save_idx + q * R) * LL_ROW : nullptr);
-                            } else if (pu[q] && writer) {
-                                save_row<0>(ka, dn[q], dt, y, yt, k,
-                                            out_traj + (int64_t)(save_idx + q * R) * ka.d_saved, a,
-                                            as, L.lead, vec_ok);
-                                if constexpr (ND > 0)
-                                    save_tangents<1>(ka, dn[q], dt, y, yt, k,
-                                                     dout_traj + (int64_t)(save_idx + q * R) * ND * ka.d_saved,
-                                                     a, as, L.lead, vec_ok);
+                            for (int q = 0; q < SU; ++q) {
+                                pu[q] = tsu[q] <= tnext; // increasing grid: the saved ones form a prefix
+                                cnt += pu[q] ? 1 : 0;
                             }
+#pragma unroll
+                            for (int q = 0; q < SU; ++q) {
+                                Poly dq;
+                                poly_prepare(((pu[q] ? tsu[q] : tprev) - tprev) * inv_dt, dt, dq);
+                                if (ND > 0 && fused_ll) {
+                                    if (pu[q] && writer)
+                                        ll_row(ka, dq, y, k, ll, save_idx + q * R, a, as, L.lead,
+                                               ll_table ? ll_lane + (int64_t)(save_idx + q * R) * LL_ROW : nullptr);
+                                } else if (pu[q] && writer) {
+                                    save_row<0>(ka, dq, y, k, out_traj + (int64_t)(save_idx + q * R) * ka.d_saved, a, as,
+                                                L.lead, vec_ok);
+                                    if constexpr (ND > 0)
+                                        save_tangents<1>(ka, dq, y, k,
+                                                         dout_traj + (int64_t)(save_idx + q * R) * ND * ka.d_saved, a, as,
+                                                         L.lead, vec_ok);
+                                }
+                            }
+                            save_idx += cnt * R;
+                            ts_next = save_idx < n_save ? ts_tab[save_idx] : M::inf();
                         }
-                        save_idx += cnt * R;
-                        ts_next = save_idx < n_save ? ts_tab[save_idx] : M::inf();
+                        pending = accept && (save_idx < n_save) && (ts_next <= tnext);
+                    }
+                }
+                while (SU == 1 && __any(pending)) {
+#ifdef DYN_DIAG_ROUNDS
+                    ++diag_rounds;
+#endif
+                    if (pending) {
+                        Poly dn;
+                        poly_prepare((ts_next - tprev) * inv_dt, dt, dn);
+                        if (ND > 0 && fused_ll) {
+                            if (writer)
+                                ll_row(ka, dn, y, k, ll, save_idx, a, as, L.lead,
+                                       ll_table ? ll_lane + (int64_t)save_idx * LL_ROW : nullptr);
+                        } else if (writer) {
+                            save_row<0>(ka, dn, y, k, out_traj + (int64_t)save_idx * ka.d_saved, a, as, L.lead, vec_ok);
+                            if constexpr (ND > 0)
+                                save_tangents<1>(ka, dn, y, k, dout_traj + (int64_t)save_idx * ND * ka.d_saved, a, as,
+                                                 L.lead, vec_ok);
+                        }
+                        save_idx += R;
+                        ts_next = ts_next2;
+                        ts_next2 = save_idx + R < n_save ? ts_tab[save_idx + R] : M::inf();
                     }
                     pending = accept && (save_idx < n_save) && (ts_next <= tnext);
                 }
-            }
-            while (SU == 1 && __any(pending)) {
-#ifdef DYN_DIAG_ROUNDS
-                ++diag_rounds;
-#endif
-                if (pending) {
-                    Dense dn;
-                    dense_prepare((ts_next - tprev) * inv_dt, dn);
-                    if (ND > 0 && fused_ll) {
-                        if (writer)
-                            ll_row(ka, dn, dt, y, yt, k, ll, save_idx, a, as, L.lead,
-                                   ll_table ? ll_lane + (int64_t)save_idx * LL_ROW : nullptr);
-                    } else if (writer) {
-#ifdef DYN_DIAG_SAMEROW   // diagnostic build: every round overwrites one of two rows (stores hit in L2, no HBM stream)
-                        save_row<0>(ka, dn, dt, y, yt, k, out_traj + (int64_t)(save_idx & 1) * ka.d_saved,
-#else
-                        save_row<0>(ka, dn, dt, y, yt, k, out_traj + (int64_t)save_idx * ka.d_saved,
-#endif
-                                    a, as, L.lead, vec_ok);
-                        if constexpr (ND > 0)
-                            save_tangents<1>(ka, dn, dt, y, yt, k,
-                                             dout_traj + (int64_t)save_idx * ND * ka.d_saved, a, as,
-                                             L.lead, vec_ok);
-                    }
-                    save_idx += R;
-                    ts_next = ts_next2;
-                    ts_next2 = save_idx + R < n_save ? ts_tab[save_idx + R] : M::inf();
-                }
-                pending = accept && (save_idx < n_save) && (ts_next <= tnext);
             }
 
             // ---- commit / reject
@@ -1486,7 +1741,7 @@ struct Solver {
             // ---- next interval: prev_dt * factor, then diffeqsolve's clip-to-end
             T next_t0 = accept ? tnext : tprev;
             T next_t1 = next_t0 + (constant ? ka.constant_dt : dt * factor);
-            if (n_jump > 0) { // wave-uniform: no cost when discontinuity_points is empty
+            if (__builtin_expect(n_jump > 0, 0)) { // wave-uniform: no cost when discontinuity_points is empty
                 const bool landed = at_jump && accept;
                 if (landed) {
                     // prev_dt is the controller's proposal before the jump clipped it
@@ -1525,56 +1780,75 @@ struct Solver {
                     done = true;
                 }
             }
-        }
+            if constexpr (PRESCALE) {
+                // the next attempt's step size: rates from their parked originals, FSAL by the ratio of the step sizes
+                const T dt_new = tnext - tprev;
+                const T ratio = act ? dt_new * inv_dt : T(1);
+#pragma unroll
+                for (int c = 0; c < NC; ++c)
+#pragma unroll
+                    for (int pp = 0; pp < NP; ++pp) k[0][c].p[pp] = k[0][c].p[pp] * ratio;
+                L.scale_rates(rate_tab, lane, dt_new);
+            }
 
-        if constexpr (ND > 0) {
-            if (fused_ll) { // wave-uniform
-                // sum over the lanes of the trajectory; a failed solve scores -inf (rejected by the sampler)
-                // (the replicas of a trajectory are adjacent lane groups of the same wave)
-                int unfinished = (st != ST_OK || save_idx < n_save) ? 1 : 0;
-                if (ll_table) {
-                    __syncthreads(); // every replica's table entries are visible
-                    if (writer && !unfinished) ll_from_table(ka, ll, ll_lane, LL_ROW, n_save, rep, R, a, as, L.lead);
-                }
-                const int span = G * R;
-                double tot = writer ? ll.acc : 0.0;
-                for (int off = span / 2; off > 0; off >>= 1) tot += __shfl_xor(tot, off);
-                double dtot[NC];
+            // ---- a trajectory that finished in this iteration is written off, and its slot asks for the next one
+            if (__builtin_expect(live && done, 0)) {
+                live = false;
+                want_ticket = pull;
+                bool scored = false;
+                if constexpr (ND > 0) {
+                    if (fused_ll) { // wave-uniform
+                        scored = true;
+                        // sum over the lanes of the trajectory; a failed solve scores -inf (rejected by the sampler)
+                        // (the replicas of a trajectory are adjacent lane groups of the same wave; they step identically,
+                        // so they arrive here in the same iteration)
+                        int unfinished = (st != ST_OK || save_idx < n_save) ? 1 : 0;
+                        if (ll_table) {
+                            __syncthreads(); // every replica's table entries are visible
+                            if (writer && !unfinished) ll_from_table(ka, ll, ll_lane, LL_ROW, n_save, rep, R, a, as, L.lead);
+                        }
+                        const int span = G * R;
+                        double tot = writer ? ll.acc : 0.0;
+                        for (int off = span / 2; off > 0; off >>= 1) tot += __shfl_xor(tot, off);
+                        double dtot[NC];
 #pragma unroll
-                for (int c = 1; c < NC; ++c) {
-                    dtot[c] = writer ? ll.dacc[c] : 0.0;
-                    for (int off = span / 2; off > 0; off >>= 1) dtot[c] += __shfl_xor(dtot[c], off);
-                }
-                for (int off = span / 2; off > 0; off >>= 1) unfinished |= __shfl_xor(unfinished, off);
-                const bool ok = unfinished == 0;
-                if (writer && a == 0 && L.lead && rep == 0) {
-                    ka.ll_out[traj] = ok ? tot : -__builtin_inf();
+                        for (int c = 1; c < NC; ++c) {
+                            dtot[c] = writer ? ll.dacc[c] : 0.0;
+                            for (int off = span / 2; off > 0; off >>= 1) dtot[c] += __shfl_xor(dtot[c], off);
+                        }
+                        for (int off = span / 2; off > 0; off >>= 1) unfinished |= __shfl_xor(unfinished, off);
+                        const bool ok = unfinished == 0;
+                        if (writer && a == 0 && L.lead && rep == 0) {
+                            const auto &kc = *cold_args<T>();
+                            kc.ll_out[traj] = ok ? tot : -__builtin_inf();
+                            double *const dll = kc.dll_out;
 #pragma unroll
-                    for (int c = 1; c < NC; ++c) ka.dll_out[traj * ND + (c - 1)] = ok ? dtot[c] : 0.0;
-                    ka.status[traj] = st;
-                    ka.n_acc[traj] = n_acc;
-                    ka.n_rej[traj] = n_rej;
+                            for (int c = 1; c < NC; ++c) dll[traj * ND + (c - 1)] = ok ? dtot[c] : 0.0;
+                            kc.status[traj] = st;
+                            kc.n_acc[traj] = n_acc;
+                            kc.n_rej[traj] = n_rej;
+                        }
+                    }
                 }
-                return;
-            }
-        }
-        // rows never reached (failed solves): +inf, like diffrax's unfilled SaveAt buffer
-        if (writer) {
-            for (; save_idx < n_save; save_idx += R) {
-                fill_row(ka, out_traj + (int64_t)save_idx * ka.d_saved, a, as, L.lead, M::inf());
-                if constexpr (ND > 0)
-                    for (int j = 0; j < ND; ++j)
-                        fill_row(ka, dout_traj + ((int64_t)save_idx * ND + j) * ka.d_saved, a, as,
-                                 L.lead, M::inf());
-            }
-            if (a == 0 && L.lead && rep == 0) {
-                ka.status[traj] = st;
+                // rows never reached (failed solves): +inf, like diffrax's unfilled SaveAt buffer
+                if (!scored && writer) {
+                    for (; save_idx < n_save; save_idx += R) {
+                        fill_row(ka, out_traj + (int64_t)save_idx * ka.d_saved, a, as, L.lead, M::inf());
+                        if constexpr (ND > 0)
+                            for (int j = 0; j < ND; ++j)
+                                fill_row(ka, dout_traj + ((int64_t)save_idx * ND + j) * ka.d_saved, a, as, L.lead, M::inf());
+                    }
+                    if (a == 0 && L.lead && rep == 0) {
+                        const auto &kc = *cold_args<T>();
+                        kc.status[traj] = st;
 #ifdef DYN_DIAG_ROUNDS
-                n_acc = diag_iters;
-                n_rej = diag_rounds;
+                        n_acc = diag_iters;
+                        n_rej = diag_rounds;
 #endif
-                ka.n_acc[traj] = n_acc;
-                ka.n_rej[traj] = n_rej;
+                        kc.n_acc[traj] = n_acc;
+                        kc.n_rej[traj] = n_rej;
+                    }
+                }
             }
         }
     }
@@ -1587,18 +1861,63 @@ solve_kernel(const KArgs<T> ka) {
     Solver<T, METHOD, GA, ST, HAS_E, HAS_WANE, HAS_C, W, ND, SPL, FEAT>::run(ka);
 }
 
+// waves of `kernel` the current device holds at once (occupancy x compute units); cached per (device, LDS size)
+template <typename K>
+static int64_t resident_waves(K kernel, size_t lds) {
+    static thread_local int c_dev = -1;
+    static thread_local size_t c_lds = 0;
+    static thread_local int64_t c_val = 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (dev == c_dev && lds == c_lds) return c_val;
+    int per_cu = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 64, lds) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+        return 0;
+    c_dev = dev;
+    c_lds = lds;
+    c_val = (int64_t)per_cu * cus;
+    return c_val;
+}
+
 // host-side launcher, one explicit instantiation per compiled shape (instances.def)
 template <typename T, int METHOD, int GA, int ST, bool HAS_E, bool HAS_WANE, bool HAS_C, int W, int ND, int SPL,
           int FEAT = 0>
-hipError_t launch(const KArgs<T> &ka, hipStream_t stream) {
+hipError_t launch(const KArgs<T> &ka_in, hipStream_t stream) {
+    KArgs<T> ka = ka_in;
     constexpr int TPW = 64 / (GA * (ST / SPL));
     const int64_t blocks = ((ka.B << ka.rep_log2) + TPW - 1) / TPW;
     if (blocks <= 0) return hipSuccess;
     size_t lds = ((size_t)ka.n_save + (ka.n_jump > 0 ? kMaxJumps : 0)) * sizeof(T); // LDS tables
     if (ND > 0 && ka.obs != nullptr && ka.rep_log2 > 0) // likelihood table of the replicated trajectories of a wave
         lds += (size_t)(64 >> ka.rep_log2) * ka.n_save * (SPL * W) * (1 + ND) * sizeof(T);
-    hipLaunchKernelGGL((solve_kernel<T, METHOD, GA, ST, HAS_E, HAS_WANE, HAS_C, W, ND, SPL, FEAT>),
-                       dim3((unsigned)blocks), dim3(64), lds, stream, ka);
+    if (((FEAT >> 1) & 0x7f) == 0) // PRESCALE: the parked rates and seeds, [SPL (1 + ND) quads][64 lanes] of four, behind the tables (rounded up to four elements)
+        lds = ((lds / sizeof(T) + 3) & ~(size_t)3) * sizeof(T) + (size_t)SPL * (1 + ND) * 64 * 4 * sizeof(T);
+    const auto kernel = solve_kernel<T, METHOD, GA, ST, HAS_E, HAS_WANE, HAS_C, W, ND, SPL, FEAT>;
+    int64_t grid = blocks;
+    if (ka.work != nullptr) {
+        // Work pulling needs a batch of more waves than the chip holds at once: then the grid is exactly the resident waves
+        // and every lane group draws trajectories until the queue is empty.  A batch that fits is one wave per TPW
+        // trajectories as ever (nothing to pull), and replicated trajectories (small batches) are static by construction.
+        // Measured (one box, MI355X, ms per launch, static grid -> pulling; docs/perf-log.md):
+        //   given order    D = 360 (TPW 2) B = 16384  2.70 -> 2.67;  D = 136 (TPW 8) B = 65536  3.43-3.55 -> 3.46-3.47;
+        //                  cfg 5 B = 65536  3.80 -> 3.76;  cfg 2 (TPW 8, 40-step trajectories) B = 65536  0.79-0.85 -> 1.05
+        //   caller's order (most step attempts first)  D = 360  2.40-2.46 -> 2.36-2.39;  cfg 5 B = 65536  3.27 -> 3.23-3.25;
+        //                  cfg 2 B = 65536  0.645-0.66 -> 0.625-0.63
+        // Every pass of the prologue stalls ALL lane groups of its wave, so with eight short trajectories per wave the passes
+        // cost more than the waiting they remove; with a queue sorted by cost, pulling is what makes longest-first work.
+        // Default therefore: pull when a wave holds at most two trajectories, or when the caller supplied the queue.
+        // DYNODE_HIP_PULL=0 / 1 forces it off / on, DYNODE_HIP_PULL_WAVES=<n> sets the grid (tests, tuning).
+        const char *mode = getenv("DYNODE_HIP_PULL");
+        const char *forced = getenv("DYNODE_HIP_PULL_WAVES");
+        const bool want = mode ? atoi(mode) != 0 : (forced != nullptr || TPW <= 2 || ka.order != nullptr);
+        int64_t resident = forced ? atoll(forced) : resident_waves(kernel, lds);
+        if (!want || ka.rep_log2 != 0 || resident <= 0 || blocks <= resident)
+            ka.work = nullptr;
+        else
+            grid = resident;
+    }
+    hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(64), lds, stream, ka);
     return hipGetLastError();
 }
 

@@ -88,6 +88,29 @@ def _dev(x, dtype, device) -> torch.Tensor:
     return torch.as_tensor(arr, dtype=dtype, device=device).contiguous()
 
 
+_WORK_COUNTERS: "dict[tuple, torch.Tensor]" = {}
+_WORK_MIN_BATCH = 1024     # fewer trajectories than the GPU has SIMDs can never exceed one resident round
+
+
+def work_counter(B: int, device, stream) -> Optional[torch.Tensor]:
+    """The two zeroed int32 words behind ``dyn_solver_opts.work_counter`` (work pulling, include/dynode_hip.h): one pair per
+    (device, stream), created once -- the kernel leaves it zeroed, and launches of one stream cannot overlap.  While a HIP
+    graph is being captured the pair is a fresh one from the graph's own pool (replays of different graphs may overlap).
+    None for batches that can never exceed one resident round."""
+    if B < _WORK_MIN_BATCH:
+        return None
+    if torch.cuda.is_current_stream_capturing():
+        return torch.zeros(2, dtype=torch.int32, device=device)
+    key = (str(device), int(stream.cuda_stream))
+    t = _WORK_COUNTERS.get(key)
+    if t is None:
+        if len(_WORK_COUNTERS) > 64:
+            _WORK_COUNTERS.clear()
+        with torch.cuda.stream(stream):
+            t = _WORK_COUNTERS[key] = torch.zeros(2, dtype=torch.int32, device=device)
+    return t
+
+
 def save_mask_bytes(model: ModelDesc, save_mask: Optional[Sequence[bool]]):
     names = model.compartment_names
     if save_mask is None:
@@ -107,7 +130,7 @@ def solve_batch(model: ModelDesc, y0, params, contact, t1: float, save_ts, *, t0
                 out: Optional[torch.Tensor] = None, stats_out: Optional[tuple] = None,
                 stream: Optional[torch.cuda.Stream] = None, dparams=None, dy0=None,
                 dout: Optional[torch.Tensor] = None, record_steps: int = 0, replay: Optional[tuple] = None,
-                order="auto") -> BatchResult:
+                order=None) -> BatchResult:
     """Integrate B parameter samples of ``model`` over [t0, t1] on the current GPU.
 
     Replaces the per-sample ``diffeqsolve`` call of dynode.simulation.simulate
@@ -123,10 +146,13 @@ def solve_batch(model: ModelDesc, y0, params, contact, t1: float, save_ts, *, t0
     ``leader[b]`` of ``steps`` (``leader=None``: row b) instead of controlling its own.  For this family ``dparams`` is
     served by `_replayed_tangents`: central differences of replayed solves on the primal's step sequence.
 
-    ``order``: dispatch order of the batch (``dyn_solve_batch_ordered``; never changes a result, see `schedule.py`).
-    ``"auto"`` (default): plain adaptive solves of at least `schedule.MIN_BATCH` trajectories are ordered by a step-count
-    forecast learned from earlier launches of the same model and settings; ``None``: the given order; an int32 device
-    tensor [B]: that permutation.
+    Large batches (more trajectory-waves than the GPU holds at once) run as a resident grid whose lane groups pull
+    trajectories from a queue as they finish (``dyn_solver_opts.work_counter``; csrc/solve_kernel.hpp ``Solver::run``).
+
+    ``order``: the queue (``dyn_solve_batch_ordered``; it never changes a result).  ``None`` (default): the batch in its
+    given order; an int32 device tensor [B]: that permutation -- a caller who knows which trajectories are expensive puts
+    them first; ``"forecast"``: opt-in, the step-count forecast of `schedule.py` learned from earlier launches of the same
+    model and settings (it needs thousands of trajectories of training and is keyed on the shared inputs' content).
     """
     device = require_gpu()
     L = _abi.lib()
@@ -175,11 +201,13 @@ def solve_batch(model: ModelDesc, y0, params, contact, t1: float, save_ts, *, t0
     if B == 0:  # empty batch: nothing to enqueue (zero-size tensors have null data pointers)
         return BatchResult(out, status, n_acc, n_rej, saved, sizes, dout)
     jt = np.ascontiguousarray(jump_ts, dtype=np.float64)
+    s = stream if stream is not None else torch.cuda.current_stream(device)
+    work_t = work_counter(B, device, s) if model.family == 0 else None
     opts = _abi.SolverOptsC(
         _METHODS[method], _DTYPES[dtype], float(rtol), float(atol), int(max_steps),
         float(constant_dt),
-        jt.ctypes.data_as(ctypes.POINTER(ctypes.c_double)) if jt.size else None, int(jt.size))
-    s = stream if stream is not None else torch.cuda.current_stream(device)
+        jt.ctypes.data_as(ctypes.POINTER(ctypes.c_double)) if jt.size else None, int(jt.size),
+        work_t.data_ptr() if work_t is not None else None)
     sched = sched_n = leader_t = None
     if record_steps and replay is not None:
         raise ValueError("record_steps and replay exclude each other")
@@ -205,19 +233,23 @@ def solve_batch(model: ModelDesc, y0, params, contact, t1: float, save_ts, *, t0
         if order.dtype != torch.int32 or tuple(order.shape) != (B,) or not order.is_contiguous() or order.device != params_t.device:
             raise ValueError(f"order must be a contiguous int32 device tensor of shape ({B},)")
         order_t = order
-    elif order == "auto":
+    elif order == "forecast":
         from . import schedule
 
         if (plain and B >= schedule.MIN_BATCH and B * D >= schedule.MIN_WORK and not constant_dt > 0.0 and schedule.enabled()
                 and not torch.cuda.is_current_stream_capturing()):
-            key = (model, dtype, method, float(rtol), float(atol), float(t0), float(t1), n_save > 0, str(device))
+            # the forecast belongs to a model, its settings AND the inputs every trajectory shares: a changed contact matrix
+            # or initial state starts a new one (small arrays: hashing them costs one device-to-host copy per call)
+            shared = (contact_t.detach().cpu().numpy().tobytes(), None if batched else y0_t.detach().cpu().numpy().tobytes(),
+                      tuple(float(v) for v in jump_ts), int(max_steps))
+            key = (model, dtype, method, float(rtol), float(atol), float(t0), float(t1), n_save > 0, str(device), hash(shared))
             cost = schedule.model_for(key, P, device, schedule.strain_symmetry(model))
             if cost.ready:
                 tpw = int(L.dyn_trajectories_per_wave(ctypes.byref(model.c())))
                 one_round = tpw > 0 and B % tpw == 0 and B // tpw <= schedule.ONE_ROUND_WAVES
                 order_t = cost.order(params_t, s, tpw if one_round else 0)
     elif order is not None:
-        raise ValueError('order must be "auto", None or an int32 tensor')
+        raise ValueError('order must be None, "forecast" or an int32 tensor')
 
     def call():
         common = (ctypes.byref(model.c()), ctypes.byref(opts), y0_t.data_ptr(), int(batched),
@@ -249,7 +281,7 @@ def solve_batch(model: ModelDesc, y0, params, contact, t1: float, save_ts, *, t0
     if rc != 0:
         raise SolveError(rc, L.dyn_last_error().decode())
     # keep inputs alive until the stream has consumed them
-    for t in (y0_t, params_t, contact_t, ts_t, dparams_t, dy0_t, sched, sched_n, leader_t, order_t):
+    for t in (y0_t, params_t, contact_t, ts_t, dparams_t, dy0_t, sched, sched_n, leader_t, order_t, work_t):
         if t is not None:
             t.record_stream(s)
     if cost is not None and cost.training:      # learn the step-count forecast from what this launch returns (schedule.py)

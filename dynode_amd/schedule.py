@@ -1,5 +1,11 @@
 """Cost-ordered dispatch of a batch: which trajectories share a wave, and which waves start first.
 
+OPT-IN since round 3 (``solve_batch(order="forecast")``).  The default dispatch needs no forecast: batches beyond one
+resident round run as a work-pulling grid (csrc/solve_kernel.hpp, ``Solver::run``), which removes the lock-step waiting and
+the round structure for any batch in its given order.  What a forecast still adds on top of that is longest-first order at the
+tail of a launch; a caller who has one -- this module's learned regression, or knowledge of its own -- passes it as the
+queue (``order=<int32 tensor>``, `dyn_solve_batch_ordered`).
+
 The solve kernels step the 2..32 trajectories of a wavefront in lock-step and the GPU starts waves in index order, so a
 launch is shorter when neighbours in the batch need similar numbers of steps and the expensive ones come first (longest
 processing time first): 10-15 % on the BASELINE shapes (`tools/probes/probe_sorted.py`).  The outputs
@@ -10,15 +16,16 @@ What is needed is a forecast of the step count of a trajectory before it is solv
 (`n_accept + n_reject`) after every launch, so the forecast is learned from the solver's own output: a ridge regression of
 the step count on a quadratic form in the standardised logarithms of the parameters that vary over the batch (SEIR-type
 models: correlation 0.93 with the true count on unseen draws of the BASELINE cfg 3 prior against 0.75-0.81 for a linear
-model, 0.98 when the strains are relabelled canonically first -- `CostModel`).  `solve_batch(order="auto")` (the default) trains on the launches
+model, 0.98 when the strains are relabelled canonically first -- `CostModel`).  `solve_batch(order="forecast")` trains on the launches
 it sees until `TRAIN_ROWS` trajectories of a (model, solver settings) pair have been observed, then orders every later batch
 with two small launches (`dyn_cost_order`: forecast + bucket, counting sort) in front of the solve.  Nothing synchronises
 with the host after the first training launch (which looks at the batch once to pick the varying parameters); a training launch
 costs a feature matrix and a 150 x 150 solve on the device next to it (a millisecond or two for 16384 rows), the first two or
 three launches of a (model, settings) pair only.
 
-The reference has no counterpart (diffrax under `vmap` on XLA:CPU runs the samples one after another); `order=None` or
-``DYNODE_ORDER=0`` switches it off, `order=<int32 tensor>` dispatches in a caller-supplied order.
+The forecast is keyed on the model, the solver settings and the CONTENT of the inputs all trajectories share (contact matrix,
+shared initial state, discontinuity points): change one and a new forecast is learned.  `reset()` forgets everything.
+The reference has no counterpart (diffrax under `vmap` on XLA:CPU runs the samples one after another).
 """
 
 from __future__ import annotations

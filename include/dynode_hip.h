@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define DYN_ABI_VERSION 6
+#define DYN_ABI_VERSION 7
 /* the save grid is staged in LDS: n_save * sizeof(real) must not exceed this */
 #define DYN_MAX_SAVE_BYTES 49152
 
@@ -133,6 +133,16 @@ typedef struct dyn_solver_opts {
     double constant_dt; /* constant_step_size; > 0 selects ConstantStepSize */
     const double *jump_ts; /* discontinuity_points */
     int32_t n_jump;
+    /* ABI 7.  Work pulling: DEVICE pointer to two int32 words that are zero when the launch starts, or NULL.  With it, a
+     * batch of more trajectory-waves than the GPU holds at once is launched as one resident grid whose lane groups draw
+     * trajectories from a queue as they finish (solve_kernel.hpp, Solver::run) instead of one wave per TPW trajectories:
+     * no lane group idles behind a longer-running partner, and nothing has to be known about the batch in advance.  The
+     * kernel leaves both words zero again, so one pair serves every launch of a stream; launches that may overlap (other
+     * streams) need pairs of their own.  The caller owns the memory, like every other buffer of this ABI.  Results never
+     * depend on it.  The library pulls where that was measured to pay: kernels with at most two trajectories per wave, and
+     * any kernel when the caller supplies the queue (dyn_solve_batch_ordered: longest-first needs dynamic assignment).
+     * NULL, batches of one resident round, and the SEIP family: a static grid, as before ABI 7. */
+    int32_t *work_counter;
 } dyn_solver_opts;
 
 /* per-trajectory status */

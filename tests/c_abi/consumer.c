@@ -68,6 +68,41 @@ int main(void) {
         if (memcmp(out, out2, sizeof out) != 0) { fprintf(stderr, "ordered dispatch changed the output\n"); return 7; }
         printf("ordered dispatch identical\n");
     }
+    /* work pulling (ABI 7, dyn_solver_opts.work_counter): a batch beyond the resident grid -- forced down to 8 waves here --
+     * is integrated by lane groups that draw trajectories from a queue; every byte must equal the static launch, and the
+     * two counter words must be zero again afterwards */
+    {
+        enum { B2 = 1500 };
+        static double p2[B2][P], a[B2][NSAVE][D], b2[B2][NSAVE][D];
+        double *d_p2, *d_a;
+        int32_t *d_stat2, *d_work, work[2] = {-1, -1};
+        for (int b = 0; b < B2; ++b) { p2[b][0] = (1.2 + 0.002 * b) / 7.0; p2[b][1] = 1.0 / (5.0 + 0.003 * b); }
+        CHECK(hipMalloc((void **)&d_p2, sizeof p2));
+        CHECK(hipMalloc((void **)&d_a, sizeof a));
+        CHECK(hipMalloc((void **)&d_stat2, sizeof(int32_t) * 3 * B2));
+        CHECK(hipMalloc((void **)&d_work, sizeof work));
+        CHECK(hipMemset(d_work, 0, sizeof work));
+        CHECK(hipMemcpy(d_p2, p2, sizeof p2, hipMemcpyHostToDevice));
+        rc = dyn_solve_batch(&m, &o, d_y0, 0, d_p2, d_c, B2, 0.0, 50.0, d_ts, NSAVE, NULL, d_a, d_stat2, d_stat2 + B2, d_stat2 + 2 * B2, NULL);
+        if (rc) { fprintf(stderr, "static launch: %d (%s)\n", rc, dyn_last_error()); return 8; }
+        CHECK(hipDeviceSynchronize());
+        CHECK(hipMemcpy(a, d_a, sizeof a, hipMemcpyDeviceToHost));
+        CHECK(hipMemset(d_a, 0xff, sizeof a));
+        setenv("DYNODE_HIP_PULL_WAVES", "8", 1);
+        o.work_counter = d_work;
+        for (int rep = 0; rep < 2; ++rep) {     /* twice: the second launch finds the counters as the first one left them */
+            rc = dyn_solve_batch(&m, &o, d_y0, 0, d_p2, d_c, B2, 0.0, 50.0, d_ts, NSAVE, NULL, d_a, d_stat2, d_stat2 + B2, d_stat2 + 2 * B2, NULL);
+            if (rc) { fprintf(stderr, "work-pulling launch: %d (%s)\n", rc, dyn_last_error()); return 9; }
+            CHECK(hipDeviceSynchronize());
+        }
+        o.work_counter = NULL;
+        unsetenv("DYNODE_HIP_PULL_WAVES");
+        CHECK(hipMemcpy(b2, d_a, sizeof b2, hipMemcpyDeviceToHost));
+        CHECK(hipMemcpy(work, d_work, sizeof work, hipMemcpyDeviceToHost));
+        if (memcmp(a, b2, sizeof a) != 0) { fprintf(stderr, "work pulling changed the output\n"); return 10; }
+        if (work[0] != 0 || work[1] != 0) { fprintf(stderr, "work counters left at %d %d\n", work[0], work[1]); return 11; }
+        printf("work pulling identical\n");
+    }
     /* an unsupported request comes back as an error code and a message, never as a crash */
     m.n_strain = 7;
     rc = dyn_solve_batch(&m, &o, d_y0, 0, d_p, d_c, B, 0.0, 50.0, d_ts, NSAVE, NULL, d_out, d_stat, d_stat + B, d_stat + 2 * B, NULL);

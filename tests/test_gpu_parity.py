@@ -234,9 +234,85 @@ def test_dispatch_order_never_changes_a_result(wl):
         solve_batch(*args, dtype=F32, order="sorted")
 
 
+@pytest.mark.parametrize("wl,waves", [(synthetic.seirs_multi_strain(1536, seed=31, W=8), 96), (synthetic.seirs_multi_strain(1301, seed=32), 24),
+                                      (synthetic.sir_age_stratified(2050, seed=33), 5), (synthetic.seirs_multi_strain(1100, seed=34, seasonal=True), 64)],
+                         ids=["cfg3_D360", "cfg3_D136_ragged", "cfg2", "cfg5"])
+def test_work_pulling_gives_the_bits_of_the_static_grid(wl, waves, monkeypatch):
+    """dyn_solver_opts.work_counter: a batch beyond the resident grid (forced down to a few waves here) is integrated by lane
+    groups that draw trajectories from a device queue as they finish.  Every output -- rows, status, step counts -- must be
+    the static launch's bit for bit, in the given order, in a caller's order and with queue entries that are not
+    trajectories; the kernel leaves the two counter words at zero."""
+    from dynode_amd import engine
+
+    m = wl.model
+    args = (m, wl.y0, wl.params, wl.contact, wl.t1, wl.save_ts)
+    monkeypatch.setenv("DYNODE_HIP_REPLICAS_LOG2", "0")      # (small states are replicated at this batch size: static by construction)
+    monkeypatch.setenv("DYNODE_HIP_PULL", "0")
+    base = solve_batch(*args, dtype=F32)
+    monkeypatch.delenv("DYNODE_HIP_PULL")
+    monkeypatch.setenv("DYNODE_HIP_PULL_WAVES", str(waves))
+    g = torch.Generator().manual_seed(3)
+    perm = torch.randperm(wl.B, generator=g).to(torch.int32).cuda()
+    heavy_first = torch.argsort((base.n_accept + base.n_reject), descending=True, stable=True).to(torch.int32)
+    for order in (None, perm, heavy_first, None):
+        r = solve_batch(*args, dtype=F32, order=order)
+        for a, b in ((r.ys, base.ys), (r.status, base.status), (r.n_accept, base.n_accept), (r.n_reject, base.n_reject)):
+            assert torch.equal(a, b)
+        torch.cuda.synchronize()
+        (work,) = [t for t in engine._WORK_COUNTERS.values()]
+        assert work.tolist() == [0, 0]
+    assert _abi_lib_kernel_was_pulling(wl, waves)
+    # entries outside 0..B-1 are skipped by whoever draws them; nothing else is touched
+    sentinel = torch.full_like(base.ys, -7.0)
+    stats = torch.full((3, wl.B), -5, dtype=torch.int32, device="cuda")
+    bad = torch.arange(wl.B, dtype=torch.int32)
+    bad[3], bad[wl.B - 2], bad[wl.B // 2] = -1, wl.B + 5, 2**31 - 1
+    solve_batch(*args, dtype=F32, order=bad.cuda(), out=sentinel, stats_out=(stats[0], stats[1], stats[2]))
+    torch.cuda.synchronize()
+    skipped = torch.zeros(wl.B, dtype=torch.bool, device="cuda")
+    skipped[3] = skipped[wl.B - 2] = skipped[wl.B // 2] = True
+    assert torch.equal(sentinel[~skipped], base.ys[~skipped]) and bool((sentinel[skipped] == -7.0).all())
+    assert bool((stats[:, skipped] == -5).all()) and torch.equal(stats[0, ~skipped], base.status[~skipped])
+    assert next(iter(engine._WORK_COUNTERS.values())).tolist() == [0, 0]
+    # float64 takes the same path: identical step counts to the oracle are checked elsewhere, here static == pulling
+    monkeypatch.setenv("DYNODE_HIP_PULL", "0")
+    b64 = solve_batch(*args, dtype=F64)
+    monkeypatch.delenv("DYNODE_HIP_PULL")
+    r64 = solve_batch(*args, dtype=F64)
+    assert torch.equal(r64.ys, b64.ys) and torch.equal(r64.n_accept, b64.n_accept) and torch.equal(r64.n_reject, b64.n_reject)
+
+
+def _abi_lib_kernel_was_pulling(wl, waves) -> bool:
+    """The forced grid must be smaller than the static one, or the test above would compare a launch with itself."""
+    import ctypes
+
+    from dynode_amd import _abi
+
+    tpw = int(_abi.lib().dyn_trajectories_per_wave(ctypes.byref(wl.model.c())))
+    return tpw > 0 and -(-wl.B // tpw) > waves
+
+
+def test_work_pulling_tangent_and_likelihood_kernels(monkeypatch):
+    """The tangent kernels (dyn_solve_batch_jvp) and the fused likelihood take the same loop: a large gradient batch pulled
+    through a small grid equals the static launch bit for bit."""
+    wl = synthetic.sir_age_stratified(3000, seed=35)
+    m = wl.model
+    dp = np.zeros((wl.B, 2, m.param_dim))
+    dp[:, 0, 0] = dp[:, 1, 1] = 1.0
+    args = (m, wl.y0, wl.params, wl.contact, 100.0, wl.save_ts[:101])
+    monkeypatch.setenv("DYNODE_HIP_REPLICAS_LOG2", "0")
+    monkeypatch.setenv("DYNODE_HIP_PULL", "0")
+    base = solve_batch(*args, dtype=F32, dparams=dp)
+    monkeypatch.delenv("DYNODE_HIP_PULL")
+    monkeypatch.setenv("DYNODE_HIP_PULL_WAVES", "9")
+    r = solve_batch(*args, dtype=F32, dparams=dp)
+    for a, b in ((r.ys, base.ys), (r.dys, base.dys), (r.status, base.status), (r.n_accept, base.n_accept)):
+        assert torch.equal(a, b)
+
+
 def test_learned_dispatch_order():
     """schedule.py: the step-count forecast is learned from what the kernels return, `dyn_cost_order` turns it into a
-    permutation (most expensive first), and `order="auto"` uses it from the second launch on without changing a bit."""
+    permutation (most expensive first), and `order="forecast"` (opt-in) uses it from the second launch on without changing a bit."""
     from dynode_amd import schedule
 
     schedule.reset()
@@ -244,7 +320,7 @@ def test_learned_dispatch_order():
     m, half = big.model, 16384           # 16384 x 136 state values: above schedule.MIN_WORK
     train = (m, big.y0[:half], big.params[:half], big.contact, big.t1, big.save_ts[::73])
     test = (m, big.y0[half:], big.params[half:], big.contact, big.t1, big.save_ts[::73])
-    first = solve_batch(*train, dtype=F32)                      # trains (16384 rows >= 12 per coefficient)
+    first = solve_batch(*train, dtype=F32, order="forecast")    # trains (16384 rows >= 12 per coefficient)
     (cm,) = schedule._MODELS.values()
     assert cm.ready and int(cm.cols.numel()) == 16 and bool((cm.cols >= 0).all())      # 16 rates, all as logarithms
     assert cm.best.sym == (4, 4)                                # exchangeable strains: the canonical labelling forecasts better
@@ -274,21 +350,28 @@ def test_learned_dispatch_order():
     assert torch.equal(torch.sort(order64.long()).values, torch.arange(half, device="cuda"))
     f64_sorted = forecast[order64.long()]
     assert float((f64_sorted[1:] - f64_sorted[:-1]).max()) <= 1.0 / schedule.KEY_SCALE + 1e-3
-    auto = solve_batch(*test, dtype=F32)                        # ordered by the forecast
+    auto = solve_batch(*test, dtype=F32, order="forecast")      # ordered by the forecast
     for a, b in ((auto.ys, plain.ys), (auto.n_accept, plain.n_accept), (auto.n_reject, plain.n_reject), (auto.status, plain.status)):
         assert torch.equal(a, b)
     assert torch.equal(first.status, torch.zeros_like(first.status))
     # constant steps: every trajectory costs the same, nothing is learned or ordered
     schedule.reset()
-    solve_batch(*test, dtype=F32, constant_dt=0.5)
+    solve_batch(*test, dtype=F32, constant_dt=0.5, order="forecast")
     assert not schedule._MODELS
-    # and it can be switched off
+    # the default never touches it, and the opt-in can be switched off
+    solve_batch(*test, dtype=F32)
+    assert not schedule._MODELS
     os.environ["DYNODE_ORDER"] = "0"
     try:
-        solve_batch(*test, dtype=F32)
+        solve_batch(*test, dtype=F32, order="forecast")
         assert not schedule._MODELS
     finally:
         del os.environ["DYNODE_ORDER"]
+    # a changed contact matrix starts a forecast of its own (keyed on the content of the shared inputs)
+    solve_batch(*train, dtype=F32, order="forecast")
+    other = (train[0], train[1], train[2], train[3] * 0.9) + train[4:]
+    solve_batch(*other, dtype=F32, order="forecast")
+    assert len(schedule._MODELS) == 2
     schedule.reset()
 
 
@@ -622,14 +705,15 @@ def test_c_consumer_of_the_abi(tmp_path):
     exe = str(tmp_path / "consumer")
     src = os.path.join(H.ROOT, "tests", "c_abi", "consumer.c")
     libdir = os.path.dirname(_abi.LIB_PATH)
-    subprocess.run(["gcc", "-std=c11", "-O2", "-D__HIP_PLATFORM_AMD__", src, "-I/opt/rocm/include",
+    subprocess.run(["gcc", "-std=gnu11", "-O2", "-D__HIP_PLATFORM_AMD__", src, "-I/opt/rocm/include",
                     "-I", os.path.join(H.ROOT, "include"), "-L", libdir, "-ldynode_hip", "-L/opt/rocm/lib", "-lamdhip64",
                     f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib", "-o", exe], check=True)
     run = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert run.returncode == 0, run.stderr
     lines = run.stdout.strip().splitlines()
-    assert lines[-1] == "unsupported rc -7" and lines[-2] == "ordered dispatch identical"       # dyn_solve_batch_ordered, reversed batch
-    lines = lines[:-1]
+    assert lines[-1] == "unsupported rc -7" and lines[-2] == "work pulling identical"           # dyn_solver_opts.work_counter, 8-wave grid
+    assert lines[-3] == "ordered dispatch identical"                                             # dyn_solve_batch_ordered, reversed batch
+    lines = lines[:-2]
     B, ts = 5, np.arange(51.0)
     p = np.array([[(2.0 + 0.1 * b) / 7.0, 1.0 / 7.0] for b in range(B)])
     want, st, na, nr = O.solve(H.omodel(ModelDesc(n_age=1)), np.array([0.9, 0.1, 0.0]), p, np.ones((1, 1)), 50.0, ts, dtype=np.float64)

@@ -50,3 +50,20 @@ def test_tsit5_dense_output_is_fourth_order_and_ends_on_b():
 def test_dopri5_midpoint_weights_are_fourth_order():
     c, A, _, cmid = O.tableau("dopri5")
     assert np.abs(_conditions(A, c, cmid, 4, theta=0.5)).max() < 5e-15
+
+
+def test_tsit5_dense_polynomial_in_the_kernel_equals_the_factored_weights():
+    """solve_kernel.hpp evaluates the dense output as a polynomial in theta (Tab<0>::bp, formed once per accepted step); the
+    table must be the expansion of the interpolant's factored weights the oracle (and diffrax) evaluate per row."""
+    import os
+    import re
+
+    src = open(os.path.join(os.path.dirname(__file__), "..", "dynode_amd", "csrc", "solve_kernel.hpp")).read()
+    body = re.search(r"static constexpr double bp\[7\]\[3\] = \{(.*?)\};", src, re.S).group(1)
+    bp = np.array([float(x) for x in re.findall(r"-?\d+\.\d+(?:e-?\d+)?", body)]).reshape(7, 3)
+    for th in np.linspace(0.0, 1.0, 41):
+        w = bp @ np.array([th**2, th**3, th**4])
+        w[0] += th                                   # the only theta^1 term: y'(t_prev) = f_1
+        assert np.abs(w - O.tsit5_dense_weights(th)).max() < 3e-14   # coefficients up to 88: cancellation at the 1e-14 level in float64
+    _, A, _, _ = O.tableau("tsit5")
+    assert np.abs(bp.sum(1) + np.eye(7)[0] - A[6]).max() < 3e-14      # theta = 1: the solution weights

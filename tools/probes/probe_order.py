@@ -40,7 +40,7 @@ def run(name, B=None):
     assert torch.equal(Co, C) and not torch.equal(po[wl.B:], p)
     yo = yo[wl.B:].contiguous() if yo.dim() == 2 else yo
     for _ in range(3):
-        solve_batch(m, yo, po[wl.B:].contiguous(), Co, big.t1, tso)          # order="auto": trains on draws that are not timed
+        solve_batch(m, yo, po[wl.B:].contiguous(), Co, big.t1, tso, order="forecast")          # order="forecast": trains on draws that are not timed
     cm = next(iter(schedule._MODELS.values()))
     if not cm.ready:
         print(f"{name}: forecast not used (R2 below {schedule.MIN_R2})", flush=True)
@@ -50,7 +50,7 @@ def run(name, B=None):
     # interleaved A/B (clocks ramp and drift inside one process: single measurements of sub-millisecond launches mislead)
     ta, tn = [], []
     for _ in range(5):
-        t, r1 = timed(m, y0, p, C, wl.t1, ts, "auto")
+        t, r1 = timed(m, y0, p, C, wl.t1, ts, "forecast")
         ta.append(t)
         tn.append(timed(m, y0, p, C, wl.t1, ts, None)[0])
     ta.sort(); tn.sort()

@@ -8,7 +8,7 @@ wl = synthetic.WORKLOADS["cfg3d136"](32768)
 m = wl.model
 a = [torch.as_tensor(x, dtype=torch.float32, device="cuda") for x in (wl.y0, wl.params, wl.contact, wl.save_ts[::61])]
 schedule.reset()
-solve_batch(m, a[0], a[1], a[2], wl.t1, a[3])
+solve_batch(m, a[0], a[1], a[2], wl.t1, a[3], order="forecast")
 (cm,) = schedule._MODELS.values()
 assert cm.ready
 s = torch.cuda.current_stream()
