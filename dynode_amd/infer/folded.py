@@ -204,16 +204,28 @@ class FoldedPotential:
             dll = grads[0] if len(grads) == 1 else torch.cat(grads, dim=1)
         return b["lp"], b["dlp"], ll, dll.reshape(C, self.n), (self.n if split else 1)
 
-    def verify(self, z: torch.Tensor, rtol_u: float = 1e-5, rtol_g: float = 1e-4) -> bool:
-        """Folded == general potential (value and gradient) at the rows of ``z`` where the general one is finite."""
+    def deviation(self, z: torch.Tensor):
+        """(max |du| / (1 + |u|), max |dg| / (1 + |g|), rows finite in the general potential but not in the folded one) at the
+        rows of ``z`` where the general potential is finite.  Evaluates into scratch buffers of its own batch size, so the
+        sampler's buffers (which hold the map of the position it is about to evaluate) are not touched -- callers pass a
+        batch size the sampler does not use (`verify` pads by one row)."""
         z = z.detach().to(torch.float64).contiguous()
         u_ref, g_ref = self.pot.potential_and_grad(z)
         u, g = self(z)
         ok = torch.isfinite(u_ref) & torch.isfinite(g_ref).all(-1)
-        same_inf = (~ok) | (torch.isfinite(u) & torch.isfinite(g).all(-1))
-        du = ((u - u_ref).abs() <= rtol_u * (1.0 + u_ref.abs())) | ~ok
-        dg = (((g - g_ref).abs() <= rtol_g * (1.0 + g_ref.abs())) | ~ok[:, None]).all(-1)
-        return bool((du & dg & same_inf).all())
+        lost = int((ok & ~(torch.isfinite(u) & torch.isfinite(g).all(-1))).sum())
+        if not bool(ok.any()):
+            return 0.0, 0.0, lost
+        du = ((u - u_ref).abs() / (1.0 + u_ref.abs()))[ok]
+        dg = ((g - g_ref).abs() / (1.0 + g_ref.abs()))[ok]
+        fin = torch.isfinite(du) & torch.isfinite(dg).all(-1)
+        return float(du[fin].max()) if bool(fin.any()) else 0.0, float(dg[fin].max()) if bool(fin.any()) else 0.0, lost
+
+    def verify(self, z: torch.Tensor, rtol_u: float = 1e-5, rtol_g: float = 1e-4) -> bool:
+        """Folded == general potential (value and gradient) at the rows of ``z`` where the general one is finite."""
+        z = torch.cat([z.detach().to(torch.float64), z.detach().to(torch.float64)[:1]], dim=0)   # C + 1 rows: buffers of their own
+        du, dg, lost = self.deviation(z)
+        return du <= rtol_u and dg <= rtol_g and lost == 0
 
     def __call__(self, z: torch.Tensor):
         """The ``potential_and_grad`` signature (fresh outputs), for the samplers that are not `KernelNUTS`."""
@@ -279,8 +291,11 @@ def discover(pot, seed: int = 0, verbose: bool = False) -> Optional[FoldedPotent
     if not bool((((pred - p2).abs() <= 1e-9 * p2.abs() + 1e-300) | ~okp).all()) or not bool((okp == torch.isfinite(p2)).all()):
         worst = float(((pred - p2).abs() / (p2.abs() + 1e-300))[okp].max()) if bool(okp.any()) else float("nan")
         return why(f"the parameter rows leave the fitted monomials away from the centre (held-out rows, worst relative deviation {worst:.3g})")
-    if not folded.verify(z2):
-        return why("folded and general potential differ on the held-out rows")
+    # (same kernels on the same parameter rows, so this can only fail through the map above; in the tails the potential is
+    # 1e3-1e5 with float32 solves behind it, hence the looser bars than on the probe rows)
+    du, dg, lost = folded.deviation(z2)
+    if du > 1e-4 or dg > 1e-2 or lost:
+        return why(f"folded and general potential differ on the held-out rows (relative: value {du:.3g}, gradient {dg:.3g}; {lost} rows lost)")
     return folded
 
 
