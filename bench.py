@@ -303,7 +303,7 @@ def main():
     ok = int(res["stats"][0].max()) == 0
     steps_mean = float((res["stats"][1] + res["stats"][2]).float().mean())
 
-    shards_match = None
+    shards_match, shard_digests = None, None
     if world > 1:
         t = torch.tensor([elapsed, kern_ms], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -317,6 +317,7 @@ def main():
             mine = torch.tensor(checksums(res["out"], res["stats"]), dtype=torch.float64, device=cdev)
             every = [torch.empty_like(mine) for _ in range(world)]
             dist.all_gather(every, mine)
+            shard_digests = [[float(v) for v in e.cpu()] for e in every]
             if rank == 0:
                 shards_match = True
                 for r in range(1, world):
@@ -351,6 +352,8 @@ def main():
                 "all_status_ok": ok,
                 "parallelism": f"{world} x independent shards, no data-path collective",
                 "shards_match_single_process": shards_match,
+                # per rank: [status sum, index-weighted accepted / rejected step counts, float64 sum of the output, of |last row|]
+                "shard_digests": shard_digests,
             },
             "roofline": roofline_block(wl, args.workload, res),
         }

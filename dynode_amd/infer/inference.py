@@ -572,7 +572,7 @@ def marginal_cdfs_by_quadrature(potential: Potential, z_grids: list) -> list:
     return out
 
 
-def ks_against_quadrature(potential: Potential, draws: dict, z_grids: list, thin: int = 20) -> dict:
+def ks_against_quadrature(potential: Potential, draws: dict, z_grids: list, thin: int = 20, cdfs: Optional[list] = None) -> dict:
     """Kolmogorov-Smirnov test of every latent site's draws (``[chains, draws]``, thinned by ``thin`` along the draws
     axis to decorrelate them) against the marginal CDF from :func:`marginal_cdfs_by_quadrature`, with the moments of
     both: ``{site: {"ks_p", "ks_stat", "n", "mean", "sd", "quad_mean", "quad_sd", "mean_z", "sd_z"}}`` where ``mean_z`` /
@@ -583,7 +583,10 @@ def ks_against_quadrature(potential: Potential, draws: dict, z_grids: list, thin
     from .diagnostics import effective_sample_size
 
     out = {}
-    for (name, v), (grid, cdf, pmf) in zip(((n, draws[n]) for n in potential.bij), marginal_cdfs_by_quadrature(potential, z_grids)):
+    # ``cdfs``: marginals computed elsewhere (the tests pass the C oracle's, so that the check does not lean on this package's
+    # own solves), in the order of ``potential.bij``
+    for (name, v), (grid, cdf, pmf) in zip(((n, draws[n]) for n in potential.bij),
+                                            cdfs if cdfs is not None else marginal_cdfs_by_quadrature(potential, z_grids)):
         x = v.detach().cpu().numpy().astype(np.float64)
         thinned = x[:, ::thin].reshape(-1)
         res = stats.kstest(thinned, lambda q: np.interp(q, grid, cdf))

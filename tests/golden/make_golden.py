@@ -35,6 +35,8 @@ def cases():
     # examples/sir_age_stratified.py:46-66,70,81-85
     wl = synthetic.sir_two_age_literal(t1=100.0)
     out.append(("sir_two_age", wl.model, wl.y0, wl.params[0], wl.contact, 100.0))
+    # BASELINE.json cfg 1 as worded: the same 2-age-group SIR, 1 parameter set, 365 days
+    out.append(("sir_two_age_365", wl.model, wl.y0, wl.params[0], wl.contact, 365.0))
     # examples/seirs.py:32-33,37,47,58 (r0=2, T_inf=7, latent 3, waning 60)
     seirs = ModelDesc(n_age=1, has_e=True, has_wane=True)
     out.append(("seirs", seirs, np.array([0.99, 0.0, 0.01, 0.0]),
@@ -64,6 +66,40 @@ def cases():
     return out
 
 
+SEIP_FIELDS = ("n_age", "n_strain", "has_e", "has_wane", "has_c", "n_wane", "normalize", "seasonal", "has_intro", "n_vax_tiers",
+               "n_vax_knots", "family", "seasonal_vax")
+
+
+def seip_cases():
+    """Two members of the SEIP family (ode_model.md; no code in the reference): the generator's draws, two trajectories each."""
+    out = []
+    for tag, shape in (("seip_4x2x3x4", dict(A=4, L=2, K1=3, M1=4, n_knots=2, seasonal_vax=True)),            # D = 480
+                       ("seip_3x3x2x3_intro", dict(A=3, L=3, K1=2, M1=3, n_knots=1, seasonal=True, intro=True))):   # D = 432
+        wl = synthetic.seip(B=2, seed=41, t1=150.0, **shape)
+        out.append((tag, wl))
+    return out
+
+
+def main_seip():
+    """tests/golden/ground_truth_seip.npz: SciPy DOP853 (rtol 1e-11) on the independent NumPy statement of the SEIP equations
+    (tests/helpers.py:rhs_seip_numpy) -- the SEIP oracle is pinned by these arrays, not by a probe run."""
+    blob, names = {}, []
+    for name, wl in seip_cases():
+        m = wl.model
+        ts = np.linspace(0.0, 150.0, 16)
+        blob[f"{name}/model"] = np.array([int(getattr(m, f)) for f in SEIP_FIELDS], dtype=np.int64)
+        blob[f"{name}/intro_age_mask"] = np.array([int(v) for v in m.intro_age_mask], dtype=np.int64)
+        blob[f"{name}/y0"] = np.asarray(wl.y0, float)
+        blob[f"{name}/params"] = np.asarray(wl.params, float)
+        blob[f"{name}/contact"] = np.asarray(wl.contact, float)
+        blob[f"{name}/ts"] = ts
+        blob[f"{name}/ys"] = np.stack([H.ground_truth_seip(m, wl.y0[b], wl.params[b], wl.contact, 150.0, ts) for b in range(wl.B)])
+        names.append(name)
+        print(f"{name:22s} D={m.state_dim:4d} n_save={ts.size} |y|max={np.abs(blob[f'{name}/ys']).max():.4g}")
+    blob["names"] = np.array(names)
+    np.savez_compressed(os.path.join(HERE, "ground_truth_seip.npz"), **blob)
+
+
 def main():
     blob = {}
     names = []
@@ -86,3 +122,4 @@ def main():
 
 if __name__ == "__main__":
     main()
+    main_seip()

@@ -255,3 +255,61 @@ def ground_truth_seip(m, y0, p, C, t1, save_ts, rtol=1e-11, atol=1e-9):
                     method="DOP853", t_eval=np.asarray(save_ts, float), rtol=rtol, atol=atol)
     assert sol.success
     return sol.y.T
+
+
+def truth_bars(m, got32, want32, y0, p, C, t1, ts, scale, label="", smooth=True, method="tsit5", rtol=1e-10, **solve_kw):
+    """Make a loose float32 HIP-vs-oracle bar earn its width: both float32 solutions (HIP, oracle) against a float64 solve of
+    the oracle at ``rtol`` (default 1e-10) -- the truth to seven digits more than either.  Two correct float32 solvers that
+    take different accept / reject decisions differ from EACH OTHER by the solver's tolerance; what must hold is that the
+    HIP solution is as close to the truth as the oracle's:
+        err_hip <= 1.5 err_oracle + 1e-6 scale,   and, for models without kinks,   err_hip <= 1e-5 scale
+    (the north star's trajectory bar; asserted when the oracle itself meets it with the same margin).  Returns the two
+    errors in units of ``scale``."""
+    truth, st, _, _ = O.solve(omodel(m), y0, p, C, t1, ts, dtype=np.float64, method=method, rtol=rtol, atol=rtol * scale, n_threads=8, **solve_kw)
+    assert st.max() == 0
+    fin = np.isfinite(truth)
+    err_hip = float(np.abs(np.asarray(got32, np.float64) - truth)[fin].max()) / scale
+    err_orc = float(np.abs(np.asarray(want32, np.float64) - truth)[fin].max()) / scale
+    print(f"[truth] {label}: |hip32 - f64 truth| = {err_hip:.3e}, |oracle32 - f64 truth| = {err_orc:.3e} (of scale {scale:g})")
+    assert err_hip <= 1.5 * err_orc + 1e-6, (label, err_hip, err_orc)
+    if smooth and err_orc <= 1e-5 / 1.5:
+        assert err_hip <= 1e-5, (label, err_hip, err_orc)
+    return err_hip, err_orc
+
+
+def oracle_sir_posterior_cdfs(obs, z_grids, tf=100.0):
+    """cfg 4's posterior oracle, INDEPENDENT of the HIP path and of the package's distributions: marginal CDFs of
+    (r0, infectious_period) of the reference's model (examples/sir_infer_parameters.py:21-59) by tensor-grid quadrature in
+    the unconstrained coordinates, with every likelihood term from float64 solves of the C oracle and every prior term from
+    scipy.stats:
+        r0 = 1.5 + sigmoid(z0),  r0 - 1.5 ~ Beta(0.5, 0.5);   T = 2 + 13 sigmoid(z1),  T ~ TruncNormal(8, 2, [2, 15])
+        beta = r0 / T, gamma = 1 / T;  incidence = max(diff(R), 1e-6);  obs ~ Poisson(incidence)
+    2-age SIR literal of sir_age_stratified.py:46-66,70,81-85.  Returns [(x_grid, cdf, pmf)] per site like
+    ``inference.marginal_cdfs_by_quadrature``."""
+    from scipy import stats
+    from scipy.special import expit, gammaln
+
+    from dynode_amd import synthetic
+
+    wl = synthetic.sir_two_age_literal(t1=tf)
+    z0, z1 = (np.asarray(g, np.float64) for g in z_grids)
+    s0, s1 = expit(z0), expit(z1)
+    r0, T = 1.5 + s0, 2.0 + 13.0 * s1
+    lp0 = stats.beta(0.5, 0.5).logpdf(s0) + np.log(s0) + np.log1p(-s0)                       # + log |d r0 / d z0|
+    lp1 = stats.truncnorm((2.0 - 8.0) / 2.0, (15.0 - 8.0) / 2.0, loc=8.0, scale=2.0).logpdf(T) + np.log(13.0) + np.log(s1) + np.log1p(-s1)
+    R0, TT = np.meshgrid(r0, T, indexing="ij")
+    params = np.stack([(R0 / TT).ravel(), (1.0 / TT).ravel()], axis=1)
+    ts = np.arange(0.0, tf + 1.0)
+    ys, st, _, _ = O.solve(omodel(wl.model), wl.y0, params, wl.contact, tf, ts, dtype=np.float64, n_threads=16)
+    assert st.max() == 0
+    inc = np.maximum(np.diff(ys[:, :, 4:6], axis=1), 1e-6)                                    # R is the third compartment of s | i | r (2 ages each)
+    obs = np.asarray(obs, np.float64)
+    ll = (obs[None] * np.log(inc) - inc - gammaln(obs + 1.0)[None]).sum((1, 2)).reshape(R0.shape)
+    lj = ll + lp0[:, None] + lp1[None, :]
+    p = np.exp(lj - lj.max())
+    p /= p.sum()
+    out = []
+    for axis, grid in ((1, r0), (0, T)):
+        marginal = p.sum(axis)
+        out.append((grid, np.cumsum(marginal) - 0.5 * marginal, marginal))
+    return out

@@ -10,6 +10,8 @@ import pytest
 import torch
 from scipy import stats
 
+import helpers as H
+
 from dynode_amd.infer import handlers
 from dynode_amd.infer.inference import MCMCProcess, Potential, init_to_median, log_posterior_grid
 from dynode_amd.simulation import odes
@@ -93,6 +95,41 @@ def test_nuts_posterior_matches_grid_quadrature(data, sampler, adaptation):
     print("mean leapfrogs/transition %.2f, gradient-solves %d" % (float(mcmc.nuts.num_steps.double().mean()), mcmc.nuts.potential_evals))
 
 
+_ORACLE_CDFS = {}
+
+
+def _oracle_marginals(data):
+    """The posterior oracle of record: quadrature on a 701 x 501 grid with float64 solves of the C oracle and scipy.stats
+    priors (tests/helpers.py:oracle_sir_posterior_cdfs) -- nothing of the HIP path, nothing of dynode_amd.infer.
+    (351,201 oracle solves: half a minute on the box's cores, once per session.)"""
+    key = data.numpy().tobytes()
+    if key not in _ORACLE_CDFS:
+        _ORACLE_CDFS[key] = H.oracle_sir_posterior_cdfs(data.numpy(), [np.linspace(-14.0, 14.0, 701), np.linspace(-6.0, 6.0, 501)])
+    return _ORACLE_CDFS[key]
+
+
+def test_quadrature_from_the_c_oracle_equals_the_hip_built_one(data):
+    """the quadrature behind the posterior checks was built from `Potential`, i.e. from HIP float64 solves -- it
+    validated the sampler, not the likelihood.  The same quadrature from the C oracle + scipy priors must give the same
+    marginal CDFs: 1e-6 in CDF on identical grids (then the KS tests below run against the oracle's)."""
+    from dynode_amd.infer.inference import marginal_cdfs_by_quadrature
+
+    zg = [torch.linspace(-14.0, 14.0, 701, dtype=torch.float64), torch.linspace(-6.0, 6.0, 501, dtype=torch.float64)]
+    odes.enable_x64(True)
+    try:
+        pot = Potential(ex.model, dict(config=ex.get_config(), tf=100, obs_data=data), 0, torch.device("cuda"))
+        hip = marginal_cdfs_by_quadrature(pot, zg)
+    finally:
+        odes.enable_x64(False)
+    want = _oracle_marginals(data)
+    for (g_h, c_h, m_h), (g_o, c_o, m_o), name in zip(hip, want, ("r0", "infectious_period")):
+        assert np.abs(g_h - g_o).max() < 1e-12
+        gap = float(np.abs(c_h - c_o).max())
+        mean_h, mean_o = float((g_h * m_h).sum()), float((g_o * m_o).sum())
+        print(f"{name}: max CDF gap HIP-built vs oracle-built {gap:.2e}, means {mean_h:.6f} / {mean_o:.6f}")
+        assert gap < 1e-6 and abs(mean_h - mean_o) < 1e-6
+
+
 def test_nuts_posterior_high_power_ks_and_moments(data):
     """cfg 4 at one GPU's share (128 chains), default per-chain adaptation as in numpyro, 12,800 thinned draws per
     site (1000 + 1000 transitions, BASELINE cfg 4): KS p > 0.01 against the quadrature CDF, sample mean and standard
@@ -104,13 +141,8 @@ def test_nuts_posterior_high_power_ks_and_moments(data):
                           nuts_max_tree_depth=10, progress_bar=False)
     process.infer(**kw)
     post = process.get_samples(group_by_chain=True)
-    odes.enable_x64(True)
-    try:
-        pot = Potential(ex.model, kw, 0, torch.device("cuda"))
-        rep = ks_against_quadrature(pot, post, [torch.linspace(-14.0, 14.0, 1401, dtype=torch.float64),
-                                                 torch.linspace(-6.0, 6.0, 1001, dtype=torch.float64)], thin=10)
-    finally:
-        odes.enable_x64(False)
+    pot = Potential(ex.model, kw, 0, torch.device("cuda"))      # (site names and order only: the CDFs are the C oracle's)
+    rep = ks_against_quadrature(pot, post, None, thin=10, cdfs=_oracle_marginals(data))
     for name, r in rep.items():
         print(name, {k: (round(v, 5) if isinstance(v, float) else v) for k, v in r.items()})
         assert r["n"] >= 10_000 and r["ks_p"] > 0.01, (name, r)

@@ -276,3 +276,28 @@ def test_batch_is_independent_of_threads_and_order():
     perm = np.random.default_rng(0).permutation(48)
     c, _, _, _ = O.solve(H.omodel(wl.model), wl.y0[perm], wl.params[perm], wl.contact, 120, synthetic.save_grid(120))
     np.testing.assert_array_equal(a[perm], c)
+
+
+def test_oracle_under_address_and_undefined_behaviour_sanitizers(tmp_path):
+    """`-fsanitize=address,undefined` on the CPU restatement.  `make -C oracle asan` builds the oracle with
+    both sanitizers; tests/c_oracle/asan_driver.c drives it through the shapes the parity suite leans on (2-age SIR at 365
+    days, 8 x 4 multi-strain with seasonal forcing / the waning chain, sub-saved compartments, discontinuity points, a constant
+    step, a vaccinated and a SEIP model; both precisions, both methods, ragged batches, n_save = 1).  Any out-of-bounds access
+    or undefined operation aborts the driver."""
+    import os
+    import shutil
+    import subprocess
+
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not installed")
+    odir = os.path.join(H.ROOT, "oracle")
+    subprocess.run(["make", "-C", odir, "asan", "-s"], check=True)
+    exe = str(tmp_path / "asan_driver")
+    build = subprocess.run(["gcc", "-std=c11", "-O1", "-g", "-fsanitize=address,undefined", "-I", odir,
+                            os.path.join(H.ROOT, "tests", "c_oracle", "asan_driver.c"), "-L", odir, "-ldynode_oracle_asan", "-lm", "-fopenmp",
+                            f"-Wl,-rpath,{odir}", "-o", exe], capture_output=True, text=True)
+    assert build.returncode == 0, build.stderr[-2000:]
+    run = subprocess.run([exe], capture_output=True, text=True, timeout=300,
+                         env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1"))
+    assert run.returncode == 0, (run.stdout[-500:], run.stderr[-3000:])
+    assert "bad=0" in run.stdout and "runtime error" not in run.stderr and "AddressSanitizer" not in run.stderr

@@ -107,6 +107,47 @@ def test_oracle_solution_vs_scipy(shape):
     assert s[:, :, 1:].sum() > 0                                    # and doses were given
 
 
+# ---- committed SciPy vectors (tests/golden/ground_truth_seip.npz, generator tests/golden/make_golden.py:main_seip)
+GT_SEIP = np.load(H.GOLDEN + "/ground_truth_seip.npz")
+
+
+def _seip_case(name):
+    from golden.make_golden import SEIP_FIELDS
+
+    f = dict(zip(SEIP_FIELDS, (int(v) for v in GT_SEIP[f"{name}/model"])))
+    for k in ("has_e", "has_wane", "has_c", "normalize", "seasonal", "has_intro", "seasonal_vax"):
+        f[k] = bool(f[k])
+    m = ModelDesc(intro_age_mask=tuple(int(v) for v in GT_SEIP[f"{name}/intro_age_mask"]), **f)
+    return (m,) + tuple(GT_SEIP[f"{name}/{k}"] for k in ("y0", "params", "contact", "ts", "ys"))
+
+
+@pytest.mark.parametrize("name", [str(n) for n in GT_SEIP["names"]])
+def test_oracle_vs_committed_scipy_vectors(name):
+    """The SEIP oracle against arrays on disk (SciPy DOP853 on the NumPy statement of the equations), tight and default
+    tolerances, float64 and float32."""
+    m, y0, p, C, ts, want = _seip_case(name)
+    assert m.state_dim == y0.shape[1] == want.shape[2]
+    tight, st, _, _ = O.solve(H.omodel(m), y0, p, C, 150.0, ts, dtype=np.float64, rtol=1e-9, atol=1e-9)
+    assert st.max() == 0 and np.abs(tight - want).max() < 2e-5              # of 1000 people; the dose cap has kinks
+    for dt in (np.float64, np.float32):
+        ys, st, _, _ = O.solve(H.omodel(m), y0, p, C, 150.0, ts, dtype=dt)
+        assert st.max() == 0 and np.abs(ys - want).max() / 1000.0 < 1e-5    # reference defaults: inside the north star's 1e-5 of scale
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", [str(n) for n in GT_SEIP["names"]])
+def test_hip_vs_committed_scipy_vectors(name):
+    import torch
+    from dynode_amd.engine import solve_batch
+
+    m, y0, p, C, ts, want = _seip_case(name)
+    tight = solve_batch(m, y0, p, C, 150.0, ts, dtype=torch.float64, rtol=1e-9, atol=1e-9)
+    assert int(tight.status.max()) == 0 and np.abs(tight.ys.cpu().numpy() - want).max() < 2e-5
+    for dt in (torch.float64, torch.float32):
+        r = solve_batch(m, y0, p, C, 150.0, ts, dtype=dt)
+        assert int(r.status.max()) == 0 and np.abs(r.ys.cpu().numpy() - want).max() / 1000.0 < 1e-5
+
+
 def test_one_strain_two_waning_states_is_the_seirs_family():
     """L = 1: history 1 / waning state 0 with full protection is R, history 1 / state 1 is susceptible again:
     s + r + waned = the SEIRS of examples/seirs.py with the same rates (age-stratified, contact C / P)."""
@@ -195,6 +236,9 @@ def test_hip_matches_oracle(shape, prec, method):
     got = r.ys.cpu().numpy()
     assert int(r.status.max()) == 0 and st.max() == 0
     assert np.abs(got - want).max() / 1000.0 < (5e-5 if prec == "f64" else 2e-4)   # a few solver tolerances (rtol 1e-5)
+    if prec == "f32":  # secondary to this: both float32 solutions against a float64 rtol 1e-9 solve -- HIP is as accurate as the oracle
+        H.truth_bars(m, got, want, wl.y0, wl.params, wl.contact, 150.0, ts, 1000.0, f"seip {_ids(shape)} {method}", smooth=False,
+                     method=method, rtol=1e-9)
     steps = (r.n_accept + r.n_reject).cpu().numpy()
     assert np.abs(steps - (na + nr)).max() <= max(8, 0.2 * (na + nr).max())
     assert np.array_equal(got[:, 0], wl.y0.astype(npd))                     # first row = initial state, exactly
@@ -668,6 +712,8 @@ def test_north_star_sizes_properties(name, B):
     want, st, na, nr = O.solve(H.omodel(m), wl.y0[idx], wl.params[idx], wl.contact, wl.t1, wl.save_ts, dtype=np.float32, n_threads=8)
     got = r.ys[torch.as_tensor(idx, device="cuda")].cpu().numpy()
     assert st.max() == 0 and np.abs(got - want).max() / 1000.0 < 5e-4          # adaptive float32: step decisions differ near the dose-cap kinks
+    # (secondary to:) against a float64 rtol 1e-9 solve of the same six trajectories the HIP solution is as accurate as the oracle's
+    H.truth_bars(m, got, want, wl.y0[idx], wl.params[idx], wl.contact, wl.t1, wl.save_ts, 1000.0, f"{name} north-star size", smooth=False, rtol=1e-9)
     assert np.abs((r.n_accept + r.n_reject).cpu().numpy()[idx] - (na + nr)).max() <= 30
     del r, r2, rp
     torch.cuda.empty_cache()
