@@ -726,7 +726,12 @@ struct Seip {
         // position inside the trajectory's lane group: the lane itself, or (NW > 1) wave * 64 + lane of the workgroup
         const int wtid = NW > 1 ? (int)threadIdx.x : lane;          // index inside the workgroup (cooperative table loads)
         const int tlane = PACKED ? lane : wtid;
-        const int a = tlane % GA, j = (tlane / GA) % H, tl = PACKED ? (int)(threadIdx.x >> 6) : (tlane / (GA * H)) % KT;
+        // (when whole waves are the tier lanes the tier is the same for every lane of the wave: taken from a scalar register,
+        // so that everything that depends on it -- "is this the top tier", which table row, which mailbox wave -- is scalar
+        // arithmetic and scalar branches instead of per-lane selects)
+        const int wave_idx = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+        const int a = tlane % GA, j = (tlane / GA) % H,
+                  tl = PACKED ? wave_idx : (TIER_X ? (wave_idx >> HB_X) % KT : (tlane / (GA * H)) % KT);
         const int grp = PACKED ? lane / GWL : (NW > 1 ? 0 : lane / G);
         const int tidx = PACKED ? tl * GWL + lane % GWL : tlane % G;   // index among the G lanes of this trajectory
         int64_t traj = (int64_t)blockIdx.x * TPW + grp;
@@ -741,7 +746,7 @@ struct Seip {
         }
         const int A = ka.A, nk = ka.n_vax_knots;
         Seip S;
-        S.wv = NW > 1 ? (int)(threadIdx.x >> 6) : 0;
+        S.wv = NW > 1 ? wave_idx : 0;
         S.xbuf = 0;
         S.pad = a >= A;
         S.hist = j;

@@ -533,7 +533,11 @@ struct Solver {
     // let rounding accumulate in the PARAMETERS over a hundred steps.  FSAL: k[0] carries the factor of the step it was
     // computed in and is rescaled by dt_new / dt_old (Solver::run).  Every kernel without vaccination tiers (whose dose
     // cap min(doses, s) is not linear in a rate).
+#ifdef DYN_DIAG_NOPRESCALE_ND      // diagnostic build (tools/diag_build.sh NOPRESCALE_ND): tangent kernels keep k = f
+    static constexpr bool PRESCALE = KV == 0 && ND == 0;
+#else
     static constexpr bool PRESCALE = KV == 0;
+#endif
     typedef T V4 __attribute__((ext_vector_type(4)));
     // quads per lane: beta[S] | gamma[S] | sigma[S] | omega[S], then the same four blocks of every seed direction (the
     // tangent of a rate-times-state term is d(rate) state + rate d(state): both carry the factor)
@@ -551,9 +555,12 @@ struct Solver {
     __device__ __forceinline__ void scale_rates(const V4 *tab, int lane, T h) {
 #pragma unroll
         for (int q = 0; q < NRQ; ++q) {
-            const V4 v = tab[q * 64 + lane] * h;
-#pragma unroll
-            for (int z = 0; z < 4; ++z) rate_ref(4 * q + z) = v[z];
+            const V4 v = tab[q * 64 + lane];
+            const V2 lo = V2{v[0], v[1]} * h, hi = V2{v[2], v[3]} * h;   // two packed multiplies per quad
+            rate_ref(4 * q) = lo[0];
+            rate_ref(4 * q + 1) = lo[1];
+            rate_ref(4 * q + 2) = hi[0];
+            rate_ref(4 * q + 3) = hi[1];
         }
         if constexpr (PAIRED_RHS) {
 #pragma unroll
@@ -1732,12 +1739,13 @@ struct Solver {
 #pragma unroll
                     for (int pp = 0; pp < NP; ++pp) {
                         y[c].p[pp] = yt[c].p[pp];
-                        k[0][c].p[pp] = k[6][c].p[pp];
+                        if constexpr (!PRESCALE) k[0][c].p[pp] = k[6][c].p[pp];   // (PRESCALE: FSAL is taken over below, together with its rescaling)
                     }
                 ++n_acc;
             } else if (act && finite) {
                 ++n_rej;
             }
+            [[maybe_unused]] const bool fsal_from_k6 = accept;
             // ---- next interval: prev_dt * factor, then diffeqsolve's clip-to-end
             T next_t0 = accept ? tnext : tprev;
             T next_t1 = next_t0 + (constant ? ka.constant_dt : dt * factor);
@@ -1755,7 +1763,7 @@ struct Solver {
 #pragma unroll
                         for (int c = 0; c < NC; ++c)
 #pragma unroll
-                            for (int pp = 0; pp < NP; ++pp) k[0][c].p[pp] = k[1][c].p[pp];
+                            for (int pp = 0; pp < NP; ++pp) k[PRESCALE ? 6 : 0][c].p[pp] = k[1][c].p[pp];   // (PRESCALE: k[6] is what becomes k[0] below)
                     }
                 }
                 if (act) at_jump = false;
@@ -1784,10 +1792,17 @@ struct Solver {
                 // the next attempt's step size: rates from their parked originals, FSAL by the ratio of the step sizes
                 const T dt_new = tnext - tprev;
                 const T ratio = act ? dt_new * inv_dt : T(1);
+                if (fsal_from_k6) {   // accepted: the last stage's derivative is the next step's first one (no separate copy)
 #pragma unroll
-                for (int c = 0; c < NC; ++c)
+                    for (int c = 0; c < NC; ++c)
 #pragma unroll
-                    for (int pp = 0; pp < NP; ++pp) k[0][c].p[pp] = k[0][c].p[pp] * ratio;
+                        for (int pp = 0; pp < NP; ++pp) k[0][c].p[pp] = k[6][c].p[pp] * ratio;
+                } else {              // rejected (or idle): the same first stage, for another step size
+#pragma unroll
+                    for (int c = 0; c < NC; ++c)
+#pragma unroll
+                        for (int pp = 0; pp < NP; ++pp) k[0][c].p[pp] = k[0][c].p[pp] * ratio;
+                }
                 L.scale_rates(rate_tab, lane, dt_new);
             }
 

@@ -57,8 +57,8 @@ kernel = instance_name(stats["Name"]) if stats else None
 lines = [f"# rocprofv3 summary `{tag}` -- bench.py --workload {workload} (B={batch} per GPU)", "",
          f"- source revision: `{build_rev()}`", f"- dispatched instance: `{kernel}`", ""]
 if stats:
-    lines += ["## kernel-trace --stats (bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extra: 50 timed + 5 warm-up launches in the "
-              "learned dispatch order, plus the untimed launches on other draws that train its forecast)", "",
+    lines += ["## kernel-trace --stats (bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extra: 50 timed + 5 warm-up launches, the batch "
+              "in its given order -- no forecast, nothing carried over between launches)", "",
               "| kernel | calls | avg ns | min ns | max ns | % of GPU time |", "|---|---|---|---|---|---|",
               f"| `{stats['Name'][:120]}` | {stats['Calls']} | {float(stats['AverageNs']):.0f} | {stats['MinNs']} | {stats['MaxNs']} | {stats['Percentage']} |"]
     for r in side:
@@ -87,6 +87,8 @@ if "SQ_WAVE_CYCLES" in mean and "SQ_WAVES" in mean:
         if k in mean:
             lines.append(f"- {k} / SQ_WAVE_CYCLES = {mean[k]/wc:.3f}")
     lines.append(f"- VALU instructions per wave = {mean.get('SQ_INSTS_VALU',0)/mean['SQ_WAVES']:.0f}; SALU per wave = {mean.get('SQ_INSTS_SALU',0)/mean['SQ_WAVES']:.0f}; LDS per wave = {mean.get('SQ_INSTS_LDS',0)/mean['SQ_WAVES']:.0f}")
+    lines.append(f"- waves per launch = {mean['SQ_WAVES']:.0f} for {batch} trajectories (a work-pulling launch is a resident grid: every wave integrates several "
+                 f"trajectories one after the other); VALU instructions per TRAJECTORY-lane-group = {mean.get('SQ_INSTS_VALU',0)/batch:.0f} x (trajectories per wave)")
     if "GRBM_GUI_ACTIVE" in mean and stats:
         lines.append(f"- effective clock ~ GRBM_GUI_ACTIVE / 8 / kernel time = {mean['GRBM_GUI_ACTIVE']/8/float(stats['AverageNs']):.2f} GHz (profiled pass)")
     lines.append("")
