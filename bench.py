@@ -38,6 +38,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+SETTLE_LAUNCHES = 12   # untimed launches before the warm-up ones (clock ramp after idle, see measure())
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy peak ~6290
 SEEDS = {"cfg2": 0, "cfg3": 1, "cfg3d136": 1, "cfg5": 5, "seip": 7, "seip3": 7, "seip83": 7, "seip84": 7}
 
@@ -190,7 +191,10 @@ def measure(wl, dev, steps: int, warmup: int, fence, order_hint_too=True):
     def step(order=None):
         return solve_batch(m, y0, params, contact, wl.t1, ts, dtype=f32, out=out, stats_out=(stats[0], stats[1], stats[2]), order=order)
 
-    for _ in range(warmup):
+    # The GPU needs some 20 ms of work to come up to its sustained clocks after the idle time of process start and input
+    # generation (per-launch times of a cold start: 2.82, 2.72, 2.67, 2.60, 2.58, 2.58, 2.50, 2.54 ... ms): SETTLE untimed
+    # launches in front of the caller's `warmup`, so that the K timed steps measure the steady state whatever W is.
+    for _ in range(SETTLE_LAUNCHES + warmup):
         step()
     fence()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
@@ -205,6 +209,8 @@ def measure(wl, dev, steps: int, warmup: int, fence, order_hint_too=True):
     order_info = {"kind": "none: the batch in its given order, no forecast, nothing carried over from earlier launches"}
     if order_hint_too:
         hint = torch.argsort(stats[1] + stats[2], descending=True, stable=True).to(torch.int32)
+        for _ in range(max(warmup, 3)):      # (the sort's first call idles the GPU for a moment: let the clocks come back before timing)
+            step(order=hint)
         given = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(min(steps, 10))]
         for e0, e1 in given:
             e0.record()
@@ -348,6 +354,7 @@ def main():
                 "trajectories_per_gpu": B,
                 "state_dim": m.state_dim,
                 "solver": "tsit5",
+                "untimed_launches_before_the_timed_region": SETTLE_LAUNCHES + args.warmup,
                 "mean_steps_per_trajectory": steps_mean,
                 "all_status_ok": ok,
                 "parallelism": f"{world} x independent shards, no data-path collective",
