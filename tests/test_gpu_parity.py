@@ -673,19 +673,31 @@ def test_randomized_parity_sweep():
     assert ran >= 60
 
 
+def test_five_ages_two_strains_seir_without_waning():
+    """A member of the RHS family outside the BASELINE shapes (5 ages x 2 strains, SEIR with cumulative incidence, no waning),
+    compiled in since round 3 (instances.def, translation unit 24): float64 parity with the oracle, identical step counts."""
+    m = ModelDesc(n_age=5, n_strain=2, has_e=True, has_wane=False, has_c=True)
+    y0, p, C, t1, ts = random_workload(m, 19, seed=6, t1=120.0)
+    got, st, na, nr = hip(m, y0, p, C, t1, ts, dtype=F64)
+    want, st_o, na_o, nr_o = O.solve(H.omodel(m), y0, p, C, t1, ts, dtype=np.float64, n_threads=8)
+    assert st.max() == 0 and np.abs(got - want).max() / 1000.0 < 1e-11
+    assert np.array_equal(na, na_o) and np.array_equal(nr, nr_o)
+
+
 @pytest.mark.on_demand_build
 def test_kernel_shapes_are_built_on_demand():
-    """A member of the RHS family that instances.def does not list (5 ages x 2 strains, SEIR with
-    cumulative incidence, no waning) is compiled with hipcc on first use, registered with the library
-    (dyn_register_instance) and then behaves like a built-in shape: float64 parity with the oracle."""
+    """A member of the RHS family that instances.def does not list (5 ages x 2 strains, SEIRS without cumulative incidence) is
+    compiled with hipcc on first use, registered with the library (dyn_register_instance) and then behaves like a built-in
+    shape: float64 parity with the oracle.  (The on-demand PATH is what this tests; the parity cases themselves run on
+    compiled-in shapes and do not need hipcc on the node.)"""
     import glob
     import os
 
     from dynode_amd import jit
 
-    m = ModelDesc(n_age=5, n_strain=2, has_e=True, has_wane=False, has_c=True)
+    m = ModelDesc(n_age=5, n_strain=2, has_e=True, has_wane=True, has_c=False)
     assert not _supported(m, F64, "tsit5") or jit._LOADED                # not a built-in shape
-    for stale in glob.glob(os.path.join(jit._OUT, "f64_m0_g8_s2_e1w0c1_*")):
+    for stale in glob.glob(os.path.join(jit._OUT, "f64_m0_g8_s2_e1w1c0_*")):
         if not jit._LOADED:
             os.remove(stale)                                             # force a real build in a fresh process
     y0, p, C, t1, ts = random_workload(m, 19, seed=6, t1=120.0)
@@ -818,15 +830,25 @@ def test_vaccination_tiers_match_oracle_and_move_people_up(ages, m, dtype):
     assert np.all(np.diff(tiers[:, :, 0], axis=1) <= 2e-3)                                 # tier 0 only loses people (up to interpolation ripple at the kink)
 
 
+def test_vaccinated_seirs_five_ages_two_tiers():
+    """A vaccinated member of the family outside the example's shapes (5 ages x 2 tiers, one strain, SEIRS), compiled in since
+    round 3: constant-step float64 parity with the oracle."""
+    m = ModelDesc(n_age=10, n_strain=1, has_e=True, has_wane=True, has_c=True, normalize=False, n_vax_tiers=2, n_vax_knots=2)
+    y0, p, C, t1, ts, pop = vax_workload(5, m, 7, seed=4)
+    r = solve_batch(m, y0, p, C, t1, ts, dtype=F64, constant_dt=0.5)
+    want, st, _, _ = O.solve(H.omodel(m), y0, p, C, t1, ts, dtype=np.float64, n_threads=8, constant_dt=0.5)
+    assert int(r.status.max()) == 0 and np.abs(r.ys.cpu().numpy() - want).max() / 1000.0 < 1e-11
+
+
 @pytest.mark.on_demand_build
 def test_vaccination_shape_built_on_demand():
-    """A vaccinated member of the family that instances.def does not list (5 ages x 2 tiers, one strain,
-    SEIRS): the on-demand build passes the vaccination lanes in the template's feature word."""
+    """A vaccinated member of the family that instances.def does not list (3 ages x 2 tiers, one strain, SEIRS): the on-demand
+    build passes the vaccination lanes in the template's feature word."""
     from dynode_amd import jit
 
-    m = ModelDesc(n_age=10, n_strain=1, has_e=True, has_wane=True, has_c=True, normalize=False, n_vax_tiers=2, n_vax_knots=2)
+    m = ModelDesc(n_age=6, n_strain=1, has_e=True, has_wane=True, has_c=True, normalize=False, n_vax_tiers=2, n_vax_knots=2)
     assert jit._features(m) == 4
-    y0, p, C, t1, ts, pop = vax_workload(5, m, 7, seed=4)
+    y0, p, C, t1, ts, pop = vax_workload(3, m, 7, seed=4)
     r = solve_batch(m, y0, p, C, t1, ts, dtype=F64, constant_dt=0.5)
     want, st, _, _ = O.solve(H.omodel(m), y0, p, C, t1, ts, dtype=np.float64, n_threads=8, constant_dt=0.5)
     assert int(r.status.max()) == 0 and np.abs(r.ys.cpu().numpy() - want).max() / 1000.0 < 1e-11

@@ -553,16 +553,46 @@ def test_tier_lanes_variant_matches_oracle(shape, prec, monkeypatch):
         assert np.abs(one.ys.cpu().numpy() - full).max() / 1000.0 < (1e-11 if prec == "f64" else 2e-5)
 
 
+# shapes beyond the bench's that the suite used to compile on demand, built in since round 3 (seip_instances.def, units 15-16):
+# (generator arguments, (tier lanes, waves) of the mapping, instance that must run)
+BUILT_IN_F64 = [
+    (dict(A=3, L=3, K1=3, M1=3, n_knots=1, seasonal_vax=True), None, "dyn::seip_kernel<double, 0, 4, 3, 3, 3, 2>"),
+    (dict(A=8, L=3, K1=2, M1=3, n_knots=1, seasonal_vax=True), (2, 2), "dyn::seip_kernel_wave_group<double, 0, 8, 3, 2, 3, 2, 2>"),
+    (dict(A=5, L=3, K1=4, M1=2, n_knots=1, intro=True), (4, 4), "dyn::seip_kernel_wave_group<double, 0, 8, 3, 4, 2, 4, 4>"),
+    (dict(A=8, L=4, K1=1, M1=3, n_knots=0), (1, 2), "dyn::seip_kernel_wave_group<double, 0, 8, 4, 1, 3, 1, 2>"),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,wg,name", BUILT_IN_F64, ids=lambda v: _ids(v) if isinstance(v, dict) else None)
+def test_more_lane_mappings_match_the_oracle_in_float64(shape, wg, name):
+    """Tier lanes (36 values per lane), two tiers on a wave each, one tier per wave with four waves, 16 histories of a single
+    tier across two waves: the instance `select_seip_entry` dispatches and constant-step float64 parity with the oracle."""
+    import torch
+    from dynode_amd import _abi, jit
+    from dynode_amd.engine import solve_batch
+
+    wl = synthetic.seip(B=5, seed=27, t1=80.0, **shape)
+    if wg is not None:
+        assert jit._seip_wave_group(wl.model) == wg
+    ts = synthetic.save_grid(80.0)
+    r = solve_batch(wl.model, wl.y0, wl.params, wl.contact, 80.0, ts, dtype=torch.float64, constant_dt=0.5)
+    assert _abi.lib().dyn_last_kernel_name().decode() == name
+    want, st, _, _ = O.solve(H.omodel(wl.model), wl.y0, wl.params, wl.contact, 80.0, ts, dtype=np.float64, n_threads=8, constant_dt=0.5)
+    assert int(r.status.max()) == 0 and np.abs(r.ys.cpu().numpy() - want).max() / 1000.0 < 1e-11
+
+
 @pytest.mark.gpu
 @pytest.mark.on_demand_build
 def test_tier_lanes_shape_built_on_demand():
-    """A three-strain shape that is not compiled in (3 ages, 3 tiers, 3 waning states: 36 values per lane): the on-demand
-    build picks the tier-lane mapping and registers it with the matching feature word."""
+    """A three-strain shape that is not compiled in (3 ages, 3 tiers, 2 waning states: 33 values per lane): the on-demand
+    build picks the tier-lane mapping and registers it with the matching feature word.  (The on-demand path is what this
+    tests; the parity cases above run on compiled-in shapes.)"""
     import torch
     from dynode_amd import jit
     from dynode_amd.engine import solve_batch
 
-    wl = synthetic.seip(B=5, seed=23, t1=90.0, A=3, L=3, K1=3, M1=3, n_knots=1, seasonal_vax=True)
+    wl = synthetic.seip(B=5, seed=23, t1=90.0, A=3, L=3, K1=3, M1=2, n_knots=1, seasonal_vax=True)
     assert jit._seip_tier_lanes(wl.model) and jit._features(wl.model) == 0x100 | 0x20 | 3
     ts = synthetic.save_grid(90.0)
     r = solve_batch(wl.model, wl.y0, wl.params, wl.contact, 90.0, ts, dtype=torch.float64, constant_dt=0.5)
@@ -572,25 +602,20 @@ def test_tier_lanes_shape_built_on_demand():
 
 @pytest.mark.gpu
 @pytest.mark.on_demand_build
-def test_wave_group_shapes_built_on_demand():
-    """Lane groups beyond a wavefront that are not compiled in: the on-demand build picks the wave-group mapping (one tier
-    per wave from three tiers on, each of two tiers on its own wave, 16 histories of a single tier across two waves) and
-    registers it under the feature word `select_seip_entry` looks for."""
+def test_wave_group_shape_built_on_demand():
+    """A lane group beyond a wavefront that is not compiled in (8 ages x 8 histories x 2 tiers x 4 waning states in float64):
+    the on-demand build picks the wave-group mapping and registers it under the feature word `select_seip_entry` looks for."""
     import torch
     from dynode_amd import _abi, jit
     from dynode_amd.engine import solve_batch
 
-    cases = [(dict(A=8, L=3, K1=2, M1=3, n_knots=1, seasonal_vax=True), (2, 2), 0x100 | 0x20 | 0x40 | 2, "dyn::seip_kernel_wave_group<double, 0, 8, 3, 2, 3, 2, 2>"),
-             (dict(A=5, L=3, K1=4, M1=2, n_knots=1, intro=True), (4, 4), 0x100 | 0x200 | 4, "dyn::seip_kernel_wave_group<double, 0, 8, 3, 4, 2, 4, 4>"),
-             (dict(A=8, L=4, K1=1, M1=3, n_knots=0), (1, 2), 0x100 | 0x40 | 1, "dyn::seip_kernel_wave_group<double, 0, 8, 4, 1, 3, 1, 2>")]
-    for shape, wg, feat, name in cases:
-        wl = synthetic.seip(B=3, seed=27, t1=60.0, **shape)
-        assert jit._seip_wave_group(wl.model) == wg and jit._features(wl.model, torch.float64) == feat
-        ts = synthetic.save_grid(60.0)
-        r = solve_batch(wl.model, wl.y0, wl.params, wl.contact, 60.0, ts, dtype=torch.float64, constant_dt=0.5)
-        assert _abi.lib().dyn_last_kernel_name().decode() == name
-        want, st, _, _ = O.solve(H.omodel(wl.model), wl.y0, wl.params, wl.contact, 60.0, ts, dtype=np.float64, n_threads=8, constant_dt=0.5)
-        assert int(r.status.max()) == 0 and np.abs(r.ys.cpu().numpy() - want).max() / 1000.0 < 1e-11
+    wl = synthetic.seip(B=3, seed=27, t1=60.0, A=8, L=3, K1=2, M1=4, n_knots=1, seasonal_vax=True)
+    assert jit._seip_wave_group(wl.model) == (2, 2) and jit._features(wl.model, torch.float64) == 0x100 | 0x20 | 0x40 | 2
+    ts = synthetic.save_grid(60.0)
+    r = solve_batch(wl.model, wl.y0, wl.params, wl.contact, 60.0, ts, dtype=torch.float64, constant_dt=0.5)
+    assert _abi.lib().dyn_last_kernel_name().decode() == "dyn::seip_kernel_wave_group<double, 0, 8, 3, 2, 4, 2, 2>"
+    want, st, _, _ = O.solve(H.omodel(wl.model), wl.y0, wl.params, wl.contact, 60.0, ts, dtype=np.float64, n_threads=8, constant_dt=0.5)
+    assert int(r.status.max()) == 0 and np.abs(r.ys.cpu().numpy() - want).max() / 1000.0 < 1e-11
 
 
 @pytest.mark.gpu
