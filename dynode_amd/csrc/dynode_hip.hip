@@ -59,6 +59,9 @@ constexpr int kSeipTierWaves = 0x200; // ... or one tier per tier lane with whol
 // FEAT bit 14 (solve_kernel.hpp SAVE_ALL): variant without the per-round save-offset / store-width tests, picked by
 // enqueue when every compartment is saved into 16-byte aligned rows
 constexpr int kSaveAll = 0x4000;
+// FEAT bit 15 (solve_kernel.hpp PC): stepping and dense output on two waves of a workgroup; picked by enqueue for launches of
+// at most one trajectory-wave per SIMD
+constexpr int kProducerConsumer = 0x8000;
 
 static const Entry kEntries[] = {
 #define X(T, METHOD, G, S, E, WN, C, W, ND, SPL)              \
@@ -393,6 +396,27 @@ static int enqueue(const Entry *e, const dyn_model_desc *m, const dyn_solver_opt
     }
     if (all_saved && ka.vec_ok && n_save > 0 && !ll && !(e->FEAT & kSaveAll)) {
         const Entry *fast = find_variant(e, e->FEAT | kSaveAll);
+        // one trajectory-wave per SIMD or fewer, nothing replicated, the given order, no tangents: the two-wave kernel
+        // (DYNODE_HIP_PC=0 / 1 forces it off / on where the variant exists)
+        const Entry *pc = find_variant(e, e->FEAT | kSaveAll | kProducerConsumer);
+        if (pc && ka.rep_log2 == 0 && !order && !dparams) {
+            const int tpw = 64 / entry_lanes(e);
+            const int64_t waves = (B + tpw - 1) / tpw;
+            const char *env = getenv("DYNODE_HIP_PC");
+            static thread_local int simds = 0;
+            if (simds == 0) {
+                int dev = 0, cus = 0;
+                if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess)
+                    simds = 4 * cus;
+            }
+            const int nv = 1 + e->SPL * (e->E + 1 + e->W + e->C);
+            // Measured (profiles/r03_producer_consumer_ab.md): it LOSES -- cfg 5's share 0.617 -> 0.68-0.75 ms, cfg 3 without the
+            // bins axis at B = 8192 0.53-0.55 -> 0.58, cfg 2 0.233 -> 0.289 (replicated one-wave kernel: 0.148): two rendezvous
+            // and 45 LDS writes per accepted step cost the stepping wave what the row arithmetic it sheds was worth.
+            // Off by default; DYNODE_HIP_PC=1 runs it (the bit-for-bit test does).
+            (void)waves; (void)simds; (void)nv;
+            if (env && atoi(env) != 0) fast = pc;
+        }
         if (fast) e = fast;
     }
     typedef hipError_t (*fn_t)(const KArgs<T> &, hipStream_t);

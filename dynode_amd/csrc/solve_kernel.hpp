@@ -465,6 +465,10 @@ struct Solver {
     // bit 14: every compartment is saved into 16-byte aligned rows (the host checks) -- the per-round tests of
     // the save offsets and of the store width fold away (the save loop is half of a daily-output solve)
     static constexpr bool SAVE_ALL = (FEAT & 0x4000) != 0;
+    // bit 15: stepping and dense output on two waves of one workgroup ("Producer / consumer" at Solver::run) -- for launches of
+    // at most one wave per SIMD, where a lone wave leaves a third of the SIMD's issue slots empty
+    static constexpr bool PC = (FEAT & 0x8000) != 0;
+    static_assert(!PC || (ND == 0 && KV == 0), "producer / consumer: primal kernels with step-scaled rates");
     static_assert(KV == 0 || ((KV == 2 || KV == 4) && GA % KV == 0), "vaccination tiers: 2 or 4 lanes per age");
     static_assert(ST % SPL == 0, "strains per lane must divide the strain count");
     static constexpr int S = SPL;        // strains held by one lane (all per-lane arrays use S)
@@ -1313,6 +1317,63 @@ struct Solver {
         }
     }
 
+    // ---- Producer / consumer (PC): a workgroup of TWO waves per TPW trajectories.  Wave 0 steps (stages, error control,
+    // dense-output coefficients) and hands every accepted step -- y, k[0] and the three coefficient planes, five planes of NP
+    // register pairs -- to wave 1 through one LDS buffer; wave 1 evaluates and stores the rows while wave 0 is already on the
+    // next step.  Same polynomial, same operands, same instructions: the rows are bit-identical to the one-wave kernel's.
+    // Barrier protocol (both waves execute the same count, 2 n + 2 for n hand-overs; no other barrier after the role split):
+    //     producer:  [ A  write buffer  B ] per accepted step ...            A  set `fin`  B
+    //     consumer:    A  [ B  read buffer  A  evaluate + store rows ] ...   B  (sees `fin`)
+    // A = "the buffer is free" (the consumer arrives right after copying it to registers), B = "a step is published".
+    struct Handoff {
+        V2 *planes;   // [5][NP][64]: y | k[0] | q2 | q3 | q4
+        T *tprev, *tnext;   // [64] each: the accepted step's interval (tnext < tprev: this lane's group did not accept)
+        int *fin;
+    };
+    __device__ __forceinline__ static void consume(const KArgs<T> &ka, const Handoff &h, const T *ts_tab, int lane, int a, int as,
+                                                   bool lead, bool writer, bool valid, int64_t traj) {
+        const int n_save = ka.n_save;
+        const bool vec_ok = ka.vec_ok != 0;
+        T *const out_traj = ka.out + traj * (int64_t)n_save * ka.d_saved;
+        int save_idx = 0;
+        T ts_next = n_save > 0 ? ts_tab[0] : M::inf();
+        T ts_next2 = n_save > 1 ? ts_tab[1] : M::inf();
+        State y[1], k[7][1];
+        __syncthreads();                       // A (the first one: nothing to wait for)
+        for (;;) {
+            __syncthreads();                   // B: a step is published, or the producer is through
+            if (*h.fin) break;
+#pragma unroll
+            for (int pp = 0; pp < NP; ++pp) {
+                y[0].p[pp] = h.planes[(0 * NP + pp) * 64 + lane];
+                k[0][0].p[pp] = h.planes[(1 * NP + pp) * 64 + lane];
+                k[1][0].p[pp] = h.planes[(2 * NP + pp) * 64 + lane];
+                k[2][0].p[pp] = h.planes[(3 * NP + pp) * 64 + lane];
+                k[3][0].p[pp] = h.planes[(4 * NP + pp) * 64 + lane];
+            }
+            const T tprev = h.tprev[lane], tnext = h.tnext[lane];
+            __syncthreads();                   // A: the buffer is free again
+            const bool accept = valid && tnext > tprev;
+            const T dt = tnext - tprev;
+            const T inv_dt = M::recip(dt);
+            bool pending = accept && (save_idx < n_save) && (ts_next <= tnext);
+            while (__any(pending)) {
+                if (pending) {
+                    Poly dn;
+                    poly_prepare((ts_next - tprev) * inv_dt, dt, dn);
+                    if (writer) save_row<0>(ka, dn, y, k, out_traj + (int64_t)save_idx * ka.d_saved, a, as, lead, vec_ok);
+                    save_idx += 1;
+                    ts_next = ts_next2;
+                    ts_next2 = save_idx + 1 < n_save ? ts_tab[save_idx + 1] : M::inf();
+                }
+                pending = accept && (save_idx < n_save) && (ts_next <= tnext);
+            }
+        }
+        // rows never reached (failed solves): +inf, like diffrax's unfilled SaveAt buffer
+        if (valid && writer)
+            for (; save_idx < n_save; ++save_idx) fill_row(ka, out_traj + (int64_t)save_idx * ka.d_saved, a, as, lead, M::inf());
+    }
+
     // ---- the solve.  A lane group is a SLOT that integrates one trajectory after the other:
     //   static launches (KArgs::work == nullptr): grid = ceil(B 2^rep / TPW) waves, slot i takes trajectory i and stops;
     //   work-pulling launches (KArgs::work != nullptr; the host sizes the grid to the waves the chip can hold at once):
@@ -1382,9 +1443,24 @@ struct Solver {
 #pragma unroll
             for (int j = 0; j < kMaxJumps; ++j) jt_tab[j] = ka.jump_ts[j];
         }
+        [[maybe_unused]] Handoff hand{nullptr, nullptr, nullptr, nullptr};
+        if constexpr (PC) {
+            hand.planes = reinterpret_cast<V2 *>(rate_tab + NRQ * 64);
+            hand.tprev = reinterpret_cast<T *>(hand.planes + 5 * NP * 64);
+            hand.tnext = hand.tprev + 64;
+            hand.fin = reinterpret_cast<int *>(hand.tnext + 64);
+            if (threadIdx.x == 0) *hand.fin = 0;
+        }
         __syncthreads();
         const bool vec_ok = ka.vec_ok != 0;
         const int as = a * ST + s0;
+        if constexpr (PC) {
+            if (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 1) { // wave 1: the rows of wave 0's trajectories
+                const int64_t t = gslot;           // (static launch, no replicas, no caller's order: enqueue() guarantees it)
+                consume(ka, hand, ts_tab, lane, a, as, L.lead, writer, t < ka.B, t < ka.B ? t : 0);
+                return;
+            }
+        }
 
         // ---- the slot's trajectory: state, stage derivatives, step control
         State y[NC], yt[NC], k[7][NC];
@@ -1666,6 +1742,25 @@ struct Solver {
             // ---- SaveAt(ts): dense output at every save time in (tprev, tnext]
             bool pending = accept && (save_idx < n_save) && (ts_next <= tnext);
             const T inv_dt = M::recip(dt);
+            if constexpr (PC) { // the rows are wave 1's: publish the accepted step (see consume())
+                pending = false;
+                if (__any(accept)) {
+                    dense_coefficients(dt, y, yt, k);
+                    __syncthreads();           // A: wave 1 has copied the previous step
+#pragma unroll
+                    for (int pp = 0; pp < NP; ++pp) {
+                        hand.planes[(0 * NP + pp) * 64 + lane] = y[0].p[pp];
+                        hand.planes[(1 * NP + pp) * 64 + lane] = k[0][0].p[pp];
+                        hand.planes[(2 * NP + pp) * 64 + lane] = k[1][0].p[pp];
+                        hand.planes[(3 * NP + pp) * 64 + lane] = k[2][0].p[pp];
+                        hand.planes[(4 * NP + pp) * 64 + lane] = k[3][0].p[pp];
+                    }
+                    hand.tprev[lane] = tprev;
+                    hand.tnext[lane] = accept ? tnext : tprev - T(1);
+                    __syncthreads();           // B: published
+                }
+                if (accept) save_idx = n_save; // (the producer does not track rows: nothing for it to fill at the end)
+            }
             if (__any(pending)) {
                 // the step's interpolant as a polynomial in theta, once for all its rows (see dense_coefficients)
                 dense_coefficients(dt, y, yt, k);
@@ -1866,12 +1961,17 @@ struct Solver {
                 }
             }
         }
+        if constexpr (PC) { // tell wave 1 that no more steps will come
+            __syncthreads();                   // A
+            if (lane == 0) *hand.fin = 1;
+            __syncthreads();                   // B
+        }
     }
 };
 
 template <typename T, int METHOD, int GA, int ST, bool HAS_E, bool HAS_WANE, bool HAS_C, int W, int ND, int SPL,
           int FEAT = 0>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__((FEAT & 0x8000) ? 128 : 64)
 solve_kernel(const KArgs<T> ka) {
     Solver<T, METHOD, GA, ST, HAS_E, HAS_WANE, HAS_C, W, ND, SPL, FEAT>::run(ka);
 }
@@ -1908,6 +2008,13 @@ hipError_t launch(const KArgs<T> &ka_in, hipStream_t stream) {
         lds += (size_t)(64 >> ka.rep_log2) * ka.n_save * (SPL * W) * (1 + ND) * sizeof(T);
     if (((FEAT >> 1) & 0x7f) == 0) // PRESCALE: the parked rates and seeds, [SPL (1 + ND) quads][64 lanes] of four, behind the tables (rounded up to four elements)
         lds = ((lds / sizeof(T) + 3) & ~(size_t)3) * sizeof(T) + (size_t)SPL * (1 + ND) * 64 * 4 * sizeof(T);
+    constexpr bool PC = (FEAT & 0x8000) != 0;
+    if constexpr (PC) { // producer / consumer: the hand-over buffer [5][NP][64] register pairs, two [64] time arrays, a flag
+        constexpr int NVL = 1 + SPL * ((HAS_E ? 1 : 0) + 1 + W + (HAS_C ? 1 : 0)), NPL = (NVL + 1) / 2;
+        lds += (size_t)5 * NPL * 64 * 2 * sizeof(T) + 2 * 64 * sizeof(T) + 16;
+        ka.work = nullptr;
+        if (ka.rep_log2 != 0 || ka.order != nullptr) return hipErrorInvalidValue; // enqueue() never asks for this
+    }
     const auto kernel = solve_kernel<T, METHOD, GA, ST, HAS_E, HAS_WANE, HAS_C, W, ND, SPL, FEAT>;
     int64_t grid = blocks;
     if (ka.work != nullptr) {
@@ -1932,7 +2039,7 @@ hipError_t launch(const KArgs<T> &ka_in, hipStream_t stream) {
         else
             grid = resident;
     }
-    hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(64), lds, stream, ka);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(PC ? 128 : 64), lds, stream, ka);
     return hipGetLastError();
 }
 

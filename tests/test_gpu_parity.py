@@ -285,6 +285,38 @@ def test_work_pulling_gives_the_bits_of_the_static_grid(wl, waves, monkeypatch):
     assert torch.equal(r64.ys, b64.ys) and torch.equal(r64.n_accept, b64.n_accept) and torch.equal(r64.n_reject, b64.n_reject)
 
 
+@pytest.mark.parametrize("wl,budget", [(synthetic.seirs_multi_strain(1101, seed=51, seasonal=True), 97), (synthetic.seirs_multi_strain(777, seed=52), 97),
+                                       (synthetic.sir_age_stratified(2050, seed=53), 40)], ids=["cfg5", "cfg3_D136", "cfg2"])
+def test_producer_consumer_waves_give_the_bits_of_the_one_wave_kernel(wl, budget, monkeypatch):
+    """FEAT bit 15: stepping on wave 0, dense output on wave 1 of a two-wave workgroup, every accepted step handed over through
+    LDS.  Same polynomial, same operands, same instructions: rows, status and step counts are the one-wave kernel's bit for
+    bit -- ragged batches, a trajectory that fails at once (NaN parameters: all rows +inf) and one that runs out of steps."""
+    from dynode_amd import _abi
+
+    m = wl.model
+    params = wl.params.copy()
+    params[5, 0] = np.nan                                          # fails before its first step
+    monkeypatch.setenv("DYNODE_HIP_REPLICAS_LOG2", "0")
+    args = (m, wl.y0, params, wl.contact, wl.t1, wl.save_ts)
+    monkeypatch.setenv("DYNODE_HIP_PC", "0")
+    base = solve_batch(*args, dtype=F32, max_steps=budget)         # (some trajectories stop at max_steps: their tails are +inf)
+    name0 = _abi.lib().dyn_last_kernel_name().decode()
+    monkeypatch.setenv("DYNODE_HIP_PC", "1")
+    r = solve_batch(*args, dtype=F32, max_steps=budget)
+    name1 = _abi.lib().dyn_last_kernel_name().decode()
+    assert name0 != name1 and name1.endswith(", 49152>") and name0.endswith(", 16384>")      # FEAT 0xC000 vs 0x4000
+    assert int(base.status[5]) == 2 and int((base.status == 1).sum()) > 0 and int((base.status == 0).sum()) > 0
+    for a, b in ((r.status, base.status), (r.n_accept, base.n_accept), (r.n_reject, base.n_reject)):
+        assert torch.equal(a, b)
+    assert torch.equal(torch.isfinite(r.ys), torch.isfinite(base.ys))
+    fin = torch.isfinite(base.ys)
+    assert torch.equal(r.ys[fin], base.ys[fin]) and bool(torch.isinf(r.ys[5]).all())
+    full = solve_batch(*args[:2], wl.params, *args[3:], dtype=F32)                            # and a clean run, default step budget
+    monkeypatch.setenv("DYNODE_HIP_PC", "0")
+    full0 = solve_batch(*args[:2], wl.params, *args[3:], dtype=F32)
+    assert int(full0.status.max()) == 0 and torch.equal(full.ys, full0.ys) and torch.equal(full.n_accept, full0.n_accept)
+
+
 def _abi_lib_kernel_was_pulling(wl, waves) -> bool:
     """The forced grid must be smaller than the static one, or the test above would compare a launch with itself."""
     import ctypes
