@@ -390,6 +390,9 @@ def main():
             torch.cuda.empty_cache()
             line["other_workloads"]["cfg4"] = nuts_side_measurement()                       # numpyro's per-chain adaptation
             line["other_workloads"]["cfg4_pooled_adaptation"] = nuts_side_measurement(adaptation="pooled")
+            # the program a drop-in user actually has: the reference-shaped model() (simulate -> diff(R) -> Poisson scored in torch,
+            # examples/sir_infer_parameters.py:model), general autograd potential, same sampler kernel
+            line["other_workloads"]["cfg4_reference_shaped_model"] = nuts_side_measurement(fused=False)
         if world == 1 and not args.no_cpu_baseline:
             sample = args.cpu_sample or (1024 if m.family == 1 else 8192 if m.state_dim >= 300 else 16384 if m.state_dim >= 100 else 65536)
             line["cpu_baseline"] = cpu_baseline(wl, min(sample, B))

@@ -162,6 +162,35 @@ static const Entry *find_entry(const dyn_model_desc *m, int dtype, int method, i
     return first;
 }
 
+// Batch-aware lane mapping.  A launch of fewer waves than SIMDs is as long as its slowest wave's instruction stream, and a
+// trajectory whose strains are spread over more lanes (SPL < S) has a shorter one -- at the price of replicated control
+// arithmetic, which is free on an otherwise empty GPU.  Measured on the 8 x 4 seasonal model, ms per launch, SPL = 4 / 2 / 1:
+// B = 4096 (512 waves of 8 trajectories) 0.597 / 0.505 / 0.484; B = 8192 0.59-0.63 / 0.64 / 0.80; B = 16384 0.86-0.96 / 1.03 /
+// 1.15.  Rule: when the default mapping fills at most half a wave per SIMD, take the finest split compiled in that still fits
+// two waves per SIMD; otherwise the first entry (instances.def order).  DYNODE_HIP_SPL overrides.
+static const Entry *entry_for_batch(const Entry *e, const dyn_model_desc *m, int dtype, int method, int nd, int64_t B) {
+    if (getenv("DYNODE_HIP_SPL") || (e->FEAT & kSeip) || e->SPL == 1 || nd != 0) return e;
+    static thread_local int simds = 0;
+    if (simds == 0) {
+        int dev = 0, cus = 0;
+        simds = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) ? 4 * cus : -1;
+    }
+    if (simds <= 0) return e;
+    const int64_t waves = (B * entry_lanes(e) + 63) / 64;
+    if (waves * 2 > simds) return e;
+    const int G = group_width(m->n_age);
+    const Entry *best = e;
+    auto consider = [&](const Entry &c) {
+        if (!matches(c, m, G, dtype, method, nd) || c.SPL >= best->SPL) return;
+        if ((B * entry_lanes(&c) + 63) / 64 > 2 * (int64_t)simds) return;
+        best = &c;
+    };
+    for (int i = 0; i < kNumEntries; ++i) consider(kEntries[i]);
+    const int n_extra = g_n_extra.load(std::memory_order_acquire);
+    for (int i = 0; i < n_extra; ++i) consider(g_extra[i]);
+    return best;
+}
+
 // the same shape with another feature word (nullptr if it is not compiled in / registered)
 static const Entry *find_variant(const Entry *e, int feat) {
     auto same = [&](const Entry &c) {
@@ -545,6 +574,7 @@ static int solve_impl(const dyn_model_desc *m, const dyn_solver_opts *o, const v
     }
     const dyn::Entry *e = dyn::find_entry(m, o->dtype, o->method, n_dir);
     if (m->family == 1) e = dyn::select_seip_entry(m, o->dtype, o->method, e);
+    else if (e) e = dyn::entry_for_batch(e, m, o->dtype, o->method, n_dir, B);
     if (!e && m->family == 1) {
         snprintf(dyn::tl_error, sizeof(dyn::tl_error),
                  "no SEIP kernel compiled for A=%d strains=%d tiers=%d waning states=%d dtype=%d method=%d; to add it "

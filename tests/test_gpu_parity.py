@@ -885,3 +885,23 @@ def test_vaccination_shape_built_on_demand():
     want, st, _, _ = O.solve(H.omodel(m), y0, p, C, t1, ts, dtype=np.float64, n_threads=8, constant_dt=0.5)
     assert int(r.status.max()) == 0 and np.abs(r.ys.cpu().numpy() - want).max() / 1000.0 < 1e-11
     assert _supported(m, F64, "tsit5")
+
+
+def test_batch_aware_lane_mapping_is_a_dispatch_choice_only(monkeypatch):
+    """A batch that fills at most half a wave per SIMD runs on the strain-split instance (a trajectory over more lanes: a shorter
+    instruction stream per wave on a mostly empty GPU).  Which instance runs depends on the batch size; the trajectories do not,
+    beyond float32 rounding of the sums over strains (another summation order) -- and in float64 every mapping gives the oracle's
+    step counts (checked per mapping in the shape sweep)."""
+    from dynode_amd import _abi
+
+    wl = synthetic.seirs_multi_strain(3072, seed=61, seasonal=True)
+    args = (wl.model, wl.y0, wl.params, wl.contact, wl.t1, wl.save_ts)
+    small = solve_batch(*args, dtype=F32)
+    name_small = _abi.lib().dyn_last_kernel_name().decode()
+    monkeypatch.setenv("DYNODE_HIP_SPL", "4")
+    base = solve_batch(*args, dtype=F32)
+    name_base = _abi.lib().dyn_last_kernel_name().decode()
+    assert name_base.endswith("1, 0, 4, 16384>") and name_small.endswith("1, 0, 1, 16384>")
+    assert int(small.status.max()) == 0 and int(base.status.max()) == 0
+    scale = wl.population
+    assert float((small.ys - base.ys).abs().max()) / scale < 1e-5
