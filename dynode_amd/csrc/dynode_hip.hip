@@ -62,6 +62,10 @@ constexpr int kSaveAll = 0x4000;
 // FEAT bit 15 (solve_kernel.hpp PC): stepping and dense output on two waves of a workgroup; picked by enqueue for launches of
 // at most one trajectory-wave per SIMD
 constexpr int kProducerConsumer = 0x8000;
+// FEAT bit 13 (solve_kernel.hpp LEAN): tangent kernel of the plain family with the options of the reference's inference example
+// (normalised, no seasonal forcing, no discontinuity points, adaptive steps, Poisson likelihood of the increments of r) fixed at
+// compile time; picked by enqueue when the call is exactly that
+constexpr int kLean = 0x2000;
 
 static const Entry kEntries[] = {
 #define X(T, METHOD, G, S, E, WN, C, W, ND, SPL)              \
@@ -447,6 +451,12 @@ static int enqueue(const Entry *e, const dyn_model_desc *m, const dyn_solver_opt
             if (env && atoi(env) != 0) fast = pc;
         }
         if (fast) e = fast;
+    }
+    if (ll && ll->slot == 3 && ll->mode == 1 && m->normalize && !m->seasonal && !m->has_intro && ka.n_jump == 0 &&
+        !(o->constant_dt > 0.0) && !sc && !order && !(e->FEAT & kLean)) {
+        const char *env = getenv("DYNODE_HIP_LEAN");       // tuning aid: 0 keeps the general instance
+        const Entry *lean = (env && atoi(env) == 0) ? nullptr : find_variant(e, e->FEAT | kLean);
+        if (lean) e = lean;
     }
     typedef hipError_t (*fn_t)(const KArgs<T> &, hipStream_t);
     const hipError_t err = ((fn_t)e->fn)(ka, stream);

@@ -469,6 +469,12 @@ struct Solver {
     // at most one wave per SIMD, where a lone wave leaves a third of the SIMD's issue slots empty
     static constexpr bool PC = (FEAT & 0x8000) != 0;
     static_assert(!PC || (ND == 0 && KV == 0), "producer / consumer: primal kernels with step-scaled rates");
+    // bit 13: the gradient-solve of the reference's inference example as compile-time facts instead of run-time switches --
+    // normalised force of infection, no seasonal forcing, no discontinuity points, adaptive steps, the Poisson likelihood of
+    // the increments of r fused in (examples/sir_infer_parameters.py:21-39).  A sampler iteration is ONE wave's serial
+    // instruction stream (128 chains on 1024 SIMDs): every switch the wave does not have to evaluate is latency.
+    static constexpr bool LEAN = (FEAT & 0x2000) != 0;
+    static_assert(!LEAN || (ND > 0 && KV == 0 && !INTRO), "lean instance: tangent kernels of the plain family");
     static_assert(KV == 0 || ((KV == 2 || KV == 4) && GA % KV == 0), "vaccination tiers: 2 or 4 lanes per age");
     static_assert(ST % SPL == 0, "strains per lane must divide the strain count");
     static constexpr int S = SPL;        // strains held by one lane (all per-lane arrays use S)
@@ -1066,8 +1072,9 @@ struct Solver {
     template <int FIRST, int CNT>
     __device__ __forceinline__ static void ll_block(const KArgs<T> &ka, const Poly &d, const State (&y)[NC],
                                                     const State (&k)[7][NC], LL &ll, int j, int off, T *tab_row) {
-        const bool have = ka.ll_mode == 0 || j > 0;
-        const T *orow = ka.obs + (int64_t)(ka.ll_mode == 0 ? j : (j > 0 ? j - 1 : 0)) * ka.ll_row + off;
+        const int ll_mode = LEAN ? 1 : ka.ll_mode;
+        const bool have = ll_mode == 0 || j > 0;
+        const T *orow = ka.obs + (int64_t)(ll_mode == 0 ? j : (j > 0 ? j - 1 : 0)) * ka.ll_row + off;
 #pragma unroll
         for (int q = 0; q < CNT; ++q) {
             const int e = FIRST + q;
@@ -1075,25 +1082,27 @@ struct Solver {
 #pragma unroll
             for (int c = 0; c < NC; ++c)
                 v[c] = poly_eval<T>(d, y[c][e], k[QP1][c][e], k[1][c][e], k[2][c][e], k[3][c][e]);
-            if (tab_row != nullptr) {
+            // (the two destinations are written in separate statements, `prev` by value: merged into one store through a
+            // pointer that is either the LDS row or &ll.prev, the whole LL struct -- accumulators included -- was pinned in
+            // scratch memory, a dependent scratch load / add / store chain in every save round of a latency-bound kernel)
+            const bool table = tab_row != nullptr;
+            if (table) {
 #pragma unroll
                 for (int c = 0; c < NC; ++c) tab_row[q * NC + c] = v[c];
-            } else {
-                if (have) {
-                    T inc[NC];
+            } else if (have) {
+                T inc[NC];
 #pragma unroll
-                    for (int c = 0; c < NC; ++c) inc[c] = ka.ll_mode == 0 ? v[c] : v[c] - ll.prev[c][q];
-                    ll_term(ka, ll, orow[q], inc);
-                }
-#pragma unroll
-                for (int c = 0; c < NC; ++c) ll.prev[c][q] = v[c];
+                for (int c = 0; c < NC; ++c) inc[c] = ll_mode == 0 ? v[c] : v[c] - ll.prev[c][q];
+                ll_term(ka, ll, orow[q], inc);
             }
+#pragma unroll
+            for (int c = 0; c < NC; ++c) ll.prev[c][q] = table ? ll.prev[c][q] : v[c];
         }
     }
     __device__ __forceinline__ static void ll_row(const KArgs<T> &ka, const Poly &d, const State (&y)[NC],
                                                   const State (&k)[7][NC], LL &ll, int j, int a, int as, bool lead,
                                                   T *tab_row) {
-        switch (ka.ll_slot) {
+        switch (LEAN ? 3 : ka.ll_slot) {
         case 0:
             if (lead) ll_block<IS, 1>(ka, d, y, k, ll, j, a, tab_row);
             break;
@@ -1114,19 +1123,19 @@ struct Solver {
     // table mode, after the solve: replica `rep` scores observation rows rep, rep + R, ...
     __device__ __forceinline__ static void ll_from_table(const KArgs<T> &ka, LL &ll, const T *tab_lane, int row_stride,
                                                          int n_save, int rep, int R, int a, int as, bool lead) {
-        const int slot = ka.ll_slot;
+        const int slot = LEAN ? 3 : ka.ll_slot, ll_mode = LEAN ? 1 : ka.ll_mode;
         const int cnt = slot == 0 ? 1 : (slot == 3 ? S * W : S);
         const int off = slot == 0 ? a : (slot == 3 ? as * W : as);
         if (slot == 0 && !lead) return;
-        const int n_obs = n_save - ka.ll_mode;
+        const int n_obs = n_save - ll_mode;
         for (int r = rep; r < n_obs; r += R) {
-            const int j = r + ka.ll_mode;
-            const T *now = tab_lane + (int64_t)j * row_stride, *before = tab_lane + (int64_t)(j - ka.ll_mode) * row_stride;
+            const int j = r + ll_mode;
+            const T *now = tab_lane + (int64_t)j * row_stride, *before = tab_lane + (int64_t)(j - ll_mode) * row_stride;
             for (int q = 0; q < cnt; ++q) {
                 T inc[NC];
 #pragma unroll
                 for (int c = 0; c < NC; ++c)
-                    inc[c] = ka.ll_mode == 0 ? now[q * NC + c] : now[q * NC + c] - before[q * NC + c];
+                    inc[c] = ll_mode == 0 ? now[q * NC + c] : now[q * NC + c] - before[q * NC + c];
                 ll_term(ka, ll, ka.obs[(int64_t)r * ka.ll_row + off + q], inc);
             }
         }
@@ -1246,7 +1255,7 @@ struct Solver {
             // per-trajectory vaccination block after the seasonal numbers:
             //   susceptibility [groups][ST], then per group: base[4], knot[n_knots], coef[n_knots]
             const int nk = ka.n_vax_knots;
-            const T *vp = p + oSe * ST + (ka.seasonal ? 3 : 0);
+            const T *vp = p + oSe * ST + (ka.seasonal ? 3 : 0);   // (KV > 0: never a lean instance)
             const T *sp_ = vp + A * ST + aa * (4 + 2 * nk);
             vnk = nk;
 #pragma unroll
@@ -1398,8 +1407,8 @@ struct Solver {
         Solver L;
         L.pad = a >= A;
         L.lead = h == 0;
-        L.normalize = ka.normalize != 0;
-        L.seasonal = ka.seasonal != 0;
+        L.normalize = LEAN ? true : ka.normalize != 0;
+        L.seasonal = LEAN ? false : ka.seasonal != 0;
         const int aa = L.pad ? 0 : a;
         const bool writer = !L.pad;
         const int s0 = h * SPL; // first global strain of this lane
@@ -1415,11 +1424,11 @@ struct Solver {
 
         const T rtol = ka.rtol, atol = ka.atol, t_end = ka.t1;
         const T Dn = T(D);
-        const bool constant = ka.constant_dt > T(0);
+        const bool constant = LEAN ? false : ka.constant_dt > T(0);
         const int n_save = ka.n_save;
         bool fused_ll = false, ll_table = false;
         if constexpr (ND > 0) {
-            fused_ll = ka.obs != nullptr;
+            fused_ll = LEAN ? true : ka.obs != nullptr;
             ll_table = fused_ll && R > 1;
         }
         // The save grid lives in LDS: a global load inside the save loop would share the
@@ -1431,7 +1440,7 @@ struct Solver {
         for (int j = lane; j < n_save; j += 64) ts_tab[j] = ka.save_ts[j];
         // discontinuity points follow the save grid in LDS (per-group index into the table)
         T *const jt_tab = ts_tab + n_save;
-        const int n_jump = ka.n_jump;
+        const int n_jump = LEAN ? 0 : ka.n_jump;
         // likelihood table (replicated trajectories): [trajectory slot][save index][lane of group][LLMAX][planes]
         constexpr int LL_ROW = G * LLMAX * NC;
         T *const ll_tab = jt_tab + (n_jump > 0 ? kMaxJumps : 0);
@@ -2003,7 +2012,7 @@ hipError_t launch(const KArgs<T> &ka_in, hipStream_t stream) {
     constexpr int TPW = 64 / (GA * (ST / SPL));
     const int64_t blocks = ((ka.B << ka.rep_log2) + TPW - 1) / TPW;
     if (blocks <= 0) return hipSuccess;
-    size_t lds = ((size_t)ka.n_save + (ka.n_jump > 0 ? kMaxJumps : 0)) * sizeof(T); // LDS tables
+    size_t lds = ((size_t)ka.n_save + (ka.n_jump > 0 ? kMaxJumps : 0)) * sizeof(T); // LDS tables (a lean instance is only dispatched with n_jump == 0)
     if (ND > 0 && ka.obs != nullptr && ka.rep_log2 > 0) // likelihood table of the replicated trajectories of a wave
         lds += (size_t)(64 >> ka.rep_log2) * ka.n_save * (SPL * W) * (1 + ND) * sizeof(T);
     if (((FEAT >> 1) & 0x7f) == 0) // PRESCALE: the parked rates and seeds, [SPL (1 + ND) quads][64 lanes] of four, behind the tables (rounded up to four elements)
