@@ -961,7 +961,7 @@ struct Seip {
             S.template stages<1>(tprev, dt, y, yt, k);
             bool keep = true, finite = true;
             T factor = T(1);
-            if (!fixed) {
+            if (__builtin_expect(!fixed, 1)) {
                 V2 ssq[2] = {V2{T(0), T(0)}, V2{T(0), T(0)}};
 #pragma unroll
                 for (int pp = 0; pp < NP; ++pp) {
@@ -1023,7 +1023,7 @@ struct Seip {
                     y.p[pp] = yt.p[pp];
                     k[0].p[pp] = k[6].p[pp];
                 }
-                if (ka.sched_out != nullptr && writer && a == 0 && j == 0 && tl == 0 && n_acc < ka.sched_cap) {
+                if (__builtin_expect(ka.sched_out != nullptr, 0) && writer && a == 0 && j == 0 && tl == 0 && n_acc < ka.sched_cap) {
                     T *rec = ka.sched_out + (traj * (int64_t)ka.sched_cap + n_acc) * 2;
                     rec[0] = tprev;
                     rec[1] = tnext;
@@ -1034,7 +1034,7 @@ struct Seip {
             }
             T next_t0 = accept ? tnext : tprev;
             T next_t1 = next_t0 + (constant ? ka.constant_dt : dt * factor);
-            if (replay) { // wave-uniform: the next recorded step; across a discontinuity point the first stage is recomputed
+            if (__builtin_expect(replay, 0)) { // wave-uniform: the next recorded step; across a discontinuity point the first stage is recomputed
                 if (act) ++si;
                 const bool more = si < n_sch;
                 next_t0 = more ? sch[2 * si] : t_end;
@@ -1058,7 +1058,7 @@ struct Seip {
                 }
                 continue;
             }
-            if (n_jump > 0) { // wave-uniform
+            if (__builtin_expect(n_jump > 0, 0)) { // wave-uniform
                 const bool landed = at_jump && accept;
                 if (landed) {
                     next_t0 = M::next(jt_tab[jidx], M::inf());
