@@ -297,6 +297,8 @@ def test_producer_consumer_waves_give_the_bits_of_the_one_wave_kernel(wl, budget
     params = wl.params.copy()
     params[5, 0] = np.nan                                          # fails before its first step
     monkeypatch.setenv("DYNODE_HIP_REPLICAS_LOG2", "0")
+    if m.n_strain > 1:
+        monkeypatch.setenv("DYNODE_HIP_SPL", str(m.n_strain))      # (batches this small would take the strain-split mapping, which has no two-wave variant)
     args = (m, wl.y0, params, wl.contact, wl.t1, wl.save_ts)
     monkeypatch.setenv("DYNODE_HIP_PC", "0")
     base = solve_batch(*args, dtype=F32, max_steps=budget)         # (some trajectories stop at max_steps: their tails are +inf)
