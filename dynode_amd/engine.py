@@ -8,6 +8,7 @@ without ``libdynode_hip.so`` every call raises.
 from __future__ import annotations
 
 import ctypes
+import os
 from dataclasses import dataclass
 from typing import Optional, Sequence
 
@@ -89,7 +90,9 @@ def _dev(x, dtype, device) -> torch.Tensor:
 
 
 _WORK_COUNTERS: "dict[tuple, torch.Tensor]" = {}
-_WORK_MIN_BATCH = 1024     # fewer trajectories than the GPU has SIMDs can never exceed one resident round
+# fewer trajectories than the GPU has SIMDs can never exceed one resident round (DYNODE_WORK_MIN_BATCH: the tests pull small
+# batches through forced grids of a few waves)
+_WORK_MIN_BATCH = 1024
 
 
 def work_counter(B: int, device, stream) -> Optional[torch.Tensor]:
@@ -97,7 +100,7 @@ def work_counter(B: int, device, stream) -> Optional[torch.Tensor]:
     (device, stream), created once -- the kernel leaves it zeroed, and launches of one stream cannot overlap.  While a HIP
     graph is being captured the pair is a fresh one from the graph's own pool (replays of different graphs may overlap).
     None for batches that can never exceed one resident round."""
-    if B < _WORK_MIN_BATCH:
+    if B < int(os.environ.get("DYNODE_WORK_MIN_BATCH", _WORK_MIN_BATCH)):
         return None
     if torch.cuda.is_current_stream_capturing():
         return torch.zeros(2, dtype=torch.int32, device=device)

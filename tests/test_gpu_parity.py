@@ -675,6 +675,27 @@ def fuzz_compare(case, dtype=F64):
     torch.cuda.synchronize()
     for a, b in ((r_scr.ys, r.ys), (r_scr.status, r.status), (r_scr.n_accept, r.n_accept), (r_scr.n_reject, r.n_reject)):
         assert torch.equal(torch.nan_to_num(a, nan=-1.0), torch.nan_to_num(b, nan=-1.0)) if a.is_floating_point() else torch.equal(a, b)
+    # ... and pulled through a grid of one or two waves (dyn_solver_opts.work_counter): every lane group reloads again and
+    # again -- under discontinuity points, sub-save masks, constant steps, failing trajectories -- and not a bit may move
+    if m.family == 0 and B > 2:
+        env = {"DYNODE_WORK_MIN_BATCH": "1", "DYNODE_HIP_PULL_WAVES": str(1 + B % 2), "DYNODE_HIP_REPLICAS_LOG2": "0"}
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            r_pull = solve_batch(m, y0, p, C, t1, ts, dtype=dtype, order=scr if B % 3 == 0 else None, **kw)
+            os.environ["DYNODE_HIP_PULL"] = "0"
+            r_stat = solve_batch(m, y0, p, C, t1, ts, dtype=dtype, **kw)          # same replica setting, static grid
+            torch.cuda.synchronize()
+        finally:
+            os.environ.pop("DYNODE_HIP_PULL", None)
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        for a, b in ((r_pull.ys, r_stat.ys), (r_pull.status, r_stat.status), (r_pull.n_accept, r_stat.n_accept), (r_pull.n_reject, r_stat.n_reject),
+                     (r_stat.status, r.status), (r_stat.n_accept, r.n_accept)):
+            assert torch.equal(torch.nan_to_num(a, nan=-1.0), torch.nan_to_num(b, nan=-1.0)) if a.is_floating_point() else torch.equal(a, b)
     want, st, na, nr = O.solve(H.omodel(m), y0, p, C, t1, ts, dtype=NP[dtype], n_threads=8, **kw)
     if dtype == F32:
         got, fin = r.ys.cpu().numpy(), np.isfinite(want)
