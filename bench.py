@@ -126,6 +126,10 @@ def nuts_side_measurement(chains=128, warmup=1000, samples=1000, fused=True, ada
 
     data = ex.synthetic_incidence(100)
     kw = dict(config=ex.get_config(), tf=100, obs_data=data)
+    # one-off costs (lazy loading of the kernels, structure discovery of the potential, the caching allocator's first blocks)
+    # are paid by a short untimed run of the same program: 16 chains x (20 + 20)
+    MCMCProcess(numpyro_model=ex.model_fused if fused else ex.model, num_warmup=20, num_samples=20, num_chains=16, nuts_max_tree_depth=10,
+                progress_bar=False, mcmc_kwargs={"adaptation": adaptation}).infer(**kw)
     proc = MCMCProcess(numpyro_model=ex.model_fused if fused else ex.model, num_warmup=warmup, num_samples=samples, num_chains=chains,
                        nuts_max_tree_depth=10, progress_bar=False, mcmc_kwargs={"adaptation": adaptation})
     torch.cuda.synchronize()
