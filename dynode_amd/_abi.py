@@ -31,7 +31,7 @@ EXPORTED_SYMBOLS = (
     "dyn_nuts_advance", "dyn_nuts_state_size", "dyn_philox4x32_10", "dyn_latent_sites",
     "dyn_solve_batch_loglik", "dyn_register_instance", "dyn_last_kernel_name", "dyn_solve_batch_record",
     "dyn_solve_batch_replay", "dyn_latent_param_map", "dyn_potential_combine", "dyn_solve_batch_ordered", "dyn_cost_order",
-    "dyn_cost_order_capacity", "dyn_nuts_advance_mapped",
+    "dyn_cost_order_capacity", "dyn_nuts_advance_mapped", "dyn_nuts_tail_size", "dyn_nuts_tail_pack",
 )
 
 MAX_COST_FEATURES = 32
@@ -73,6 +73,7 @@ class SolverOptsC(ctypes.Structure):
         ("jump_ts", ctypes.POINTER(ctypes.c_double)),
         ("n_jump", ctypes.c_int32),
         ("work_counter", ctypes.c_void_p),     # ABI 7: two zeroed int32 words on the device, or None (engine.work_counter)
+        ("nuts_tail", ctypes.c_void_p),        # ABI 8: host blob of dyn_nuts_tail_pack, or None (infer/folded.py)
     ]
 
 
@@ -207,6 +208,11 @@ def lib() -> ctypes.CDLL:
         L.dyn_nuts_advance_mapped.restype = ctypes.c_int
         L.dyn_nuts_advance_mapped.argtypes = ([ctypes.POINTER(NutsStateC), ctypes.POINTER(SiteDescC), ctypes.c_int32, ctypes.c_int32,
                                                ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32] + [ctypes.c_void_p] * 6)
+        L.dyn_nuts_tail_size.restype = ctypes.c_int32
+        L.dyn_nuts_tail_size.argtypes = []
+        L.dyn_nuts_tail_pack.restype = ctypes.c_int
+        L.dyn_nuts_tail_pack.argtypes = ([ctypes.POINTER(NutsStateC), ctypes.POINTER(SiteDescC), ctypes.c_int32, ctypes.c_int32,
+                                          ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32] + [ctypes.c_void_p] * 6)
         L.dyn_cost_order_capacity.restype = ctypes.c_int32
         L.dyn_cost_order_capacity.argtypes = [ctypes.c_int32]
         L.dyn_cost_order.restype = ctypes.c_int

@@ -66,6 +66,9 @@ constexpr int kProducerConsumer = 0x8000;
 // (normalised, no seasonal forcing, no discontinuity points, adaptive steps, Poisson likelihood of the increments of r) fixed at
 // compile time; picked by enqueue when the call is exactly that
 constexpr int kLean = 0x2000;
+// FEAT bit 12 (solve_kernel.hpp FUSED): a lean instance that also runs the sampler's state machine for the chains its waves
+// scored; picked when the call carries dyn_solver_opts::nuts_tail
+constexpr int kFused = 0x1000;
 
 static const Entry kEntries[] = {
 #define X(T, METHOD, G, S, E, WN, C, W, ND, SPL)              \
@@ -457,6 +460,22 @@ static int enqueue(const Entry *e, const dyn_model_desc *m, const dyn_solver_opt
         const char *env = getenv("DYNODE_HIP_LEAN");       // tuning aid: 0 keeps the general instance
         const Entry *lean = (env && atoi(env) == 0) ? nullptr : find_variant(e, e->FEAT | kLean);
         if (lean) e = lean;
+    }
+    ka.nuts_tail = nullptr;
+    if (o->nuts_tail) {
+        // one launch per sampler iteration: only where the wave <-> chain correspondence holds (include/dynode_hip.h)
+        const dynnuts::Tail *const t = static_cast<const dynnuts::Tail *>(o->nuts_tail);
+        if (t->magic != dynnuts::kTailMagic) return DYN_ERR_OPTS; // not a dyn_nuts_tail_pack blob
+        const int rows = t->rows_per_chain;
+        const Entry *fused = (e->FEAT & kLean) ? find_variant(e, e->FEAT | kFused) : nullptr;
+        const int nt = (64 / entry_lanes(e)) >> ka.rep_log2; // trajectories per wave
+        if (!fused || rows < 1 || nt < rows || nt % rows != 0 || B != (int64_t)t->st.n_chains * rows || rows * e->ND != t->st.dim ||
+            (t->map.f64 != 0) != (sizeof(T) == 8) || t->map.params != params || t->map.seeds != dparams) {
+            snprintf(tl_error, sizeof(tl_error), "nuts_tail: this call cannot carry the sampler's side (see dyn_solver_opts::nuts_tail)");
+            return DYN_ERR_UNSUPPORTED;
+        }
+        e = fused;
+        ka.nuts_tail = t;
     }
     typedef hipError_t (*fn_t)(const KArgs<T> &, hipStream_t);
     const hipError_t err = ((fn_t)e->fn)(ka, stream);

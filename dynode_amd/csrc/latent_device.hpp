@@ -67,14 +67,16 @@ __device__ inline SiteValue eval_site(const dyn_site_desc &d, double zi) {
 
 // One chain of `latent_param_map`: sites, log prior, parameter row(s) and tangent seeds of the monomial parameter map
 // p_j = coef_j prod_i x_i^expo[j][i] at the unconstrained position `zrow` (comments at the kernel in latent_kernel.hip).
-template <typename T>
-__device__ inline void map_chain(const SiteTable &tab, int64_t C, int64_t c, const double *zrow, double *__restrict__ x_out,
+template <typename T, typename TAB>   // TAB: SiteTable in whatever address space the caller holds it (kernel argument, kernarg segment)
+__device__ inline void map_chain(const TAB &tab, int64_t C, int64_t c, const double *zrow, double *__restrict__ x_out,
                                  double *__restrict__ lp_out, double *__restrict__ dlp_dz, int P, const double *__restrict__ coef,
                                  const double *__restrict__ expo, T *__restrict__ params, T *__restrict__ seeds, int split) {
     const int n = tab.n;
     double total = 0.0, x[DYN_MAX_SITES], rel[DYN_MAX_SITES];   // rel_i = (dx_i/dz_i) / x_i (0 where x_i == 0: see the seeds below)
     for (int i = 0; i < n; ++i) {
-        const SiteValue v = eval_site(tab.s[i], zrow[i]);
+        dyn_site_desc site;
+        __builtin_memcpy(&site, &tab.s[i], sizeof(site));
+        const SiteValue v = eval_site(site, zrow[i]);
         total += v.lp;
         x[i] = v.x;
         rel[i] = v.x != 0.0 ? v.dx / v.x : 0.0;
@@ -104,7 +106,9 @@ __device__ inline void map_chain(const SiteTable &tab, int64_t C, int64_t c, con
                 const double ek = k == i ? e - 1.0 : expo[j * n + k];
                 if (ek != 0.0) q *= pow(x[k], ek);
             }
-            return q * eval_site(tab.s[i], zrow[i]).dx;
+            dyn_site_desc site;
+            __builtin_memcpy(&site, &tab.s[i], sizeof(site));
+            return q * eval_site(site, zrow[i]).dx;
         };
         if (split) { // one direction per trajectory: chain c becomes rows c n .. c n + n - 1 of an n C batch with one seed row each
             for (int i = 0; i < n; ++i) {     // (neighbours: the copies of a chain take the same steps, so they share a wave for free)

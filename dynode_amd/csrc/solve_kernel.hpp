@@ -16,6 +16,8 @@
 // HBM traffic is the compulsory I/O only: P + D floats in, n_save*D_saved floats out.
 // The whole [t0,t1] solve (all steps, accept/reject, dense output) runs inside ONE launch.
 #pragma once
+#include "nuts_device.hpp"
+
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -81,6 +83,10 @@ struct KArgs {
     // work[0] hands out queue entries beyond the first one of every slot, work[1] counts retired slots; the kernel leaves
     // both at zero again (Solver::run).
     int32_t *work;
+    // Fused sampler iteration (dyn_solver_opts::nuts_tail; FUSED instances only): the sampler run whose chains this batch's
+    // trajectories belong to (HOST memory: launch() hands the struct to the kernel by value; the kernel only tests the
+    // pointer), or nullptr.
+    const dynnuts::Tail *nuts_tail;
 };
 constexpr int kMaxJumps = 16;
 
@@ -475,6 +481,12 @@ struct Solver {
     // instruction stream (128 chains on 1024 SIMDs): every switch the wave does not have to evaluate is latency.
     static constexpr bool LEAN = (FEAT & 0x2000) != 0;
     static_assert(!LEAN || (ND > 0 && KV == 0 && !INTRO), "lean instance: tangent kernels of the plain family");
+    // FEAT bit 12: a lean instance whose waves, once their trajectories are scored, run the NUTS state machine of the chains
+    // those trajectories belong to (nuts_device.hpp) -- the sampler iteration as one launch.  Static grids only.
+    static constexpr bool FUSED = (FEAT & 0x1000) != 0;
+    static_assert(!FUSED || LEAN, "the fused sampler tail rides on the lean instance");
+    // where solve_kernel_fused's second argument (dynnuts::Tail, by value) sits in the kernel-argument segment
+    static constexpr size_t kTailOffset = (sizeof(KArgs<T>) + alignof(dynnuts::Tail) - 1) / alignof(dynnuts::Tail) * alignof(dynnuts::Tail);
     static_assert(KV == 0 || ((KV == 2 || KV == 4) && GA % KV == 0), "vaccination tiers: 2 or 4 lanes per age");
     static_assert(ST % SPL == 0, "strains per lane must divide the strain count");
     static constexpr int S = SPL;        // strains held by one lane (all per-lane arrays use S)
@@ -1975,6 +1987,23 @@ struct Solver {
             if (lane == 0) *hand.fin = 1;
             __syncthreads();                   // B
         }
+        if constexpr (FUSED) {
+            // ---- the sampler's side of the iteration, for the chains whose trajectories this wave has just scored (a static
+            // launch without a caller's order: the wave's slots hold trajectories t0 .. t0 + nt - 1; enqueue() checked that
+            // whole chains fall into waves).  One lane per chain, as in nuts_advance.
+            const auto &kc = *cold_args<T>();
+            if (kc.nuts_tail != nullptr) {
+                // the kernel's second argument, read where it is used (like cold_args: nothing of it lives through the stepping loop)
+                const auto &tl = *reinterpret_cast<const dynnuts::Tail __attribute__((address_space(4))) *>(
+                    reinterpret_cast<const char __attribute__((address_space(4))) *>(&kc) + kTailOffset);
+                __threadfence(); // ll_out / dll_out of this wave's trajectories have reached memory
+                const int rows = tl.rows_per_chain;
+                const int nt = TPW >> kc.rep_log2;
+                const int64_t t0 = ((int64_t)blockIdx.x * TPW) >> kc.rep_log2;
+                const int64_t c = t0 / rows + lane;
+                if (lane < nt / rows && c < (int64_t)tl.st.n_chains) dynnuts::fused_tail(tl, (int)c, kc.ll_out, kc.dll_out);
+            }
+        }
     }
 };
 
@@ -1982,6 +2011,14 @@ template <typename T, int METHOD, int GA, int ST, bool HAS_E, bool HAS_WANE, boo
           int FEAT = 0>
 __global__ void __launch_bounds__((FEAT & 0x8000) ? 128 : 64)
 solve_kernel(const KArgs<T> ka) {
+    Solver<T, METHOD, GA, ST, HAS_E, HAS_WANE, HAS_C, W, ND, SPL, FEAT>::run(ka);
+}
+
+// ... of a FUSED instance: the sampler run rides along as a second argument (Solver::run reads it at kTailOffset)
+template <typename T, int METHOD, int GA, int ST, bool HAS_E, bool HAS_WANE, bool HAS_C, int W, int ND, int SPL,
+          int FEAT = 0>
+__global__ void __launch_bounds__(64)
+solve_kernel_fused(const KArgs<T> ka, const dynnuts::Tail tail) {
     Solver<T, METHOD, GA, ST, HAS_E, HAS_WANE, HAS_C, W, ND, SPL, FEAT>::run(ka);
 }
 
@@ -2024,6 +2061,14 @@ hipError_t launch(const KArgs<T> &ka_in, hipStream_t stream) {
         ka.work = nullptr;
         if (ka.rep_log2 != 0 || ka.order != nullptr) return hipErrorInvalidValue; // enqueue() never asks for this
     }
+    if constexpr ((FEAT & 0x1000) != 0) { // fused sampler tail: the wave <-> chain correspondence of a static grid in the given order
+        if (ka.order != nullptr || ka.nuts_tail == nullptr) return hipErrorInvalidValue; // enqueue() never asks for this
+        ka.work = nullptr;
+        hipLaunchKernelGGL((solve_kernel_fused<T, METHOD, GA, ST, HAS_E, HAS_WANE, HAS_C, W, ND, SPL, FEAT>), dim3((unsigned)blocks),
+                           dim3(64), lds, stream, ka, *ka.nuts_tail);
+        return hipGetLastError();
+    } else {
+    ka.nuts_tail = nullptr;
     const auto kernel = solve_kernel<T, METHOD, GA, ST, HAS_E, HAS_WANE, HAS_C, W, ND, SPL, FEAT>;
     int64_t grid = blocks;
     if (ka.work != nullptr) {
@@ -2050,6 +2095,7 @@ hipError_t launch(const KArgs<T> &ka_in, hipStream_t stream) {
     }
     hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(PC ? 128 : 64), lds, stream, ka);
     return hipGetLastError();
+    }
 }
 
 } // namespace dyn

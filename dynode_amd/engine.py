@@ -392,7 +392,8 @@ def solve_batch_loglik(model: ModelDesc, y0, params, contact, t1: float, save_ts
                        dparams, increments: bool = True, floor: float = 1e-6, dy0=None, t0: float = 0.0,
                        method: str = "tsit5", dtype: torch.dtype = torch.float32, rtol: float = 1e-5,
                        atol: float = 1e-6, max_steps: int = 10**6, constant_dt: float = 0.0,
-                       jump_ts: Sequence[float] = (), stream: Optional[torch.cuda.Stream] = None):
+                       jump_ts: Sequence[float] = (), stream: Optional[torch.cuda.Stream] = None,
+                       nuts_tail: Optional[int] = None):
     """Tangent solve with the Poisson observation likelihood fused in (``dyn_solve_batch_loglik``):
     returns ``(logp [B], dlogp [B, n_dir], status, n_accept, n_reject)`` and writes no trajectory.
 
@@ -400,6 +401,10 @@ def solve_batch_loglik(model: ModelDesc, y0, params, contact, t1: float, save_ts
     ``obs_compartment`` at the save times (``increments=False``, ``len(save_ts)`` rows of ``obs``) or
     its increments between them (``increments=True``, one row fewer); the constant
     ``-lgamma(obs + 1)`` is left to the caller.  ``dparams`` [B, n_dir, P] are the seed directions.
+
+    ``nuts_tail``: host address of a ``dyn_nuts_tail_pack`` blob (``infer/folded.py``) -- the launch then also runs the
+    sampler's side of the iteration for the chains it scored (``dyn_solver_opts::nuts_tail``); `SolveError` with code
+    ``DYN_ERR_UNSUPPORTED`` when this call cannot carry it (nothing was enqueued).
     """
     device = require_gpu()
     L = _abi.lib()
@@ -441,6 +446,8 @@ def solve_batch_loglik(model: ModelDesc, y0, params, contact, t1: float, save_ts
     opts = _abi.SolverOptsC(
         _METHODS[method], _DTYPES[dtype], float(rtol), float(atol), int(max_steps), float(constant_dt),
         jt.ctypes.data_as(ctypes.POINTER(ctypes.c_double)) if jt.size else None, int(jt.size))
+    if nuts_tail:
+        opts.nuts_tail = int(nuts_tail)
     s = stream if stream is not None else torch.cuda.current_stream(device)
     def call():
         return L.dyn_solve_batch_loglik(

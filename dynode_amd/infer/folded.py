@@ -181,8 +181,29 @@ class FoldedPotential:
                                                   b["lp"].data_ptr(), b["dlp"].data_ptr(), b["params"].data_ptr(),
                                                   b["seeds"].data_ptr(), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
 
-    def solve_current(self, C: int):
-        """The gradient-solve on the parameter rows and seeds the buffers hold: ``(lp, dlp, ll, dll, ll_stride)``."""
+    def pack_tail(self, st, C: int):
+        """`dyn_nuts_tail_pack`: the (host) blob that lets the gradient-solve run the sampler's side of an iteration itself
+        (``solve_current(C, nuts_tail=...)``: ONE launch per iteration).  ``st`` must carry this potential's prior-side
+        buffers in ``pot_lp`` / ``pot_dlp``.  Returns the blob (keep it alive for as long as launches use it), or None when
+        the library refuses (more than four sampled sites)."""
+        from ..engine import _DTYPES
+
+        L = _abi.lib()
+        b = self._buffers(C)
+        arr, n = self.pot.site_table
+        blob = ctypes.create_string_buffer(int(L.dyn_nuts_tail_size()))
+        rc = L.dyn_nuts_tail_pack(ctypes.byref(st), arr, n, self.P, self.coef.data_ptr(), self.expo.data_ptr(),
+                                  _DTYPES[self.dtype], int(self.split_directions(C)), b["x"].data_ptr(), b["lp"].data_ptr(),
+                                  b["dlp"].data_ptr(), b["params"].data_ptr(), b["seeds"].data_ptr(), blob)
+        if rc == -7:
+            return None
+        if rc:
+            raise RuntimeError(f"dyn_nuts_tail_pack: {_abi.ERR_NAMES.get(rc, rc)}")
+        return blob
+
+    def solve_current(self, C: int, nuts_tail=None):
+        """The gradient-solve on the parameter rows and seeds the buffers hold: ``(lp, dlp, ll, dll, ll_stride)``.
+        ``nuts_tail`` (a `pack_tail` blob): the same launch also advances the sampler (`engine.solve_batch_loglik`)."""
         from ..engine import solve_batch_loglik
         from .autodiff import direction_chunks
 
@@ -191,13 +212,20 @@ class FoldedPotential:
         method = c["kw"].get("method", "tsit5")
         if split:      # n C trajectories with one direction each: ll [n C], dll [n C, 1]
             ll, dll, *_ = solve_batch_loglik(c["model"], c["y0"], b["params"], c["contact"], c["t1"], c["save_ts"], c["obs"],
-                                             c["comp"], dparams=b["seeds"], increments=c["increments"], floor=c["floor"], **c["kw"])
+                                             c["comp"], dparams=b["seeds"], increments=c["increments"], floor=c["floor"],
+                                             nuts_tail=None if nuts_tail is None else ctypes.addressof(nuts_tail), **c["kw"])
         else:
             ll, grads, start = None, [], 0
-            for nd in direction_chunks(c["model"], method, self.dtype, self.n):
+            chunks = list(direction_chunks(c["model"], method, self.dtype, self.n))
+            if nuts_tail is not None and len(chunks) != 1:
+                from ..engine import SolveError
+
+                raise SolveError(-7, "nuts_tail: the directions of a chain take more than one launch")
+            for nd in chunks:
                 seeds = b["seeds"] if nd == self.n else b["seeds"][:, start:start + nd].contiguous()
                 lp_, dlp_, *_ = solve_batch_loglik(c["model"], c["y0"], b["params"], c["contact"], c["t1"], c["save_ts"], c["obs"],
-                                                   c["comp"], dparams=seeds, increments=c["increments"], floor=c["floor"], **c["kw"])
+                                                   c["comp"], dparams=seeds, increments=c["increments"], floor=c["floor"],
+                                                   nuts_tail=None if nuts_tail is None else ctypes.addressof(nuts_tail), **c["kw"])
                 ll = lp_ if ll is None else ll
                 grads.append(dlp_)
                 start += nd

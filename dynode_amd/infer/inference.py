@@ -349,6 +349,9 @@ class MCMCProcess(InferenceProcess):
                                     of its sampled sites and whose only likelihood is the solve's (``infer/folded.py``: the
                                     reference's own inference example is one) is evaluated in three launches per gradient
                                     instead of ~26; any other model silently keeps the general potential (``"verbose"`` says why)
+                     ``fuse``       ``True`` (default) / ``False``: with a folded potential of at most four sites, the
+                                    gradient-solve's waves also run the sampler's side for the chains they scored
+                                    (``dyn_solver_opts::nuts_tail``): a sampler iteration is ONE launch, same draws
     """
 
     num_samples: PositiveInt
@@ -362,7 +365,7 @@ class MCMCProcess(InferenceProcess):
 
     _NUTS_FIXED = {"adapt_step_size": True, "adapt_mass_matrix": True, "regularize_mass_matrix": True,
                    "find_heuristic_step_size": False}
-    _MCMC_OWN = ("sampler", "adaptation", "gradient", "fd_step", "stretch", "thin", "hip_graph", "fold")
+    _MCMC_OWN = ("sampler", "adaptation", "gradient", "fd_step", "stretch", "thin", "hip_graph", "fold", "fuse")
 
     def _check_kwargs(self) -> int:
         """Every key of ``nuts_kwargs`` / ``mcmc_kwargs`` is honoured or refused; returns the thinning factor."""
@@ -442,7 +445,8 @@ class MCMCProcess(InferenceProcess):
         if kind == "kernel" and (pot.dim > 8 or self.nuts_max_tree_depth > 10):
             kind = "graph"
         cls = {"kernel": KernelNUTS, "graph": GraphNUTS, "eager": BatchedNUTS}[kind]
-        extra = {"adaptation": self.mcmc_kwargs.get("adaptation", "per_chain")} if kind == "kernel" else {}
+        extra = {"adaptation": self.mcmc_kwargs.get("adaptation", "per_chain"),
+                 "fuse": bool(self.mcmc_kwargs.get("fuse", True))} if kind == "kernel" else {}
         pg = pot.potential_and_grad
         if self.mcmc_kwargs.get("gradient", "autograd") == "finite_difference":
             # NUTS for models without tangent kernels: central differences over the latent coordinates (Potential above)

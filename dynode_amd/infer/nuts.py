@@ -16,6 +16,7 @@ communicates.
 from __future__ import annotations
 
 import math
+import os
 import sys
 from dataclasses import dataclass
 from typing import Callable, Optional
@@ -789,8 +790,14 @@ class KernelNUTS(LockstepNUTS):
     kernel is fixed, so the sampler stays exact.
     """
 
-    def __init__(self, *args, block: int = 64, use_graph: bool = True, adaptation: str = "per_chain", **kw):
+    def __init__(self, *args, block: int = 64, use_graph: bool = True, adaptation: str = "per_chain", fuse: bool = True, **kw):
         super().__init__(*args, **kw)
+        self.fuse = bool(fuse)
+        # iterations captured into one HIP graph: between two graph launches the GPU idles for about 8 us (a tenth of a cfg 4
+        # iteration), between two kernel nodes of one graph it does not
+        self.unroll = max(1, int(os.environ.get("DYNODE_NUTS_UNROLL", "16")))
+        if int(block) % self.unroll:
+            self.unroll = 1
         if adaptation not in ("per_chain", "pooled"):
             raise ValueError("adaptation must be 'per_chain' or 'pooled'")
         self.block, self.use_graph, self.adaptation = int(block), bool(use_graph), adaptation
@@ -866,8 +873,31 @@ class KernelNUTS(LockstepNUTS):
         if folded is not None:
             folded.map_now(S["z_eval"])
 
+        # ... and where the library can fuse the sampler's side into the gradient-solve (dyn_solver_opts::nuts_tail: whole
+        # chains inside a wave, at most four sites), an iteration is that ONE launch.  DYNODE_NUTS_FUSE=0 keeps the two.
+        tail = {"blob": None}
+        if folded is not None and self.fuse and hasattr(folded, "pack_tail") and os.environ.get("DYNODE_NUTS_FUSE", "1") != "0":
+            b = folded._buffers(C)
+            st.pot_lp, st.pot_dlp, st.pot_offset = b["lp"].data_ptr(), b["dlp"].data_ptr(), float(folded.offset)
+            tail["blob"] = folded.pack_tail(st, C)
+        self.launches_per_iteration = None
+
         def iteration():
+            if tail["blob"] is not None:
+                from ..engine import SolveError
+
+                try:
+                    keep_alive[:] = folded.solve_current(C, nuts_tail=tail["blob"])[:4]
+                    if st.pooled:   # readers of the next launch see the pool as it stands now (nuts_kernel.hip: advance)
+                        S["pool_ro"].copy_(S["pool"])
+                    self.launches_per_iteration = 1
+                    return
+                except SolveError as err:
+                    if err.code != -7:
+                        raise
+                    tail["blob"] = None    # nothing was enqueued: this and every later iteration take the two launches
             if folded is not None:
+                self.launches_per_iteration = 2
                 lp_, dlp_, ll_, dll_, stride = folded.solve_current(C)
                 keep_alive[:] = [lp_, dlp_, ll_, dll_]
                 st.pot_lp, st.pot_dlp, st.pot_ll, st.pot_dll = lp_.data_ptr(), dlp_.data_ptr(), ll_.data_ptr(), dll_.data_ptr()
@@ -889,15 +919,17 @@ class KernelNUTS(LockstepNUTS):
                     torch.cuda.synchronize()
                     graph = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(graph):
-                        iteration()
+                        for _ in range(self.unroll):
+                            iteration()
                 except Exception as err:  # pragma: no cover - depends on the model
                     torch.cuda.synchronize()
                     print(f"[dynode_amd] NUTS iteration not graph-capturable ({type(err).__name__}: {str(err)[:120]}); eager", file=sys.stderr, flush=True)
                     graph, self.use_graph = None, False
-            for _ in range(self.block):
-                if graph is not None:
+            if graph is not None:
+                for _ in range(self.block // self.unroll):
                     graph.replay()
-                else:
+            else:
+                for _ in range(self.block):
                     iteration()
             self.evals += self.block
             blocks += 1
@@ -911,5 +943,5 @@ class KernelNUTS(LockstepNUTS):
             if progress is not None:
                 m = int(S["it"].min())
                 progress(max(m - 1, 0), m <= num_warmup)
-        self._keep = (graph, st, S)
+        self._keep = (graph, st, S, tail["blob"])
         return NUTSResult(S["out_z"], S["out_acc"], S["out_n"].long(), S["out_div"].bool(), S["eps"], S["imm"], self.evals)

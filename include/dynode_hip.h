@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define DYN_ABI_VERSION 7
+#define DYN_ABI_VERSION 8
 /* the save grid is staged in LDS: n_save * sizeof(real) must not exceed this */
 #define DYN_MAX_SAVE_BYTES 49152
 
@@ -143,6 +143,18 @@ typedef struct dyn_solver_opts {
      * any kernel when the caller supplies the queue (dyn_solve_batch_ordered: longest-first needs dynamic assignment).
      * NULL, batches of one resident round, and the SEIP family: a static grid, as before ABI 7. */
     int32_t *work_counter;
+    /* Fused sampler iteration (ABI 8, dyn_solve_batch_loglik only): HOST pointer to a blob written by dyn_nuts_tail_pack,
+     * or NULL.  When set, every wave of the gradient-solve goes on, after scoring its trajectories, to run the NUTS state
+     * machine (what dyn_nuts_advance_mapped does in a launch of its own) for the chains whose trajectories it just scored,
+     * reading log-likelihood and gradient from what it wrote and leaving the parameter rows / tangent seeds of the chains'
+     * next positions in `params` / `dparams` (which must be the blob's buffers) for the next call: one launch per sampler
+     * iteration instead of two, the same draws bit for bit.  The blob is read during the call (it travels as a kernel
+     * argument), so a captured HIP graph holds its own copy.  Needs the chain-major batch of dyn_nuts_advance_mapped (chain c
+     * = trajectories c*rows .. c*rows + rows - 1), every chain's trajectories inside one wave, no caller order, at most 4
+     * sampled dimensions and the likelihood options of the reference's inference example (poisson on slot 3 increments);
+     * otherwise the call returns DYN_ERR_UNSUPPORTED with nothing enqueued and the caller keeps its two launches
+     * (DYN_ERR_OPTS: the pointer is not a packed blob). */
+    const void *nuts_tail;
 } dyn_solver_opts;
 
 /* per-trajectory status */
@@ -393,6 +405,15 @@ int dyn_potential_combine(int64_t C, int32_t n, const double *lp, const double *
 int dyn_nuts_advance_mapped(const dyn_nuts_state *st, const dyn_site_desc *sites, int32_t n_sites, int32_t P, const double *coef,
                             const double *expo, int32_t dtype, int32_t split_directions, double *x, double *lp, double *dlp_dz,
                             void *params, void *seeds, void *stream);
+/* The blob dyn_solver_opts::nuts_tail points at: the arguments of dyn_nuts_advance_mapped, written to `blob` (HOST memory of
+ * dyn_nuts_tail_size() bytes, owned by the caller).  st->pot_lp / pot_dlp / pot_offset must be set (= lp, dlp_dz);
+ * st->pot_ll / pot_dll are not used -- the fused launch reads what it wrote itself.  The device buffers named inside must stay
+ * valid and unmoved for as long as launches use the blob (a sampler run: the state buffers never move).  DYN_ERR_UNSUPPORTED:
+ * more than 4 sampled dimensions. */
+int32_t dyn_nuts_tail_size(void);
+int dyn_nuts_tail_pack(const dyn_nuts_state *st, const dyn_site_desc *sites, int32_t n_sites, int32_t P, const double *coef,
+                       const double *expo, int32_t dtype, int32_t split_directions, double *x, double *lp, double *dlp_dz,
+                       void *params, void *seeds, void *blob);
 
 /*
  * Dispatch order.  dyn_solve_batch_ordered is dyn_solve_batch with one more argument: grid slot i integrates trajectory

@@ -455,6 +455,69 @@ def test_folded_potential_equals_the_general_one(data):
     assert torch.allclose(ua, ub, rtol=1e-12, atol=1e-8) and torch.allclose(ga, gb, rtol=1e-9, atol=1e-7)
 
 
+@pytest.mark.parametrize("adaptation", ["per_chain", "pooled"])
+@pytest.mark.parametrize("chains", [16, 1200])
+def test_one_launch_per_iteration_draws_the_same_chains(data, adaptation, chains):
+    """dyn_solver_opts::nuts_tail: the gradient-solve's waves run the sampler's side for the chains they scored.  Same
+    arithmetic, same random streams: every draw equals the two-launch iteration's bit for bit (16 chains: directions split
+    over trajectory pairs, 8 replicas each; 1200: both directions in one trajectory)."""
+    from dynode_amd.infer import folded
+    from dynode_amd.infer.nuts import KernelNUTS
+
+    kw = dict(config=ex.get_config(), tf=100, obs_data=data)
+    pot = Potential(ex.model_fused, kw, 0, torch.device("cuda"))
+    z0 = pot.initial(chains, init_to_median, 3)
+    runs = {}
+    for fuse in (True, False):
+        f = folded.discover(pot)
+        assert f is not None
+        sampler = KernelNUTS(f, max_tree_depth=6, target_accept=0.8, seed=11, adaptation=adaptation, fuse=fuse, block=16)
+        sampler.recheck_blocks = ()
+        res = sampler.run(z0, 160, 40)
+        runs[fuse] = (res.samples.clone(), res.accept_prob.clone(), res.num_steps.clone(), res.step_size.clone(), sampler.launches_per_iteration)
+    assert runs[True][4] == 1 and runs[False][4] == 2
+    for a, b in zip(runs[True][:4], runs[False][:4]):
+        assert torch.equal(a, b)
+    assert bool(torch.isfinite(runs[True][0]).all()) and float(runs[True][0].std()) > 0
+
+
+def test_a_call_that_cannot_carry_the_sampler_is_refused(data):
+    """A nuts_tail the library did not pack is an option error; a packed one whose chains are not this batch's returns
+    DYN_ERR_UNSUPPORTED.  Nothing runs either way."""
+    import ctypes
+
+    from dynode_amd import _abi
+    from dynode_amd.engine import SolveError, solve_batch_loglik
+    from dynode_amd.infer import folded
+
+    kw = dict(config=ex.get_config(), tf=100, obs_data=data)
+    pot = Potential(ex.model_fused, kw, 0, torch.device("cuda"))
+    f = folded.discover(pot)
+    z = pot.initial(16, init_to_median, 3)
+    f(z)
+    b, c = f._buffers(16), f.call
+
+    def solve(blob, rows=None):
+        sl = slice(None) if rows is None else slice(0, rows)
+        return solve_batch_loglik(c["model"], c["y0"], b["params"][sl], c["contact"], c["t1"], c["save_ts"], c["obs"], c["comp"],
+                                  dparams=b["seeds"][sl], increments=c["increments"], floor=c["floor"],
+                                  nuts_tail=ctypes.addressof(blob), **c["kw"])
+
+    size = int(_abi.lib().dyn_nuts_tail_size())
+    with pytest.raises(SolveError) as err:
+        solve(ctypes.create_string_buffer(size))
+    assert err.value.code == -4
+    # a real blob (the sampler state of 16 chains), offered to a batch of 8 chains' rows
+    st = _abi.NutsStateC()
+    st.n_chains, st.dim, st.max_depth, st.num_warmup, st.num_samples = 16, 2, 6, 10, 10
+    st.pot_lp, st.pot_dlp = b["lp"].data_ptr(), b["dlp"].data_ptr()
+    blob = f.pack_tail(st, 16)
+    assert blob is not None and len(blob) == size
+    with pytest.raises(SolveError) as err:
+        solve(blob, rows=16)
+    assert err.value.code == -7 and "nuts_tail" in str(err.value)
+
+
 def test_models_without_the_structure_keep_the_general_potential(data, capsys):
     from dynode_amd.infer import folded
 
