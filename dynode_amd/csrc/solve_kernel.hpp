@@ -16,6 +16,13 @@
 // HBM traffic is the compulsory I/O only: P + D floats in, n_save*D_saved floats out.
 // The whole [t0,t1] solve (all steps, accept/reject, dense output) runs inside ONE launch.
 #pragma once
+// (diagnostic builds, tools/diag_build.sh W3: every solve kernel compiled for three waves per SIMD)
+#ifdef DYN_DIAG_W3
+#define DYN_KERNEL_ATTR __attribute__((amdgpu_waves_per_eu(3, 3)))
+#endif
+#ifndef DYN_KERNEL_ATTR
+#define DYN_KERNEL_ATTR
+#endif
 #include "nuts_device.hpp"
 
 #include <hip/hip_runtime.h>
@@ -2007,9 +2014,20 @@ struct Solver {
     }
 };
 
+// Waves per SIMD the kernel is compiled for, (min, max).  The D = 360 ensemble kernel (8 ages x 4 strain lanes, eight waning
+// bins) needs 188 registers left alone: two waves per SIMD, whose vector units are then busy 87 % of the time.  Compiled for
+// three (168 registers: the compiler parks fourteen loop-invariant values in scratch and reloads them where the right-hand side
+// uses them) the same launch is 1.7 % shorter (2.54 -> 2.50 ms, one box, A/B in docs/perf-log.md).  Everything else: the
+// compiler's default range.
+template <typename T, int METHOD, int GA, int ST, int W, int ND, int SPL, int FEAT>
+constexpr int waves_per_simd(bool upper) {
+    return (sizeof(T) == 4 && METHOD == 0 && GA == 8 && ST == 4 && W == 8 && ND == 0 && SPL == 1 && (FEAT & ~0x4000) == 0) ? 3 : (upper ? 8 : 1);
+}
+
 template <typename T, int METHOD, int GA, int ST, bool HAS_E, bool HAS_WANE, bool HAS_C, int W, int ND, int SPL,
           int FEAT = 0>
-__global__ void __launch_bounds__((FEAT & 0x8000) ? 128 : 64)
+__global__ void __launch_bounds__((FEAT & 0x8000) ? 128 : 64) DYN_KERNEL_ATTR
+__attribute__((amdgpu_waves_per_eu(waves_per_simd<T, METHOD, GA, ST, W, ND, SPL, FEAT>(false), waves_per_simd<T, METHOD, GA, ST, W, ND, SPL, FEAT>(true))))
 solve_kernel(const KArgs<T> ka) {
     Solver<T, METHOD, GA, ST, HAS_E, HAS_WANE, HAS_C, W, ND, SPL, FEAT>::run(ka);
 }

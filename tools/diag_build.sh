@@ -11,7 +11,7 @@ W=$(mktemp -d)
 mkdir -p "$W/dynode_amd" "$W/include"
 cp -r "$ROOT/dynode_amd/csrc" "$W/dynode_amd/" && cp "$ROOT/include/dynode_hip.h" "$W/include/"
 rm -rf "$W/dynode_amd/csrc/build"
-make -C "$W/dynode_amd/csrc" -j8 -s HIPFLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -DDYN_DIAG_$V" 2>&1 | grep -v warning || true
+make -C "$W/dynode_amd/csrc" -j8 -s ${DIAG_TARGET:-all} HIPFLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -DDYN_DIAG_$V" 2>&1 | grep -v warning || true
 cp "$W/dynode_amd/lib/libdynode_hip.so" "$ROOT/tools/probes/_lib_$V.so"
 rm -rf "$W"
 echo "$ROOT/tools/probes/_lib_$V.so"
