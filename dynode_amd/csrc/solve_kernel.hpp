@@ -512,6 +512,7 @@ struct Solver {
     // round (all computed for ILP, stores predicated) instead of one.
     static constexpr int SU = (NV * NC <= 4) ? 4 : (NV * NC <= 9 ? 2 : 1);
     static constexpr int NDA = ND > 0 ? ND : 1; // array extent for tangent-only data
+    using Scalar = T;
     using M = Mth<T>;
     using TB = Tab<METHOD>;
 
@@ -1401,618 +1402,202 @@ struct Solver {
         if (valid && writer)
             for (; save_idx < n_save; ++save_idx) fill_row(ka, out_traj + (int64_t)save_idx * ka.d_saved, a, as, lead, M::inf());
     }
+    // ================================================================ the family interface of Stepper<F> (stepper.hpp)
+    static constexpr int NDIR = ND;                 // tangent directions (planes 1..ND of the state)
+    static constexpr bool PULLS = true;             // slots may draw further trajectories from KArgs::work
+    static constexpr bool REPLAYS = false;          // (recorded step schedules: the SEIP family)
+    static constexpr bool IDLE_SLOTS_LOAD = false;  // a slot beyond the batch idles without data
+    int a, as;            // age lane; (age, first global strain of this lane) = a ST + s0: the lane's place in a compartment
+    bool writer, leader;  // the lane stores rows (not a pad lane) / reports the trajectory's status (age 0, strain lane 0)
 
-    // ---- the solve.  A lane group is a SLOT that integrates one trajectory after the other:
-    //   static launches (KArgs::work == nullptr): grid = ceil(B 2^rep / TPW) waves, slot i takes trajectory i and stops;
-    //   work-pulling launches (KArgs::work != nullptr; the host sizes the grid to the waves the chip can hold at once):
-    //     slot i starts with trajectory i and, whenever its trajectory finishes, draws the next index from a device
-    //     counter (atomicAdd) and re-runs the prologue under its group's lanes while the other groups of the wave keep
-    //     stepping.  The lane groups of a wave still step in lock-step, but none of them waits for a finished partner for
-    //     longer than the rest of an iteration, and the launch ends when the queue is empty -- no max-over-groups of whole
-    //     trajectories, no round structure, nothing learned in advance.  With KArgs::order the queue is that permutation
-    //     (most expensive first, if the caller knows): tickets index it.
-    // Every trajectory is computed from its own inputs alone, with the same instructions whatever slot runs it, so the
-    // results do not depend on the assignment (tests/test_gpu_parity.py: dispatch order / batch position invariance).
-    __device__ __forceinline__ static void run(const KArgs<T> &ka) {
-        const int lane = threadIdx.x & 63;
-        const int a = lane % GA;          // age lane
+    // lane indices and what every trajectory of the launch shares (contact row, model switches); -> the lane's slot in the wave
+    __device__ __forceinline__ int init(const KArgs<T> &ka, int lane) {
+        a = lane % GA;                    // age lane
         const int h = (lane / GA) % GS;   // strain lane: strains h*SPL .. h*SPL+SPL-1
-        const int grp = lane / G;
-        const int64_t gslot = (int64_t)blockIdx.x * TPW + grp;
-        const int R = 1 << ka.rep_log2;                 // replicas per trajectory (static launches only)
-        const int rep = (int)(gslot & (R - 1));         // this group's replica number
-        const bool pull = ka.work != nullptr;
         const int A = ka.A;
-        Solver L;
-        L.pad = a >= A;
-        L.lead = h == 0;
-        L.normalize = LEAN ? true : ka.normalize != 0;
-        L.seasonal = LEAN ? false : ka.seasonal != 0;
-        const int aa = L.pad ? 0 : a;
-        const bool writer = !L.pad;
-        const int s0 = h * SPL; // first global strain of this lane
-
-        const int D = A * (1 + ST * ((HAS_E ? 1 : 0) + 1 + W + (HAS_C ? 1 : 0)));   // state dimension (compartment-major layout)
-
-        // ---- contact row, pre-permuted to the xor-exchange order (shared by every trajectory of the launch)
+        pad = a >= A;
+        lead = h == 0;
+        normalize = LEAN ? true : ka.normalize != 0;
+        seasonal = LEAN ? false : ka.seasonal != 0;
+        const int aa = pad ? 0 : a;
+        writer = !pad;
+        leader = a == 0 && lead;
+        as = a * ST + h * SPL;
+        // contact row, pre-permuted to the xor-exchange order
 #pragma unroll
         for (int k = 0; k < GA; ++k) {
             const int b = a ^ k;
-            L.Cx[k] = (!L.pad && b < A) ? ka.contact[aa * A + b] : T(0);
+            Cx[k] = (!pad && b < A) ? ka.contact[aa * A + b] : T(0);
         }
+        return lane / G;
+    }
+    __device__ __forceinline__ static int state_dim(const KArgs<T> &ka) { // compartment-major layout
+        return ka.A * (1 + ST * ((HAS_E ? 1 : 0) + 1 + W + (HAS_C ? 1 : 0)));
+    }
 
-        const T rtol = ka.rtol, atol = ka.atol, t_end = ka.t1;
-        const T Dn = T(D);
-        const bool constant = LEAN ? false : ka.constant_dt > T(0);
-        const int n_save = ka.n_save;
-        bool fused_ll = false, ll_table = false;
+    // LDS behind the save grid and the discontinuity points
+    struct Tables {
+        bool fused_ll, ll_table;   // tangent kernels: the likelihood is scored instead of rows / ... through the table of replicated trajectories
+        T *ll_lane;                // likelihood table (replicated trajectories): [trajectory slot][save index][lane of group][LLMAX][planes]
+        V4 *rate_tab;              // PRESCALE: the rates (and their seeds) as loaded, [quad][lane], 16-byte aligned behind the other tables
+        Handoff hand;              // PC: the accepted step on its way to the row-writing wave
+    };
+    static constexpr int LL_ROW = G * LLMAX * NC;
+    __device__ __forceinline__ void carve(const KArgs<T> &ka, Tables &tb, T *ts_tab, T *free_lds, int lane, int grp, int n_save, int n_jump) const {
+        tb.fused_ll = tb.ll_table = false;
         if constexpr (ND > 0) {
-            fused_ll = LEAN ? true : ka.obs != nullptr;
-            ll_table = fused_ll && R > 1;
+            tb.fused_ll = LEAN ? true : ka.obs != nullptr;
+            tb.ll_table = tb.fused_ll && ka.rep_log2 > 0;
         }
-        // The save grid lives in LDS: a global load inside the save loop would share the
-        // in-order vmcnt counter with the output stores, and waiting for it would drain every
-        // store of the previous round (measured: the dominant stall of the save path).
-        // LDS reads count on lgkmcnt, so stores stay fire-and-forget.
-        extern __shared__ __attribute__((aligned(32))) unsigned char dyn_smem[];
-        T *const ts_tab = reinterpret_cast<T *>(dyn_smem); // LDS address space: ds_read only
-        for (int j = lane; j < n_save; j += 64) ts_tab[j] = ka.save_ts[j];
-        // discontinuity points follow the save grid in LDS (per-group index into the table)
-        T *const jt_tab = ts_tab + n_save;
-        const int n_jump = LEAN ? 0 : ka.n_jump;
-        // likelihood table (replicated trajectories): [trajectory slot][save index][lane of group][LLMAX][planes]
-        constexpr int LL_ROW = G * LLMAX * NC;
-        T *const ll_tab = jt_tab + (n_jump > 0 ? kMaxJumps : 0);
-        T *const ll_lane = ll_tab + ((int64_t)((lane / G) >> ka.rep_log2) * n_save * LL_ROW + (lane % G) * (LLMAX * NC));
-        // PRESCALE: the rates (and their seeds) as loaded, [quad][lane], 16-byte aligned behind the other tables
-        V4 *const rate_tab = reinterpret_cast<V4 *>(
-            ts_tab + (((n_save + (n_jump > 0 ? kMaxJumps : 0) + (ll_table ? (64 >> ka.rep_log2) * n_save * LLMAX * NC : 0)) + 3) & ~3));
-        if (n_jump > 0 && lane == 0) {
-#pragma unroll
-            for (int j = 0; j < kMaxJumps; ++j) jt_tab[j] = ka.jump_ts[j];
-        }
-        [[maybe_unused]] Handoff hand{nullptr, nullptr, nullptr, nullptr};
+        tb.ll_lane = free_lds + ((int64_t)((lane / G) >> ka.rep_log2) * n_save * LL_ROW + (lane % G) * (LLMAX * NC));
+        tb.rate_tab = reinterpret_cast<V4 *>(
+            ts_tab + (((n_save + (n_jump > 0 ? kMaxJumps : 0) + (tb.ll_table ? (64 >> ka.rep_log2) * n_save * LLMAX * NC : 0)) + 3) & ~3));
+        tb.hand = Handoff{nullptr, nullptr, nullptr, nullptr};
         if constexpr (PC) {
-            hand.planes = reinterpret_cast<V2 *>(rate_tab + NRQ * 64);
-            hand.tprev = reinterpret_cast<T *>(hand.planes + 5 * NP * 64);
-            hand.tnext = hand.tprev + 64;
-            hand.fin = reinterpret_cast<int *>(hand.tnext + 64);
-            if (threadIdx.x == 0) *hand.fin = 0;
+            tb.hand.planes = reinterpret_cast<V2 *>(tb.rate_tab + NRQ * 64);
+            tb.hand.tprev = reinterpret_cast<T *>(tb.hand.planes + 5 * NP * 64);
+            tb.hand.tnext = tb.hand.tprev + 64;
+            tb.hand.fin = reinterpret_cast<int *>(tb.hand.tnext + 64);
+            if (threadIdx.x == 0) *tb.hand.fin = 0;
         }
-        __syncthreads();
-        const bool vec_ok = ka.vec_ok != 0;
-        const int as = a * ST + s0;
-        if constexpr (PC) {
-            if (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 1) { // wave 1: the rows of wave 0's trajectories
-                const int64_t t = gslot;           // (static launch, no replicas, no caller's order: enqueue() guarantees it)
-                consume(ka, hand, ts_tab, lane, a, as, L.lead, writer, t < ka.B, t < ka.B ? t : 0);
-                return;
-            }
-        }
+    }
 
-        // ---- the slot's trajectory: state, stage derivatives, step control
-        State y[NC], yt[NC], k[7][NC];
+    // parameters and initial state (plane 0) with its seeds (planes 1..ND) of trajectory `traj`, under this group's lanes.
+    // The lane's indices and the layout offsets are re-derived HERE from values the compiler cannot see through (lane_c,
+    // the cold kernel arguments): hoisted out of the stepping loop, the address arithmetic of this block would hold a dozen
+    // registers through every iteration (the D = 136 kernel sits at the 256-register line)
+    template <typename KA>
+    __device__ __forceinline__ void load_trajectory(const KA &kc, int64_t traj, int lane_c, Tables &tb, State (&y)[NC]) {
+        const int Ac = kc.A;
+        const int a_c = lane_c % GA, s0_c = ((lane_c / GA) % GS) * SPL, aa_c = a_c >= Ac ? 0 : a_c;
+        const int cE = Ac, cI = Ac + (HAS_E ? Ac * ST : 0), cR = cI + Ac * ST, cC = cR + Ac * ST * W;
+        const int Dc = cC + (HAS_C ? Ac * ST : 0);
+        load_parameters(kc, traj, a_c, aa_c, s0_c);
+        if constexpr (PRESCALE) park_rates(tb.rate_tab, lane_c);
+        // initial state (plane 0) and its seeds (planes 1..ND)
 #pragma unroll
-        for (int c = 0; c < NC; ++c) { // (also the pad element of every plane: zero for good -- nothing but the pairwise stepper touches it)
-#pragma unroll
-            for (int pp = 0; pp < NP; ++pp) {
-                y[c].p[pp] = V2{T(0), T(0)};
-                yt[c].p[pp] = V2{T(0), T(0)};
-#pragma unroll
-                for (int q = 0; q < 7; ++q) k[q][c].p[pp] = V2{T(0), T(0)};
-            }
-        }
-        int64_t traj = 0;
-        bool live = false, done = true;      // live: a trajectory is loaded and not yet written off; done: nothing to step
-        T tprev = ka.t0, tnext = ka.t0, ts_next = M::inf(), ts_next2 = M::inf(), dt_unclipped = T(0);
-        int save_idx = 0, jidx = 0, waited = 0;
-        bool at_jump = false;
-        int64_t steps = 0;
-        int32_t n_acc = 0, n_rej = 0, st = ST_OK;
-        T *out_traj = ka.out, *dout_traj = nullptr;
-        LL ll;
-#ifdef DYN_DIAG_ROUNDS
-        int diag_iters = 0, diag_rounds = 0;
-#endif
-        // first assignment: slot i takes entry i of the queue
-        bool need_load = false, want_ticket = false;
-        {
-            int64_t t = gslot >> ka.rep_log2;
-            if (t < ka.B) {
-                if (ka.order) t = ka.order[t];
-                // an order that is not a permutation never makes the kernel touch memory outside the batch: the entry is skipped
-                if ((uint64_t)t < (uint64_t)ka.B) {
-                    traj = t;
-                    need_load = true;
-                } else {
-                    want_ticket = pull;
-                }
-            }
-        }
-
-        for (;;) {
-            // A slot that needs work waits an iteration or two when another group of its wave is on the last step of ITS
-            // trajectory (tnext == t_end): one pass of the prologue then serves both (the pass costs the wave about a third of
-            // an iteration however many of its groups it loads).
-            bool draw = false;
-            if (__builtin_expect(__any(want_ticket), 0)) { // wave-uniform
-                const bool closing = __any(!done && !(tnext < t_end));
-                draw = want_ticket && !(closing && waited < 2);
-                waited += (want_ticket && !draw) ? 1 : 0;
-            }
-            if (__builtin_expect(draw, 0)) { // (lane-group uniform) draw the next entry of the queue
-                waited = 0;
-                const auto &kc = *cold_args<T>();
-                int32_t *const work = kc.work;
-                const int32_t *const order = kc.order;
-                const int64_t B = kc.B;
-                const int64_t n_slots = (int64_t)gridDim.x * TPW;
-                for (;;) {
-                    long long t = 0;
-                    if ((lane & (G - 1)) == 0) {
-                        t = n_slots + (long long)atomicAdd(work, 1);
-                        if (t >= B) {
-                            // this slot retires; the last one to retire re-arms the counters, so that the caller can hand
-                            // the same two words to its next launch on the stream without clearing them
-                            if (atomicAdd(work + 1, 1) == (int)(n_slots - 1)) {
-                                __atomic_store_n(work, 0, __ATOMIC_RELAXED);
-                                __atomic_store_n(work + 1, 0, __ATOMIC_RELAXED);
-                            }
-                        }
-                    }
-                    t = __shfl(t, lane & ~(G - 1), 64);
-                    if (t >= B) break;
-                    if (order) t = order[t];
-                    if ((uint64_t)t < (uint64_t)B) {
-                        traj = t;
-                        need_load = true;
-                        break;
-                    }
-                }
-                want_ticket = false;
-            }
-            if (__builtin_expect(need_load, 0)) { // ---- prologue of trajectory `traj`, under this group's lanes
-                need_load = false;
-                const auto &kc = *cold_args<T>();
-                // the lane's indices and the layout offsets are re-derived HERE from values the compiler cannot see through:
-                // hoisted out of the stepping loop, the address arithmetic of this block would hold a dozen registers through
-                // every iteration (the D = 136 kernel sits at the 256-register line)
-                int lane_c = lane;
-                asm volatile("" : "+v"(lane_c));
-                const int Ac = kc.A;
-                const int a_c = lane_c % GA, s0_c = ((lane_c / GA) % GS) * SPL, aa_c = a_c >= Ac ? 0 : a_c;
-                const int cE = Ac, cI = Ac + (HAS_E ? Ac * ST : 0), cR = cI + Ac * ST, cC = cR + Ac * ST * W;
-                const int Dc = cC + (HAS_C ? Ac * ST : 0);
-                L.load_parameters(kc, traj, a_c, aa_c, s0_c);
-                if constexpr (PRESCALE) L.park_rates(rate_tab, lane_c);
-                // initial state (plane 0) and its seeds (planes 1..ND)
-#pragma unroll
-                for (int c = 0; c < NC; ++c) {
-                    const T *src;
-                    bool zero = L.pad;
-                    if (c == 0) {
-                        src = kc.y0 + (kc.y0_batched ? traj * Dc : 0);
-                    } else {
-                        const T *const dy0 = kc.dy0;
-                        zero = zero || dy0 == nullptr;
-                        src = dy0 + ((kc.dy0_batched ? traj * ND : 0) + (c - 1)) * (int64_t)Dc;
-                    }
-                    y[c][IS] = zero ? T(0) : src[aa_c];
-#pragma unroll
-                    for (int l = 0; l < S; ++l) {
-                        const int sg = aa_c * ST + s0_c + l; // (age, global strain)
-                        if constexpr (HAS_E) y[c][IE + l] = zero ? T(0) : src[cE + sg];
-                        y[c][II + l] = zero ? T(0) : src[cI + sg];
-#pragma unroll
-                        for (int w = 0; w < W; ++w) y[c][IR + l * W + w] = zero ? T(0) : src[cR + sg * W + w];
-                        if constexpr (HAS_C) y[c][IC + l] = zero ? T(0) : src[cC + sg];
-                    }
-                }
-                tprev = kc.t0;
-                L.rhs(tprev, y, k[0]);
-                // NaN / inf in the initial state or its derivative (e.g. NaN parameters): fail at once
-                bool lane_ok = true; // comparisons, not x - x: under -ffp-contract an expression minus itself need not be 0
-#pragma unroll
-                for (int v = 0; v < NV; ++v)
-                    lane_ok = lane_ok && (M::abs(y[0][v]) < M::inf()) && (M::abs(k[0][0][v]) < M::inf());
-                const unsigned long long bad_lanes = __ballot(!lane_ok);
-                const unsigned long long group_mask = (G == 64 ? ~0ull : ((1ull << G) - 1ull)) << ((lane_c / G) * G);
-                const bool start_ok = (bad_lanes & group_mask) == 0ull;
-
-                if (constant) {
-                    tnext = tprev + ka.constant_dt;
-                } else {
-                    // Hairer-Norsett-Wanner II.4 starting step (diffrax _select_initial_step), primal only
-                    // the replicated s (element 0) enters every norm once: only the lead strain lane counts it
-                    const T w_s = L.lead ? T(1) : T(0);
-                    T n0 = 0, n1 = 0;
-                    T rsc[NV];   // float32: 1 / scale (three divisions per element would be half of this block's instructions); float64: scale
-#pragma unroll
-                    for (int v = 0; v < NV; ++v) {
-                        rsc[v] = M::rcp_ctl(atol + M::abs(y[0][v]) * rtol);
-                        const T q0 = M::div_ctl(y[0][v], rsc[v]), q1 = M::div_ctl(k[0][0][v], rsc[v]);
-                        n0 += (v == IS ? w_s : T(1)) * (q0 * q0);
-                        n1 += (v == IS ? w_s : T(1)) * (q1 * q1);
-                    }
-                    const T d0 = M::sqrt(group_sum<G>(n0) / Dn), d1 = M::sqrt(group_sum<G>(n1) / Dn);
-                    const bool small = (d0 < T(1e-5)) || (d1 < T(1e-5));
-                    const T h0 = small ? T(1e-6) : T(0.01) * (d0 / d1);
-#pragma unroll
-                    for (int c = 0; c < NC; ++c)
-#pragma unroll
-                        for (int pp = 0; pp < NP; ++pp) yt[c].p[pp] = y[c].p[pp] + h0 * k[0][c].p[pp];
-                    L.rhs(tprev + h0, yt, k[1]);
-                    T s2 = 0;
-#pragma unroll
-                    for (int v = 0; v < NV; ++v) {
-                        const T q2 = M::div_ctl(k[1][0][v] - k[0][0][v], rsc[v]);
-                        s2 += (v == IS ? w_s : T(1)) * (q2 * q2);
-                    }
-                    const T d2 = M::sqrt(group_sum<G>(s2) / Dn) / h0;
-                    const T max_d = M::max(d1, d2);
-                    tnext = tprev + M::min(T(100) * h0, Control<T>::initial_h1(max_d, h0));
-                }
-                tnext = M::min(tnext, t_end);
-
-                save_idx = rep; // replica r owns save times r, r + R, r + 2R, ...
-                // jump bookkeeping (restates oracle/dynode_oracle_impl.inc): steps are clipped to land just
-                // before a jump, restart just after it with FSAL recomputed and the unclipped step size
-                jidx = 0;
-                at_jump = false;
-                dt_unclipped = T(0);
-                if (n_jump > 0) {
-                    while (jidx < n_jump && jt_tab[jidx] <= tprev) ++jidx;
-                    if (jidx < n_jump && jt_tab[jidx] < tnext) {
-                        dt_unclipped = tnext - tprev;
-                        tnext = M::next(jt_tab[jidx], -M::inf());
-                        at_jump = true;
-                    }
-                }
-                if constexpr (PRESCALE) { // from here on the rates and k[0] carry the factor of the step about to be tried
-                    const T dt0 = tnext - tprev;
-                    L.scale_rates(rate_tab, lane_c, dt0);
-#pragma unroll
-                    for (int c = 0; c < NC; ++c)
-#pragma unroll
-                        for (int pp = 0; pp < NP; ++pp) k[0][c].p[pp] = k[0][c].p[pp] * dt0;
-                }
-                // next two save times kept in registers (the read of ts[idx+2] overlaps a whole round)
-                ts_next = save_idx < n_save ? ts_tab[save_idx] : M::inf();
-                ts_next2 = save_idx + R < n_save ? ts_tab[save_idx + R] : M::inf();
-                steps = 0;
-                n_acc = 0;
-                n_rej = 0;
-                st = start_ok ? ST_OK : ST_NONFINITE;
-                done = !(tprev < t_end) || !start_ok;
-                live = true;
-                out_traj = kc.out + traj * (int64_t)n_save * ka.d_saved;
-                if constexpr (ND > 0) {
-                    dout_traj = kc.dout + traj * (int64_t)n_save * ND * ka.d_saved;
-                    ll.acc = 0.0;
-#pragma unroll
-                    for (int c = 0; c < NC; ++c) {
-                        ll.dacc[c] = 0.0;
-#pragma unroll
-                        for (int q = 0; q < LLMAX; ++q) ll.prev[c][q] = T(0);
-                    }
-                }
-#ifdef DYN_DIAG_ROUNDS
-                diag_iters = diag_rounds = 0;
-#endif
-            }
-            if (!__any(live)) break;
-
-#ifdef DYN_DIAG_ROUNDS
-            ++diag_iters;
-#endif
-            const T dt = tnext - tprev;
-            // ---- stages 2..7 (k[] hold f; k[0] is FSAL)
-#pragma unroll
-            for (int sg = 1; sg < 7; ++sg) {
-#pragma unroll
-                for (int c = 0; c < NC; ++c)
-#pragma unroll
-                    for (int pp = 0; pp < NP; ++pp) { // register pairs: v_pk_fma_f32
-                        if constexpr (PRESCALE) {   // k[] hold dt f: y + sum a k, the chain starts on y
-                            V2 acc = T(TB::a[sg][0]) * k[0][c].p[pp] + y[c].p[pp];
-#pragma unroll
-                            for (int q = 1; q < sg; ++q)
-                                if (TB::a[sg][q] != 0.0) acc += T(TB::a[sg][q]) * k[q][c].p[pp];
-                            yt[c].p[pp] = acc;
-                        } else {
-                            V2 acc = T(TB::a[sg][0]) * k[0][c].p[pp];
-#pragma unroll
-                            for (int q = 1; q < sg; ++q)
-                                if (TB::a[sg][q] != 0.0) acc += T(TB::a[sg][q]) * k[q][c].p[pp];
-                            yt[c].p[pp] = y[c].p[pp] + dt * acc;
-                        }
-                    }
-                L.rhs(tprev + T(TB::c[sg]) * dt, yt, k[sg]);
-            }
-            // after stage 7, yt == y1 (a[6][:] == b) and k[6] == f(tnext, y1)
-
-            // ---- embedded error, RMS norm over the whole (primal) state, I-controller
-            bool keep = true, finite = true;
-            T factor = T(1);
-            if (__builtin_expect(!constant, 1)) {
-                // scaled error per element, pair by pair: only |.|, max and the reciprocal are one-element instructions
-                V2 ssq[2] = {V2{T(0), T(0)}, V2{T(0), T(0)}};   // two partial sums: no dependent packed FMAs back to back
-#pragma unroll
-                for (int pp = 0; pp < NP; ++pp) {
-                    V2 e2 = T(TB::berr[0]) * k[0][0].p[pp];
-#pragma unroll
-                    for (int q = 1; q < 7; ++q)
-                        if (TB::berr[q] != 0.0) e2 += T(TB::berr[q]) * k[q][0].p[pp];
-                    const V2 ym = V2{M::max_abs(y[0].p[pp][0], yt[0].p[pp][0]), M::max_abs(y[0].p[pp][1], yt[0].p[pp][1])};
-                    const V2 sc = ym * rtol + atol;
-                    V2 r = (PRESCALE ? e2 : dt * e2) * V2{M::rcp_fast(sc[0]), M::rcp_fast(sc[1])};
-                    if (GS > 1 && pp == IS / 2) r[IS % 2] = L.lead ? r[IS % 2] : T(0); // the replicated s counts once
-                    ssq[pp & 1] += r * r;       // (the pad element of an odd NV carries e = 0)
-                }
-                const V2 ss2 = ssq[0] + ssq[1];
-                const T ss = ss2[0] + ss2[1];
-                Control<T>::decide(M::sqrt(group_sum<G>(ss) / Dn), tprev, dt, keep, finite, factor);
+        for (int c = 0; c < NC; ++c) {
+            const T *src;
+            bool zero = pad;
+            if (c == 0) {
+                src = kc.y0 + (kc.y0_batched ? traj * Dc : 0);
             } else {
-                T chk = 0;
-#pragma unroll
-                for (int v = 0; v < NV; ++v) chk += (T)yt[0][v] - (T)yt[0][v];
-                chk = group_sum<G>(chk);
-                finite = (chk == T(0));
+                const T *const dy0 = kc.dy0;
+                zero = zero || dy0 == nullptr;
+                src = dy0 + ((kc.dy0_batched ? traj * ND : 0) + (c - 1)) * (int64_t)Dc;
             }
-            const bool act = !done;
-            steps += act ? 1 : 0;
-            if (act && !finite) {
-                st = ST_NONFINITE;
-                done = true;
-            }
-            const bool accept = act && finite && keep;
-
-            // ---- SaveAt(ts): dense output at every save time in (tprev, tnext]
-            bool pending = accept && (save_idx < n_save) && (ts_next <= tnext);
-            const T inv_dt = M::recip(dt);
-            if constexpr (PC) { // the rows are wave 1's: publish the accepted step (see consume())
-                pending = false;
-                if (__any(accept)) {
-                    dense_coefficients(dt, y, yt, k);
-                    __syncthreads();           // A: wave 1 has copied the previous step
+            y[c][IS] = zero ? T(0) : src[aa_c];
 #pragma unroll
-                    for (int pp = 0; pp < NP; ++pp) {
-                        hand.planes[(0 * NP + pp) * 64 + lane] = y[0].p[pp];
-                        hand.planes[(1 * NP + pp) * 64 + lane] = k[0][0].p[pp];
-                        hand.planes[(2 * NP + pp) * 64 + lane] = k[1][0].p[pp];
-                        hand.planes[(3 * NP + pp) * 64 + lane] = k[2][0].p[pp];
-                        hand.planes[(4 * NP + pp) * 64 + lane] = k[3][0].p[pp];
-                    }
-                    hand.tprev[lane] = tprev;
-                    hand.tnext[lane] = accept ? tnext : tprev - T(1);
-                    __syncthreads();           // B: published
-                }
-                if (accept) save_idx = n_save; // (the producer does not track rows: nothing for it to fill at the end)
-            }
-            if (__any(pending)) {
-                // the step's interpolant as a polynomial in theta, once for all its rows (see dense_coefficients)
-                dense_coefficients(dt, y, yt, k);
-                if constexpr (SU > 1) {
-                    while (__any(pending)) {
-                        if (pending) {
-                            T tsu[SU];
-                            bool pu[SU];
-                            tsu[0] = ts_next;
+            for (int l = 0; l < S; ++l) {
+                const int sg = aa_c * ST + s0_c + l; // (age, global strain)
+                if constexpr (HAS_E) y[c][IE + l] = zero ? T(0) : src[cE + sg];
+                y[c][II + l] = zero ? T(0) : src[cI + sg];
 #pragma unroll
-                            for (int q = 1; q < SU; ++q)
-                                tsu[q] = save_idx + q * R < n_save ? ts_tab[save_idx + q * R] : M::inf();
-                            int cnt = 0;
-#pragma unroll
-                            for (int q = 0; q < SU; ++q) {
-                                pu[q] = tsu[q] <= tnext; // increasing grid: the saved ones form a prefix
-                                cnt += pu[q] ? 1 : 0;
-                            }
-#pragma unroll
-                            for (int q = 0; q < SU; ++q) {
-                                Poly dq;
-                                poly_prepare(((pu[q] ? tsu[q] : tprev) - tprev) * inv_dt, dt, dq);
-                                if (ND > 0 && fused_ll) {
-                                    if (pu[q] && writer)
-                                        ll_row(ka, dq, y, k, ll, save_idx + q * R, a, as, L.lead,
-                                               ll_table ? ll_lane + (int64_t)(save_idx + q * R) * LL_ROW : nullptr);
-                                } else if (pu[q] && writer) {
-                                    save_row<0>(ka, dq, y, k, out_traj + (int64_t)(save_idx + q * R) * ka.d_saved, a, as,
-                                                L.lead, vec_ok);
-                                    if constexpr (ND > 0)
-                                        save_tangents<1>(ka, dq, y, k,
-                                                         dout_traj + (int64_t)(save_idx + q * R) * ND * ka.d_saved, a, as,
-                                                         L.lead, vec_ok);
-                                }
-                            }
-                            save_idx += cnt * R;
-                            ts_next = save_idx < n_save ? ts_tab[save_idx] : M::inf();
-                        }
-                        pending = accept && (save_idx < n_save) && (ts_next <= tnext);
-                    }
-                }
-                while (SU == 1 && __any(pending)) {
-#ifdef DYN_DIAG_ROUNDS
-                    ++diag_rounds;
-#endif
-                    if (pending) {
-                        Poly dn;
-                        poly_prepare((ts_next - tprev) * inv_dt, dt, dn);
-                        if (ND > 0 && fused_ll) {
-                            if (writer)
-                                ll_row(ka, dn, y, k, ll, save_idx, a, as, L.lead,
-                                       ll_table ? ll_lane + (int64_t)save_idx * LL_ROW : nullptr);
-                        } else if (writer) {
-                            save_row<0>(ka, dn, y, k, out_traj + (int64_t)save_idx * ka.d_saved, a, as, L.lead, vec_ok);
-                            if constexpr (ND > 0)
-                                save_tangents<1>(ka, dn, y, k, dout_traj + (int64_t)save_idx * ND * ka.d_saved, a, as,
-                                                 L.lead, vec_ok);
-                        }
-                        save_idx += R;
-                        ts_next = ts_next2;
-                        ts_next2 = save_idx + R < n_save ? ts_tab[save_idx + R] : M::inf();
-                    }
-                    pending = accept && (save_idx < n_save) && (ts_next <= tnext);
-                }
-            }
-
-            // ---- commit / reject
-            if (accept) {
-#pragma unroll
-                for (int c = 0; c < NC; ++c)
-#pragma unroll
-                    for (int pp = 0; pp < NP; ++pp) {
-                        y[c].p[pp] = yt[c].p[pp];
-                        if constexpr (!PRESCALE) k[0][c].p[pp] = k[6][c].p[pp];   // (PRESCALE: FSAL is taken over below, together with its rescaling)
-                    }
-                ++n_acc;
-            } else if (act && finite) {
-                ++n_rej;
-            }
-            [[maybe_unused]] const bool fsal_from_k6 = accept;
-            // ---- next interval: prev_dt * factor, then diffeqsolve's clip-to-end
-            T next_t0 = accept ? tnext : tprev;
-            T next_t1 = next_t0 + (constant ? ka.constant_dt : dt * factor);
-            if (__builtin_expect(n_jump > 0, 0)) { // wave-uniform: no cost when discontinuity_points is empty
-                const bool landed = at_jump && accept;
-                if (landed) {
-                    // prev_dt is the controller's proposal before the jump clipped it
-                    next_t0 = M::next(jt_tab[jidx], M::inf());
-                    next_t1 = next_t0 + (constant ? ka.constant_dt : dt_unclipped * factor);
-                    ++jidx;
-                }
-                if (__any(landed)) { // FSAL is invalid across a jump: k[0] = f(t_jump+, y)
-                    L.rhs(next_t0, y, k[1]);
-                    if (landed) {
-#pragma unroll
-                        for (int c = 0; c < NC; ++c)
-#pragma unroll
-                            for (int pp = 0; pp < NP; ++pp) k[PRESCALE ? 6 : 0][c].p[pp] = k[1][c].p[pp];   // (PRESCALE: k[6] is what becomes k[0] below)
-                    }
-                }
-                if (act) at_jump = false;
-                if (act && jidx < n_jump) {
-                    const T tj = jt_tab[jidx];
-                    if (tj < next_t1 && tj > next_t0) {
-                        dt_unclipped = next_t1 - next_t0;
-                        next_t1 = M::next(tj, -M::inf());
-                        at_jump = true;
-                    }
-                }
-            }
-            const T tp = M::min(next_t0, t_end);
-            if (Control<T>::clip_to_end(next_t1, tp, accept, t_end)) at_jump = false;
-            if (!done) {
-                tprev = tp;
-                tnext = next_t1;
-                if (!(tprev < t_end)) {
-                    done = true;
-                } else if (steps >= ka.max_steps) {
-                    st = ST_MAX_STEPS;
-                    done = true;
-                }
-            }
-            if constexpr (PRESCALE) {
-                // the next attempt's step size: rates from their parked originals, FSAL by the ratio of the step sizes
-                const T dt_new = tnext - tprev;
-                const T ratio = act ? dt_new * inv_dt : T(1);
-                if (fsal_from_k6) {   // accepted: the last stage's derivative is the next step's first one (no separate copy)
-#pragma unroll
-                    for (int c = 0; c < NC; ++c)
-#pragma unroll
-                        for (int pp = 0; pp < NP; ++pp) k[0][c].p[pp] = k[6][c].p[pp] * ratio;
-                } else {              // rejected (or idle): the same first stage, for another step size
-#pragma unroll
-                    for (int c = 0; c < NC; ++c)
-#pragma unroll
-                        for (int pp = 0; pp < NP; ++pp) k[0][c].p[pp] = k[0][c].p[pp] * ratio;
-                }
-                L.scale_rates(rate_tab, lane, dt_new);
-            }
-
-            // ---- a trajectory that finished in this iteration is written off, and its slot asks for the next one
-            if (__builtin_expect(live && done, 0)) {
-                live = false;
-                want_ticket = pull;
-                bool scored = false;
-                if constexpr (ND > 0) {
-                    if (fused_ll) { // wave-uniform
-                        scored = true;
-                        // sum over the lanes of the trajectory; a failed solve scores -inf (rejected by the sampler)
-                        // (the replicas of a trajectory are adjacent lane groups of the same wave; they step identically,
-                        // so they arrive here in the same iteration)
-                        int unfinished = (st != ST_OK || save_idx < n_save) ? 1 : 0;
-                        if (ll_table) {
-                            __syncthreads(); // every replica's table entries are visible
-                            if (writer && !unfinished) ll_from_table(ka, ll, ll_lane, LL_ROW, n_save, rep, R, a, as, L.lead);
-                        }
-                        const int span = G * R;
-                        double tot = writer ? ll.acc : 0.0;
-                        for (int off = span / 2; off > 0; off >>= 1) tot += __shfl_xor(tot, off);
-                        double dtot[NC];
-#pragma unroll
-                        for (int c = 1; c < NC; ++c) {
-                            dtot[c] = writer ? ll.dacc[c] : 0.0;
-                            for (int off = span / 2; off > 0; off >>= 1) dtot[c] += __shfl_xor(dtot[c], off);
-                        }
-                        for (int off = span / 2; off > 0; off >>= 1) unfinished |= __shfl_xor(unfinished, off);
-                        const bool ok = unfinished == 0;
-                        if (writer && a == 0 && L.lead && rep == 0) {
-                            const auto &kc = *cold_args<T>();
-                            kc.ll_out[traj] = ok ? tot : -__builtin_inf();
-                            double *const dll = kc.dll_out;
-#pragma unroll
-                            for (int c = 1; c < NC; ++c) dll[traj * ND + (c - 1)] = ok ? dtot[c] : 0.0;
-                            kc.status[traj] = st;
-                            kc.n_acc[traj] = n_acc;
-                            kc.n_rej[traj] = n_rej;
-                        }
-                    }
-                }
-                // rows never reached (failed solves): +inf, like diffrax's unfilled SaveAt buffer
-                if (!scored && writer) {
-                    for (; save_idx < n_save; save_idx += R) {
-                        fill_row(ka, out_traj + (int64_t)save_idx * ka.d_saved, a, as, L.lead, M::inf());
-                        if constexpr (ND > 0)
-                            for (int j = 0; j < ND; ++j)
-                                fill_row(ka, dout_traj + ((int64_t)save_idx * ND + j) * ka.d_saved, a, as, L.lead, M::inf());
-                    }
-                    if (a == 0 && L.lead && rep == 0) {
-                        const auto &kc = *cold_args<T>();
-                        kc.status[traj] = st;
-#ifdef DYN_DIAG_ROUNDS
-                        n_acc = diag_iters;
-                        n_rej = diag_rounds;
-#endif
-                        kc.n_acc[traj] = n_acc;
-                        kc.n_rej[traj] = n_rej;
-                    }
-                }
-            }
-        }
-        if constexpr (PC) { // tell wave 1 that no more steps will come
-            __syncthreads();                   // A
-            if (lane == 0) *hand.fin = 1;
-            __syncthreads();                   // B
-        }
-        if constexpr (FUSED) {
-            // ---- the sampler's side of the iteration, for the chains whose trajectories this wave has just scored (a static
-            // launch without a caller's order: the wave's slots hold trajectories t0 .. t0 + nt - 1; enqueue() checked that
-            // whole chains fall into waves).  One lane per chain, as in nuts_advance.
-            const auto &kc = *cold_args<T>();
-            if (kc.nuts_tail != nullptr) {
-                // the kernel's second argument, read where it is used (like cold_args: nothing of it lives through the stepping loop)
-                const auto &tl = *reinterpret_cast<const dynnuts::Tail __attribute__((address_space(4))) *>(
-                    reinterpret_cast<const char __attribute__((address_space(4))) *>(&kc) + kTailOffset);
-                __threadfence(); // ll_out / dll_out of this wave's trajectories have reached memory
-                const int rows = tl.rows_per_chain;
-                const int nt = TPW >> kc.rep_log2;
-                const int64_t t0 = ((int64_t)blockIdx.x * TPW) >> kc.rep_log2;
-                const int64_t c = t0 / rows + lane;
-                if (lane < nt / rows && c < (int64_t)tl.st.n_chains) dynnuts::fused_tail(tl, (int)c, kc.ll_out, kc.dll_out);
+                for (int w = 0; w < W; ++w) y[c][IR + l * W + w] = zero ? T(0) : src[cR + sg * W + w];
+                if constexpr (HAS_C) y[c][IC + l] = zero ? T(0) : src[cC + sg];
             }
         }
     }
+    __device__ __forceinline__ static bool start_ok(bool lane_ok, int lane_c) { // no lane of the trajectory saw NaN / inf
+        const unsigned long long bad_lanes = __ballot(!lane_ok);
+        const unsigned long long group_mask = (G == 64 ? ~0ull : ((1ull << G) - 1ull)) << ((lane_c / G) * G);
+        return (bad_lanes & group_mask) == 0ull;
+    }
+    __device__ __forceinline__ static T traj_sum(T v) { return group_sum<G>(v); }
+    // the replicated s enters every norm once: only the lead strain lane counts it
+    __device__ __forceinline__ T weigh(int v, T x) const { return (v == IS ? (lead ? T(1) : T(0)) : T(1)) * x; }
+    __device__ __forceinline__ void count_once(int pp, V2 &r) const {
+        if (GS > 1 && pp == IS / 2) r[IS % 2] = lead ? r[IS % 2] : T(0);
+    }
+
+    // rows: where they go, the step's interpolant, one row, a row never reached
+    struct Output {
+        T *out_traj, *dout_traj;
+        LL ll;
+    };
+    template <typename KA>
+    __device__ __forceinline__ static void begin_output(const KA &kc, Output &o, int64_t traj, int n_save) {
+        o.out_traj = kc.out + traj * (int64_t)n_save * kc.d_saved;
+        o.dout_traj = nullptr;
+        if constexpr (ND > 0) {
+            o.dout_traj = kc.dout + traj * (int64_t)n_save * ND * kc.d_saved;
+            o.ll.acc = 0.0;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                o.ll.dacc[c] = 0.0;
+#pragma unroll
+                for (int q = 0; q < LLMAX; ++q) o.ll.prev[c][q] = T(0);
+            }
+        }
+    }
+    __device__ __forceinline__ static void dense_begin(T dt, const State (&y)[NC], const State (&y1)[NC], State (&k)[7][NC]) {
+        dense_coefficients(dt, y, y1, k);
+    }
+    // the row of save time tprev + theta dt (`on`: this lane stores it): the saved compartments and their tangents, or --
+    // tangent kernels with the likelihood fused in -- the row's contribution to the score
+    __device__ __forceinline__ void emit_row(const KArgs<T> &ka, const Tables &tb, Output &o, T theta, T dt, const State (&y)[NC],
+                                             const State (&)[NC], const State (&k)[7][NC], int save_idx, bool on, bool vec_ok) const {
+        Poly dq;
+        poly_prepare(theta, dt, dq);
+        if (ND > 0 && tb.fused_ll) {
+            if (on) ll_row(ka, dq, y, k, o.ll, save_idx, a, as, lead, tb.ll_table ? tb.ll_lane + (int64_t)save_idx * LL_ROW : nullptr);
+        } else if (on) {
+            save_row<0>(ka, dq, y, k, o.out_traj + (int64_t)save_idx * ka.d_saved, a, as, lead, vec_ok);
+            if constexpr (ND > 0) save_tangents<1>(ka, dq, y, k, o.dout_traj + (int64_t)save_idx * ND * ka.d_saved, a, as, lead, vec_ok);
+        }
+    }
+    __device__ __forceinline__ void fill_row(const KArgs<T> &ka, const Output &o, int save_idx, T v) const {
+        fill_row(ka, o.out_traj + (int64_t)save_idx * ka.d_saved, a, as, lead, v);
+        if constexpr (ND > 0)
+            for (int j = 0; j < ND; ++j) fill_row(ka, o.dout_traj + ((int64_t)save_idx * ND + j) * ka.d_saved, a, as, lead, v);
+    }
+    // tangent kernels with the likelihood fused in: the finished trajectory's score (and status) instead of rows; -> scored
+    __device__ __forceinline__ bool finish_score(const KArgs<T> &ka, const Tables &tb, Output &o, int64_t traj, int32_t st, int save_idx, int n_save, int rep,
+                                                 int R, int32_t n_acc, int32_t n_rej, bool writer_now) const {
+        if (!tb.fused_ll) return false; // wave-uniform
+        LL &ll = o.ll;
+        // sum over the lanes of the trajectory; a failed solve scores -inf (rejected by the sampler)
+        // (the replicas of a trajectory are adjacent lane groups of the same wave; they step identically,
+        // so they arrive here in the same iteration)
+        int unfinished = (st != ST_OK || save_idx < n_save) ? 1 : 0;
+        if (tb.ll_table) {
+            __syncthreads(); // every replica's table entries are visible
+            if (writer_now && !unfinished) ll_from_table(ka, ll, tb.ll_lane, LL_ROW, n_save, rep, R, a, as, lead);
+        }
+        const int span = G * R;
+        double tot = writer_now ? ll.acc : 0.0;
+        for (int off = span / 2; off > 0; off >>= 1) tot += __shfl_xor(tot, off);
+        double dtot[NC];
+#pragma unroll
+        for (int c = 1; c < NC; ++c) {
+            dtot[c] = writer_now ? ll.dacc[c] : 0.0;
+            for (int off = span / 2; off > 0; off >>= 1) dtot[c] += __shfl_xor(dtot[c], off);
+        }
+        for (int off = span / 2; off > 0; off >>= 1) unfinished |= __shfl_xor(unfinished, off);
+        const bool ok = unfinished == 0;
+        if (writer_now && leader && rep == 0) {
+            const auto &kc = *cold_args<T>();
+            kc.ll_out[traj] = ok ? tot : -__builtin_inf();
+            double *const dll = kc.dll_out;
+#pragma unroll
+            for (int c = 1; c < NC; ++c) dll[traj * ND + (c - 1)] = ok ? dtot[c] : 0.0;
+            kc.status[traj] = st;
+            kc.n_acc[traj] = n_acc;
+            kc.n_rej[traj] = n_rej;
+        }
+        return true;
+    }
+    // PC: the row-writing wave of a two-wave workgroup
+    __device__ __forceinline__ void consume(const KArgs<T> &ka, const Handoff &h, const T *ts_tab, int lane, bool valid, int64_t traj) const {
+        consume(ka, h, ts_tab, lane, a, as, lead, writer, valid, traj);
+    }
 };
+
+} // namespace dyn
+
+#include "stepper.hpp"
+
+namespace dyn {
 
 // Waves per SIMD the kernel is compiled for, (min, max).  The D = 360 ensemble kernel (8 ages x 4 strain lanes, eight waning
 // bins) needs 188 registers left alone: two waves per SIMD, whose vector units are then busy 87 % of the time.  Compiled for
@@ -2029,7 +1614,7 @@ template <typename T, int METHOD, int GA, int ST, bool HAS_E, bool HAS_WANE, boo
 __global__ void __launch_bounds__((FEAT & 0x8000) ? 128 : 64) DYN_KERNEL_ATTR
 __attribute__((amdgpu_waves_per_eu(waves_per_simd<T, METHOD, GA, ST, W, ND, SPL, FEAT>(false), waves_per_simd<T, METHOD, GA, ST, W, ND, SPL, FEAT>(true))))
 solve_kernel(const KArgs<T> ka) {
-    Solver<T, METHOD, GA, ST, HAS_E, HAS_WANE, HAS_C, W, ND, SPL, FEAT>::run(ka);
+    Stepper<Solver<T, METHOD, GA, ST, HAS_E, HAS_WANE, HAS_C, W, ND, SPL, FEAT>>::run(ka);
 }
 
 // ... of a FUSED instance: the sampler run rides along as a second argument (Solver::run reads it at kTailOffset)
@@ -2037,7 +1622,7 @@ template <typename T, int METHOD, int GA, int ST, bool HAS_E, bool HAS_WANE, boo
           int FEAT = 0>
 __global__ void __launch_bounds__(64)
 solve_kernel_fused(const KArgs<T> ka, const dynnuts::Tail tail) {
-    Solver<T, METHOD, GA, ST, HAS_E, HAS_WANE, HAS_C, W, ND, SPL, FEAT>::run(ka);
+    Stepper<Solver<T, METHOD, GA, ST, HAS_E, HAS_WANE, HAS_C, W, ND, SPL, FEAT>>::run(ka);
 }
 
 // waves of `kernel` the current device holds at once (occupancy x compute units); cached per (device, LDS size)
