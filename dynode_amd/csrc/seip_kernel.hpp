@@ -1,7 +1,8 @@
 // seip_kernel.hpp -- the SEIP family (include/dynode_hip.h "SEIP"; ode_model.md:15-53, 70-105, 176-211):
-// age x immune history x vaccination tier x waning state, fused with the same adaptive Tsit5 / Dopri5
-// stepper as solve_kernel.hpp (the controller is the shared Control<T>, the dense output and the age contraction are
-// Solver's own functions; same status codes).
+// age x immune history x vaccination tier x waning state, as a model family of the library's one stepping loop
+// (stepper.hpp, Stepper<Seip<...>>::run): this file is the lane mapping, the per-trajectory tables, the right-hand side
+// and the row writer; starting step, step control, discontinuity points, SaveAt rounds and recorded schedules are the
+// stepper's (the dense-output weights and the age contraction are Solver's own functions; same status codes).
 //
 // Lane mapping: a trajectory owns GA x H lanes, GA = power of two >= n_age in the low lane bits (so the
 // age contraction is the DPP gather of solve_kernel.hpp, unchanged), H = 2^L immune histories above
@@ -147,7 +148,8 @@ struct Seip {
         if constexpr (CACHE_SUS) return susr[(slot * M1 + m) * L + l];
         else return sus[(kc * M1 + m) * L + l];
     }
-    const T *spl;      // LDS: spline[K1][4 + 2 nk] of this lane's age
+    mutable const T *spl;      // LDS: spline[K1][4 + 2 nk] of this lane's age
+    int spl_off;               // ... as an element offset into the workgroup's LDS (rhs)
     int nk, hist, tl; // tl: tier lane (KT = 2), 0 otherwise
     bool pad, seasonal, seasonal_vax, intro;
 
@@ -176,6 +178,17 @@ struct Seip {
     }
 
     __device__ __forceinline__ void rhs(T t, const PS &y, PS &dy) const {
+        // The dose splines stay in LDS and are read where they are used, in EVERY evaluation: shared between the evaluations of
+        // a step attempt (or hoisted out of the stepping loop) their coefficients would be dozens of values held in registers
+        // next to nine copies of the state -- the two-waves-per-SIMD kernels sit at their 256-register line (D = 960: 79
+        // spilled registers and 7.27 ms without this, 34 and 6.5 ms with it).  The table's OFFSET passes through an empty asm
+        // statement, which common-subexpression elimination cannot see through (the pointer stays visibly LDS: ds_read).
+        if constexpr (!CACHE_SUS) {
+            extern __shared__ __attribute__((aligned(32))) unsigned char dyn_smem[];
+            int po = spl_off;
+            asm volatile("" : "+v"(po));
+            spl = reinterpret_cast<const T *>(dyn_smem) + po;
+        }
         if constexpr (NW > 1) rhs_wave_group(t, y, dy);
         else if constexpr (KT == 2) rhs_tier_lanes(t, y, dy);
         else rhs_one_lane(t, y, dy);
@@ -672,31 +685,6 @@ struct Seip {
         }
     }
 
-    // stages SG..6 of the step (k[0] is FSAL); compile-time stage index: every k[q][v] is a named register
-    template <int SG>
-    __device__ __forceinline__ void stages(T tprev, T dt, const PS &y, PS &yt, PS (&k)[7]) const {
-        if constexpr (SG < 7) {
-#pragma unroll
-            for (int pp = 0; pp < NP; ++pp) { // register pairs: v_pk_fma_f32
-                V2 acc = T(TB::a[SG][0]) * k[0].p[pp];
-#pragma unroll
-                for (int r = 1; r < SG; ++r)
-                    if (TB::a[SG][r] != 0.0) acc += T(TB::a[SG][r]) * k[r].p[pp];
-                yt.p[pp] = y.p[pp] + dt * acc;
-            }
-            rhs(tprev + T(TB::c[SG]) * dt, yt, k[SG]);
-            stages<SG + 1>(tprev, dt, y, yt, k);
-        }
-    }
-
-    // dense output of every element of the lane at one save time (all register pairs at once)
-    __device__ __forceinline__ static void interpolate(const Dense &d, T dt, const PS &y, const PS &y1, const PS (&k)[7], PS &o) {
-#pragma unroll
-        for (int j = 0; j < NP; ++j)
-            o.p[j] = Lanes::template dense_eval<V2>(d, dt, y.p[j], y1.p[j], k[0].p[j], k[1].p[j], k[2].p[j], k[3].p[j], k[4].p[j],
-                                                    k[5].p[j], k[6].p[j]);
-    }
-
     template <int FIRST, int CNT>
     __device__ __forceinline__ static void save_block(const PS &o, T *dst, bool vec_ok) {
         T v[CNT];
@@ -721,428 +709,260 @@ struct Seip {
         }
     }
 
-    __device__ __forceinline__ static void run(const KArgs<T> &ka) {
-        const int lane = threadIdx.x & 63;
+    // ================================================================ the family interface of Stepper<F> (stepper.hpp)
+    using Scalar = T;
+    using State = PS;
+    static constexpr int NC = 1, NDIR = 0, SU = 1;
+    static constexpr int GW = GWL;                  // lanes of one wave that hold one trajectory
+    static constexpr bool PRESCALE = false, PC = false, LEAN = false, FUSED = false;
+    static constexpr size_t kTailOffset = 0;
+    static constexpr bool PULLS = false;            // a static grid: the waves of a group meet at barriers, slot for slot
+    static constexpr bool REPLAYS = true;           // recorded step schedules (KArgs::sched_*: dyn_solve_batch_record / _replay)
+    static constexpr bool IDLE_SLOTS_LOAD = true;   // a slot beyond the batch keeps in step on the last trajectory's data
+    static constexpr int SUSN = H * K1 * M1 * L;    // susceptibility table of one trajectory
+    int a, g, tidx;       // age lane; (age, history) group in memory order; index among the G lanes of the trajectory
+    bool writer, leader;  // the lane stores rows (not a pad lane) / reports the trajectory's status
+
+    // lane indices and what every trajectory of the launch shares; -> the lane's trajectory slot in the workgroup
+    __device__ __forceinline__ int init(const KArgs<T> &ka, int lane) {
         // position inside the trajectory's lane group: the lane itself, or (NW > 1) wave * 64 + lane of the workgroup
-        const int wtid = NW > 1 ? (int)threadIdx.x : lane;          // index inside the workgroup (cooperative table loads)
+        const int wtid = NW > 1 ? (int)threadIdx.x : lane;
         const int tlane = PACKED ? lane : wtid;
         // (when whole waves are the tier lanes the tier is the same for every lane of the wave: taken from a scalar register,
         // so that everything that depends on it -- "is this the top tier", which table row, which mailbox wave -- is scalar
         // arithmetic and scalar branches instead of per-lane selects)
         const int wave_idx = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-        const int a = tlane % GA, j = (tlane / GA) % H,
-                  tl = PACKED ? wave_idx : (TIER_X ? (wave_idx >> HB_X) % KT : (tlane / (GA * H)) % KT);
-        const int grp = PACKED ? lane / GWL : (NW > 1 ? 0 : lane / G);
-        const int tidx = PACKED ? tl * GWL + lane % GWL : tlane % G;   // index among the G lanes of this trajectory
-        int64_t traj = (int64_t)blockIdx.x * TPW + grp;
-        bool valid_traj = traj < ka.B;
-        if (!valid_traj) traj = ka.B - 1;
-        if (ka.order) { // dispatch order (KArgs::order)
-            traj = ka.order[traj];
-            if ((uint64_t)traj >= (uint64_t)ka.B) {
-                valid_traj = false;
-                traj = ka.B - 1;
-            }
+        a = tlane % GA;
+        hist = (tlane / GA) % H;
+        tl = PACKED ? wave_idx : (TIER_X ? (wave_idx >> HB_X) % KT : (tlane / (GA * H)) % KT);
+        tidx = PACKED ? tl * GWL + lane % GWL : tlane % G;
+        const int A = ka.A;
+        wv = NW > 1 ? wave_idx : 0;
+        xbuf = 0;
+        pad = a >= A;
+        nk = ka.n_vax_knots;
+        seasonal = ka.seasonal != 0;
+        seasonal_vax = ka.seasonal_vax != 0;
+        intro = ka.has_intro != 0;
+        const int aa = pad ? 0 : a;
+        g = aa * H + hist;
+        writer = !pad;
+        leader = a == 0 && hist == 0 && tl == 0;
+#pragma unroll
+        for (int k = 0; k < GA; ++k) {
+            const int b = a ^ k;
+            ages.Cx[k] = (!pad && b < A) ? ka.contact[aa * A + b] : T(0);
         }
-        const int A = ka.A, nk = ka.n_vax_knots;
-        Seip S;
-        S.wv = NW > 1 ? wave_idx : 0;
-        S.xbuf = 0;
-        S.pad = a >= A;
-        S.hist = j;
-        S.tl = tl;
-        S.nk = nk;
-        S.seasonal = ka.seasonal != 0;
-        S.seasonal_vax = ka.seasonal_vax != 0;
-        const int aa = S.pad ? 0 : a;
-        const bool writer = valid_traj && !S.pad;
+        return PACKED ? lane / GWL : (NW > 1 ? 0 : lane / G);
+    }
+    __device__ __forceinline__ static int state_dim(const KArgs<T> &ka) {
+        return ka.A * H * K1 * M1 + 3 * ka.A * H * K1 * L;
+    }
 
-        // ---- LDS: save grid, then per trajectory slot the susceptibility table and the splines
-        extern __shared__ __attribute__((aligned(32))) unsigned char dyn_smem[];
-        T *const ts_tab = reinterpret_cast<T *>(dyn_smem);
-        const int n_save = ka.n_save;
-        constexpr int SUSN = H * K1 * M1 * L;
+    // LDS behind the save grid and the discontinuity points: per trajectory slot the susceptibility table and the dose splines,
+    // then (replay) every slot's recorded schedule, then the mailbox of a wave group
+    struct Tables {
+        T *tab;      // this slot's tables
+        T *sch;      // this slot's schedule: the (t_prev, t_next) pairs it must take (a global load inside the stepping loop
+        int n_sch;   // would wait for every store issued before it: the loads and stores share vmcnt)
+    };
+    __device__ __forceinline__ void carve(const KArgs<T> &ka, Tables &tb, T *, T *free_lds, int, int grp, int, int) {
+        const int spln = ka.A * K1 * (4 + 2 * ka.n_vax_knots);
+        const bool replay = ka.sched_in != nullptr;
+        tb.tab = free_lds + grp * (SUSN + spln);
+        T *const sch_base = free_lds + TPW * (SUSN + spln);
+        tb.sch = sch_base + grp * (2 * ka.sched_cap);
+        tb.n_sch = 0;
+        xw = sch_base + (replay ? TPW * 2 * ka.sched_cap : 0);   // (16-byte aligned by construction of the table sizes or not: 4-byte words)
+    }
+
+    // parameters, tables (into LDS, by the trajectory's lanes) and this lane's chunk of every compartment
+    template <typename KA>
+    __device__ __forceinline__ void load_trajectory(const KA &ka, int64_t traj, int, Tables &tb, PS (&ys)[1]) {
+        PS &y = ys[0];
+        const int A = ka.A;
+        const int aa = pad ? 0 : a;
         const int spln = A * K1 * (4 + 2 * nk);
-        const int n_jump = ka.n_jump;
-        T *const jt_tab = ts_tab + n_save; // discontinuity points follow the save grid
-        T *const tab = jt_tab + (n_jump > 0 ? kMaxJumps : 0) + grp * (SUSN + spln);
         const T *p = ka.params + traj * ka.P;
         const T *q = p + 3 * L + M1;
-        S.intro = ka.has_intro != 0;
 #pragma unroll
-        for (int l = 0; l < L; ++l) S.itime[l] = S.iinv[l] = S.iamp[l] = T(0);
+        for (int l = 0; l < L; ++l) itime[l] = iinv[l] = iamp[l] = T(0);
         const T *intro_p = q;
-        if (S.intro) q += 3 * L;
-        S.amp = S.phase = S.w_season = S.tau = T(0);
-        if (S.seasonal) {
-            S.amp = q[0];
-            S.phase = q[1];
-            S.w_season = T(6.283185307179586476925286766559) / q[2];
+        if (intro) q += 3 * L;
+        amp = phase = w_season = tau = T(0);
+        if (seasonal) {
+            amp = q[0];
+            phase = q[1];
+            w_season = T(6.283185307179586476925286766559) / q[2];
             q += 3;
         }
-        if (S.seasonal_vax) {
-            S.tau = q[0];
+        if (seasonal_vax) {
+            tau = q[0];
             q += 1;
         }
-        S.pop = S.pad ? T(0) : q[aa];
+        pop = pad ? T(0) : q[aa];
         q += A;
-        if (S.intro) {
+        if (intro) {
 #pragma unroll
             for (int l = 0; l < L; ++l) {
                 const T scale = intro_p[L + l];
-                const bool here = !S.pad && ((ka.intro_mask[l] >> aa) & 1ull);
-                S.itime[l] = intro_p[l];
-                S.iinv[l] = T(1) / scale;
-                S.iamp[l] = here ? intro_p[2 * L + l] / (scale * T(2.5066282746310002)) * S.pop : T(0);
+                const bool here = !pad && ((ka.intro_mask[l] >> aa) & 1ull);
+                itime[l] = intro_p[l];
+                iinv[l] = T(1) / scale;
+                iamp[l] = here ? intro_p[2 * L + l] / (scale * T(2.5066282746310002)) * pop : T(0);
             }
         }
-        for (int n = wtid; n < n_save; n += 64 * NW) ts_tab[n] = ka.save_ts[n];
+        T *const tab = tb.tab;
         for (int n = tidx; n < SUSN + spln; n += G) tab[n] = q[n];
-        if (n_jump > 0 && wtid < kMaxJumps) jt_tab[wtid] = ka.jump_ts[wtid];
-        // replay: the (t_prev, t_next) pairs this trajectory must take, staged in LDS behind the tables (a global load
-        // inside the stepping loop would wait for every store issued before it: the loads and stores share vmcnt)
-        const bool replay = ka.sched_in != nullptr;
-        T *const sch_base = jt_tab + (n_jump > 0 ? kMaxJumps : 0) + TPW * (SUSN + spln);
-        T *const sch = sch_base + grp * (2 * ka.sched_cap);
-        int n_sch = 0;
-        if (replay) {
+        if (ka.sched_in != nullptr) { // replay: the leader's schedule, staged in LDS
             const int64_t lead = ka.sched_leader ? ka.sched_leader[traj] : traj;
-            n_sch = ka.sched_n_in[lead];
+            tb.n_sch = ka.sched_n_in[lead];
             const T *src = ka.sched_in + lead * (int64_t)(2 * ka.sched_cap);
-            for (int n = tidx; n < 2 * (n_sch > 0 ? n_sch : 0); n += G) sch[n] = src[n];
+            for (int n = tidx; n < 2 * (tb.n_sch > 0 ? tb.n_sch : 0); n += G) tb.sch[n] = src[n];
         }
-        // the mailbox of a wave group follows the schedule (16-byte aligned by construction of the table sizes or not: 4-byte words)
-        S.xw = sch_base + (replay ? TPW * 2 * ka.sched_cap : 0);   // the mailbox of the wave group: behind every trajectory's schedule
         __syncthreads();
-        S.sus = tab + j * (K1 * M1 * L);
-        S.spl = tab + SUSN + aa * K1 * (4 + 2 * nk);
+        sus = tab + hist * (K1 * M1 * L);
+        spl = tab + SUSN + aa * K1 * (4 + 2 * nk);
+        {
+            extern __shared__ __attribute__((aligned(32))) unsigned char dyn_smem[];
+            spl_off = (int)(spl - reinterpret_cast<const T *>(dyn_smem));
+        }
         if constexpr (CACHE_SUS) {
 #pragma unroll
             for (int sl = 0; sl < KL; ++sl) {
                 const int kt = sl * KT + tl, kc = kt < K1 ? kt : K;   // padded slots hold nobody: any valid row will do
 #pragma unroll
-                for (int q = 0; q < M1 * L; ++q) S.susr[sl * M1 * L + q] = S.sus[kc * M1 * L + q];
-                const T *c = S.spl + kc * (4 + 2 * nk);
+                for (int q = 0; q < M1 * L; ++q) susr[sl * M1 * L + q] = sus[kc * M1 * L + q];
+                const T *c = spl + kc * (4 + 2 * nk);
 #pragma unroll
                 for (int n = 0; n < 4; ++n) {
                     const bool on = n < nk;
-                    S.splr[sl * 12 + n] = c[n];
-                    S.splr[sl * 12 + 4 + n] = c[on ? 4 + n : 0];
-                    S.splr[sl * 12 + 8 + n] = on ? c[on ? 4 + nk + n : 0] : T(0);
+                    splr[sl * 12 + n] = c[n];
+                    splr[sl * 12 + 4 + n] = c[on ? 4 + n : 0];
+                    splr[sl * 12 + 8 + n] = on ? c[on ? 4 + nk + n : 0] : T(0);
                 }
             }
         }
 #pragma unroll
         for (int l = 0; l < L; ++l) {
-            S.beta[l] = p[l];
-            S.gamma[l] = p[L + l];
-            S.sigma[l] = p[2 * L + l];
+            beta[l] = p[l];
+            gamma[l] = p[L + l];
+            sigma[l] = p[2 * L + l];
         }
 #pragma unroll
-        for (int m = 0; m < M1; ++m) S.omega[m] = p[3 * L + m];
-#pragma unroll
-        for (int k = 0; k < GA; ++k) {
-            const int b = a ^ k;
-            S.ages.Cx[k] = (!S.pad && b < A) ? ka.contact[aa * A + b] : T(0);
-        }
+        for (int m = 0; m < M1; ++m) omega[m] = p[3 * L + m];
 
-        // ---- state: this lane's chunk of every compartment
-        const int g = aa * H + j; // (age, history) group in memory order
-        // memory layout: every (age, history) group holds K1 tiers; a lane holds them all (KT = 1) or tiers tl, tl + 2 (KT = 2)
+        // memory layout: every (age, history) group holds K1 tiers; a lane holds them all (KT = 1) or tiers tl, tl + KT, ...
         const int offE = A * H * K1 * M1, nE = A * H * K1 * L;
         const int D = offE + 3 * nE;
-        PS y, yt, k[7];
-        y.clear_pad();
-        yt.clear_pad();
+        const T *src = ka.y0 + (ka.y0_batched ? traj * D : 0);
+        if constexpr (KT == 1) { // a lane's tiers are contiguous in memory
 #pragma unroll
-        for (int q = 0; q < 7; ++q) k[q].clear_pad();
-        {
-            const T *src = ka.y0 + (ka.y0_batched ? traj * D : 0);
-            if constexpr (KT == 1) { // a lane's tiers are contiguous in memory
+            for (int v = 0; v < NS; ++v) y[v] = pad ? T(0) : src[g * NS + v];
 #pragma unroll
-                for (int v = 0; v < NS; ++v) y[v] = S.pad ? T(0) : src[g * NS + v];
+            for (int v = 0; v < NE; ++v) {
+                y[IE + v] = pad ? T(0) : src[offE + g * NE + v];
+                y[II + v] = pad ? T(0) : src[offE + nE + g * NE + v];
+                y[IC + v] = pad ? T(0) : src[offE + 2 * nE + g * NE + v];
+            }
+        } else
 #pragma unroll
-                for (int v = 0; v < NE; ++v) {
-                    y[IE + v] = S.pad ? T(0) : src[offE + g * NE + v];
-                    y[II + v] = S.pad ? T(0) : src[offE + nE + g * NE + v];
-                    y[IC + v] = S.pad ? T(0) : src[offE + 2 * nE + g * NE + v];
-                }
-            } else
+        for (int sl = 0; sl < KL; ++sl) {
+            const int kt = sl * KT + tl;           // tier of this slot
+            const bool live = !pad && kt < K1;
+            const int gk = g * K1 + (kt < K1 ? kt : 0);
 #pragma unroll
-            for (int sl = 0; sl < KL; ++sl) {
-                const int kt = sl * KT + tl;           // tier of this slot
-                const bool live = !S.pad && kt < K1;
-                const int gk = g * K1 + (kt < K1 ? kt : 0);
+            for (int m = 0; m < M1; ++m) y[sl * M1 + m] = live ? src[gk * M1 + m] : T(0);
 #pragma unroll
-                for (int m = 0; m < M1; ++m) y[sl * M1 + m] = live ? src[gk * M1 + m] : T(0);
-#pragma unroll
-                for (int l = 0; l < L; ++l) {
-                    y[IE + sl * L + l] = live ? src[offE + gk * L + l] : T(0);
-                    y[II + sl * L + l] = live ? src[offE + nE + gk * L + l] : T(0);
-                    y[IC + sl * L + l] = live ? src[offE + 2 * nE + gk * L + l] : T(0);
-                }
+            for (int l = 0; l < L; ++l) {
+                y[IE + sl * L + l] = live ? src[offE + gk * L + l] : T(0);
+                y[II + sl * L + l] = live ? src[offE + nE + gk * L + l] : T(0);
+                y[IC + sl * L + l] = live ? src[offE + 2 * nE + gk * L + l] : T(0);
             }
         }
+    }
+    __device__ __forceinline__ static void begin_attempt() {}
+    __device__ __forceinline__ void rhs(T t, const PS (&y)[1], PS (&dy)[1]) const { rhs(t, y[0], dy[0]); }
+    __device__ __forceinline__ bool start_ok(bool lane_ok, int) const { return !wg_any(!lane_ok); } // no lane of the trajectory saw NaN / inf
+    __device__ __forceinline__ static T weigh(int, T x) { return x; }   // (no element is held by more than one lane)
+    __device__ __forceinline__ static void count_once(int, V2 &) {}
 
-        const T rtol = ka.rtol, atol = ka.atol, t_end = ka.t1;
-        const T Dn = T(D);
-        const bool constant = ka.constant_dt > T(0);
-        T tprev = ka.t0, tnext;
-        S.rhs(tprev, y, k[0]);
-        bool lane_ok = true;
+    // rows: weighted sums of the stages (the polynomial form does not pay at the 1.3 rows per accepted step of these models)
+    struct Output {
+        T *out_traj;
+    };
+    template <typename KA>
+    __device__ __forceinline__ static void begin_output(const KA &ka, Output &o, int64_t traj, int n_save) {
+        o.out_traj = ka.out + traj * (int64_t)n_save * ka.d_saved;
+    }
+    __device__ __forceinline__ static void dense_begin(T, const PS (&)[1], const PS (&)[1], PS (&)[7][1]) {}
+    __device__ __forceinline__ void emit_row(const KArgs<T> &ka, const Tables &, Output &out, T theta, T dt, const PS (&y)[1],
+                                             const PS (&yt)[1], const PS (&k)[7][1], int save_idx, bool on, bool vec_ok) const {
+        Dense dn;
+        Lanes::dense_prepare(theta, dn);
+        if (on) {
+            T *row = out.out_traj + (int64_t)save_idx * ka.d_saved;
+            PS o;
 #pragma unroll
-        for (int v = 0; v < NV; ++v) lane_ok = lane_ok && (M::abs(y[v]) < M::inf()) && (M::abs(k[0][v]) < M::inf());
-        const unsigned long long bad_lanes = __ballot(!lane_ok);
-        const unsigned long long group_mask = (GWL >= 64 ? ~0ull : ((1ull << (GWL & 63)) - 1ull)) << (grp * (GWL & 63));
-        bool start_ok = (bad_lanes & group_mask) == 0ull;
-        if constexpr (NW > 1) start_ok = !S.wg_any(!lane_ok);
-
-        if (replay) {
-            tnext = n_sch > 0 ? sch[1] : tprev;
-        } else if (constant) {
-            tnext = tprev + ka.constant_dt;
-        } else { // Hairer-Norsett-Wanner II.4 starting step, as in solve_kernel.hpp
-            T n0 = 0, n1 = 0;
-#pragma unroll
-            for (int v = 0; v < NV; ++v) {
-                const T sc = atol + M::abs(y[v]) * rtol;
-                const T q0 = y[v] / sc, q1 = k[0][v] / sc;
-                n0 += q0 * q0;
-                n1 += q1 * q1;
-            }
-            const T d0 = M::sqrt(S.traj_sum(n0) / Dn), d1 = M::sqrt(S.traj_sum(n1) / Dn);
-            const bool small = (d0 < T(1e-5)) || (d1 < T(1e-5));
-            const T h0 = small ? T(1e-6) : T(0.01) * (d0 / d1);
-#pragma unroll
-            for (int pp = 0; pp < NP; ++pp) yt.p[pp] = y.p[pp] + h0 * k[0].p[pp];
-            S.rhs(tprev + h0, yt, k[1]);
-            T s2 = 0;
-#pragma unroll
-            for (int v = 0; v < NV; ++v) {
-                const T sc = atol + M::abs(y[v]) * rtol;
-                const T q2 = (k[1][v] - k[0][v]) / sc;
-                s2 += q2 * q2;
-            }
-            const T d2 = M::sqrt(S.traj_sum(s2) / Dn) / h0;
-            const T max_d = M::max(d1, d2);
-            tnext = tprev + M::min(T(100) * h0, Control<T>::initial_h1(max_d, h0));
-        }
-        tnext = M::min(tnext, t_end);
-
-        // discontinuity_points, as in solve_kernel.hpp: steps are clipped to land just before a jump and restart
-        // just after it with the first stage recomputed and the unclipped step size
-        int jidx = 0;
-        bool at_jump = false;
-        T dt_unclipped = T(0);
-        if (n_jump > 0 && !replay) {
-            while (jidx < n_jump && jt_tab[jidx] <= tprev) ++jidx;
-            if (jidx < n_jump && jt_tab[jidx] < tnext) {
-                dt_unclipped = tnext - tprev;
-                tnext = M::next(jt_tab[jidx], -M::inf());
-                at_jump = true;
-            }
-        }
-        int si = 0;          // replay: index of the step being taken
-        int save_idx = 0;
-        T ts_next = save_idx < n_save ? ts_tab[save_idx] : M::inf();
-        int64_t steps = 0;
-        int32_t n_acc = 0, n_rej = 0, st = start_ok ? ST_OK : ST_NONFINITE;
-        bool done = !(tprev < t_end) || !start_ok;
-        if (replay && n_sch <= 0) {     // the leader ran out of schedule space (or never stepped): nothing to follow
-            if (n_sch < 0) st = ST_MAX_STEPS;
-            done = true;
-        }
-        T *const out_traj = ka.out + traj * (int64_t)n_save * ka.d_saved;
-        const bool vec_ok = ka.vec_ok != 0;
-        const bool fixed = constant || replay;   // every step is taken as given: no error estimate, no rejection
-
-        while (__any(!done)) {
-            const T dt = tnext - tprev;
-            S.template stages<1>(tprev, dt, y, yt, k);
-            bool keep = true, finite = true;
-            T factor = T(1);
-            if (__builtin_expect(!fixed, 1)) {
-                V2 ssq[2] = {V2{T(0), T(0)}, V2{T(0), T(0)}};
-#pragma unroll
-                for (int pp = 0; pp < NP; ++pp) {
-                    V2 e2 = T(TB::berr[0]) * k[0].p[pp];
-#pragma unroll
-                    for (int r = 1; r < 7; ++r)
-                        if (TB::berr[r] != 0.0) e2 += T(TB::berr[r]) * k[r].p[pp];
-                    const V2 ym = V2{M::max_abs(y.p[pp][0], yt.p[pp][0]), M::max_abs(y.p[pp][1], yt.p[pp][1])};
-                    const V2 sc = ym * rtol + atol;
-                    const V2 r2 = (dt * e2) * V2{M::rcp_fast(sc[0]), M::rcp_fast(sc[1])};
-                    ssq[pp & 1] += r2 * r2;   // (the pad element of an odd NV carries e = 0)
-                }
-                const V2 ss2 = ssq[0] + ssq[1];
-                const T ss = ss2[0] + ss2[1];
-                Control<T>::decide(M::sqrt(S.traj_sum(ss) / Dn), tprev, dt, keep, finite, factor);
+            for (int jj = 0; jj < NP; ++jj)
+                o.p[jj] = Lanes::template dense_eval<V2>(dn, dt, y[0].p[jj], yt[0].p[jj], k[0][0].p[jj], k[1][0].p[jj], k[2][0].p[jj],
+                                                         k[3][0].p[jj], k[4][0].p[jj], k[5][0].p[jj], k[6][0].p[jj]);
+            if constexpr (KT == 1) {
+                if (ka.save_off[0] >= 0) save_block<0, NS>(o, row + ka.save_off[0] + g * NS, vec_ok);
+                if (ka.save_off[1] >= 0) save_block<IE, NE>(o, row + ka.save_off[1] + g * NE, vec_ok);
+                if (ka.save_off[2] >= 0) save_block<II, NE>(o, row + ka.save_off[2] + g * NE, vec_ok);
+                if (ka.save_off[4] >= 0) save_block<IC, NE>(o, row + ka.save_off[4] + g * NE, vec_ok);
             } else {
-                bool ok = true;
-#pragma unroll
-                for (int v = 0; v < NV; ++v) ok = ok && (M::abs(yt[v]) < M::inf());
-                if constexpr (NW > 1) finite = !S.wg_any(!ok);
-                else finite = ((__ballot(!ok) & group_mask) == 0ull);
-            }
-            const bool act = !done;
-            steps += act ? 1 : 0;
-            if (act && !finite) {
-                st = ST_NONFINITE;
-                done = true;
-            }
-            const bool accept = act && finite && keep;
-
-            bool pending = accept && (save_idx < n_save) && (ts_next <= tnext);
-            const T inv_dt = M::recip(dt);
-            while (__any(pending)) {
-                if (pending) {
-                    Dense dn;
-                    Lanes::dense_prepare((ts_next - tprev) * inv_dt, dn);
-                    if (writer) {
-                        T *row = out_traj + (int64_t)save_idx * ka.d_saved;
-                        PS o;
-                        interpolate(dn, dt, y, yt, k, o);
-                        if constexpr (KT == 1) {
-                            if (ka.save_off[0] >= 0) save_block<0, NS>(o, row + ka.save_off[0] + g * NS, vec_ok);
-                            if (ka.save_off[1] >= 0) save_block<IE, NE>(o, row + ka.save_off[1] + g * NE, vec_ok);
-                            if (ka.save_off[2] >= 0) save_block<II, NE>(o, row + ka.save_off[2] + g * NE, vec_ok);
-                            if (ka.save_off[4] >= 0) save_block<IC, NE>(o, row + ka.save_off[4] + g * NE, vec_ok);
-                        } else {
-                            save_slots<0>(ka, o, row, g, tl, vec_ok);
-                        }
-                    }
-                    ++save_idx;
-                    ts_next = save_idx < n_save ? ts_tab[save_idx] : M::inf();
-                }
-                pending = accept && (save_idx < n_save) && (ts_next <= tnext);
-            }
-
-            if (accept) {
-#pragma unroll
-                for (int pp = 0; pp < NP; ++pp) {
-                    y.p[pp] = yt.p[pp];
-                    k[0].p[pp] = k[6].p[pp];
-                }
-                if (__builtin_expect(ka.sched_out != nullptr, 0) && writer && a == 0 && j == 0 && tl == 0 && n_acc < ka.sched_cap) {
-                    T *rec = ka.sched_out + (traj * (int64_t)ka.sched_cap + n_acc) * 2;
-                    rec[0] = tprev;
-                    rec[1] = tnext;
-                }
-                ++n_acc;
-            } else if (act && finite) {
-                ++n_rej;
-            }
-            T next_t0 = accept ? tnext : tprev;
-            T next_t1 = next_t0 + (constant ? ka.constant_dt : dt * factor);
-            if (__builtin_expect(replay, 0)) { // wave-uniform: the next recorded step; across a discontinuity point the first stage is recomputed
-                if (act) ++si;
-                const bool more = si < n_sch;
-                next_t0 = more ? sch[2 * si] : t_end;
-                next_t1 = more ? sch[2 * si + 1] : t_end;
-                const bool gap = act && accept && more && next_t0 != tnext;
-                if (__any(gap)) {
-                    S.rhs(next_t0, y, k[1]);
-                    if (gap) {
-#pragma unroll
-                        for (int pp = 0; pp < NP; ++pp) k[0].p[pp] = k[1].p[pp];
-                    }
-                }
-                if (act && finite) {
-                    tprev = next_t0;
-                    tnext = next_t1;
-                    if (!more) done = true;
-                    else if (steps >= ka.max_steps) {
-                        st = ST_MAX_STEPS;
-                        done = true;
-                    }
-                }
-                continue;
-            }
-            if (__builtin_expect(n_jump > 0, 0)) { // wave-uniform
-                const bool landed = at_jump && accept;
-                if (landed) {
-                    next_t0 = M::next(jt_tab[jidx], M::inf());
-                    next_t1 = next_t0 + (constant ? ka.constant_dt : dt_unclipped * factor);
-                    ++jidx;
-                }
-                if (__any(landed)) { // FSAL is invalid across a jump: k[0] = f(t_jump+, y)
-                    S.rhs(next_t0, y, k[1]);
-                    if (landed) {
-#pragma unroll
-                        for (int pp = 0; pp < NP; ++pp) k[0].p[pp] = k[1].p[pp];
-                    }
-                }
-                if (act) at_jump = false;
-                if (act && jidx < n_jump) {
-                    const T tj = jt_tab[jidx];
-                    if (tj < next_t1 && tj > next_t0) {
-                        dt_unclipped = next_t1 - next_t0;
-                        next_t1 = M::next(tj, -M::inf());
-                        at_jump = true;
-                    }
-                }
-            }
-            const T tp = M::min(next_t0, t_end);
-            if (Control<T>::clip_to_end(next_t1, tp, accept, t_end)) at_jump = false;
-            if (!done) {
-                tprev = tp;
-                tnext = next_t1;
-                if (!(tprev < t_end)) {
-                    done = true;
-                } else if (steps >= ka.max_steps) {
-                    st = ST_MAX_STEPS;
-                    done = true;
-                }
+                save_slots<0>(ka, o, row, g, tl, vec_ok);
             }
         }
-
-        if (writer) {
-            for (; save_idx < n_save; ++save_idx) { // rows never reached: +inf, like an unfilled SaveAt buffer
-                T *row = out_traj + (int64_t)save_idx * ka.d_saved;
-                if constexpr (KT == 1) {
-                    if (ka.save_off[0] >= 0)
-                        for (int v = 0; v < NS; ++v) row[ka.save_off[0] + g * NS + v] = M::inf();
-                    for (int c = 1; c <= 4; ++c)
-                        if (c != 3 && ka.save_off[c] >= 0)
-                            for (int v = 0; v < NE; ++v) row[ka.save_off[c] + g * NE + v] = M::inf();
-                } else {
-                    for (int sl = 0; sl < KL; ++sl) {
-                        const int kt = sl * KT + tl;
-                        if (kt >= K1) continue;
-                        const int gk = g * K1 + kt;
-                        if (ka.save_off[0] >= 0)
-                            for (int m = 0; m < M1; ++m) row[ka.save_off[0] + gk * M1 + m] = M::inf();
-                        for (int c = 1; c <= 4; ++c)
-                            if (c != 3 && ka.save_off[c] >= 0)
-                                for (int l = 0; l < L; ++l) row[ka.save_off[c] + gk * L + l] = M::inf();
-                    }
-                }
+    }
+    __device__ __forceinline__ void fill_row(const KArgs<T> &ka, const Output &out, int save_idx, T v) const { // a row never reached
+        T *row = out.out_traj + (int64_t)save_idx * ka.d_saved;
+        if constexpr (KT == 1) {
+            if (ka.save_off[0] >= 0)
+                for (int e = 0; e < NS; ++e) row[ka.save_off[0] + g * NS + e] = v;
+            for (int c = 1; c <= 4; ++c)
+                if (c != 3 && ka.save_off[c] >= 0)
+                    for (int e = 0; e < NE; ++e) row[ka.save_off[c] + g * NE + e] = v;
+        } else {
+            for (int sl = 0; sl < KL; ++sl) {
+                const int kt = sl * KT + tl;
+                if (kt >= K1) continue;
+                const int gk = g * K1 + kt;
+                if (ka.save_off[0] >= 0)
+                    for (int m = 0; m < M1; ++m) row[ka.save_off[0] + gk * M1 + m] = v;
+                for (int c = 1; c <= 4; ++c)
+                    if (c != 3 && ka.save_off[c] >= 0)
+                        for (int l = 0; l < L; ++l) row[ka.save_off[c] + gk * L + l] = v;
             }
-            if (a == 0 && j == 0 && tl == 0) {
-                ka.status[traj] = st;
-                ka.n_acc[traj] = n_acc;
-                ka.n_rej[traj] = n_rej;
-                if (ka.sched_n_out != nullptr) ka.sched_n_out[traj] = n_acc <= ka.sched_cap ? n_acc : -1;
-            }
+        }
+    }
+    // record: the accepted step into KArgs::sched_out (dyn_solve_batch_record)
+    __device__ __forceinline__ void record_step(const KArgs<T> &ka, int64_t traj, int32_t n_acc, T tprev, T tnext, bool writer_now) const {
+        if (__builtin_expect(ka.sched_out != nullptr, 0) && writer_now && leader && n_acc < ka.sched_cap) {
+            T *rec = ka.sched_out + (traj * (int64_t)ka.sched_cap + n_acc) * 2;
+            rec[0] = tprev;
+            rec[1] = tnext;
         }
     }
 };
 
 template <typename T, int METHOD, int GA, int L, int K1, int M1, int KT = 1>
 __global__ void __launch_bounds__(64) seip_kernel(const KArgs<T> ka) {
-    Seip<T, METHOD, GA, L, K1, M1, KT>::run(ka);
+    Stepper<Seip<T, METHOD, GA, L, K1, M1, KT>>::run(ka);
 }
 
 // small per-lane states (tier lanes, <= 20 values): cap the registers at 256 so that two waves share a SIMD
 template <typename T, int METHOD, int GA, int L, int K1, int M1, int KT = 1>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) seip_kernel_two_waves(const KArgs<T> ka) {
-    Seip<T, METHOD, GA, L, K1, M1, KT>::run(ka);
+    Stepper<Seip<T, METHOD, GA, L, K1, M1, KT>>::run(ka);
 }
 
 // wave groups: one trajectory per workgroup of NW waves (lane groups of 128 or 256)
 template <typename T, int METHOD, int GA, int L, int K1, int M1, int KT, int NW>
 __global__ void __launch_bounds__(64 * NW) seip_kernel_wave_group(const KArgs<T> ka) {
-    Seip<T, METHOD, GA, L, K1, M1, KT, NW>::run(ka);
+    Stepper<Seip<T, METHOD, GA, L, K1, M1, KT, NW>>::run(ka);
 }
 
 template <typename T, int METHOD, int GA, int L, int K1, int M1, int KT = 1, int NW = 1>

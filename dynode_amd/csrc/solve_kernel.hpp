@@ -1404,6 +1404,7 @@ struct Solver {
     }
     // ================================================================ the family interface of Stepper<F> (stepper.hpp)
     static constexpr int NDIR = ND;                 // tangent directions (planes 1..ND of the state)
+    static constexpr int GW = G;                    // lanes of one wave that hold one trajectory
     static constexpr bool PULLS = true;             // slots may draw further trajectories from KArgs::work
     static constexpr bool REPLAYS = false;          // (recorded step schedules: the SEIP family)
     static constexpr bool IDLE_SLOTS_LOAD = false;  // a slot beyond the batch idles without data
@@ -1503,6 +1504,7 @@ struct Solver {
         const unsigned long long group_mask = (G == 64 ? ~0ull : ((1ull << G) - 1ull)) << ((lane_c / G) * G);
         return (bad_lanes & group_mask) == 0ull;
     }
+    __device__ __forceinline__ static void begin_attempt() {}
     __device__ __forceinline__ static T traj_sum(T v) { return group_sum<G>(v); }
     // the replicated s enters every norm once: only the lead strain lane counts it
     __device__ __forceinline__ T weigh(int v, T x) const { return (v == IS ? (lead ? T(1) : T(0)) : T(1)) * x; }

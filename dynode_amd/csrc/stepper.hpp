@@ -27,7 +27,7 @@ struct Stepper {
     using TB = typename F::TB;
     using State = typename F::State;
     using V2 = typename F::V2;
-    static constexpr int NV = F::NV, NP = F::NP, NC = F::NC, ND = F::NDIR, G = F::G, TPW = F::TPW, SU = F::SU;
+    static constexpr int NV = F::NV, NP = F::NP, NC = F::NC, ND = F::NDIR, GW = F::GW, TPW = F::TPW, SU = F::SU;
     static constexpr bool PRESCALE = F::PRESCALE, PC = F::PC, LEAN = F::LEAN, FUSED = F::FUSED;
 
     // ---- the solve.  A lane group is a SLOT that integrates one trajectory after the other:
@@ -135,6 +135,19 @@ struct Stepper {
             }
         }
 
+        // ---- prologue of the slot's trajectory (stepper_prologue.inc).  A family whose slots draw trajectories (PULLS) runs it
+        // inside the stepping loop, whenever a slot has drawn one; a static family once, in front of the loop -- the loop then
+        // carries nothing of it (the SEIP wave groups sit at their register lines).
+        if constexpr (!F::PULLS) {
+            if (need_load || F::IDLE_SLOTS_LOAD) {
+#define DYN_STEPPER_ARGS ka
+#include "stepper_prologue.inc"
+#undef DYN_STEPPER_ARGS
+            }
+        }
+        // (a static family tests at the bottom -- while any of its trajectories has steps to take -- and writes them off behind
+        // the loop: with the test at the top the exit edge would carry the whole loop state through the latch)
+        if (F::PULLS || __any(live && !done))
         for (;;) {
             // A slot that needs work waits an iteration or two when another group of its wave is on the last step of ITS
             // trajectory (tnext == t_end): one pass of the prologue then serves both (the pass costs the wave about a third of
@@ -154,7 +167,7 @@ struct Stepper {
                 const int64_t n_slots = (int64_t)gridDim.x * TPW;
                 for (;;) {
                     long long t = 0;
-                    if ((lane & (G - 1)) == 0) {
+                    if ((lane & (GW - 1)) == 0) {
                         t = n_slots + (long long)atomicAdd(work, 1);
                         if (t >= B) {
                             // this slot retires; the last one to retire re-arms the counters, so that the caller can hand
@@ -165,7 +178,7 @@ struct Stepper {
                             }
                         }
                     }
-                    t = __shfl(t, lane & ~(G - 1), 64);
+                    t = __shfl(t, lane & ~(GW - 1), 64);
                     if (t >= B) break;
                     if (order) t = order[t];
                     if ((uint64_t)t < (uint64_t)B) {
@@ -176,111 +189,18 @@ struct Stepper {
                 }
                 want_ticket = false;
             }
-            if (__builtin_expect(need_load, 0)) { // ---- prologue of trajectory `traj`, under this group's lanes
-                need_load = false;
-                const auto &kc = *cold_args<T>();
-                // the lane's indices and the layout offsets are re-derived HERE from values the compiler cannot see through:
-                // hoisted out of the stepping loop, the address arithmetic of this block would hold a dozen registers through
-                // every iteration (the D = 136 kernel sits at the 256-register line)
-                int lane_c = lane;
-                asm volatile("" : "+v"(lane_c));
-                L.load_trajectory(kc, traj, lane_c, tb, y);   // parameters, tables, initial state (plane 0) and its seeds (planes 1..ND)
-                tprev = kc.t0;
-                L.rhs(tprev, y, k[0]);
-                // NaN / inf in the initial state or its derivative (e.g. NaN parameters): fail at once
-                bool lane_ok = true; // comparisons, not x - x: under -ffp-contract an expression minus itself need not be 0
-#pragma unroll
-                for (int v = 0; v < NV; ++v)
-                    lane_ok = lane_ok && (M::abs(y[0][v]) < M::inf()) && (M::abs(k[0][0][v]) < M::inf());
-                const bool start_ok = L.start_ok(lane_ok, lane_c);
-
-                if (replay) {   // (REPLAYS) the trajectory takes the steps of a recorded schedule
-                    if constexpr (F::REPLAYS) tnext = tb.n_sch > 0 ? tb.sch[1] : tprev;
-                } else if (constant) {
-                    tnext = tprev + ka.constant_dt;
-                } else {
-                    // Hairer-Norsett-Wanner II.4 starting step (diffrax _select_initial_step), primal only
-                    // (an element replicated over the lanes of the trajectory enters every norm once: F::weigh)
-                    T n0 = 0, n1 = 0;
-                    T rsc[NV];   // float32: 1 / scale (three divisions per element would be half of this block's instructions); float64: scale
-#pragma unroll
-                    for (int v = 0; v < NV; ++v) {
-                        rsc[v] = M::rcp_ctl(atol + M::abs(y[0][v]) * rtol);
-                        const T q0 = M::div_ctl(y[0][v], rsc[v]), q1 = M::div_ctl(k[0][0][v], rsc[v]);
-                        n0 += L.weigh(v, q0 * q0);
-                        n1 += L.weigh(v, q1 * q1);
-                    }
-                    const T d0 = M::sqrt(L.traj_sum(n0) / Dn), d1 = M::sqrt(L.traj_sum(n1) / Dn);
-                    const bool small = (d0 < T(1e-5)) || (d1 < T(1e-5));
-                    const T h0 = small ? T(1e-6) : T(0.01) * (d0 / d1);
-#pragma unroll
-                    for (int c = 0; c < NC; ++c)
-#pragma unroll
-                        for (int pp = 0; pp < NP; ++pp) yt[c].p[pp] = y[c].p[pp] + h0 * k[0][c].p[pp];
-                    L.rhs(tprev + h0, yt, k[1]);
-                    T s2 = 0;
-#pragma unroll
-                    for (int v = 0; v < NV; ++v) {
-                        const T q2 = M::div_ctl(k[1][0][v] - k[0][0][v], rsc[v]);
-                        s2 += L.weigh(v, q2 * q2);
-                    }
-                    const T d2 = M::sqrt(L.traj_sum(s2) / Dn) / h0;
-                    const T max_d = M::max(d1, d2);
-                    tnext = tprev + M::min(T(100) * h0, Control<T>::initial_h1(max_d, h0));
+            if constexpr (F::PULLS) {
+                if (__builtin_expect(need_load, 0)) {
+                    // (the cold copy of the kernel arguments: cold_args() in solve_kernel.hpp)
+#define DYN_STEPPER_ARGS (*cold_args<T>())
+#include "stepper_prologue.inc"
+#undef DYN_STEPPER_ARGS
                 }
-                tnext = M::min(tnext, t_end);
-
-                save_idx = rep; // replica r owns save times r, r + R, r + 2R, ...
-                // jump bookkeeping (restates oracle/dynode_oracle_impl.inc): steps are clipped to land just
-                // before a jump, restart just after it with FSAL recomputed and the unclipped step size
-                jidx = 0;
-                at_jump = false;
-                dt_unclipped = T(0);
-                if (n_jump > 0 && !replay) {
-                    while (jidx < n_jump && jt_tab[jidx] <= tprev) ++jidx;
-                    if (jidx < n_jump && jt_tab[jidx] < tnext) {
-                        dt_unclipped = tnext - tprev;
-                        tnext = M::next(jt_tab[jidx], -M::inf());
-                        at_jump = true;
-                    }
-                }
-                if constexpr (PRESCALE) { // from here on the rates and k[0] carry the factor of the step about to be tried
-                    const T dt0 = tnext - tprev;
-                    L.scale_rates(tb.rate_tab, lane_c, dt0);
-#pragma unroll
-                    for (int c = 0; c < NC; ++c)
-#pragma unroll
-                        for (int pp = 0; pp < NP; ++pp) k[0][c].p[pp] = k[0][c].p[pp] * dt0;
-                }
-                // next two save times kept in registers (the read of ts[idx+2] overlaps a whole round)
-                ts_next = save_idx < n_save ? ts_tab[save_idx] : M::inf();
-                ts_next2 = save_idx + R < n_save ? ts_tab[save_idx + R] : M::inf();
-                steps = 0;
-                n_acc = 0;
-                n_rej = 0;
-                st = start_ok ? ST_OK : ST_NONFINITE;
-                done = !(tprev < t_end) || !start_ok;
-                live = true;
-                if constexpr (F::IDLE_SLOTS_LOAD) {
-                    if (idle_slot) { // in step with its workgroup, nothing of its own to do
-                        done = true;
-                        live = false;
-                        writer = false;
-                    }
-                }
-                if constexpr (F::REPLAYS) {
-                    si = 0;
-                    if (replay && tb.n_sch <= 0) {   // the leader ran out of schedule space (or never stepped): nothing to follow
-                        if (tb.n_sch < 0) st = ST_MAX_STEPS;
-                        done = true;
-                    }
-                }
-                L.begin_output(kc, out, traj, n_save);
-#ifdef DYN_DIAG_ROUNDS
-                diag_iters = diag_rounds = 0;
-#endif
             }
-            if (!__any(live)) break;
+            if constexpr (F::PULLS) {
+                if (!__any(live)) break;
+            }
+            L.begin_attempt();   // (a family may fence values it wants re-read in every step attempt rather than held across the loop)
 
 #ifdef DYN_DIAG_ROUNDS
             ++diag_iters;
@@ -516,29 +436,18 @@ struct Stepper {
                 L.scale_rates(tb.rate_tab, lane, dt_new);
             }
 
-            // ---- a trajectory that finished in this iteration is written off, and its slot asks for the next one
-            if (__builtin_expect(live && done, 0)) {
-                live = false;
-                want_ticket = pull;
-                // (tangent kernels with the likelihood fused in: the trajectory's score instead of rows -- Solver::finish_score)
-                bool scored = false;
-                if constexpr (ND > 0) scored = L.finish_score(ka, tb, out, traj, st, save_idx, n_save, rep, R, n_acc, n_rej, writer);
-                // rows never reached (failed solves): +inf, like diffrax's unfilled SaveAt buffer
-                if (!scored && writer) {
-                    for (; save_idx < n_save; save_idx += R) L.fill_row(ka, out, save_idx, M::inf());
-                    if (L.leader && rep == 0) {
-                        const auto &kc = *cold_args<T>();
-                        kc.status[traj] = st;
-#ifdef DYN_DIAG_ROUNDS
-                        n_acc = diag_iters;
-                        n_rej = diag_rounds;
-#endif
-                        kc.n_acc[traj] = n_acc;
-                        kc.n_rej[traj] = n_rej;
-                        if constexpr (F::REPLAYS)
-                            if (kc.sched_n_out != nullptr) kc.sched_n_out[traj] = n_acc <= kc.sched_cap ? n_acc : -1;
-                    }
+            // ---- a trajectory that finished in this iteration is written off (stepper_writeoff.inc), and its slot asks for the next one
+            if constexpr (F::PULLS) {
+                if (__builtin_expect(live && done, 0)) {
+#include "stepper_writeoff.inc"
                 }
+            } else {
+                if (!__any(live && !done)) break;
+            }
+        }
+        if constexpr (!F::PULLS) { // a static family: behind the loop
+            if (live) {
+#include "stepper_writeoff.inc"
             }
         }
         if constexpr (PC) { // tell wave 1 that no more steps will come

@@ -1,5 +1,5 @@
 """dev probe: A/B of library builds on ONE box over the side workloads (cfg3d136, cfg2, cfg5 share): HIP-event ms per launch.
-Usage: python tools/probes/ab_other.py A B   (tools/probes/_lib_<name>.so)"""
+Usage: python tools/probes/ab_other.py A B [workload ...]   (tools/probes/_lib_<name>.so)"""
 import os, sys, subprocess, json
 root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 if len(sys.argv) > 1 and sys.argv[1] == "--child":
@@ -26,9 +26,10 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
         res[name] = round(e0.elapsed_time(e1) / 40, 4)
     print(json.dumps(res))
     sys.exit(0)
-names = ["cfg3", "cfg3d136", "cfg2", "cfg5", "seip", "seip83"]
+known = ("cfg3", "cfg3d136", "cfg2", "cfg5", "seip", "seip3", "seip83", "seip84")
+names = [a for a in sys.argv[1:] if a in known] or ["cfg3", "cfg3d136", "cfg2", "cfg5", "seip", "seip83"]
 for rep in range(3):
-    for v in sys.argv[1:]:
+    for v in [a for a in sys.argv[1:] if a not in known]:
         env = dict(os.environ, DYNODE_HIP_LIB=os.path.join(root, "tools", "probes", f"_lib_{v}.so"))
         out = subprocess.run([sys.executable, os.path.abspath(__file__), "--child"] + names, env=env, capture_output=True, text=True)
         print(v, rep, out.stdout.strip().splitlines()[-1] if out.stdout.strip() else out.stderr[-400:], flush=True)
