@@ -115,7 +115,7 @@ def _stamp() -> str:
     global _STAMP
     if _STAMP is None:
         h = hashlib.sha1()
-        files = [os.path.join(_CSRC, f) for f in sorted(os.listdir(_CSRC)) if f.endswith((".hpp", ".h"))]
+        files = [os.path.join(_CSRC, f) for f in sorted(os.listdir(_CSRC)) if f.endswith((".hpp", ".h", ".inc"))]
         files.append(os.path.join(os.path.dirname(os.path.dirname(_CSRC)), "include", "dynode_hip.h"))   # the argument structs
         for path in files:
             if os.path.exists(path):

@@ -24,6 +24,10 @@ with open(os.path.join(root, "profiles", f"{tag}_nuts_kernel_stats.csv"), "w") a
 tr = list(csv.DictReader(open(trace)))
 tr.sort(key=lambda r: int(r["Start_Timestamp"]))
 idx = [i for i, r in enumerate(tr) if "nuts_advance" in r["Kernel_Name"]]
+fused = False
+if len(idx) < 8:   # one launch per iteration (dyn_solver_opts::nuts_tail): the iteration ends with the fused gradient-solve
+    idx = [i for i, r in enumerate(tr) if "solve_kernel_fused" in r["Kernel_Name"]]
+    fused = True
 # steady state: iterations in the last quarter of the run
 sel = idx[len(idx) * 3 // 4:]
 per_iter, span, solve, adv = [], [], [], []
@@ -35,7 +39,7 @@ for a, b in zip(sel[:-1], sel[1:]):
 mean = lambda x: sum(x) / max(len(x), 1)
 total = sum(int(r["TotalDurationNs"]) for r in rows)
 get = lambda pat: next((r for r in rows if pat in r["Name"]), None)
-sk, na = get("solve_kernel<float"), get("nuts_advance")
+sk, na = get("solve_kernel_fused<float") or get("solve_kernel<float"), get("nuts_advance")
 bench = {}
 for line in open(log):
     if line.startswith("{"):
@@ -45,11 +49,11 @@ with open(os.path.join(root, "profiles", f"{tag}_nuts_iteration.md"), "w") as f:
     f.write("Command: `rocprofv3 --kernel-trace --stats -- python3 tools/bench_nuts.py --chains 128 --warmup 300 --samples 300 "
             + " ".join(sys.argv[4:]) + "` (`tools/profile_nuts.sh`)\n")
     f.write("(kernel-trace inflates every tiny launch to about 4.4 us).\n\n")
-    f.write(f"- sampler iterations (`dyn_nuts_advance` launches): {len(idx)}\n")
+    f.write(f"- sampler iterations ({'fused gradient-solve + sampler launches, `solve_kernel_fused`' if fused else '`dyn_nuts_advance` launches'}): {len(idx)}\n")
     f.write(f"- kernels per iteration (steady state): {mean(per_iter):.1f}; iteration span under trace {mean(span):.1f} us\n")
     if sk:
         f.write(f"- gradient-solve kernel `{short(sk['Name'])}`: {sk['Calls']} calls, avg {float(sk['AverageNs']) / 1e3:.1f} us ({sk['Percentage']} % of GPU time)\n")
-    if na:
+    if na and not fused:
         f.write(f"- `dynnuts::nuts_advance`: {na['Calls']} calls, avg {float(na['AverageNs']) / 1e3:.1f} us, min {float(na['MinNs']) / 1e3:.1f}, max {float(na['MaxNs']) / 1e3:.1f} ({na['Percentage']} %); steady state {mean(adv):.1f} us\n")
     f.write(f"- total GPU kernel time {total / 1e9:.2f} s; kernels not named above belong to the model's torch program (none when the potential is folded, infer/folded.py)\n")
     if bench:
