@@ -501,3 +501,34 @@ def test_observation_cache_never_scores_a_new_dataset_against_an_old_one():
     buf.mul_(4.0)                                                                   # refilled in place
     b = odes._observation_constants(buf, torch.float64, dev)
     assert torch.equal(b[0], torch.full((5, 2), 4.0, dtype=torch.float64))
+
+
+def test_the_stepping_loop_is_written_once():
+    """One stepper for every right-hand side (the reference has one `diffeqsolve`, odes.py:133-144): the step-size controller,
+    the clip to the end of the interval and the starting step are called from `csrc/stepper.hpp` (+ its two includes) and
+    from nowhere else; the model families (`solve_kernel.hpp`: Solver, `seip_kernel.hpp`: Seip) implement the interface its
+    header documents and carry no loop of their own."""
+    import os
+    import re
+
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "dynode_amd", "csrc")
+    calls = {}
+    for name in sorted(os.listdir(csrc)):
+        if not name.endswith((".hpp", ".inc", ".hip", ".def")):
+            continue
+        text = open(os.path.join(csrc, name)).read()
+        text = re.sub(r"//[^\n]*", "", text)
+        for fn in ("decide", "clip_to_end", "initial_h1"):
+            n = len(re.findall(r"Control<T>::" + fn + r"\(", text))
+            if n:
+                calls.setdefault(fn, {})[name] = n
+    assert calls == {"decide": {"stepper.hpp": 1}, "clip_to_end": {"stepper.hpp": 1}, "initial_h1": {"stepper_prologue.inc": 1}}
+    hooks = ("init(", "carve(", "load_trajectory(", "begin_attempt(", "start_ok(", "weigh(", "count_once(", "begin_output(",
+             "dense_begin(", "emit_row(", "fill_row(")
+    for family in ("solve_kernel.hpp", "seip_kernel.hpp"):
+        text = open(os.path.join(csrc, family)).read()
+        for h in hooks:
+            assert re.search(r"\b" + re.escape(h), text), (family, h)
+        assert "__any(!done)" not in re.sub(r"//[^\n]*", "", text)      # (no "while a trajectory has steps to take" of their own)
+    seip = re.sub(r"//[^\n]*", "", open(os.path.join(csrc, "seip_kernel.hpp")).read())
+    assert "Stepper<Seip<" in seip and "while (__any" not in seip
