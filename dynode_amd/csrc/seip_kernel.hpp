@@ -213,10 +213,10 @@ struct Seip {
         }
         ages.contract(x, lam);
         T season = T(1), phi = T(0);
-        if (seasonal) season = T(1) + amp * M::sin(w_season * t + phase);
+        if (seasonal) season = T(1) + amp * M::sin_lib(w_season * t + phase);
         if (seasonal_vax) {
             // sin^1000 by squaring (the oracle multiplies in the same order): 1000 = 2 * (256+128+64+32+16+4)
-            const T sn = M::sin(T(6.283185307179586476925286766559) * (t + tau) / T(730));
+            const T sn = M::sin_lib(T(6.283185307179586476925286766559) * (t + tau) / T(730));
             const T u = sn * sn, u2 = u * u, u4 = u2 * u2, u8 = u4 * u4, u16 = u8 * u8, u32 = u16 * u16,
                     u64 = u32 * u32, u128 = u64 * u64, u256 = u128 * u128;
             phi = ((((u256 * u128) * u64) * u32) * u16) * u4;
@@ -315,9 +315,9 @@ struct Seip {
         }
         ages.contract(x, lam);
         T season = T(1), phi = T(0);
-        if (seasonal) season = T(1) + amp * M::sin(w_season * t + phase);
+        if (seasonal) season = T(1) + amp * M::sin_lib(w_season * t + phase);
         if (seasonal_vax) {
-            const T sn = M::sin(T(6.283185307179586476925286766559) * (t + tau) / T(730));
+            const T sn = M::sin_lib(T(6.283185307179586476925286766559) * (t + tau) / T(730));
             const T u = sn * sn, u2 = u * u, u4 = u2 * u2, u8 = u4 * u4, u16 = u8 * u8, u32 = u16 * u16,
                     u64 = u32 * u32, u128 = u64 * u64, u256 = u128 * u128;
             phi = ((((u256 * u128) * u64) * u32) * u16) * u4;
@@ -420,9 +420,9 @@ struct Seip {
         const int tlw = TIER_X ? (wv >> HB_X) : 0, hw = wv & (NXH - 1);
         (void)hw;
         T phi = T(0), season = T(1);
-        if (seasonal) season = T(1) + amp * M::sin(w_season * t + phase);
+        if (seasonal) season = T(1) + amp * M::sin_lib(w_season * t + phase);
         if (seasonal_vax) {
-            const T sn = M::sin(T(6.283185307179586476925286766559) * (t + tau) / T(730));
+            const T sn = M::sin_lib(T(6.283185307179586476925286766559) * (t + tau) / T(730));
             const T u = sn * sn, u2 = u * u, u4 = u2 * u2, u8 = u4 * u4, u16 = u8 * u8, u32 = u16 * u16,
                     u64 = u32 * u32, u128 = u64 * u64, u256 = u128 * u128;
             phi = ((((u256 * u128) * u64) * u32) * u16) * u4;

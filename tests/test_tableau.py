@@ -67,3 +67,34 @@ def test_tsit5_dense_polynomial_in_the_kernel_equals_the_factored_weights():
         assert np.abs(w - O.tsit5_dense_weights(th)).max() < 3e-14   # coefficients up to 88: cancellation at the 1e-14 level in float64
     _, A, _, _ = O.tableau("tsit5")
     assert np.abs(bp.sum(1) + np.eye(7)[0] - A[6]).max() < 3e-14      # theta = 1: the solution weights
+
+
+def test_seasonal_sine_of_the_float32_kernels():
+    """`Mth<float>::sin` (csrc/solve_kernel.hpp): x - n pi by three Cody-Waite FMAs, the odd Taylor polynomial to x^13, the sign
+    from n's parity.  The same arithmetic in NumPy (an FMA = the product and sum in float64, rounded once) against float64:
+    within 1.3e-7 everywhere a seasonal argument w t + phase can be (years of a yearly cycle and far beyond)."""
+    f32 = np.float32
+
+    def fma(a, b, c):
+        return (a.astype(np.float64) * np.float64(b) + c.astype(np.float64)).astype(f32) if np.isscalar(b) else \
+            (a.astype(np.float64) * b.astype(np.float64) + c.astype(np.float64)).astype(f32)
+
+    def kernel_sin(x):
+        x = x.astype(f32)
+        n = np.rint(x * f32(0.318309886183790671538)).astype(f32)
+        r = fma(n, f32(-3.140625), x)
+        r = fma(n, f32(-9.67502593994140625e-4), r)
+        r = fma(n, f32(-1.509957990978376432e-7), r)
+        r2 = (r * r).astype(f32)
+        p = np.full_like(x, f32(1.0 / 6227020800.0))
+        for c in (-1.0 / 39916800.0, 1.0 / 362880.0, -1.0 / 5040.0, 1.0 / 120.0, -1.0 / 6.0):
+            p = fma(p, r2, np.full_like(x, f32(c)))
+        s = fma(r, (p * r2).astype(f32), r)
+        return np.where(n.astype(np.int64) & 1, -s, s).astype(f32)
+
+    rng = np.random.default_rng(0)
+    for lo, hi in ((-7.0, 7.0), (0.0, 3000.0), (-2e4, 2e4)):
+        x = rng.uniform(lo, hi, 400_000).astype(f32)
+        assert np.abs(kernel_sin(x).astype(np.float64) - np.sin(x.astype(np.float64))).max() < 1.3e-7
+    edge = np.array([0.0, -0.0, np.pi, -np.pi, np.pi / 2, 1e-30, 2e5], dtype=f32)
+    assert np.abs(kernel_sin(edge).astype(np.float64) - np.sin(edge.astype(np.float64))).max() < 2e-7

@@ -22,7 +22,8 @@ def run(wl, reps=40):
     return e0.elapsed_time(e1) / reps, r.ys
 
 
-for name, B in (("cfg2", 4096), ("cfg2", 16384), ("cfg2", 1024)):
+import sys as _s
+for name, B in ([(a.split(":")[0], int(a.split(":")[1])) for a in _s.argv[1:]] or [("cfg2", 4096), ("cfg2", 16384), ("cfg2", 1024)]):
     wl = synthetic.WORKLOADS[name](B)
     ref = None
     for rnd in range(2):
