@@ -881,7 +881,7 @@ struct Seip {
             }
         }
     }
-    __device__ __forceinline__ static void begin_attempt() {}
+    __device__ __forceinline__ static void begin_attempt(const PS (&)[1]) {}   // (the population of an age is a parameter here)
     __device__ __forceinline__ void rhs(T t, const PS (&y)[1], PS (&dy)[1]) const { rhs(t, y[0], dy[0]); }
     __device__ __forceinline__ bool start_ok(bool lane_ok, int) const { return !wg_any(!lane_ok); } // no lane of the trajectory saw NaN / inf
     __device__ __forceinline__ static T weigh(int, T x) { return x; }   // (no element is held by more than one lane)

@@ -643,6 +643,70 @@ struct Solver {
         }
     }
 
+    // ---- the age's population, once per step attempt.  Every flow of these models moves people between compartments of the
+    // same age (infection, progression, recovery, waning; visitors are never added to the state), so s + e + i + r of an age --
+    // and the sum of every tangent plane -- is the same at the six stage states of a step in exact arithmetic: each stage
+    // derivative sums to zero.  The reference recomputes it in every right-hand side (examples/*.py: `pop = s + e + i + r`);
+    // here it is formed from the step's starting state (Stepper: begin_attempt) and reused by the stages, which tracks the
+    // state's rounding drift like the reference does, one step late, and drops ~12 of each right-hand side's instructions
+    // (a cross-lane sum and a reciprocal among them).  Not with vaccination tiers: there the contact groups are (age, tier)
+    // and doses move people between them.
+    static constexpr bool POP_PER_ATTEMPT = KV == 0;
+    T pop_N, pop_invN, pop_dN[NDA];
+    __device__ __forceinline__ T population(const State &y0) const {
+        if constexpr (PAIRED_RHS) {
+            constexpr int PE = IE / 2, PI = II / 2, PR = IR / 2;
+            V2 tot = y0.p[PI];
+#pragma unroll
+            for (int q = 1; q < SP; ++q) tot += y0.p[PI + q];
+#pragma unroll
+            for (int q = 0; q < SP; ++q) {
+                if constexpr (HAS_E) tot += y0.p[PE + q];
+                tot += y0.p[PR + q];
+            }
+            return y0[IS] + strain_sum(tot[0] + tot[1]);
+        } else {
+            // everyone of this lane's strains who is not susceptible: the elements e | i | r sit in front of c and s (0 .. IC - 1);
+            // whole register pairs are added pairwise (packed adds), the two halves and an odd last element at the end
+            T others;
+            if constexpr (IC >= 4) {
+                V2 tot = y0.p[0];
+#pragma unroll
+                for (int q = 1; q < IC / 2; ++q) tot += y0.p[q];
+                others = tot[0] + tot[1];
+                if constexpr (IC % 2 == 1) others += y0[IC - 1];
+            } else {
+                others = y0[0];
+#pragma unroll
+                for (int v = 1; v < IC; ++v) others += y0[v];
+            }
+            return y0[IS] + strain_sum(others);
+        }
+    }
+    __device__ __forceinline__ T population_tangent(const State &u) const {
+        T dse = 0, dsi = 0, dsr = 0;
+#pragma unroll
+        for (int l = 0; l < S; ++l) {
+            if constexpr (HAS_E) dse += u[IE + l];
+            dsi += u[II + l];
+#pragma unroll
+            for (int w = 0; w < W; ++w) dsr += u[IR + l * W + w];
+        }
+        return u[IS] + strain_sum((dse + dsi) + dsr);
+    }
+    // Stepper hook: the state a step attempt starts from
+    __device__ __forceinline__ void begin_attempt(const State (&y)[NC]) {
+        if constexpr (POP_PER_ATTEMPT) {
+            pop_N = population(y[0]);
+            pop_invN = T(1);
+            if (normalize) pop_invN = pad ? T(0) : M::recip(pop_N);
+            if constexpr (ND > 0) {
+#pragma unroll
+                for (int j = 0; j < ND; ++j) pop_dN[j] = population_tangent(y[1 + j]);
+            }
+        }
+    }
+
     // f(t, y) for this lane's age bin (plane 0) and its JVP (planes 1..ND);
     // reference RHS: see include/dynode_hip.h
     // f(t, y) written on register pairs over the strains (plain multi-strain shapes in float32: the 8 age x 4 strain models).
@@ -650,18 +714,8 @@ struct Solver {
     // net flow of s -- are formed pairwise first and across the pair last (a different, equally valid summation order).
     __device__ __forceinline__ void rhs_strain_pairs(T t, const State &y0, State &dy) const {
         constexpr int PE = IE / 2, PI = II / 2, PR = IR / 2, PC = IC / 2;
-        V2 tot = y0.p[PI];
-#pragma unroll
-        for (int q = 1; q < SP; ++q) tot += y0.p[PI + q];
-#pragma unroll
-        for (int q = 0; q < SP; ++q) {
-            if constexpr (HAS_E) tot += y0.p[PE + q];
-            tot += y0.p[PR + q];
-        }
         const T s = y0[IS];
-        const T N = s + strain_sum(tot[0] + tot[1]);
-        T invN = T(1);
-        if (normalize) invN = pad ? T(0) : M::recip(N);
+        const T invN = pop_invN;   // (PAIRED_RHS implies KV == 0: the population of the step's starting state, begin_attempt)
         T season = T(1);
         if (__builtin_expect(seasonal, 0)) season = T(1) + amp * M::sin(w_season * t + phase);
         T x[S], acc[S];
@@ -704,23 +758,15 @@ struct Solver {
             return;
         }
         const State &y0 = y[0];
-        // everyone of this lane's strains who is not susceptible: the elements e | i | r sit in front of c and s (0 .. IC - 1);
-        // whole register pairs are added pairwise (packed adds), the two halves and an odd last element at the end
-        T others;
-        if constexpr (IC >= 4) {
-            V2 tot = y0.p[0];
-#pragma unroll
-            for (int q = 1; q < IC / 2; ++q) tot += y0.p[q];
-            others = tot[0] + tot[1];
-            if constexpr (IC % 2 == 1) others += y0[IC - 1];
+        T N, invN;
+        if constexpr (POP_PER_ATTEMPT) { // the population of the step's starting state (begin_attempt)
+            N = pop_N;
+            invN = pop_invN;
         } else {
-            others = y0[0];
-#pragma unroll
-            for (int v = 1; v < IC; ++v) others += y0[v];
+            N = population(y0);
+            invN = T(1);
+            if (normalize) invN = pad ? T(0) : M::recip(N);
         }
-        const T N = y0[IS] + strain_sum(others);
-        T invN = T(1);
-        if (normalize) invN = pad ? T(0) : M::recip(N);
         T season = T(1), sin_arg = T(0), cos_arg = T(0);
         if (__builtin_expect(seasonal, 0)) {
             const T arg = w_season * t + phase;
@@ -808,15 +854,7 @@ struct Solver {
             for (int j = 0; j < ND; ++j) {
                 const State &u = y[1 + j];
                 State &du = dy[1 + j];
-                T dse = 0, dsi = 0, dsr = 0;
-#pragma unroll
-                for (int l = 0; l < S; ++l) {
-                    if constexpr (HAS_E) dse += u[IE + l];
-                    dsi += u[II + l];
-#pragma unroll
-                    for (int w = 0; w < W; ++w) dsr += u[IR + l * W + w];
-                }
-                const T dN = u[IS] + strain_sum((dse + dsi) + dsr);
+                const T dN = POP_PER_ATTEMPT ? pop_dN[j] : population_tangent(u);
                 const T dinvN = normalize ? -(invN * invN) * dN : T(0); // pad: invN == 0
                 T dseason = T(0);
                 if (seasonal)
@@ -1528,7 +1566,6 @@ struct Solver {
         const unsigned long long group_mask = (G == 64 ? ~0ull : ((1ull << G) - 1ull)) << ((lane_c / G) * G);
         return (bad_lanes & group_mask) == 0ull;
     }
-    __device__ __forceinline__ static void begin_attempt() {}
     __device__ __forceinline__ static T traj_sum(T v) { return group_sum<G>(v); }
     // the replicated s enters every norm once: only the lead strain lane counts it
     __device__ __forceinline__ T weigh(int v, T x) const { return (v == IS ? (lead ? T(1) : T(0)) : T(1)) * x; }

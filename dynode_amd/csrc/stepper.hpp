@@ -13,7 +13,7 @@
 //   F L; L.init(ka, lane)                       lane indices, shared model data (contact row, switches)
 //   L.carve(ka, lds, ...)                       the family's LDS tables behind the save grid and the discontinuity points
 //   L.load_trajectory(kc, traj, ..., y)         parameters, tables and initial state (+ seeds) of trajectory `traj`
-//   L.rhs(t, y, k)                              k = f(t, y) (k = dt f under PRESCALE), all planes
+//   L.begin_attempt(y); L.rhs(t, y, k)          per-attempt data from the step's starting state; k = f(t, y) (k = dt f under PRESCALE), all planes
 //   L.traj_sum(x), L.start_ok(lane_ok)          reductions over the lanes (and waves) of the trajectory
 //   L.dense_begin / L.write_row / L.fill_row    dense output of an accepted step, one saved row, a row never reached
 #pragma once
@@ -200,7 +200,7 @@ struct Stepper {
             if constexpr (F::PULLS) {
                 if (!__any(live)) break;
             }
-            L.begin_attempt();   // (a family may fence values it wants re-read in every step attempt rather than held across the loop)
+            L.begin_attempt(y);  // what the family forms once per step attempt from the state it starts from (Solver: the age's population)
 
 #ifdef DYN_DIAG_ROUNDS
             ++diag_iters;
