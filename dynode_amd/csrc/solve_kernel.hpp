@@ -1669,7 +1669,8 @@ namespace dyn {
 // compiler's default range.
 template <typename T, int METHOD, int GA, int ST, int W, int ND, int SPL, int FEAT>
 constexpr int waves_per_simd(bool upper) {
-    return (sizeof(T) == 4 && METHOD == 0 && GA == 8 && ST == 4 && W == 8 && ND == 0 && SPL == 1 && (FEAT & ~0x4000) == 0) ? 3 : (upper ? 8 : 1);
+    return (sizeof(T) == 4 && METHOD == 0 && GA == 8 && ST == 4 && ND == 0 && (FEAT & ~0x4000) == 0 &&
+            ((W == 8 && SPL == 1) || (W == 1 && SPL == 2))) ? 3 : (upper ? 8 : 1);
 }
 
 template <typename T, int METHOD, int GA, int ST, bool HAS_E, bool HAS_WANE, bool HAS_C, int W, int ND, int SPL,
