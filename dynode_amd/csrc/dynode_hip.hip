@@ -622,7 +622,7 @@ static int solve_impl(const dyn_model_desc *m, const dyn_solver_opts *o, const v
     if (sc && (sc->cap < 1 || (sc->out && !sc->n_out) || (sc->in && !sc->n_in))) return DYN_ERR_SIZE;
     if (e && m->family == 1) { // susceptibility table and splines of every trajectory of a wave sit in LDS
         const size_t per_traj = (size_t)(1 << m->n_strain) * dyn::seip_tiers(m) * m->n_wane * m->n_strain +
-                                (size_t)m->n_age * dyn::seip_tiers(m) * (4 + 2 * m->n_vax_knots) +
+                                (size_t)m->n_age * dyn::seip_tiers(m) * 12 /* Seip::kSplRow: padded spline rows */ +
                                 (sc && sc->in ? (size_t)2 * sc->cap : 0); /* replayed schedule */
         const int nw = dyn::entry_waves(e), ktl = dyn::entry_tier_lanes(e), kl = (dyn::seip_tiers(m) + ktl - 1) / ktl;
         const size_t mailbox = nw > 1 ? (size_t)2 * nw * 64 * (m->n_strain + kl * 4 + m->n_wane + 2 * m->n_strain) : 0; /* >= 2 NW NSLOT 64 */

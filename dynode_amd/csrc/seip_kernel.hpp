@@ -132,14 +132,12 @@ struct Seip {
                 const T lag = M::max(t - r[4 + n], T(0));
                 nu += r[8 + n] * (lag * lag * lag);
             }
-        } else {
+        } else { // LDS row: the cubic's 4 coefficients | 4 knots | 4 knot coefficients, padded beyond nk by knots never reached and zeros
             nu = c[0] + t * (c[1] + t * (c[2] + t * c[3]));
 #pragma unroll
-            for (int n = 0; n < 4; ++n) { // branch-free: knots beyond nk (wave-uniform) contribute coef = 0
-                const bool on = n < nk;
-                const T knot = c[on ? 4 + n : 0], coef = on ? c[on ? 4 + nk + n : 0] : T(0);
-                const T lag = M::max(t - knot, T(0));
-                nu += coef * (lag * lag * lag);
+            for (int n = 0; n < 4; ++n) {
+                const T lag = M::max(t - c[4 + n], T(0));
+                nu += c[8 + n] * (lag * lag * lag);
             }
         }
         return nu;
@@ -228,7 +226,7 @@ struct Seip {
         T rate[K1];
 #pragma unroll
         for (int k = 0; k < K1; ++k) {
-            const T nu = dose_rate_at(k, spl + k * (4 + 2 * nk), t);
+            const T nu = dose_rate_at(k, spl + k * kSplRow, t);
             T tot = y[k * M1];
 #pragma unroll
             for (int m = 1; m < M1; ++m) tot += y[k * M1 + m];
@@ -332,7 +330,7 @@ struct Seip {
             const int k = sl * 2 + tl;          // this slot's tier
             const bool live = k < K1, top = k == K;
             const int kc = live ? k : K;        // padded slots hold nobody: any valid table row will do
-            const T nu = dose_rate_at(sl, spl + kc * (4 + 2 * nk), t);
+            const T nu = dose_rate_at(sl, spl + kc * kSplRow, t);
             T tot = y[sl * M1];
 #pragma unroll
             for (int m = 1; m < M1; ++m) tot += y[sl * M1 + m];
@@ -442,7 +440,7 @@ struct Seip {
         for (int sl = 0; sl < KL; ++sl) {
             const int k = sl * KT + tl;
             const int kc = k < K1 ? k : K;
-            const T nu = dose_rate_at(sl, spl + kc * (4 + 2 * nk), t);
+            const T nu = dose_rate_at(sl, spl + kc * kSplRow, t);
             dose[sl] = M::max(nu, T(0)) * pop;
             T tt = y[sl * M1];
 #pragma unroll
@@ -720,6 +718,7 @@ struct Seip {
     static constexpr bool REPLAYS = true;           // recorded step schedules (KArgs::sched_*: dyn_solve_batch_record / _replay)
     static constexpr bool IDLE_SLOTS_LOAD = true;   // a slot beyond the batch keeps in step on the last trajectory's data
     static constexpr int SUSN = H * K1 * M1 * L;    // susceptibility table of one trajectory
+    static constexpr int kSplRow = 12;              // one dose spline in LDS: 4 cubic coefficients | 4 knots | 4 knot coefficients
     int a, g, tidx;       // age lane; (age, history) group in memory order; index among the G lanes of the trajectory
     bool writer, leader;  // the lane stores rows (not a pad lane) / reports the trajectory's status
 
@@ -767,7 +766,7 @@ struct Seip {
         int n_sch;   // would wait for every store issued before it: the loads and stores share vmcnt)
     };
     __device__ __forceinline__ void carve(const KArgs<T> &ka, Tables &tb, T *, T *free_lds, int, int grp, int, int) {
-        const int spln = ka.A * K1 * (4 + 2 * ka.n_vax_knots);
+        const int spln = ka.A * K1 * kSplRow;
         const bool replay = ka.sched_in != nullptr;
         tb.tab = free_lds + grp * (SUSN + spln);
         T *const sch_base = free_lds + TPW * (SUSN + spln);
@@ -782,7 +781,7 @@ struct Seip {
         PS &y = ys[0];
         const int A = ka.A;
         const int aa = pad ? 0 : a;
-        const int spln = A * K1 * (4 + 2 * nk);
+        const int spln = A * K1 * kSplRow;
         const T *p = ka.params + traj * ka.P;
         const T *q = p + 3 * L + M1;
 #pragma unroll
@@ -813,7 +812,20 @@ struct Seip {
             }
         }
         T *const tab = tb.tab;
-        for (int n = tidx; n < SUSN + spln; n += G) tab[n] = q[n];
+        for (int n = tidx; n < SUSN; n += G) tab[n] = q[n];
+        {   // the dose splines, one row of kSplRow per (age, tier): the parameter row's 4 + 2 nk values spread to fixed places, so
+            // that the right-hand side reads a row with constant offsets and no "is this knot in use" selects
+            const T *const src = q + SUSN;
+            const int rowlen = 4 + 2 * nk;
+            for (int n = tidx; n < spln; n += G) {
+                const int row = n / kSplRow, jj = n % kSplRow;
+                T v;
+                if (jj < 4) v = src[row * rowlen + jj];
+                else if (jj < 8) v = (jj - 4 < nk) ? src[row * rowlen + jj] : M::inf();            // a knot that is never reached
+                else v = (jj - 8 < nk) ? src[row * rowlen + 4 + nk + (jj - 8)] : T(0);
+                tab[SUSN + n] = v;
+            }
+        }
         if (ka.sched_in != nullptr) { // replay: the leader's schedule, staged in LDS
             const int64_t lead = ka.sched_leader ? ka.sched_leader[traj] : traj;
             tb.n_sch = ka.sched_n_in[lead];
@@ -822,7 +834,7 @@ struct Seip {
         }
         __syncthreads();
         sus = tab + hist * (K1 * M1 * L);
-        spl = tab + SUSN + aa * K1 * (4 + 2 * nk);
+        spl = tab + SUSN + aa * K1 * kSplRow;
         {
             extern __shared__ __attribute__((aligned(32))) unsigned char dyn_smem[];
             spl_off = (int)(spl - reinterpret_cast<const T *>(dyn_smem));
@@ -833,14 +845,9 @@ struct Seip {
                 const int kt = sl * KT + tl, kc = kt < K1 ? kt : K;   // padded slots hold nobody: any valid row will do
 #pragma unroll
                 for (int q = 0; q < M1 * L; ++q) susr[sl * M1 * L + q] = sus[kc * M1 * L + q];
-                const T *c = spl + kc * (4 + 2 * nk);
+                const T *c = spl + kc * kSplRow;
 #pragma unroll
-                for (int n = 0; n < 4; ++n) {
-                    const bool on = n < nk;
-                    splr[sl * 12 + n] = c[n];
-                    splr[sl * 12 + 4 + n] = c[on ? 4 + n : 0];
-                    splr[sl * 12 + 8 + n] = on ? c[on ? 4 + nk + n : 0] : T(0);
-                }
+                for (int n = 0; n < kSplRow; ++n) splr[sl * 12 + n] = c[n];
             }
         }
 #pragma unroll
@@ -971,7 +978,7 @@ hipError_t launch_seip(const KArgs<T> &ka, hipStream_t stream) {
     constexpr int TPW = Shape::TPW;
     const int64_t blocks = (ka.B + TPW - 1) / TPW;
     if (blocks <= 0) return hipSuccess;
-    const size_t per_traj = (size_t)(1 << L) * K1 * M1 * L + (size_t)ka.A * K1 * (4 + 2 * ka.n_vax_knots);
+    const size_t per_traj = (size_t)(1 << L) * K1 * M1 * L + (size_t)ka.A * K1 * Shape::kSplRow;
     const size_t lds = ((size_t)ka.n_save + (ka.n_jump > 0 ? kMaxJumps : 0) + TPW * per_traj +
                         (ka.sched_in != nullptr ? (size_t)TPW * 2 * ka.sched_cap : 0) +
                         (NW > 1 ? (size_t)2 * NW * Shape::NSLOT * 64 : 0)) * sizeof(T);

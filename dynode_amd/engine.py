@@ -306,7 +306,7 @@ def schedule_capacity(model: ModelDesc, dtype, n_save: int) -> int:
     while ga < A:
         ga <<= 1
     tpw = max(1, 64 // (ga * H))            # the most trajectories any lane mapping puts in a wave (one lane per age x history)
-    per_traj = H * K1 * M1 * nL + A * K1 * (4 + 2 * nk)
+    per_traj = H * K1 * M1 * nL + A * K1 * 12          # (dose splines sit in LDS as rows of 12: csrc/seip_kernel.hpp kSplRow)
     words = 65536 // (8 if dtype == torch.float64 else 4) - n_save - 16 - tpw * per_traj      # wave groups: their mailbox has LDS of its own
     return int(max(8, min(SCHEDULE_CAP, words // (2 * tpw))))
 
