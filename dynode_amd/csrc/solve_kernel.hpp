@@ -417,6 +417,22 @@ struct Control {
         f = M::max(f, keep ? T(1) : T(0.2));
         factor = M::min(f, T(10));
     }
+    // the same from the MEAN SQUARE of the scaled error, err = sqrt(ms): float32 goes without the square root --
+    // err < 1 <=> ms < 1, err^(-1/5) = ms^(-1/10) through the same v_log_f32 / v_exp_f32 pair -- which is ten instructions of
+    // every step attempt (the correctly rounded sqrtf is a v_sqrt_f32 plus denormal scaling and two refinement steps);
+    // float64 keeps the oracle's operation order (its step counts are compared one for one)
+    static __device__ __forceinline__ void decide_ms(T ms, T tprev, T dt, bool &keep, bool &finite, T &factor) {
+        if constexpr (sizeof(T) == 4) {
+            if (!(ms == ms)) ms = M::inf();
+            keep = ms < T(1);
+            finite = !(ms == M::inf() && !(tprev + T(0.2) * dt > tprev));
+            T f = T(0.9) * M::pow_fast(ms, T(-0.1));
+            f = M::max(f, keep ? T(1) : T(0.2));
+            factor = M::min(f, T(10));
+        } else {
+            decide(M::sqrt(ms), tprev, dt, keep, finite, factor);
+        }
+    }
     // diffeqsolve's clip-to-end; returns true when the step was clipped (a pending jump clip is then void)
     static __device__ __forceinline__ bool clip_to_end(T &next_t1, T tp, bool accept, T t_end) {
         if (next_t1 > t_end - M::clip_tol) {
@@ -1467,6 +1483,7 @@ struct Solver {
     // ================================================================ the family interface of Stepper<F> (stepper.hpp)
     static constexpr int NDIR = ND;                 // tangent directions (planes 1..ND of the state)
     static constexpr int GW = G;                    // lanes of one wave that hold one trajectory
+    static constexpr bool ROOTLESS_NORM = KV == 0;  // the controller works on the mean square of the error (Control::decide_ms); not with the dose cap's kinks
     static constexpr bool PULLS = true;             // slots may draw further trajectories from KArgs::work
     static constexpr bool REPLAYS = false;          // (recorded step schedules: the SEIP family)
     static constexpr bool IDLE_SLOTS_LOAD = false;  // a slot beyond the batch idles without data

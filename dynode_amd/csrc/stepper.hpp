@@ -251,7 +251,10 @@ struct Stepper {
                 }
                 const V2 ss2 = ssq[0] + ssq[1];
                 const T ss = ss2[0] + ss2[1];
-                Control<T>::decide(M::sqrt(L.traj_sum(ss) / Dn), tprev, dt, keep, finite, factor);
+                // (families whose right-hand side has kinks keep the oracle's operation order to the letter: where a step lands
+                // relative to a kink is decided by float32 rounding, and their parity bars were measured with it)
+                if constexpr (F::ROOTLESS_NORM) Control<T>::decide_ms(L.traj_sum(ss) / Dn, tprev, dt, keep, finite, factor);
+                else Control<T>::decide(M::sqrt(L.traj_sum(ss) / Dn), tprev, dt, keep, finite, factor);
             } else {
                 T chk = 0;
 #pragma unroll

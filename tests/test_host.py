@@ -518,11 +518,12 @@ def test_the_stepping_loop_is_written_once():
             continue
         text = open(os.path.join(csrc, name)).read()
         text = re.sub(r"//[^\n]*", "", text)
-        for fn in ("decide", "clip_to_end", "initial_h1"):
+        for fn in ("decide", "decide_ms", "clip_to_end", "initial_h1"):
             n = len(re.findall(r"Control<T>::" + fn + r"\(", text))
             if n:
                 calls.setdefault(fn, {})[name] = n
-    assert calls == {"decide": {"stepper.hpp": 1}, "clip_to_end": {"stepper.hpp": 1}, "initial_h1": {"stepper_prologue.inc": 1}}
+    assert calls == {"decide": {"stepper.hpp": 1}, "decide_ms": {"stepper.hpp": 1}, "clip_to_end": {"stepper.hpp": 1},
+                     "initial_h1": {"stepper_prologue.inc": 1}}
     hooks = ("init(", "carve(", "load_trajectory(", "begin_attempt(", "start_ok(", "weigh(", "count_once(", "begin_output(",
              "dense_begin(", "emit_row(", "fill_row(")
     for family in ("solve_kernel.hpp", "seip_kernel.hpp"):
