@@ -1055,12 +1055,15 @@ struct Solver {
         a = a * d.theta + q1;
         return a * d.scale + y0v;
     }
+    // (PP0 .. PP1 - 1: the register pairs whose rows will be evaluated -- all of them, or, lean instance, the pairs that hold
+    // the scored compartment: the other elements' coefficients would be 21 packed FMAs per pair and plane for nobody)
+    template <int PP0 = 0, int PP1 = NP>
     __device__ __forceinline__ static void dense_coefficients(T dt, const State (&y)[NC], const State (&y1)[NC],
                                                               State (&k)[7][NC]) {
 #pragma unroll
         for (int c = 0; c < NC; ++c)
 #pragma unroll
-            for (int pp = 0; pp < NP; ++pp) {
+            for (int pp = PP0; pp < PP1; ++pp) {
                 const V2 k0 = k[0][c].p[pp], k1 = k[1][c].p[pp], k2 = k[2][c].p[pp], k3 = k[3][c].p[pp],
                          k4 = k[4][c].p[pp], k5 = k[5][c].p[pp], k6 = k[6][c].p[pp];
                 if constexpr (METHOD == 0) {
@@ -1611,7 +1614,8 @@ struct Solver {
         }
     }
     __device__ __forceinline__ static void dense_begin(T dt, const State (&y)[NC], const State (&y1)[NC], State (&k)[7][NC]) {
-        dense_coefficients(dt, y, y1, k);
+        if constexpr (LEAN) dense_coefficients<IR / 2, (IR + S * W - 1) / 2 + 1>(dt, y, y1, k);   // rows = the likelihood of the increments of r
+        else dense_coefficients(dt, y, y1, k);
     }
     // the row of save time tprev + theta dt (`on`: this lane stores it): the saved compartments and their tangents, or --
     // tangent kernels with the likelihood fused in -- the row's contribution to the score
