@@ -1770,11 +1770,16 @@ hipError_t launch(const KArgs<T> &ka_in, hipStream_t stream) {
         //                  cfg 2 B = 65536  0.645-0.66 -> 0.625-0.63
         // Every pass of the prologue stalls ALL lane groups of its wave, so with eight short trajectories per wave the passes
         // cost more than the waiting they remove; with a queue sorted by cost, pulling is what makes longest-first work.
-        // Default therefore: pull when a wave holds at most two trajectories, or when the caller supplied the queue.
+        // Since the D = 360 kernel runs three waves per SIMD (waves_per_simd below) the static grid wins there too -- the
+        // hardware starts the next wave (pair of trajectories) the moment one retires, and 6144 slots leave 2.7 jobs each:
+        //   D = 360 B = 16384, bench.py, three alternations on one box: static 2.332 ms (0.464), pulling 2.385 (0.454);
+        //   with the caller's exact order: static 2.24-2.28, pulling 2.30-2.40;  D = 136 B = 65536 in the caller's order:
+        //   static 3.186, pulling 3.167;  cfg 5 B = 65536: 3.286 -> 3.259.
+        // Default therefore: pull when the caller supplied the queue and a wave holds more than two trajectories.
         // DYNODE_HIP_PULL=0 / 1 forces it off / on, DYNODE_HIP_PULL_WAVES=<n> sets the grid (tests, tuning).
         const char *mode = getenv("DYNODE_HIP_PULL");
         const char *forced = getenv("DYNODE_HIP_PULL_WAVES");
-        const bool want = mode ? atoi(mode) != 0 : (forced != nullptr || TPW <= 2 || ka.order != nullptr);
+        const bool want = mode ? atoi(mode) != 0 : (forced != nullptr || (TPW > 2 && ka.order != nullptr));
         int64_t resident = forced ? atoll(forced) : resident_waves(kernel, lds);
         if (!want || ka.rep_log2 != 0 || resident <= 0 || blocks <= resident)
             ka.work = nullptr;

@@ -139,9 +139,10 @@ typedef struct dyn_solver_opts {
      * no lane group idles behind a longer-running partner, and nothing has to be known about the batch in advance.  The
      * kernel leaves both words zero again, so one pair serves every launch of a stream; launches that may overlap (other
      * streams) need pairs of their own.  The caller owns the memory, like every other buffer of this ABI.  Results never
-     * depend on it.  The library pulls where that was measured to pay: kernels with at most two trajectories per wave, and
-     * any kernel when the caller supplies the queue (dyn_solve_batch_ordered: longest-first needs dynamic assignment).
-     * NULL, batches of one resident round, and the SEIP family: a static grid, as before ABI 7. */
+     * depend on it.  The library pulls where that was measured to pay: when the caller supplies the queue
+     * (dyn_solve_batch_ordered: longest-first needs dynamic assignment) and a wave holds more than two trajectories;
+     * DYNODE_HIP_PULL=1 pulls wherever the batch exceeds one resident round.  NULL, batches of one resident round, and the
+     * SEIP family: a static grid, as before ABI 7. */
     int32_t *work_counter;
     /* Fused sampler iteration (ABI 8, dyn_solve_batch_loglik only): HOST pointer to a blob written by dyn_nuts_tail_pack,
      * or NULL.  When set, every wave of the gradient-solve goes on, after scoring its trajectories, to run the NUTS state

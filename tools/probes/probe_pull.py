@@ -37,7 +37,10 @@ if __name__ == "__main__":
             bytes_ = wl.bytes_per_trajectory(4) * wl.B
             ref = None
             for rnd in range(2):
-                for tag, env in (("static", {"DYNODE_HIP_PULL": "0"}), ("pull", {"DYNODE_HIP_PULL": "1"}), ("static+sorted", {"DYNODE_HIP_PULL": "0"}), ("pull+sorted", {"DYNODE_HIP_PULL": "1"})):
+                for tag, env in (("static", {"DYNODE_HIP_PULL": "0"}), ("pull", {"DYNODE_HIP_PULL": "1"}),
+                                 ("pull-2048", {"DYNODE_HIP_PULL": "1", "DYNODE_HIP_PULL_WAVES": "2048"}),
+                                 ("pull-2560", {"DYNODE_HIP_PULL": "1", "DYNODE_HIP_PULL_WAVES": "2560"}),
+                                 ("static+sorted", {"DYNODE_HIP_PULL": "0"}), ("pull+sorted", {"DYNODE_HIP_PULL": "1"})):
                     for k in ("DYNODE_HIP_PULL", "DYNODE_HIP_PULL_WAVES"):
                         os.environ.pop(k, None)
                     os.environ.update(env)
