@@ -57,6 +57,12 @@ struct Stepper {
         const bool replay = F::REPLAYS && ka.sched_in != nullptr;   // recorded step schedules (KArgs::sched_*): launch-wide
         const bool fixed = constant || replay;                      // every step is taken as given: no error estimate, no rejection
         const int n_save = ka.n_save;
+        // Small states interpolate SU save times per save round (all computed, stores predicated: instruction-level parallelism
+        // for a latency-bound wave) -- while a replica has that many per step.  With eight replicas per trajectory
+        // a step holds about one of a replica's save times, and a round of SU candidates computes mostly discarded rows:
+        // then one row per round (cfg 2 at B = 1024, eight replicas: 0.105 -> 0.1007 ms; four replicas prefer the rounds of four: 0.1144 vs 0.1178).  Launch-wide, so the two-ahead
+        // save time of the single-row rounds stays consistent.
+        [[maybe_unused]] const bool multi_rows = SU > 1 && ka.rep_log2 < 3;
         // The save grid lives in LDS: a global load inside the save loop would share the
         // in-order vmcnt counter with the output stores, and waiting for it would drain every
         // store of the previous round (measured: the dominant stall of the save path).
@@ -297,7 +303,7 @@ struct Stepper {
                 // in theta, dense_coefficients; Seip: nothing, its rows are weighted sums of the stages)
                 L.dense_begin(dt, y, yt, k);
                 if constexpr (SU > 1) {
-                    while (__any(pending)) {
+                    while (multi_rows && __any(pending)) {
                         if (pending) {
                             T tsu[SU];
                             bool pu[SU];
@@ -322,7 +328,7 @@ struct Stepper {
                         pending = accept && (save_idx < n_save) && (ts_next <= tnext);
                     }
                 }
-                while (SU == 1 && __any(pending)) {
+                while ((SU == 1 || !multi_rows) && __any(pending)) {
 #ifdef DYN_DIAG_ROUNDS
                     ++diag_rounds;
 #endif
