@@ -903,7 +903,7 @@ struct Seip {
     __device__ __forceinline__ static void begin_output(const KA &ka, Output &o, int64_t traj, int n_save) {
         o.out_traj = ka.out + traj * (int64_t)n_save * ka.d_saved;
     }
-    __device__ __forceinline__ static void dense_begin(T, const PS (&)[1], const PS (&)[1], PS (&)[7][1]) {}
+    __device__ __forceinline__ static void dense_begin(const Tables &, T, const PS (&)[1], const PS (&)[1], PS (&)[7][1]) {}
     __device__ __forceinline__ void emit_row(const KArgs<T> &ka, const Tables &, Output &out, T theta, T dt, const PS (&y)[1],
                                              const PS (&yt)[1], const PS (&k)[7][1], int save_idx, bool on, bool vec_ok) const {
         Dense dn;

@@ -1057,13 +1057,16 @@ struct Solver {
     }
     // (PP0 .. PP1 - 1: the register pairs whose rows will be evaluated -- all of them, or, lean instance, the pairs that hold
     // the scored compartment: the other elements' coefficients would be 21 packed FMAs per pair and plane for nobody)
+    // (`pairs`: bit pp set = register pair pp holds an element of a compartment that is saved / scored -- wave-uniform, from
+    // the save mask (Solver::carve); a sub-save, the reference's `sub_save_indices`, leaves the other pairs' 21 packed FMAs out)
     template <int PP0 = 0, int PP1 = NP>
     __device__ __forceinline__ static void dense_coefficients(T dt, const State (&y)[NC], const State (&y1)[NC],
-                                                              State (&k)[7][NC]) {
+                                                              State (&k)[7][NC], uint32_t pairs = ~0u) {
 #pragma unroll
         for (int c = 0; c < NC; ++c)
 #pragma unroll
             for (int pp = PP0; pp < PP1; ++pp) {
+                if (!((pairs >> pp) & 1u)) continue;
                 const V2 k0 = k[0][c].p[pp], k1 = k[1][c].p[pp], k2 = k[2][c].p[pp], k3 = k[3][c].p[pp],
                          k4 = k[4][c].p[pp], k5 = k[5][c].p[pp], k6 = k[6][c].p[pp];
                 if constexpr (METHOD == 0) {
@@ -1524,7 +1527,21 @@ struct Solver {
         T *ll_lane;                // likelihood table (replicated trajectories): [trajectory slot][save index][lane of group][LLMAX][planes]
         V4 *rate_tab;              // PRESCALE: the rates (and their seeds) as loaded, [quad][lane], 16-byte aligned behind the other tables
         Handoff hand;              // PC: the accepted step on its way to the row-writing wave
+        uint32_t pairs;            // register pairs holding an element of a saved (or scored) compartment: dense_coefficients
     };
+    // bit pp of the result: pair pp holds an element of a compartment whose rows are needed (slots: s, e, i, r, c)
+    __device__ __forceinline__ static uint32_t pairs_of(bool s_, bool e_, bool i_, bool r_, bool c_) {
+        uint32_t m = 0;
+        auto add = [&](int first, int cnt) {
+            for (int q = 0; q < cnt; ++q) m |= 1u << ((first + q) >> 1);
+        };
+        if (s_) add(IS, 1);
+        if (e_) add(IE, NE);
+        if (i_) add(II, S);
+        if (r_) add(IR, S * W);
+        if (c_) add(IC, NCU);
+        return m;
+    }
     static constexpr int LL_ROW = G * LLMAX * NC;
     __device__ __forceinline__ void carve(const KArgs<T> &ka, Tables &tb, T *ts_tab, T *free_lds, int lane, int grp, int n_save, int n_jump) const {
         tb.fused_ll = tb.ll_table = false;
@@ -1535,6 +1552,12 @@ struct Solver {
         tb.ll_lane = free_lds + ((int64_t)((lane / G) >> ka.rep_log2) * n_save * LL_ROW + (lane % G) * (LLMAX * NC));
         tb.rate_tab = reinterpret_cast<V4 *>(
             ts_tab + (((n_save + (n_jump > 0 ? kMaxJumps : 0) + (tb.ll_table ? (64 >> ka.rep_log2) * n_save * LLMAX * NC : 0)) + 3) & ~3));
+        if (tb.fused_ll) {
+            const int slot = LEAN ? 3 : ka.ll_slot;
+            tb.pairs = pairs_of(slot == 0, slot == 1, slot == 2, slot == 3, slot == 4);
+        } else {
+            tb.pairs = pairs_of(ka.save_off[0] >= 0, ka.save_off[1] >= 0, ka.save_off[2] >= 0, ka.save_off[3] >= 0, ka.save_off[4] >= 0);
+        }
         tb.hand = Handoff{nullptr, nullptr, nullptr, nullptr};
         if constexpr (PC) {
             tb.hand.planes = reinterpret_cast<V2 *>(tb.rate_tab + NRQ * 64);
@@ -1613,9 +1636,10 @@ struct Solver {
             }
         }
     }
-    __device__ __forceinline__ static void dense_begin(T dt, const State (&y)[NC], const State (&y1)[NC], State (&k)[7][NC]) {
+    __device__ __forceinline__ static void dense_begin(const Tables &tb, T dt, const State (&y)[NC], const State (&y1)[NC], State (&k)[7][NC]) {
         if constexpr (LEAN) dense_coefficients<IR / 2, (IR + S * W - 1) / 2 + 1>(dt, y, y1, k);   // rows = the likelihood of the increments of r
-        else dense_coefficients(dt, y, y1, k);
+        else if constexpr (SAVE_ALL) dense_coefficients(dt, y, y1, k);
+        else dense_coefficients(dt, y, y1, k, tb.pairs);
     }
     // the row of save time tprev + theta dt (`on`: this lane stores it): the saved compartments and their tangents, or --
     // tangent kernels with the likelihood fused in -- the row's contribution to the score

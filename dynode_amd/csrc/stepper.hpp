@@ -282,7 +282,7 @@ struct Stepper {
             if constexpr (PC) { // the rows are wave 1's: publish the accepted step (see consume())
                 pending = false;
                 if (__any(accept)) {
-                    L.dense_begin(dt, y, yt, k);
+                    L.dense_begin(tb, dt, y, yt, k);
                     __syncthreads();           // A: wave 1 has copied the previous step
 #pragma unroll
                     for (int pp = 0; pp < NP; ++pp) {
@@ -301,7 +301,7 @@ struct Stepper {
             if (__any(pending)) {
                 // what the family prepares once per accepted step for all its rows (Solver: the interpolant as a polynomial
                 // in theta, dense_coefficients; Seip: nothing, its rows are weighted sums of the stages)
-                L.dense_begin(dt, y, yt, k);
+                L.dense_begin(tb, dt, y, yt, k);
                 if constexpr (SU > 1) {
                     while (multi_rows && __any(pending)) {
                         if (pending) {
