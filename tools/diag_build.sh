@@ -1,9 +1,9 @@
 #!/bin/bash
 # Builds a diagnostic variant of libdynode_hip.so next to the real one and prints its path:
-#   tools/diag_build.sh NOINTERP   save rows hold y + a weight instead of the dense-output polynomial (no interpolation arithmetic)
-#   tools/diag_build.sh SAMEROW    every save round overwrites one of two rows (stores stay in L2: no HBM stream)
-#   tools/diag_build.sh ROUNDS     n_accept / n_reject return loop iterations / save rounds per wave
-# Use with DYNODE_HIP_LIB=<path> python tools/probes/probe_perf.py cfg3   (DESIGN.md section 9 has the readings)
+#   tools/diag_build.sh ROUNDS          n_accept / n_reject return loop iterations / save rounds per wave
+#   tools/diag_build.sh NOPRESCALE_ND   tangent kernels keep k = f (no step-scaled rates)
+#   tools/diag_build.sh W3              every solve kernel compiled for three waves per SIMD
+# Use with DYNODE_HIP_LIB=<path> (python tools/probes/ab_bench.py / ab_other.py take the variant names); docs/perf-log.md has the readings.
 set -e
 V=${1:?variant}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
