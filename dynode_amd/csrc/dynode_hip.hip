@@ -66,6 +66,9 @@ constexpr int kProducerConsumer = 0x8000;
 // (normalised, no seasonal forcing, no discontinuity points, adaptive steps, Poisson likelihood of the increments of r) fixed at
 // compile time; picked by enqueue when the call is exactly that
 constexpr int kLean = 0x2000;
+// FEAT bit 11 (solve_kernel.hpp ADAPTIVE_NO_JUMPS): adaptive steps and no discontinuity points as compile-time facts; picked
+// by enqueue on top of a SAVE_ALL variant when the call has neither
+constexpr int kAdaptiveNoJumps = 0x0800;
 // FEAT bit 12 (solve_kernel.hpp FUSED): a lean instance that also runs the sampler's state machine for the chains its waves
 // scored; picked when the call carries dyn_solver_opts::nuts_tail
 constexpr int kFused = 0x1000;
@@ -455,6 +458,11 @@ static int enqueue(const Entry *e, const dyn_model_desc *m, const dyn_solver_opt
             if (env && atoi(env) != 0) fast = pc;
         }
         if (fast) e = fast;
+        if ((e->FEAT & kSaveAll) && !(e->FEAT & kProducerConsumer) && ka.n_jump == 0 && !(o->constant_dt > 0.0)) {
+            const char *env = getenv("DYNODE_HIP_PLAIN");      // tuning aid: 0 keeps the general instance
+            const Entry *plain = (env && atoi(env) == 0) ? nullptr : find_variant(e, e->FEAT | kAdaptiveNoJumps);
+            if (plain) e = plain;
+        }
     }
     if (ll && ll->slot == 3 && ll->mode == 1 && m->normalize && !m->seasonal && !m->has_intro && ka.n_jump == 0 &&
         !(o->constant_dt > 0.0) && !sc && !order && !(e->FEAT & kLean)) {

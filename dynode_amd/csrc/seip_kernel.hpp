@@ -714,6 +714,7 @@ struct Seip {
     static constexpr int GW = GWL;                  // lanes of one wave that hold one trajectory
     static constexpr bool PRESCALE = false, PC = false, LEAN = false, FUSED = false;
     static constexpr size_t kTailOffset = 0;
+    static constexpr bool ADAPTIVE_NO_JUMPS = false;
     static constexpr bool ROOTLESS_NORM = false;    // (kinks: the dose cap, the seasonal reset)
     static constexpr bool PULLS = false;            // a static grid: the waves of a group meet at barriers, slot for slot
     static constexpr bool REPLAYS = true;           // recorded step schedules (KArgs::sched_*: dyn_solve_batch_record / _replay)

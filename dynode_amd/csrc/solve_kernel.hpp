@@ -1489,6 +1489,10 @@ struct Solver {
     // ================================================================ the family interface of Stepper<F> (stepper.hpp)
     static constexpr int NDIR = ND;                 // tangent directions (planes 1..ND of the state)
     static constexpr int GW = G;                    // lanes of one wave that hold one trajectory
+    // FEAT bit 11: adaptive steps without discontinuity points as compile-time facts (what every BASELINE ensemble is): the
+    // constant-step and jump bookkeeping -- four per-lane values and a dozen scalar ones, a handful of uniform branches per
+    // attempt -- leaves the loop.  enqueue() picks the variant when the call has neither (lean instances imply it).
+    static constexpr bool ADAPTIVE_NO_JUMPS = LEAN || (FEAT & 0x0800) != 0;
     static constexpr bool ROOTLESS_NORM = KV == 0;  // the controller works on the mean square of the error (Control::decide_ms); not with the dose cap's kinks
     static constexpr bool PULLS = true;             // slots may draw further trajectories from KArgs::work
     static constexpr bool REPLAYS = false;          // (recorded step schedules: the SEIP family)
@@ -1714,7 +1718,7 @@ namespace dyn {
 // compiler's default range.
 template <typename T, int METHOD, int GA, int ST, int W, int ND, int SPL, int FEAT>
 constexpr int waves_per_simd(bool upper) {
-    return (sizeof(T) == 4 && METHOD == 0 && GA == 8 && ST == 4 && ND == 0 && (FEAT & ~0x4000) == 0 &&
+    return (sizeof(T) == 4 && METHOD == 0 && GA == 8 && ST == 4 && ND == 0 && (FEAT & ~0x4800) == 0 &&
             ((W == 8 && SPL == 1) || (W == 1 && SPL == 2))) ? 3 : (upper ? 8 : 1);
 }
 

@@ -53,7 +53,7 @@ struct Stepper {
 
         const T rtol = ka.rtol, atol = ka.atol, t_end = ka.t1;
         const T Dn = T(L.state_dim(ka));
-        const bool constant = LEAN ? false : ka.constant_dt > T(0);
+        const bool constant = F::ADAPTIVE_NO_JUMPS ? false : ka.constant_dt > T(0);
         const bool replay = F::REPLAYS && ka.sched_in != nullptr;   // recorded step schedules (KArgs::sched_*): launch-wide
         const bool fixed = constant || replay;                      // every step is taken as given: no error estimate, no rejection
         const int n_save = ka.n_save;
@@ -72,7 +72,7 @@ struct Stepper {
         for (int j = lane; j < n_save; j += 64) ts_tab[j] = ka.save_ts[j];
         // discontinuity points follow the save grid in LDS (per-group index into the table)
         T *const jt_tab = ts_tab + n_save;
-        const int n_jump = LEAN ? 0 : ka.n_jump;
+        const int n_jump = F::ADAPTIVE_NO_JUMPS ? 0 : ka.n_jump;
         if (n_jump > 0 && lane == 0) {
 #pragma unroll
             for (int j = 0; j < kMaxJumps; ++j) jt_tab[j] = ka.jump_ts[j];
@@ -359,7 +359,23 @@ struct Stepper {
             [[maybe_unused]] const bool fsal_from_k6 = accept;
             // ---- next interval: prev_dt * factor, then diffeqsolve's clip-to-end
             T next_t0 = accept ? tnext : tprev;
-            T next_t1 = next_t0 + (constant ? ka.constant_dt : dt * factor);
+            // (the product is rounded on its own in every instance: where `constant` is a compile-time false the compiler would
+            // otherwise contract dt * factor + next_t0 into one FMA, and an instance with the switch compiled in would take
+            // steps that differ in the last bit from the general one -- sub-saves are compared bit for bit with full saves)
+            T next_t1;
+            if constexpr (LEAN) { // (no general twin to agree with: the contracted form it has always had)
+                next_t1 = next_t0 + dt * factor;
+            } else {
+                T next_len;
+                {
+#pragma clang fp contract(off)
+                    next_len = constant ? ka.constant_dt : dt * factor;
+                }
+                {
+#pragma clang fp contract(off)
+                    next_t1 = next_t0 + next_len;
+                }
+            }
             if (__builtin_expect(replay, 0)) { // launch-uniform: the next recorded step; across a discontinuity point the first stage is recomputed
                 if constexpr (F::REPLAYS) {
                     if (act) ++si;
