@@ -69,6 +69,8 @@ constexpr int kLean = 0x2000;
 // FEAT bit 11 (solve_kernel.hpp ADAPTIVE_NO_JUMPS): adaptive steps and no discontinuity points as compile-time facts; picked
 // by enqueue on top of a SAVE_ALL variant when the call has neither
 constexpr int kAdaptiveNoJumps = 0x0800;
+// FEAT bit 10 (solve_kernel.hpp PULLS = false): static-grid-only instance; picked where launch() would not pull anyway
+constexpr int kStaticOnly = 0x0400;
 // FEAT bit 12 (solve_kernel.hpp FUSED): a lean instance that also runs the sampler's state machine for the chains its waves
 // scored; picked when the call carries dyn_solver_opts::nuts_tail
 constexpr int kFused = 0x1000;
@@ -462,6 +464,12 @@ static int enqueue(const Entry *e, const dyn_model_desc *m, const dyn_solver_opt
             const char *env = getenv("DYNODE_HIP_PLAIN");      // tuning aid: 0 keeps the general instance
             const Entry *plain = (env && atoi(env) == 0) ? nullptr : find_variant(e, e->FEAT | kAdaptiveNoJumps);
             if (plain) e = plain;
+        }
+        // launch() pulls only with a caller's queue on waves of more than two trajectories: every other launch is static
+        if ((e->FEAT & kSaveAll) && !(e->FEAT & kProducerConsumer) && (64 / entry_lanes(e) <= 2 || !order) &&
+            !getenv("DYNODE_HIP_PULL") && !getenv("DYNODE_HIP_PULL_WAVES")) {
+            const Entry *st = find_variant(e, e->FEAT | kStaticOnly);
+            if (st) e = st;
         }
     }
     if (ll && ll->slot == 3 && ll->mode == 1 && m->normalize && !m->seasonal && !m->has_intro && ka.n_jump == 0 &&

@@ -1494,7 +1494,9 @@ struct Solver {
     // attempt -- leaves the loop.  enqueue() picks the variant when the call has neither (lean instances imply it).
     static constexpr bool ADAPTIVE_NO_JUMPS = LEAN || (FEAT & 0x0800) != 0;
     static constexpr bool ROOTLESS_NORM = KV == 0;  // the controller works on the mean square of the error (Control::decide_ms); not with the dose cap's kinks
-    static constexpr bool PULLS = true;             // slots may draw further trajectories from KArgs::work
+    // FEAT bit 10: a static-grid-only instance -- prologue in front of the stepping loop, write-off behind it, nothing of the
+    // queue in between (Stepper: PULLS = false).  For shapes whose launches are static anyway (launch(): two trajectories per wave).
+    static constexpr bool PULLS = (FEAT & 0x0400) == 0;   // slots may draw further trajectories from KArgs::work
     static constexpr bool REPLAYS = false;          // (recorded step schedules: the SEIP family)
     static constexpr bool IDLE_SLOTS_LOAD = false;  // a slot beyond the batch idles without data
     int a, as;            // age lane; (age, first global strain of this lane) = a ST + s0: the lane's place in a compartment
@@ -1718,7 +1720,7 @@ namespace dyn {
 // compiler's default range.
 template <typename T, int METHOD, int GA, int ST, int W, int ND, int SPL, int FEAT>
 constexpr int waves_per_simd(bool upper) {
-    return (sizeof(T) == 4 && METHOD == 0 && GA == 8 && ST == 4 && ND == 0 && (FEAT & ~0x4800) == 0 &&
+    return (sizeof(T) == 4 && METHOD == 0 && GA == 8 && ST == 4 && ND == 0 && (FEAT & ~0x4C00) == 0 &&
             ((W == 8 && SPL == 1) || (W == 1 && SPL == 2))) ? 3 : (upper ? 8 : 1);
 }
 
@@ -1787,6 +1789,7 @@ hipError_t launch(const KArgs<T> &ka_in, hipStream_t stream) {
     ka.nuts_tail = nullptr;
     const auto kernel = solve_kernel<T, METHOD, GA, ST, HAS_E, HAS_WANE, HAS_C, W, ND, SPL, FEAT>;
     int64_t grid = blocks;
+    if ((FEAT & 0x0400) != 0) ka.work = nullptr;   // (a static-only instance)
     if (ka.work != nullptr) {
         // Work pulling needs a batch of more waves than the chip holds at once: then the grid is exactly the resident waves
         // and every lane group draws trajectories until the queue is empty.  A batch that fits is one wave per TPW

@@ -306,7 +306,7 @@ def test_producer_consumer_waves_give_the_bits_of_the_one_wave_kernel(wl, budget
     monkeypatch.setenv("DYNODE_HIP_PC", "1")
     r = solve_batch(*args, dtype=F32, max_steps=budget)
     name1 = _abi.lib().dyn_last_kernel_name().decode()
-    assert name0 != name1 and name1.endswith(", 49152>") and name0.endswith((", 16384>", ", 18432>"))      # FEAT 0xC000 vs 0x4000 (or 0x4800: + adaptive, no jumps)
+    assert name0 != name1 and name1.endswith(", 49152>") and name0.endswith((", 16384>", ", 18432>", ", 19456>"))      # FEAT 0xC000 vs 0x4000 (or 0x4800: + adaptive, no jumps)
     assert int(base.status[5]) == 2 and int((base.status == 1).sum()) > 0 and int((base.status == 0).sum()) > 0
     for a, b in ((r.status, base.status), (r.n_accept, base.n_accept), (r.n_reject, base.n_reject)):
         assert torch.equal(a, b)
@@ -924,7 +924,7 @@ def test_batch_aware_lane_mapping_is_a_dispatch_choice_only(monkeypatch):
     monkeypatch.setenv("DYNODE_HIP_SPL", "4")
     base = solve_batch(*args, dtype=F32)
     name_base = _abi.lib().dyn_last_kernel_name().decode()
-    assert name_base.endswith(("1, 0, 4, 16384>", "1, 0, 4, 18432>")) and name_small.endswith("1, 0, 1, 16384>")
+    assert name_base.endswith(("1, 0, 4, 16384>", "1, 0, 4, 18432>", "1, 0, 4, 19456>")) and name_small.endswith("1, 0, 1, 16384>")
     assert int(small.status.max()) == 0 and int(base.status.max()) == 0
     scale = wl.population
     assert float((small.ys - base.ys).abs().max()) / scale < 1e-5
@@ -933,5 +933,5 @@ def test_batch_aware_lane_mapping_is_a_dispatch_choice_only(monkeypatch):
     mid = solve_batch(wl2.model, wl2.y0, wl2.params, wl2.contact, wl2.t1, wl2.save_ts[::30], dtype=F32)
     name_mid = _abi.lib().dyn_last_kernel_name().decode()
     if torch.cuda.get_device_properties(0).multi_processor_count == 256:
-        assert name_mid.split(">")[0].endswith("1, 0, 2, 0") or name_mid.endswith(("1, 0, 2, 16384>", "1, 0, 2, 18432>")), name_mid
+        assert name_mid.split(">")[0].endswith("1, 0, 2, 0") or name_mid.endswith(("1, 0, 2, 16384>", "1, 0, 2, 18432>", "1, 0, 2, 19456>")), name_mid
     assert int(mid.status.max()) == 0
