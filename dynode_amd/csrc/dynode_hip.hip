@@ -460,16 +460,24 @@ static int enqueue(const Entry *e, const dyn_model_desc *m, const dyn_solver_opt
             if (env && atoi(env) != 0) fast = pc;
         }
         if (fast) e = fast;
-        if ((e->FEAT & kSaveAll) && !(e->FEAT & kProducerConsumer) && ka.n_jump == 0 && !(o->constant_dt > 0.0)) {
-            const char *env = getenv("DYNODE_HIP_PLAIN");      // tuning aid: 0 keeps the general instance
-            const Entry *plain = (env && atoi(env) == 0) ? nullptr : find_variant(e, e->FEAT | kAdaptiveNoJumps);
-            if (plain) e = plain;
-        }
-        // launch() pulls only with a caller's queue on waves of more than two trajectories: every other launch is static
-        if ((e->FEAT & kSaveAll) && !(e->FEAT & kProducerConsumer) && (64 / entry_lanes(e) <= 2 || !order) &&
-            !getenv("DYNODE_HIP_PULL") && !getenv("DYNODE_HIP_PULL_WAVES")) {
-            const Entry *st = find_variant(e, e->FEAT | kStaticOnly);
-            if (st) e = st;
+        if ((e->FEAT & kSaveAll) && !(e->FEAT & kProducerConsumer)) {
+            // further compile-time facts of the call: adaptive steps without discontinuity points (bit 11; DYNODE_HIP_PLAIN=0
+            // keeps the general instance), a static grid (bit 10: launch() pulls only with a caller's queue on waves of more
+            // than two trajectories; DYNODE_HIP_PULL / _PULL_WAVES keep the pulling instances).  The most specific variant
+            // compiled in wins.
+            const char *env = getenv("DYNODE_HIP_PLAIN");
+            const bool nojump = ka.n_jump == 0 && !(o->constant_dt > 0.0) && !(env && atoi(env) == 0);
+            const bool stat = (64 / entry_lanes(e) <= 2 || !order) && !getenv("DYNODE_HIP_PULL") && !getenv("DYNODE_HIP_PULL_WAVES");
+            const int want[3] = {(nojump ? kAdaptiveNoJumps : 0) | (stat ? kStaticOnly : 0), stat ? kStaticOnly : 0,
+                                 nojump ? kAdaptiveNoJumps : 0};
+            for (int i = 0; i < 3; ++i) {
+                if (want[i] == 0) continue;
+                const Entry *v = find_variant(e, e->FEAT | want[i]);
+                if (v) {
+                    e = v;
+                    break;
+                }
+            }
         }
     }
     if (ll && ll->slot == 3 && ll->mode == 1 && m->normalize && !m->seasonal && !m->has_intro && ka.n_jump == 0 &&
