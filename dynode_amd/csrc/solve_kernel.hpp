@@ -112,6 +112,7 @@ struct Mth<float> {
         asm("v_max_f32 %0, |%1|, |%2|" : "=v"(r) : "v"(a), "v"(b));
         return r;
     }
+    static __device__ __forceinline__ float fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
     static __device__ __forceinline__ float sqrt(float x) { return sqrtf(x); }
     // sin(x) for the seasonal forcing 1 + amp sin(w t + phase), evaluated in every right-hand side.  The library sinf is ~32
     // vector instructions and two branches (octant reduction, BOTH polynomials, selection, the Payne-Hanek path for huge
@@ -171,6 +172,7 @@ struct Mth<double> {
     }
     static __device__ __forceinline__ double sqrt(double x) { return ::sqrt(x); }
     static __device__ __forceinline__ double sin(double x) { return ::sin(x); }
+    static __device__ __forceinline__ double fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
     static __device__ __forceinline__ double sin_lib(double x) { return ::sin(x); }
     static __device__ __forceinline__ double cos(double x) { return ::cos(x); }
     static __device__ __forceinline__ double rcp_fast(double x) { return 1.0 / x; }
@@ -710,6 +712,17 @@ struct Solver {
         }
         return u[IS] + strain_sum((dse + dsi) + dsr);
     }
+    // a b + c d with the association pinned (ONE rounding of c d, then an FMA): left to the compiler, which of the two products
+    // is fused depends on the code around the expression, and two instances of the same arithmetic (one / two tangent
+    // directions per trajectory, the fused sampler launch and the plain one) would differ in the last bit of a gradient
+    __device__ __forceinline__ static T two_products(T a, T b, T c, T d) {
+        T cd;
+        {
+#pragma clang fp contract(off)
+            cd = c * d;
+        }
+        return M::fma(a, b, cd);
+    }
     // Stepper hook: the state a step attempt starts from
     __device__ __forceinline__ void begin_attempt(const State (&y)[NC]) {
         if constexpr (POP_PER_ATTEMPT) {
@@ -877,7 +890,7 @@ struct Solver {
                     dseason = damp[j] * sin_arg + amp * cos_arg * (dw_season[j] * t + dphase[j]);
                 T dx[S], dacc[S];
 #pragma unroll
-                for (int l = 0; l < S; ++l) dx[l] = u[II + l] * invN + y0[II + l] * dinvN;
+                for (int l = 0; l < S; ++l) dx[l] = two_products(u[II + l], invN, y0[II + l], dinvN);
                 if constexpr (INTRO) {
                     // pulse = pct * base * bell(u), base = mask / (scale sqrt(2 pi)), u = (t - time) / scale:
                     // d/dtime = pulse * u / scale, d/dscale = pulse * (u^2 - 1) / scale, d/dpct = base * bell
@@ -895,13 +908,13 @@ struct Solver {
                 for (int l = 0; l < S; ++l) {
                     const T bs = beta[l] * season;
                     const T dbs = dbeta[j][l] * season + beta[l] * dseason;
-                    T dfoi = dbs * acc[l] + bs * dacc[l];
+                    T dfoi = two_products(dbs, acc[l], bs, dacc[l]);
                     if constexpr (KV > 0) dfoi = dfoi * sus[l] + (bs * acc[l]) * dsus[j][l];
-                    const T dflux = dfoi * y0[IS] + foi[l] * u[IS];
-                    const T dg_i = dgamma[j][l] * y0[II + l] + gamma[l] * u[II + l];
+                    const T dflux = two_products(dfoi, y0[IS], foi[l], u[IS]);
+                    const T dg_i = two_products(dgamma[j][l], y0[II + l], gamma[l], u[II + l]);
                     dout_s += dflux;
                     if constexpr (HAS_E) {
-                        const T ds_e = dsigma[j][l] * y0[IE + l] + sigma[l] * u[IE + l];
+                        const T ds_e = two_products(dsigma[j][l], y0[IE + l], sigma[l], u[IE + l]);
                         du[IE + l] = dflux - ds_e;
                         du[II + l] = ds_e - dg_i;
                     } else {
@@ -911,8 +924,7 @@ struct Solver {
                         T dinflow = dg_i;
 #pragma unroll
                         for (int w = 0; w < W; ++w) {
-                            const T d_o = T(W) * (domega[j][l] * y0[IR + l * W + w] +
-                                                  omega[l] * u[IR + l * W + w]);
+                            const T d_o = T(W) * two_products(domega[j][l], y0[IR + l * W + w], omega[l], u[IR + l * W + w]);
                             du[IR + l * W + w] = dinflow - d_o;
                             dinflow = d_o;
                         }
@@ -1496,7 +1508,7 @@ struct Solver {
     static constexpr bool ROOTLESS_NORM = KV == 0;  // the controller works on the mean square of the error (Control::decide_ms); not with the dose cap's kinks
     // FEAT bit 10: a static-grid-only instance -- prologue in front of the stepping loop, write-off behind it, nothing of the
     // queue in between (Stepper: PULLS = false).  For shapes whose launches are static anyway (launch(): two trajectories per wave).
-    static constexpr bool PULLS = (FEAT & 0x0400) == 0;   // slots may draw further trajectories from KArgs::work
+    static constexpr bool PULLS = (FEAT & 0x0400) == 0 && !LEAN;   // slots may draw further trajectories from KArgs::work (a lean instance is only dispatched without a caller's queue: a static grid)
     static constexpr bool REPLAYS = false;          // (recorded step schedules: the SEIP family)
     static constexpr bool IDLE_SLOTS_LOAD = false;  // a slot beyond the batch idles without data
     int a, as;            // age lane; (age, first global strain of this lane) = a ST + s0: the lane's place in a compartment
@@ -1789,7 +1801,7 @@ hipError_t launch(const KArgs<T> &ka_in, hipStream_t stream) {
     ka.nuts_tail = nullptr;
     const auto kernel = solve_kernel<T, METHOD, GA, ST, HAS_E, HAS_WANE, HAS_C, W, ND, SPL, FEAT>;
     int64_t grid = blocks;
-    if ((FEAT & 0x0400) != 0) ka.work = nullptr;   // (a static-only instance)
+    if ((FEAT & 0x0400) != 0 || (FEAT & 0x2000) != 0) ka.work = nullptr;   // (a static-only instance)
     if (ka.work != nullptr) {
         // Work pulling needs a batch of more waves than the chip holds at once: then the grid is exactly the resident waves
         // and every lane group draws trajectories until the queue is empty.  A batch that fits is one wave per TPW
