@@ -178,9 +178,10 @@ static const Entry *find_entry(const dyn_model_desc *m, int dtype, int method, i
 // trajectory whose strains are spread over more lanes (SPL < S) has a shorter one -- at the price of replicated control
 // arithmetic, which is free on an otherwise empty GPU.  Measured on the 8 x 4 seasonal model, ms per launch, SPL = 4 / 2 / 1
 // (the SPL = 2 kernel fits three waves per SIMD, the SPL = 1 kernel four): B = 4096 (512 waves of 8 trajectories) 0.597 / 0.505 /
-// 0.46; B = 8192 0.55-0.58 / 0.54 / 0.63; B = 16384 (D = 136) 0.87-0.91 / 0.90 / 1.03; B = 65536 3.50 / 3.73 / 4.58.  Rule: when
-// the default mapping fills at most one wave per SIMD, take the finest split compiled in that still fits two waves per SIMD;
-// otherwise the first entry (instances.def order).  DYNODE_HIP_SPL overrides.
+// 0.46; B = 8192 0.55-0.58 / 0.54-0.57 / 0.63 (a wash: which of the first two wins changes from build to build and box to box);
+// B = 16384 (D = 136) 0.87-0.91 / 0.90 / 1.03; B = 65536 3.50 / 3.73 / 4.58.  Rule: when the default mapping fills at most half a
+// wave per SIMD, take the finest split compiled in that still fits two waves per SIMD; otherwise the first entry
+// (instances.def order).  DYNODE_HIP_SPL overrides.
 static const Entry *entry_for_batch(const Entry *e, const dyn_model_desc *m, int dtype, int method, int nd, int64_t B) {
     if (getenv("DYNODE_HIP_SPL") || (e->FEAT & kSeip) || e->SPL == 1 || nd != 0) return e;
     static thread_local int simds = 0;
@@ -190,7 +191,7 @@ static const Entry *entry_for_batch(const Entry *e, const dyn_model_desc *m, int
     }
     if (simds <= 0) return e;
     const int64_t waves = (B * entry_lanes(e) + 63) / 64;
-    if (waves > simds) return e;   // (more than one wave per SIMD: the widest per-lane state has the fewest instructions per trajectory)
+    if (waves * 2 > simds) return e;   // (more than half a wave per SIMD: the widest per-lane state has the fewest instructions per trajectory)
     const int G = group_width(m->n_age);
     const Entry *best = e;
     auto consider = [&](const Entry &c) {

@@ -911,7 +911,7 @@ def test_vaccination_shape_built_on_demand():
 
 
 def test_batch_aware_lane_mapping_is_a_dispatch_choice_only(monkeypatch):
-    """A batch that fills at most one wave per SIMD runs on a strain-split instance (a trajectory over more lanes: a shorter
+    """A batch that fills at most half a wave per SIMD runs on a strain-split instance (a trajectory over more lanes: a shorter
     instruction stream per wave on a mostly empty GPU; the finest split that still fits two waves per SIMD).  Which instance runs depends on the batch size; the trajectories do not,
     beyond float32 rounding of the sums over strains (another summation order) -- and in float64 every mapping gives the oracle's
     step counts (checked per mapping in the shape sweep)."""
@@ -929,9 +929,9 @@ def test_batch_aware_lane_mapping_is_a_dispatch_choice_only(monkeypatch):
     scale = wl.population
     assert float((small.ys - base.ys).abs().max()) / scale < 1e-5
     monkeypatch.delenv("DYNODE_HIP_SPL")
-    wl2 = synthetic.seirs_multi_strain(8192, seed=62, seasonal=True)       # one wave per SIMD on 256 CUs: two strains per lane
+    wl2 = synthetic.seirs_multi_strain(8192, seed=62, seasonal=True)       # one wave per SIMD on 256 CUs: the default mapping stays
     mid = solve_batch(wl2.model, wl2.y0, wl2.params, wl2.contact, wl2.t1, wl2.save_ts[::30], dtype=F32)
     name_mid = _abi.lib().dyn_last_kernel_name().decode()
     if torch.cuda.get_device_properties(0).multi_processor_count == 256:
-        assert name_mid.split(">")[0].endswith("1, 0, 2, 0") or name_mid.endswith(("1, 0, 2, 16384>", "1, 0, 2, 18432>", "1, 0, 2, 19456>")), name_mid
+        assert ", 1, 0, 4, " in name_mid, name_mid
     assert int(mid.status.max()) == 0
