@@ -30,7 +30,10 @@ namespace dyn {
     extern template hipError_t launch_seip<T, METHOD, GA, L, K1, M1, 2>(const KArgs<T> &, hipStream_t);
 #define YW(T, METHOD, GA, L, K1, M1, KT, NW) \
     extern template hipError_t launch_seip<T, METHOD, GA, L, K1, M1, KT, NW>(const KArgs<T> &, hipStream_t);
+#define YP(T, METHOD, GA, L, K1, M1, KT, NW) \
+    extern template hipError_t launch_seip<T, METHOD, GA, L, K1, M1, KT, NW, 1>(const KArgs<T> &, hipStream_t);
 #include "seip_instances.def"
+#undef YP
 #undef YW
 #undef YT
 #undef Y
@@ -56,6 +59,9 @@ constexpr int kSeip = 0x100;
 constexpr int kSeipTierLanes = 0x20; // SEIP entry with the tiers dealt over two lanes (seip_kernel.hpp, KT = 2)
 constexpr int kSeipWaves2 = 0x40, kSeipWaves4 = 0x80; // ... whose trajectory is owned by a workgroup of 2 / 4 waves (NW)
 constexpr int kSeipTierWaves = 0x200; // ... or one tier per tier lane with whole waves as tier lanes: KT = K1, NW = K1 x (lanes / 64)
+// ... compiled without seasonal terms, introduced strains, recorded schedules and discontinuity points (Seip OPT bit 0);
+// enqueue swaps it in for a call that uses none of them
+constexpr int kSeipPlain = 0x1000;
 // FEAT bit 14 (solve_kernel.hpp SAVE_ALL): variant without the per-round save-offset / store-width tests, picked by
 // enqueue when every compartment is saved into 16-byte aligned rows
 constexpr int kSaveAll = 0x4000;
@@ -102,7 +108,13 @@ static const Entry kEntries[] = {
     {DType<T>::id, METHOD, GA, L, 1, 1, 1, M1, 0, 1,                                                             \
      kSeip | (KT > 2 ? kSeipTierWaves : ((KT == 2 ? kSeipTierLanes : 0) | (NW == 2 ? kSeipWaves2 : kSeipWaves4))) | K1, \
      (void *)(hipError_t(*)(const KArgs<T> &, hipStream_t)) & launch_seip<T, METHOD, GA, L, K1, M1, KT, NW>},
+#define YP(T, METHOD, GA, L, K1, M1, KT, NW)                                                                     \
+    {DType<T>::id, METHOD, GA, L, 1, 1, 1, M1, 0, 1,                                                             \
+     kSeip | kSeipPlain |                                                                                        \
+         (KT > 2 ? kSeipTierWaves : ((KT == 2 ? kSeipTierLanes : 0) | (NW == 2 ? kSeipWaves2 : (NW == 4 ? kSeipWaves4 : 0)))) | K1, \
+     (void *)(hipError_t(*)(const KArgs<T> &, hipStream_t)) & launch_seip<T, METHOD, GA, L, K1, M1, KT, NW, 1>},
 #include "seip_instances.def"
+#undef YP
 #undef YW
 #undef YT
 #undef Y
@@ -264,12 +276,12 @@ static void note_kernel(const Entry *e) {
         const int k1 = e->FEAT & 0x1f, kt = entry_tier_lanes(e);
         const int nv = ((k1 + kt - 1) / kt) * (e->W + 3 * e->S);
         if (entry_waves(e) > 1)
-            snprintf(tl_kernel, sizeof(tl_kernel), "dyn::seip_kernel_wave_group<%s, %d, %d, %d, %d, %d, %d, %d>", t, e->method, e->G,
-                     e->S, k1, e->W, kt, entry_waves(e));
+            snprintf(tl_kernel, sizeof(tl_kernel), "dyn::seip_kernel_wave_group<%s, %d, %d, %d, %d, %d, %d, %d, %d>", t, e->method, e->G,
+                     e->S, k1, e->W, kt, entry_waves(e), (e->FEAT & kSeipPlain) ? 1 : 0);
         else
-            snprintf(tl_kernel, sizeof(tl_kernel), "dyn::%s<%s, %d, %d, %d, %d, %d, %d>",
+            snprintf(tl_kernel, sizeof(tl_kernel), "dyn::%s<%s, %d, %d, %d, %d, %d, %d, %d>",
                      (e->dtype == DYN_F32 && nv <= 20) ? "seip_kernel_two_waves" : "seip_kernel", t, e->method, e->G, e->S, k1,
-                     e->W, kt);
+                     e->W, kt, (e->FEAT & kSeipPlain) ? 1 : 0);
         return;
     }
     snprintf(tl_kernel, sizeof(tl_kernel), "dyn::solve_kernel<%s, %d, %d, %d, %s, %s, %s, %d, %d, %d, %d>", t, e->method,
@@ -628,8 +640,17 @@ static int solve_impl(const dyn_model_desc *m, const dyn_solver_opts *o, const v
         return DYN_ERR_UNSUPPORTED;
     }
     const dyn::Entry *e = dyn::find_entry(m, o->dtype, o->method, n_dir);
-    if (m->family == 1) e = dyn::select_seip_entry(m, o->dtype, o->method, e);
-    else if (e) e = dyn::entry_for_batch(e, m, o->dtype, o->method, n_dir, B);
+    if (m->family == 1) {
+        e = dyn::select_seip_entry(m, o->dtype, o->method, e);
+        // a call with no seasonal term, no introduced strain, no recorded schedule and adaptive steps without discontinuity
+        // points takes the variant compiled without them, when that shape has one (DYNODE_HIP_SEIP_PLAIN=0: tuning aid)
+        const char *pl = getenv("DYNODE_HIP_SEIP_PLAIN");
+        if (e && !m->seasonal && !m->seasonal_vax && !m->has_intro && !sc && o->n_jump == 0 && !(o->constant_dt > 0) &&
+            !(pl && atoi(pl) == 0)) {
+            const dyn::Entry *plain = dyn::find_variant(e, e->FEAT | dyn::kSeipPlain);
+            if (plain) e = plain;
+        }
+    } else if (e) e = dyn::entry_for_batch(e, m, o->dtype, o->method, n_dir, B);
     if (!e && m->family == 1) {
         snprintf(dyn::tl_error, sizeof(dyn::tl_error),
                  "no SEIP kernel compiled for A=%d strains=%d tiers=%d waning states=%d dtype=%d method=%d; to add it "

@@ -38,8 +38,12 @@ namespace dyn {
 // bit -- select the wave; what crossed lanes with an xor exchange crosses waves through a small LDS mailbox, with ONE
 // workgroup barrier per right-hand side (two when the vaccination flow needs a cross-wave tier total first); the error
 // norm takes one more per step.  All waves of a trajectory see bit-identical norms, so their control flow is identical.
-template <typename T, int METHOD, int GA, int L, int K1, int M1, int KT = 1, int NW = 1>
+template <typename T, int METHOD, int GA, int L, int K1, int M1, int KT = 1, int NW = 1, int OPT = 0>
 struct Seip {
+    // OPT bit 0 ("plain"): no seasonal forcing, no seasonal vaccination reset, no introduced strains, no recorded schedules,
+    // adaptive steps, no discontinuity points -- as compile-time facts (enqueue() picks the variant when the call is that):
+    // their fields and branches leave the right-hand side and the stepping loop (the D = 960 kernel sits at its register line)
+    static constexpr bool PLAIN = (OPT & 1) != 0;
     static constexpr int H = 1 << L, G = GA * H * KT, K = K1 - 1;
     // one tier per wave with an (age, history) plane smaller than a wavefront: the planes of 64 / (GA H) trajectories sit side
     // by side in every wave of the group ("packed": 4 ages x 8 histories = 32 lanes, two trajectories per group of three waves)
@@ -149,7 +153,10 @@ struct Seip {
     mutable const T *spl;      // LDS: spline[K1][4 + 2 nk] of this lane's age
     int spl_off;               // ... as an element offset into the workgroup's LDS (rhs)
     int nk, hist, tl; // tl: tier lane (KT = 2), 0 otherwise
-    bool pad, seasonal, seasonal_vax, intro;
+    bool pad, seasonal_rt, seasonal_vax_rt, intro_rt;
+    __device__ __forceinline__ bool seasonal() const { return PLAIN ? false : seasonal_rt; }
+    __device__ __forceinline__ bool seasonal_vax() const { return PLAIN ? false : seasonal_vax_rt; }
+    __device__ __forceinline__ bool intro() const { return PLAIN ? false : intro_rt; }
 
     // sum over the immune histories that live in this wave (all of them unless NW > 1 splits the history bits)
     __device__ __forceinline__ static T hist_sum(T v) {
@@ -202,7 +209,7 @@ struct Seip {
             for (int k = 1; k < K1; ++k) a += y[II + k * L + l];
             x[l] = hist_sum(a);
         }
-        if (intro) { // infectious visitors: I_b + Normal(t; time, scale) * pct * P_b (ode_model.md:176-183)
+        if (intro()) { // infectious visitors: I_b + Normal(t; time, scale) * pct * P_b (ode_model.md:176-183)
 #pragma unroll
             for (int l = 0; l < L; ++l) {
                 const T u = (t - itime[l]) * iinv[l];
@@ -211,8 +218,8 @@ struct Seip {
         }
         ages.contract(x, lam);
         T season = T(1), phi = T(0);
-        if (seasonal) season = T(1) + amp * M::sin_lib(w_season * t + phase);
-        if (seasonal_vax) {
+        if (seasonal()) season = T(1) + amp * M::sin_lib(w_season * t + phase);
+        if (seasonal_vax()) {
             // sin^1000 by squaring (the oracle multiplies in the same order): 1000 = 2 * (256+128+64+32+16+4)
             const T sn = M::sin_lib(T(6.283185307179586476925286766559) * (t + tau) / T(730));
             const T u = sn * sn, u2 = u * u, u4 = u2 * u2, u8 = u4 * u4, u16 = u8 * u8, u32 = u16 * u16,
@@ -304,7 +311,7 @@ struct Seip {
             a = hist_sum(a);
             x[l] = a + xchg_xor<TB_>(a);
         }
-        if (intro) {
+        if (intro()) {
 #pragma unroll
             for (int l = 0; l < L; ++l) {
                 const T u = (t - itime[l]) * iinv[l];
@@ -313,8 +320,8 @@ struct Seip {
         }
         ages.contract(x, lam);
         T season = T(1), phi = T(0);
-        if (seasonal) season = T(1) + amp * M::sin_lib(w_season * t + phase);
-        if (seasonal_vax) {
+        if (seasonal()) season = T(1) + amp * M::sin_lib(w_season * t + phase);
+        if (seasonal_vax()) {
             const T sn = M::sin_lib(T(6.283185307179586476925286766559) * (t + tau) / T(730));
             const T u = sn * sn, u2 = u * u, u4 = u2 * u2, u8 = u4 * u4, u16 = u8 * u8, u32 = u16 * u16,
                     u64 = u32 * u32, u128 = u64 * u64, u256 = u128 * u128;
@@ -381,7 +388,7 @@ struct Seip {
         }
         recover_slots<0>(y, dy);
         if constexpr (K > 0) {
-            if (seasonal_vax) { // wave-uniform: the top tier falls back one -- to the partner lane
+            if (seasonal_vax()) { // wave-uniform: the top tier falls back one -- to the partner lane
                 constexpr int sK = K / 2, tK = K % 2, sD = (K - 1) / 2;
                 const bool holder = tl == tK;
 #pragma unroll
@@ -418,8 +425,8 @@ struct Seip {
         const int tlw = TIER_X ? (wv >> HB_X) : 0, hw = wv & (NXH - 1);
         (void)hw;
         T phi = T(0), season = T(1);
-        if (seasonal) season = T(1) + amp * M::sin_lib(w_season * t + phase);
-        if (seasonal_vax) {
+        if (seasonal()) season = T(1) + amp * M::sin_lib(w_season * t + phase);
+        if (seasonal_vax()) {
             const T sn = M::sin_lib(T(6.283185307179586476925286766559) * (t + tau) / T(730));
             const T u = sn * sn, u2 = u * u, u4 = u2 * u2, u8 = u4 * u4, u16 = u8 * u8, u32 = u16 * u16,
                     u64 = u32 * u32, u128 = u64 * u64, u256 = u128 * u128;
@@ -470,7 +477,7 @@ struct Seip {
             }
         }
         if constexpr (TIER_X && K > 0) {
-            if (seasonal_vax) { // the holder of the top tier offers what falls back one tier
+            if (seasonal_vax()) { // the holder of the top tier offers what falls back one tier
                 const bool holder = tl == tK;
 #pragma unroll
                 for (int m = 0; m < M1; ++m) *xslot(b, wv, S_SV + m) = holder ? phi * y[sK * M1 + m] : T(0);
@@ -562,7 +569,7 @@ struct Seip {
 #pragma unroll
             for (int sl = 0; sl + 1 < KL; ++sl) up[sl + 1] = rate[sl] * totl[sl];
         }
-        if (intro) {
+        if (intro()) {
 #pragma unroll
             for (int l = 0; l < L; ++l) {
                 const T u = (t - itime[l]) * iinv[l];
@@ -616,7 +623,7 @@ struct Seip {
         }
         // ---- seasonal vaccination: the top tier falls back one
         if constexpr (K > 0) {
-            if (seasonal_vax) {
+            if (seasonal_vax()) {
                 if constexpr (KT == 1) {
 #pragma unroll
                     for (int m = 0; m < M1; ++m) {
@@ -714,10 +721,10 @@ struct Seip {
     static constexpr int GW = GWL;                  // lanes of one wave that hold one trajectory
     static constexpr bool PRESCALE = false, PC = false, LEAN = false, FUSED = false;
     static constexpr size_t kTailOffset = 0;
-    static constexpr bool ADAPTIVE_NO_JUMPS = false;
+    static constexpr bool ADAPTIVE_NO_JUMPS = PLAIN;
     static constexpr bool ROOTLESS_NORM = false;    // (kinks: the dose cap, the seasonal reset)
     static constexpr bool PULLS = false;            // a static grid: the waves of a group meet at barriers, slot for slot
-    static constexpr bool REPLAYS = true;           // recorded step schedules (KArgs::sched_*: dyn_solve_batch_record / _replay)
+    static constexpr bool REPLAYS = !PLAIN;         // recorded step schedules (KArgs::sched_*: dyn_solve_batch_record / _replay)
     static constexpr bool IDLE_SLOTS_LOAD = true;   // a slot beyond the batch keeps in step on the last trajectory's data
     static constexpr int SUSN = H * K1 * M1 * L;    // susceptibility table of one trajectory
     static constexpr int kSplRow = 12;              // one dose spline in LDS: 4 cubic coefficients | 4 knots | 4 knot coefficients
@@ -742,9 +749,9 @@ struct Seip {
         xbuf = 0;
         pad = a >= A;
         nk = ka.n_vax_knots;
-        seasonal = ka.seasonal != 0;
-        seasonal_vax = ka.seasonal_vax != 0;
-        intro = ka.has_intro != 0;
+        seasonal_rt = ka.seasonal != 0;
+        seasonal_vax_rt = ka.seasonal_vax != 0;
+        intro_rt = ka.has_intro != 0;
         const int aa = pad ? 0 : a;
         g = aa * H + hist;
         writer = !pad;
@@ -789,21 +796,21 @@ struct Seip {
 #pragma unroll
         for (int l = 0; l < L; ++l) itime[l] = iinv[l] = iamp[l] = T(0);
         const T *intro_p = q;
-        if (intro) q += 3 * L;
+        if (intro()) q += 3 * L;
         amp = phase = w_season = tau = T(0);
-        if (seasonal) {
+        if (seasonal()) {
             amp = q[0];
             phase = q[1];
             w_season = T(6.283185307179586476925286766559) / q[2];
             q += 3;
         }
-        if (seasonal_vax) {
+        if (seasonal_vax()) {
             tau = q[0];
             q += 1;
         }
         pop = pad ? T(0) : q[aa];
         q += A;
-        if (intro) {
+        if (intro()) {
 #pragma unroll
             for (int l = 0; l < L; ++l) {
                 const T scale = intro_p[L + l];
@@ -957,29 +964,31 @@ struct Seip {
     }
 };
 
-template <typename T, int METHOD, int GA, int L, int K1, int M1, int KT = 1>
+template <typename T, int METHOD, int GA, int L, int K1, int M1, int KT = 1, int OPT = 0>
 __global__ void __launch_bounds__(64) seip_kernel(const KArgs<T> ka) {
-    Stepper<Seip<T, METHOD, GA, L, K1, M1, KT>>::run(ka);
+    Stepper<Seip<T, METHOD, GA, L, K1, M1, KT, 1, OPT>>::run(ka);
 }
 
 // small per-lane states (tier lanes, <= 20 values): cap the registers at 256 so that two waves share a SIMD
-template <typename T, int METHOD, int GA, int L, int K1, int M1, int KT = 1>
+template <typename T, int METHOD, int GA, int L, int K1, int M1, int KT = 1, int OPT = 0>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) seip_kernel_two_waves(const KArgs<T> ka) {
-    Stepper<Seip<T, METHOD, GA, L, K1, M1, KT>>::run(ka);
+    Stepper<Seip<T, METHOD, GA, L, K1, M1, KT, 1, OPT>>::run(ka);
 }
 
 // wave groups: one trajectory per workgroup of NW waves (lane groups of 128 or 256)
-template <typename T, int METHOD, int GA, int L, int K1, int M1, int KT, int NW>
+template <typename T, int METHOD, int GA, int L, int K1, int M1, int KT, int NW, int OPT = 0>
 __global__ void __launch_bounds__(64 * NW) seip_kernel_wave_group(const KArgs<T> ka) {
-    Stepper<Seip<T, METHOD, GA, L, K1, M1, KT, NW>>::run(ka);
+    Stepper<Seip<T, METHOD, GA, L, K1, M1, KT, NW, OPT>>::run(ka);
 }
 
-template <typename T, int METHOD, int GA, int L, int K1, int M1, int KT = 1, int NW = 1>
+template <typename T, int METHOD, int GA, int L, int K1, int M1, int KT = 1, int NW = 1, int OPT = 0>
 hipError_t launch_seip(const KArgs<T> &ka, hipStream_t stream) {
-    using Shape = Seip<T, METHOD, GA, L, K1, M1, KT, NW>;
+    using Shape = Seip<T, METHOD, GA, L, K1, M1, KT, NW, OPT>;
     constexpr int TPW = Shape::TPW;
     const int64_t blocks = (ka.B + TPW - 1) / TPW;
     if (blocks <= 0) return hipSuccess;
+    if ((OPT & 1) != 0 && (ka.seasonal || ka.seasonal_vax || ka.has_intro || ka.sched_in || ka.sched_out || ka.n_jump > 0 || ka.constant_dt > T(0)))
+        return hipErrorInvalidValue; // enqueue() never asks a plain instance for any of these
     const size_t per_traj = (size_t)(1 << L) * K1 * M1 * L + (size_t)ka.A * K1 * Shape::kSplRow;
     const size_t lds = ((size_t)ka.n_save + (ka.n_jump > 0 ? kMaxJumps : 0) + TPW * per_traj +
                         (ka.sched_in != nullptr ? (size_t)TPW * 2 * ka.sched_cap : 0) +
@@ -988,16 +997,16 @@ hipError_t launch_seip(const KArgs<T> &ka, hipStream_t stream) {
         // one or two workgroups per CU (one wave per SIMD at ~400 registers): beyond the default 64 KB of dynamic LDS the
         // kernel attribute has to allow it (160 KB per CU)
         if (lds > 65536) {
-            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&seip_kernel_wave_group<T, METHOD, GA, L, K1, M1, KT, NW>),
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&seip_kernel_wave_group<T, METHOD, GA, L, K1, M1, KT, NW, OPT>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
         }
-        hipLaunchKernelGGL((seip_kernel_wave_group<T, METHOD, GA, L, K1, M1, KT, NW>), dim3((unsigned)blocks), dim3(64 * NW), lds, stream, ka);
+        hipLaunchKernelGGL((seip_kernel_wave_group<T, METHOD, GA, L, K1, M1, KT, NW, OPT>), dim3((unsigned)blocks), dim3(64 * NW), lds, stream, ka);
     }
     else if constexpr (sizeof(T) == 4 && Shape::NV <= 20)
-        hipLaunchKernelGGL((seip_kernel_two_waves<T, METHOD, GA, L, K1, M1, KT>), dim3((unsigned)blocks), dim3(64), lds, stream, ka);
+        hipLaunchKernelGGL((seip_kernel_two_waves<T, METHOD, GA, L, K1, M1, KT, OPT>), dim3((unsigned)blocks), dim3(64), lds, stream, ka);
     else
-        hipLaunchKernelGGL((seip_kernel<T, METHOD, GA, L, K1, M1, KT>), dim3((unsigned)blocks), dim3(64), lds, stream, ka);
+        hipLaunchKernelGGL((seip_kernel<T, METHOD, GA, L, K1, M1, KT, OPT>), dim3((unsigned)blocks), dim3(64), lds, stream, ka);
     return hipGetLastError();
 }
 

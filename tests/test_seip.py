@@ -556,10 +556,10 @@ def test_tier_lanes_variant_matches_oracle(shape, prec, monkeypatch):
 # shapes beyond the bench's that the suite used to compile on demand, built in since round 3 (seip_instances.def, units 15-16):
 # (generator arguments, (tier lanes, waves) of the mapping, instance that must run)
 BUILT_IN_F64 = [
-    (dict(A=3, L=3, K1=3, M1=3, n_knots=1, seasonal_vax=True), None, "dyn::seip_kernel<double, 0, 4, 3, 3, 3, 2>"),
-    (dict(A=8, L=3, K1=2, M1=3, n_knots=1, seasonal_vax=True), (2, 2), "dyn::seip_kernel_wave_group<double, 0, 8, 3, 2, 3, 2, 2>"),
-    (dict(A=5, L=3, K1=4, M1=2, n_knots=1, intro=True), (4, 4), "dyn::seip_kernel_wave_group<double, 0, 8, 3, 4, 2, 4, 4>"),
-    (dict(A=8, L=4, K1=1, M1=3, n_knots=0), (1, 2), "dyn::seip_kernel_wave_group<double, 0, 8, 4, 1, 3, 1, 2>"),
+    (dict(A=3, L=3, K1=3, M1=3, n_knots=1, seasonal_vax=True), None, "dyn::seip_kernel<double, 0, 4, 3, 3, 3, 2, 0>"),
+    (dict(A=8, L=3, K1=2, M1=3, n_knots=1, seasonal_vax=True), (2, 2), "dyn::seip_kernel_wave_group<double, 0, 8, 3, 2, 3, 2, 2, 0>"),
+    (dict(A=5, L=3, K1=4, M1=2, n_knots=1, intro=True), (4, 4), "dyn::seip_kernel_wave_group<double, 0, 8, 3, 4, 2, 4, 4, 0>"),
+    (dict(A=8, L=4, K1=1, M1=3, n_knots=0), (1, 2), "dyn::seip_kernel_wave_group<double, 0, 8, 4, 1, 3, 1, 2, 0>"),
 ]
 
 
@@ -613,7 +613,7 @@ def test_wave_group_shape_built_on_demand():
     assert jit._seip_wave_group(wl.model) == (2, 2) and jit._features(wl.model, torch.float64) == 0x100 | 0x20 | 0x40 | 2
     ts = synthetic.save_grid(60.0)
     r = solve_batch(wl.model, wl.y0, wl.params, wl.contact, 60.0, ts, dtype=torch.float64, constant_dt=0.5)
-    assert _abi.lib().dyn_last_kernel_name().decode() == "dyn::seip_kernel_wave_group<double, 0, 8, 3, 2, 4, 2, 2>"
+    assert _abi.lib().dyn_last_kernel_name().decode() == "dyn::seip_kernel_wave_group<double, 0, 8, 3, 2, 4, 2, 2, 0>"
     want, st, _, _ = O.solve(H.omodel(wl.model), wl.y0, wl.params, wl.contact, 60.0, ts, dtype=np.float64, n_threads=8, constant_dt=0.5)
     assert int(r.status.max()) == 0 and np.abs(r.ys.cpu().numpy() - want).max() / 1000.0 < 1e-11
 
@@ -629,7 +629,7 @@ def test_wave_groups_dispatch_sub_save_jumps_and_replay():
     wl = synthetic.seip(B=11, seed=9, t1=120.0, **WAVE_GROUP_SHAPES[0])
     m, ts = wl.model, synthetic.save_grid(120.0, 4)
     full = solve_batch(m, wl.y0, wl.params, wl.contact, 120.0, ts, dtype=torch.float64, jump_ts=(31.5, 60.0), record_steps=512)
-    assert _abi.lib().dyn_last_kernel_name().decode().startswith("dyn::seip_kernel_wave_group<double, 0, 8, 3, 2, 2, 2, 2>")
+    assert _abi.lib().dyn_last_kernel_name().decode().startswith("dyn::seip_kernel_wave_group<double, 0, 8, 3, 2, 2, 2, 2, 0>")
     want, st, na, nr = O.solve(H.omodel(m), wl.y0, wl.params, wl.contact, 120.0, ts, dtype=np.float64, n_threads=8, jump_ts=(31.5, 60.0))
     got = full.ys.cpu().numpy()
     assert int(full.status.max()) == 0 and st.max() == 0 and np.abs(got - want).max() / 1000.0 < 5e-5
@@ -660,7 +660,7 @@ def test_one_tier_per_wave_and_tier_lanes_are_the_same_model(monkeypatch):
     m, ts = wl.model, synthetic.save_grid(120.0)
     want, st, _, _ = O.solve(H.omodel(m), wl.y0, wl.params, wl.contact, 120.0, ts, dtype=np.float32, n_threads=8, constant_dt=0.5)
     got = {}
-    for flag, name in (("1", "dyn::seip_kernel_wave_group<float, 0, 8, 3, 3, 4, 3, 3>"), ("0", "dyn::seip_kernel_wave_group<float, 0, 8, 3, 3, 4, 2, 2>")):
+    for flag, name in (("1", "dyn::seip_kernel_wave_group<float, 0, 8, 3, 3, 4, 3, 3, 0>"), ("0", "dyn::seip_kernel_wave_group<float, 0, 8, 3, 3, 4, 2, 2, 0>")):
         monkeypatch.setenv("DYNODE_HIP_SEIP_TIER_WAVES", flag)
         rc = solve_batch(m, wl.y0, wl.params, wl.contact, 120.0, ts, constant_dt=0.5)
         assert _abi.lib().dyn_last_kernel_name().decode() == name
@@ -684,7 +684,7 @@ def test_packed_tier_waves_two_trajectories_per_wave_group(monkeypatch):
     m, ts = wl.model, synthetic.save_grid(120.0)
     want, st, _, _ = O.solve(H.omodel(m), wl.y0, wl.params, wl.contact, 120.0, ts, dtype=np.float32, n_threads=8, constant_dt=0.5)
     got = {}
-    for flag, name in (("1", "dyn::seip_kernel_wave_group<float, 0, 4, 3, 3, 4, 3, 3>"), ("0", "dyn::seip_kernel<float, 0, 4, 3, 3, 4, 2>")):
+    for flag, name in (("1", "dyn::seip_kernel_wave_group<float, 0, 4, 3, 3, 4, 3, 3, 0>"), ("0", "dyn::seip_kernel<float, 0, 4, 3, 3, 4, 2, 0>")):
         monkeypatch.setenv("DYNODE_HIP_SEIP_TIER_WAVES", flag)
         rc = solve_batch(m, wl.y0, wl.params, wl.contact, 120.0, ts, constant_dt=0.5)
         assert _abi.lib().dyn_last_kernel_name().decode() == name
@@ -704,6 +704,50 @@ def test_packed_tier_waves_two_trajectories_per_wave_group(monkeypatch):
     leader = np.array([0, 0, 2, 2, 4, 4, 6])                                                    # neighbours follow different leaders
     led = solve_batch(m, wl.y0, wl.params, wl.contact, 120.0, ts, jump_ts=(40.25,), replay=(steps, count, leader))
     assert torch.equal(led.ys[leader], full.ys[leader]) and torch.equal(led.n_accept, full.n_accept[leader])
+
+
+PLAIN_INSTANCES = [("seip", "dyn::seip_kernel_two_waves<float, 0, 8, 2, 3, 4, 2, %d>"),
+                   ("seip3", "dyn::seip_kernel_wave_group<float, 0, 4, 3, 3, 4, 3, 3, %d>"),
+                   ("seip83", "dyn::seip_kernel_wave_group<float, 0, 8, 3, 3, 4, 3, 3, %d>"),
+                   ("seip84", "dyn::seip_kernel_wave_group<float, 0, 8, 4, 3, 4, 3, 6, %d>")]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,kernel", PLAIN_INSTANCES, ids=[n for n, _ in PLAIN_INSTANCES])
+def test_calls_without_seasonal_terms_take_the_plain_instance(name, kernel, monkeypatch):
+    """The bench shapes are compiled a second time with "no seasonal forcing, no seasonal vaccination, no introduced strains,
+    no recorded schedule, adaptive steps, no discontinuity points" as compile-time facts (seip_kernel.hpp `OPT` bit 0;
+    `kSeipPlain` in dynode_hip.hip).  A call that uses none of them runs that instance, any other call the general one; the two
+    are the same model: each is the float32 oracle's solution to the tolerance and as accurate against a float64 solve."""
+    import torch
+    from dynode_amd import _abi
+    from dynode_amd.engine import solve_batch
+
+    wl = synthetic.WORKLOADS[name](7)
+    m, ts = wl.model, wl.save_ts
+    assert not (m.seasonal or m.seasonal_vax or m.has_intro)
+    last = lambda: _abi.lib().dyn_last_kernel_name().decode()
+    plain = solve_batch(m, wl.y0, wl.params, wl.contact, wl.t1, ts)
+    assert last() == kernel % 1
+    monkeypatch.setenv("DYNODE_HIP_SEIP_PLAIN", "0")
+    general = solve_batch(m, wl.y0, wl.params, wl.contact, wl.t1, ts)
+    assert last() == kernel % 0
+    monkeypatch.delenv("DYNODE_HIP_SEIP_PLAIN")
+    want, st, na, nr = O.solve(H.omodel(m), wl.y0, wl.params, wl.contact, wl.t1, ts, dtype=np.float32, n_threads=8)
+    assert st.max() == 0
+    for r, tag in ((plain, "plain"), (general, "general")):
+        got = r.ys.cpu().numpy()
+        assert int(r.status.max()) == 0 and np.abs(got - want).max() / 1000.0 < 5e-4
+        H.truth_bars(m, got, want, wl.y0, wl.params, wl.contact, wl.t1, ts, 1000.0, f"{name} {tag}", smooth=False, rtol=1e-9)
+        assert np.abs((r.n_accept + r.n_reject).cpu().numpy() - (na + nr)).max() <= 30
+    assert float((plain.ys - general.ys).abs().max()) / 1000.0 < 2e-4
+    # what the plain instance was compiled without goes to the general one
+    for extra in (dict(jump_ts=(100.5,)), dict(constant_dt=0.5), dict(record_steps=1024)):
+        r = solve_batch(m, wl.y0, wl.params, wl.contact, wl.t1, ts, **extra)
+        assert last() == kernel % 0 and int(r.status.max()) == 0
+    wc, stc, _, _ = O.solve(H.omodel(m), wl.y0, wl.params, wl.contact, wl.t1, ts, dtype=np.float32, n_threads=8, constant_dt=0.5)
+    rc = solve_batch(m, wl.y0, wl.params, wl.contact, wl.t1, ts, constant_dt=0.5)
+    assert np.abs(rc.ys.cpu().numpy() - wc).max() / 1000.0 < 2e-5
 
 
 @pytest.mark.gpu
