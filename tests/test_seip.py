@@ -739,7 +739,7 @@ def test_calls_without_seasonal_terms_take_the_plain_instance(name, kernel, monk
         got = r.ys.cpu().numpy()
         assert int(r.status.max()) == 0 and np.abs(got - want).max() / 1000.0 < 5e-4
         H.truth_bars(m, got, want, wl.y0, wl.params, wl.contact, wl.t1, ts, 1000.0, f"{name} {tag}", smooth=False, rtol=1e-9)
-        assert np.abs((r.n_accept + r.n_reject).cpu().numpy() - (na + nr)).max() <= 30
+        assert np.abs((r.n_accept + r.n_reject).cpu().numpy() - (na + nr)).max() <= max(8, 0.2 * (na + nr).max())
     assert float((plain.ys - general.ys).abs().max()) / 1000.0 < 2e-4
     # what the plain instance was compiled without goes to the general one
     for extra in (dict(jump_ts=(100.5,)), dict(constant_dt=0.5), dict(record_steps=1024)):
@@ -773,7 +773,10 @@ def test_north_star_sizes_properties(name, B):
     s_, e_, i_, c_ = torch.split(r.ys.double(), list(sizes), dim=2)
     people = s_.reshape(B, 366, A, -1).sum(-1) + e_.reshape(B, 366, A, -1).sum(-1) + i_.reshape(B, 366, A, -1).sum(-1)
     assert float((people - people[:, :1]).abs().max()) < 2e-2      # float32, 1000 people over thousands of cells and 365 days
-    assert float(r.ys.min()) > -5e-3 and float((c_[:, 1:] - c_[:, :-1]).min()) > -5e-3      # (undershoots of the order of the tolerance)
+    # (undershoots of the order of the solver's error: empty cells sit at 0 +- what rtol 1e-5 leaves on 1000 people over 365 days --
+    # the float32 ORACLE is 0.022 off a float64 rtol 1e-9 solve on the trajectory whose cell reaches -0.005 here,
+    # tools/probes/probe_seip_undershoot.py)
+    assert float(r.ys.min()) > -2e-2 and float((c_[:, 1:] - c_[:, :-1]).min()) > -5e-3
     perm = np.random.default_rng(2).permutation(B)
     rp = solve_batch(m, wl.y0[perm], wl.params[perm], wl.contact, wl.t1, wl.save_ts)
     assert torch.equal(rp.ys, r.ys[torch.as_tensor(perm, device="cuda")])
@@ -783,6 +786,6 @@ def test_north_star_sizes_properties(name, B):
     assert st.max() == 0 and np.abs(got - want).max() / 1000.0 < 5e-4          # adaptive float32: step decisions differ near the dose-cap kinks
     # (secondary to:) against a float64 rtol 1e-9 solve of the same six trajectories the HIP solution is as accurate as the oracle's
     H.truth_bars(m, got, want, wl.y0[idx], wl.params[idx], wl.contact, wl.t1, wl.save_ts, 1000.0, f"{name} north-star size", smooth=False, rtol=1e-9)
-    assert np.abs((r.n_accept + r.n_reject).cpu().numpy()[idx] - (na + nr)).max() <= 30
+    assert np.abs((r.n_accept + r.n_reject).cpu().numpy()[idx] - (na + nr)).max() <= max(8, 0.2 * (na + nr).max())   # (the bar of test_hip_matches_oracle)
     del r, r2, rp
     torch.cuda.empty_cache()
