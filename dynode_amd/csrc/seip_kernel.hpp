@@ -21,6 +21,9 @@
 #ifndef DYN_SEIP_CACHE_TW
 #define DYN_SEIP_CACHE_TW 1
 #endif
+#ifndef DYN_SEIP_CACHE_6
+#define DYN_SEIP_CACHE_6 1
+#endif
 #ifndef DYN_SEIP_CACHE_SUS
 #define DYN_SEIP_CACHE_SUS 1
 #endif
@@ -121,7 +124,7 @@ struct Seip {
     // ... and a copy in registers of the rows this lane multiplies by in EVERY right-hand side (its tiers x waning states x
     // strains), where the register file has the room: the LDS reads sit behind the mailbox writes of a wave group (nothing
     // hoists them), and with one wave per SIMD nobody hides their latency
-    static constexpr bool CACHE_SUS = DYN_SEIP_CACHE_SUS && (NW == 2 || (KT > 2 && NW == 3 && DYN_SEIP_CACHE_TW)) && (9 * NV + KL * (M1 * L + 12) + 70) * (int)(sizeof(T) / 4) <= 500;
+    static constexpr bool CACHE_SUS = DYN_SEIP_CACHE_SUS && (NW == 2 || (KT > 2 && (NW == 3 || (NW == 6 && PLAIN && DYN_SEIP_CACHE_6)) && DYN_SEIP_CACHE_TW)) && (9 * NV + KL * (M1 * L + 12) + 70) * (int)(sizeof(T) / 4) <= 500;
     T susr[CACHE_SUS ? KL * M1 * L : 1];
     T splr[CACHE_SUS ? KL * 12 : 1];   // per slot: the cubic's 4 coefficients, 4 knots, 4 knot coefficients (0 beyond nk)
     // nu(t) of one dose tier: cubic + truncated-power terms (reference utils/splines.py:10-109 conditional_knots), from the LDS
