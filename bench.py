@@ -23,7 +23,9 @@ Rank 0 prints ONE JSON line, including
   roofline     : algorithmic HBM bytes per launch / mean kernel duration (HIP events on the
                  launch stream) against the 8 TB/s HBM3E peak, with the name of the kernel instance
                  that was dispatched (dyn_last_kernel_name) and, when profiles/traffic.json holds a
-                 PMC measurement of that same instance, the measured HBM traffic per launch,
+                 PMC measurement of that same instance, the measured HBM traffic per launch;
+                 `measured_on_this_box` (N = 1): this box's device-to-device copy and fill rates on a
+                 buffer the size of one launch's output, and the achieved rate as a fraction of each,
   cpu_baseline : the CPU oracle (oracle/, "port") timed on this host's cores on a bounded sample.
 """
 
@@ -269,6 +271,33 @@ def checksums(out, stats):
             float(out.sum(dtype=torch.float64)), float(out[:, -1].abs().sum(dtype=torch.float64))]
 
 
+def measured_device_bandwidth(dev, out_bytes: int):
+    """the nominal 8 TB/s next to what this box's HBM delivers to the simplest possible kernels --
+    a device-to-device copy (one read + one write per byte) and a fill (writes only, the solve's pattern: > 99 % of its
+    algorithmic bytes are output rows) of a buffer the size of one launch's output.  torch's copy / fill kernels on the
+    current stream, HIP events around 10 repetitions after 3 untimed ones; GB/s of bytes moved."""
+    import torch
+
+    n = max(out_bytes // 4, 1 << 26)
+    src = torch.empty(n, dtype=torch.float32, device=dev).normal_()
+    dst = torch.empty_like(src)
+    res = {}
+    for name, fn, moved in (("copy", lambda: dst.copy_(src), 8 * n), ("fill", lambda: dst.fill_(1.0), 4 * n)):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        res[name + "_GBps"] = moved * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    res["buffer_bytes"] = 4 * n
+    del src, dst
+    torch.cuda.empty_cache()
+    return res
+
+
 def roofline_block(wl, workload: str, res):
     bytes_traj = wl.bytes_per_trajectory(4)
     achieved = bytes_traj * wl.B / (res["kernel_ms"] * 1e-3) / 1e9  # GB/s per GPU, dominant (only) kernel
@@ -403,6 +432,13 @@ def main():
             "roofline": roofline_block(wl, args.workload, res),
         }
         del res
+        if world == 1:
+            torch.cuda.empty_cache()
+            bw = measured_device_bandwidth(dev, line["roofline"]["algorithmic_bytes_per_trajectory"] * B)
+            line["roofline"]["measured_on_this_box"] = dict(
+                bw, frac_of_copy=line["roofline"]["achieved"] / bw["copy_GBps"], frac_of_fill=line["roofline"]["achieved"] / bw["fill_GBps"],
+                note="device-to-device copy and fill of a buffer the size of one launch's output (torch kernels, HIP events): "
+                     "`frac` above stays against the nominal 8 TB/s")
         if world == 1 and not args.no_extra and args.workload == "cfg3":
             torch.cuda.empty_cache()
             # the same model without the bins axis, as a second full roofline block (20 launches, one event pair each)
