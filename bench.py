@@ -432,7 +432,7 @@ def main():
             "roofline": roofline_block(wl, args.workload, res),
         }
         del res
-        if world == 1:
+        if world == 1 and not args.no_extra:
             torch.cuda.empty_cache()
             bw = measured_device_bandwidth(dev, line["roofline"]["algorithmic_bytes_per_trajectory"] * B)
             line["roofline"]["measured_on_this_box"] = dict(
