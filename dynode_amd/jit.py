@@ -129,10 +129,19 @@ def _stamp() -> str:
     return _STAMP
 
 
+_SEIP_PLAIN = 0x1000     # csrc/dynode_hip.hip kSeipPlain
+
+
+def _seip_plain(model, dtype) -> bool:
+    """An on-demand SEIP build carries the plain instance too when calls on this model can reach it: float32 (where it was
+    measured: 5-20 % on the built-in shapes) and a model without seasonal forcing, seasonal vaccination or introduced strains."""
+    return (model.family == 1 and dtype == torch.float32 and not (model.seasonal or model.seasonal_vax or model.has_intro))
+
+
 def _name(model, dtype, method, n_dir, spl) -> str:
     return (f"{'f64' if dtype == torch.float64 else 'f32'}_m{method}_g{_group_width(model.n_age)}_s{model.n_strain}"
             f"_e{int(model.has_e)}w{int(model.has_wane)}c{int(model.has_c)}_W{model.n_wane}_nd{n_dir}_spl{spl}"
-            f"_f{_features(model, dtype)}_{_stamp()}")
+            f"_f{_features(model, dtype)}{'p' if _seip_plain(model, dtype) else ''}_{_stamp()}")
 
 
 def _source(model, dtype, method, n_dir, spl) -> str:
@@ -143,10 +152,19 @@ def _source(model, dtype, method, n_dir, spl) -> str:
         wg = _seip_wave_group(model)
         args = f"{t}, {method}, {_group_width(A)}, {L}, {K1}, {M1}" + (
             f", {wg[0]}, {wg[1]}" if wg is not None else (", 2" if _seip_tier_lanes(model, dtype) else ""))
-        return (f'#include "{os.path.join(_CSRC, "seip_kernel.hpp")}"\n'
-                f"namespace dyn {{ template hipError_t launch_seip<{args}>(const KArgs<{t}> &, hipStream_t); }}\n"
-                f'extern "C" void *dyn_extra_launch(void) {{\n'
-                f"    return (void *)(hipError_t(*)(const dyn::KArgs<{t}> &, hipStream_t)) & dyn::launch_seip<{args}>;\n}}\n")
+        src = (f'#include "{os.path.join(_CSRC, "seip_kernel.hpp")}"\n'
+               f"namespace dyn {{ template hipError_t launch_seip<{args}>(const KArgs<{t}> &, hipStream_t); }}\n"
+               f'extern "C" void *dyn_extra_launch(void) {{\n'
+               f"    return (void *)(hipError_t(*)(const dyn::KArgs<{t}> &, hipStream_t)) & dyn::launch_seip<{args}>;\n}}\n")
+        if _seip_plain(model, dtype):
+            # ... and the same mapping compiled without seasonal terms, introductions, schedules and discontinuity points
+            # (Seip OPT bit 0; dynode_hip.hip kSeipPlain): what a call that uses none of them is dispatched to
+            kt, nw = wg if wg is not None else ((2, 1) if _seip_tier_lanes(model, dtype) else (1, 1))
+            full = f"{t}, {method}, {_group_width(A)}, {L}, {K1}, {M1}, {kt}, {nw}, 1"
+            src += (f"namespace dyn {{ template hipError_t launch_seip<{full}>(const KArgs<{t}> &, hipStream_t); }}\n"
+                    f'extern "C" void *dyn_extra_launch_plain(void) {{\n'
+                    f"    return (void *)(hipError_t(*)(const dyn::KArgs<{t}> &, hipStream_t)) & dyn::launch_seip<{full}>;\n}}\n")
+        return src
     args = (f"{t}, {method}, {_group_width(model.n_age)}, {model.n_strain}, {b(model.has_e)}, {b(model.has_wane)}, "
             f"{b(model.has_c)}, {model.n_wane}, {n_dir}, {spl}, {_features(model)}")
     return (f'#include "{os.path.join(_CSRC, "solve_kernel.hpp")}"\n'
@@ -210,5 +228,12 @@ def ensure_kernel(model: _abi.ModelDesc, dtype=torch.float32, method: str = "tsi
                                      _features(model, dtype), ctypes.c_void_p(extra.dyn_extra_launch()))
         if rc:
             raise RuntimeError(f"dyn_register_instance: {_abi.ERR_NAMES.get(rc, rc)}")
+        if _seip_plain(model, dtype) and hasattr(extra, "dyn_extra_launch_plain"):
+            extra.dyn_extra_launch_plain.restype = ctypes.c_void_p
+            rc = L.dyn_register_instance(opts.dtype, mid, _group_width(model.n_age), model.n_strain, int(model.has_e),
+                                         int(model.has_wane), int(model.has_c), model.n_wane, n_dir, spl,
+                                         _features(model, dtype) | _SEIP_PLAIN, ctypes.c_void_p(extra.dyn_extra_launch_plain()))
+            if rc:
+                raise RuntimeError(f"dyn_register_instance (plain): {_abi.ERR_NAMES.get(rc, rc)}")
         _LOADED[name] = extra
     return True

@@ -751,6 +751,31 @@ def test_calls_without_seasonal_terms_take_the_plain_instance(name, kernel, monk
 
 
 @pytest.mark.gpu
+@pytest.mark.on_demand_build
+def test_on_demand_float32_build_carries_the_plain_instance():
+    """A float32 SEIP shape that is not compiled in, on a model without seasonal terms or introduced strains: the on-demand build
+    holds the general AND the plain instance (`jit._seip_plain`), registered under `FEAT` and `FEAT | kSeipPlain`; an adaptive call
+    without discontinuity points runs the plain one, a constant-step call the general one, both are the oracle's solution."""
+    import torch
+    from dynode_amd import _abi
+    from dynode_amd.engine import solve_batch
+
+    wl = synthetic.seip(B=5, seed=12, t1=90.0, A=5, L=2, K1=2, M1=3, n_knots=1)
+    m, ts = wl.model, synthetic.save_grid(90.0)
+    last = lambda: _abi.lib().dyn_last_kernel_name().decode()
+    r = solve_batch(m, wl.y0, wl.params, wl.contact, 90.0, ts)
+    assert last().endswith(", 1>"), last()
+    want, st, na, nr = O.solve(H.omodel(m), wl.y0, wl.params, wl.contact, 90.0, ts, dtype=np.float32, n_threads=8)
+    got = r.ys.cpu().numpy()
+    assert int(r.status.max()) == 0 and st.max() == 0 and np.abs(got - want).max() / 1000.0 < 2e-4
+    H.truth_bars(m, got, want, wl.y0, wl.params, wl.contact, 90.0, ts, 1000.0, "on-demand plain", smooth=False, rtol=1e-9)
+    rc = solve_batch(m, wl.y0, wl.params, wl.contact, 90.0, ts, constant_dt=0.5)
+    assert last().endswith(", 0>"), last()
+    wc, stc, _, _ = O.solve(H.omodel(m), wl.y0, wl.params, wl.contact, 90.0, ts, dtype=np.float32, n_threads=8, constant_dt=0.5)
+    assert int(rc.status.max()) == 0 and np.abs(rc.ys.cpu().numpy() - wc).max() / 1000.0 < 2e-5
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name,B", [("seip83", 768), ("seip84", 384), ("seip3", 1025)])
 def test_north_star_sizes_properties(name, B):
     """The SEIP shapes `bench.py` measures (8 ages x 3 and x 4 strains as wave groups of one tier per wave; 4 ages x 3 strains
