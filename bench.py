@@ -375,6 +375,14 @@ def main():
     elapsed, kern_ms = res["elapsed"], res["kernel_ms"]
     ok = int(res["stats"][0].max()) == 0
     steps_mean = float((res["stats"][1] + res["stats"][2]).float().mean())
+    # lock-step cost of a static grid: a wave's loop runs until the slowest of its trajectories is through
+    import ctypes
+    from dynode_amd import _abi
+    tpw = int(_abi.lib().dyn_trajectories_per_wave(ctypes.byref(m.c())))
+    wave_iters = None
+    if tpw > 0 and B % tpw == 0:
+        attempts = (res["stats"][1] + res["stats"][2]).reshape(B // tpw, tpw)
+        wave_iters = float(attempts.amax(dim=1).float().mean())
 
     shards_match, shard_digests = None, None
     if world > 1:
@@ -423,6 +431,10 @@ def main():
                 "solver": "tsit5",
                 "untimed_launches_before_the_timed_region": SETTLE_LAUNCHES + args.warmup,
                 "mean_steps_per_trajectory": steps_mean,
+                # static grid, trajectories dealt to waves in the given order: mean over waves of the most step attempts among
+                # a wave's trajectories (= its loop iterations; the wave's other trajectories idle for the difference)
+                "trajectories_per_wave": tpw,
+                "mean_loop_iterations_per_wave": wave_iters,
                 "all_status_ok": ok,
                 "parallelism": f"{world} x independent shards, no data-path collective",
                 "shards_match_single_process": shards_match,

@@ -89,6 +89,15 @@ if "SQ_WAVE_CYCLES" in mean and "SQ_WAVES" in mean:
     lines.append(f"- VALU instructions per wave = {mean.get('SQ_INSTS_VALU',0)/mean['SQ_WAVES']:.0f}; SALU per wave = {mean.get('SQ_INSTS_SALU',0)/mean['SQ_WAVES']:.0f}; LDS per wave = {mean.get('SQ_INSTS_LDS',0)/mean['SQ_WAVES']:.0f}")
     lines.append(f"- waves per launch = {mean['SQ_WAVES']:.0f} for {batch} trajectories (a work-pulling launch is a resident grid: every wave integrates several "
                  f"trajectories one after the other); VALU instructions per TRAJECTORY-lane-group = {mean.get('SQ_INSTS_VALU',0)/batch:.0f} x (trajectories per wave)")
+    try:   # the bench line of the traced run: step attempts per trajectory and loop iterations per wave (lock-step cost)
+        log = open(os.path.join(out_dir, "trace.log")).read().splitlines()
+        cfg = next(json.loads(l) for l in reversed(log) if l.startswith("{") and '"metric"' in l)["config"]
+        if cfg.get("mean_loop_iterations_per_wave") is not None:
+            lines.append(f"- step attempts per trajectory (mean) = {cfg['mean_steps_per_trajectory']:.1f}; loop iterations per wave (mean over waves of "
+                         f"the most attempts among its {cfg['trajectories_per_wave']} trajectories, static grid in the given order) = "
+                         f"{cfg['mean_loop_iterations_per_wave']:.1f}")
+    except (OSError, StopIteration, KeyError, ValueError):
+        pass
     if "GRBM_GUI_ACTIVE" in mean and stats:
         lines.append(f"- effective clock ~ GRBM_GUI_ACTIVE / 8 / kernel time = {mean['GRBM_GUI_ACTIVE']/8/float(stats['AverageNs']):.2f} GHz (profiled pass)")
     lines.append("")
