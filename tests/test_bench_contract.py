@@ -42,6 +42,9 @@ def test_bench_line_has_every_field_of_the_contract():
     assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-12 and 0.2 < roof["frac"] < 0.8
     assert roof["traffic"] is None or roof["traffic"] > 3e9
+    # lock-step cost of the static grid, reported next to the mean: a wave loops as long as its slowest trajectory needs
+    cfg = d["config"]
+    assert cfg["trajectories_per_wave"] == 2 and cfg["mean_steps_per_trajectory"] <= cfg["mean_loop_iterations_per_wave"] < 1.2 * cfg["mean_steps_per_trajectory"]
     cpu = d["cpu_baseline"]
     assert cpu["kind"] == "port" and cpu["unit"] == "trajectories/s" and cpu["cores"] >= 1 and cpu["value"] > 0 and cpu["sample"]
     # value = trajectories of all steps over the wall clock; the kernel-only rate cannot be lower
