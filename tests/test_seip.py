@@ -741,6 +741,13 @@ def test_calls_without_seasonal_terms_take_the_plain_instance(name, kernel, monk
         H.truth_bars(m, got, want, wl.y0, wl.params, wl.contact, wl.t1, ts, 1000.0, f"{name} {tag}", smooth=False, rtol=1e-9)
         assert np.abs((r.n_accept + r.n_reject).cpu().numpy() - (na + nr)).max() <= max(8, 0.2 * (na + nr).max())
     assert float((plain.ys - general.ys).abs().max()) / 1000.0 < 2e-4
+    # sub-saves on the plain instance: the same trajectories, the saved compartments' columns bit for bit
+    mask = np.array([1, 0, 0, 1], dtype=np.uint8)
+    sub = solve_batch(m, wl.y0, wl.params, wl.contact, wl.t1, ts, save_mask=mask)
+    assert last() == kernel % 1
+    sizes = m.compartment_sizes
+    cols = np.concatenate([np.arange(sizes[0]), sum(sizes[:3]) + np.arange(sizes[3])])
+    assert np.array_equal(sub.ys.cpu().numpy(), plain.ys.cpu().numpy()[:, :, cols]) and torch.equal(sub.n_accept, plain.n_accept)
     # what the plain instance was compiled without goes to the general one
     for extra in (dict(jump_ts=(100.5,)), dict(constant_dt=0.5), dict(record_steps=1024)):
         r = solve_batch(m, wl.y0, wl.params, wl.contact, wl.t1, ts, **extra)
