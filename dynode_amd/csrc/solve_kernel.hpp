@@ -251,7 +251,7 @@ struct Tab<1> { // Dopri5
 // xchg_xor<K>(v): lane l receives the value held by lane l ^ K.  Built from DPP row
 // permutations (VALU operand modifiers: no LDS pipe, no lgkmcnt wait) composed as
 //   K in 1..3  : quad_perm            K in 4..7  : row_half_mirror (l -> l^7) then quad_perm
-//   K in 8..15 : row_mirror (l -> l^15) then the K^15 case
+//   K = 8      : row_ror:8;   K in 9..15 : row_mirror (l -> l^15) then the K^15 case
 //   K in 16..31: ds_swizzle xor 16 first;   K >= 32: ds_bpermute xor 32 first.
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float v) {
@@ -284,6 +284,7 @@ __device__ __forceinline__ T xchg_xor(T v) {
     else if constexpr (K == 2) return dpp_mov<0x4E>(v); // quad_perm [2,3,0,1]
     else if constexpr (K == 3) return dpp_mov<0x1B>(v); // quad_perm [3,2,1,0]
     else if constexpr (K < 8) return xchg_xor<(K ^ 7)>(dpp_mov<0x141>(v));   // row_half_mirror
+    else if constexpr (K == 8) return dpp_mov<0x128>(v);                     // row_ror:8 -- in a row of 16, l + 8 mod 16 = l ^ 8: one move, not two
     else if constexpr (K < 16) return xchg_xor<(K ^ 15)>(dpp_mov<0x140>(v)); // row_mirror
     else if constexpr (K < 32) return xchg_xor<(K ^ 16)>(swz_xor16(v));
     else return xchg_xor<(K ^ 32)>(__shfl_xor(v, 32, 64));
