@@ -59,7 +59,8 @@ constexpr int kSeip = 0x100;
 constexpr int kSeipTierLanes = 0x20; // SEIP entry with the tiers dealt over two lanes (seip_kernel.hpp, KT = 2)
 constexpr int kSeipWaves2 = 0x40, kSeipWaves4 = 0x80; // ... whose trajectory is owned by a workgroup of 2 / 4 waves (NW)
 constexpr int kSeipTierWaves = 0x200; // ... or one tier per tier lane with whole waves as tier lanes: KT = K1, NW = K1 x (lanes / 64)
-// ... compiled without seasonal terms, introduced strains, recorded schedules and discontinuity points (Seip OPT bit 0);
+// ... compiled without seasonal terms, introduced strains, recorded schedules, discontinuity points and a dose spline's third
+// and fourth knot (Seip OPT bit 0);
 // enqueue swaps it in for a call that uses none of them
 constexpr int kSeipPlain = 0x1000;
 // FEAT bit 14 (solve_kernel.hpp SAVE_ALL): variant without the per-round save-offset / store-width tests, picked by
@@ -642,10 +643,10 @@ static int solve_impl(const dyn_model_desc *m, const dyn_solver_opts *o, const v
     const dyn::Entry *e = dyn::find_entry(m, o->dtype, o->method, n_dir);
     if (m->family == 1) {
         e = dyn::select_seip_entry(m, o->dtype, o->method, e);
-        // a call with no seasonal term, no introduced strain, no recorded schedule and adaptive steps without discontinuity
-        // points takes the variant compiled without them, when that shape has one (DYNODE_HIP_SEIP_PLAIN=0: tuning aid)
+        // a call with no seasonal term, no introduced strain, dose splines of at most two knots, no recorded schedule and adaptive
+        // steps without discontinuity points takes the variant compiled without them, when that shape has one (DYNODE_HIP_SEIP_PLAIN=0: tuning aid)
         const char *pl = getenv("DYNODE_HIP_SEIP_PLAIN");
-        if (e && !m->seasonal && !m->seasonal_vax && !m->has_intro && !sc && o->n_jump == 0 && !(o->constant_dt > 0) &&
+        if (e && !m->seasonal && !m->seasonal_vax && !m->has_intro && m->n_vax_knots <= 2 && !sc && o->n_jump == 0 && !(o->constant_dt > 0) &&
             !(pl && atoi(pl) == 0)) {
             const dyn::Entry *plain = dyn::find_variant(e, e->FEAT | dyn::kSeipPlain);
             if (plain) e = plain;

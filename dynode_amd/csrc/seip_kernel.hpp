@@ -44,9 +44,12 @@ namespace dyn {
 template <typename T, int METHOD, int GA, int L, int K1, int M1, int KT = 1, int NW = 1, int OPT = 0>
 struct Seip {
     // OPT bit 0 ("plain"): no seasonal forcing, no seasonal vaccination reset, no introduced strains, no recorded schedules,
-    // adaptive steps, no discontinuity points -- as compile-time facts (enqueue() picks the variant when the call is that):
+    // adaptive steps, no discontinuity points, dose splines of at most two knots -- as compile-time facts (enqueue() picks the variant when the call is that):
     // their fields and branches leave the right-hand side and the stepping loop (the D = 960 kernel sits at its register line)
     static constexpr bool PLAIN = (OPT & 1) != 0;
+    // ... and at most two knots per dose spline (the rows hold four: knots beyond the model's own are +inf with coefficient
+    // 0, two truncated-power terms that add exactly zero to every evaluation)
+    static constexpr int NKC = PLAIN ? 2 : 4;
     static constexpr int H = 1 << L, G = GA * H * KT, K = K1 - 1;
     // one tier per wave with an (age, history) plane smaller than a wavefront: the planes of 64 / (GA H) trajectories sit side
     // by side in every wave of the group ("packed": 4 ages x 8 histories = 32 lanes, two trajectories per group of three waves)
@@ -135,14 +138,14 @@ struct Seip {
             const T *r = splr + slot * 12;
             nu = r[0] + t * (r[1] + t * (r[2] + t * r[3]));
 #pragma unroll
-            for (int n = 0; n < 4; ++n) {
+            for (int n = 0; n < NKC; ++n) {
                 const T lag = M::max(t - r[4 + n], T(0));
                 nu += r[8 + n] * (lag * lag * lag);
             }
         } else { // LDS row: the cubic's 4 coefficients | 4 knots | 4 knot coefficients, padded beyond nk by knots never reached and zeros
             nu = c[0] + t * (c[1] + t * (c[2] + t * c[3]));
 #pragma unroll
-            for (int n = 0; n < 4; ++n) {
+            for (int n = 0; n < NKC; ++n) {
                 const T lag = M::max(t - c[4 + n], T(0));
                 nu += c[8 + n] * (lag * lag * lag);
             }
@@ -990,7 +993,7 @@ hipError_t launch_seip(const KArgs<T> &ka, hipStream_t stream) {
     constexpr int TPW = Shape::TPW;
     const int64_t blocks = (ka.B + TPW - 1) / TPW;
     if (blocks <= 0) return hipSuccess;
-    if ((OPT & 1) != 0 && (ka.seasonal || ka.seasonal_vax || ka.has_intro || ka.sched_in || ka.sched_out || ka.n_jump > 0 || ka.constant_dt > T(0)))
+    if ((OPT & 1) != 0 && (ka.seasonal || ka.seasonal_vax || ka.has_intro || ka.sched_in || ka.sched_out || ka.n_jump > 0 || ka.constant_dt > T(0) || ka.n_vax_knots > 2))
         return hipErrorInvalidValue; // enqueue() never asks a plain instance for any of these
     const size_t per_traj = (size_t)(1 << L) * K1 * M1 * L + (size_t)ka.A * K1 * Shape::kSplRow;
     const size_t lds = ((size_t)ka.n_save + (ka.n_jump > 0 ? kMaxJumps : 0) + TPW * per_traj +

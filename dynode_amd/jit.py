@@ -134,8 +134,9 @@ _SEIP_PLAIN = 0x1000     # csrc/dynode_hip.hip kSeipPlain
 
 def _seip_plain(model, dtype) -> bool:
     """An on-demand SEIP build carries the plain instance too when calls on this model can reach it: float32 (where it was
-    measured: 5-20 % on the built-in shapes) and a model without seasonal forcing, seasonal vaccination or introduced strains."""
-    return (model.family == 1 and dtype == torch.float32 and not (model.seasonal or model.seasonal_vax or model.has_intro))
+    measured: 5-20 % on the built-in shapes) and a model without seasonal forcing, seasonal vaccination or introduced strains, with dose splines of at most two knots."""
+    return (model.family == 1 and dtype == torch.float32 and not (model.seasonal or model.seasonal_vax or model.has_intro)
+            and model.n_vax_knots <= 2)
 
 
 def _name(model, dtype, method, n_dir, spl) -> str:

@@ -716,7 +716,7 @@ PLAIN_INSTANCES = [("seip", "dyn::seip_kernel_two_waves<float, 0, 8, 2, 3, 4, 2,
 @pytest.mark.parametrize("name,kernel", PLAIN_INSTANCES, ids=[n for n, _ in PLAIN_INSTANCES])
 def test_calls_without_seasonal_terms_take_the_plain_instance(name, kernel, monkeypatch):
     """The bench shapes are compiled a second time with "no seasonal forcing, no seasonal vaccination, no introduced strains,
-    no recorded schedule, adaptive steps, no discontinuity points" as compile-time facts (seip_kernel.hpp `OPT` bit 0;
+    no recorded schedule, adaptive steps, no discontinuity points, at most two knots per dose spline" as compile-time facts (seip_kernel.hpp `OPT` bit 0;
     `kSeipPlain` in dynode_hip.hip).  A call that uses none of them runs that instance, any other call the general one; the two
     are the same model: each is the float32 oracle's solution to the tolerance and as accurate against a float64 solve."""
     import torch
@@ -755,6 +755,14 @@ def test_calls_without_seasonal_terms_take_the_plain_instance(name, kernel, monk
     wc, stc, _, _ = O.solve(H.omodel(m), wl.y0, wl.params, wl.contact, wl.t1, ts, dtype=np.float32, n_threads=8, constant_dt=0.5)
     rc = solve_batch(m, wl.y0, wl.params, wl.contact, wl.t1, ts, constant_dt=0.5)
     assert np.abs(rc.ys.cpu().numpy() - wc).max() / 1000.0 < 2e-5
+    # ... and so does a dose spline with a third knot (the plain instance evaluates two truncated-power terms, the rows hold four)
+    A, L, _, K1, M1, _ = m.seip_dims
+    w3 = synthetic.seip(B=3, seed=8, t1=90.0, A=A, L=L, K1=K1, M1=M1, n_knots=3)
+    t3 = synthetic.save_grid(90.0)
+    r3 = solve_batch(w3.model, w3.y0, w3.params, w3.contact, 90.0, t3)
+    assert last() == kernel % 0
+    want3, st3, _, _ = O.solve(H.omodel(w3.model), w3.y0, w3.params, w3.contact, 90.0, t3, dtype=np.float32, n_threads=8)
+    assert int(r3.status.max()) == 0 and st3.max() == 0 and np.abs(r3.ys.cpu().numpy() - want3).max() / 1000.0 < 5e-4
 
 
 @pytest.mark.gpu
