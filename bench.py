@@ -40,7 +40,8 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-SETTLE_LAUNCHES = 12   # untimed launches before the warm-up ones (clock ramp after idle, see measure())
+SETTLE_LAUNCHES = 12   # untimed launches before the warm-up ones (clock ramp after idle, see measure()) ...
+SETTLE_MS = 40.0       # ... or as many as it takes to put this much work in front of them, whichever is more
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy peak ~6290
 SEEDS = {"cfg2": 0, "cfg3": 1, "cfg3d136": 1, "cfg5": 5, "seip": 7, "seip3": 7, "seip83": 7, "seip84": 7}
 
@@ -234,7 +235,15 @@ def measure(wl, dev, steps: int, warmup: int, fence, order_hint_too=True):
     # The GPU needs some 20 ms of work to come up to its sustained clocks after the idle time of process start and input
     # generation (per-launch times of a cold start: 2.82, 2.72, 2.67, 2.60, 2.58, 2.58, 2.50, 2.54 ... ms): SETTLE untimed
     # launches in front of the caller's `warmup`, so that the K timed steps measure the steady state whatever W is.
-    for _ in range(SETTLE_LAUNCHES + warmup):
+    # ... counted in WORK, not launches: a 0.13 ms launch (cfg 2) would otherwise be timed 2 ms after the idle gap.
+    p0, p1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    step()
+    p0.record()
+    step()
+    p1.record()
+    torch.cuda.synchronize()
+    settle = max(SETTLE_LAUNCHES, int(np.ceil(SETTLE_MS / max(p0.elapsed_time(p1), 1e-3))))
+    for _ in range(settle + warmup):
         step()
     fence()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
@@ -259,7 +268,8 @@ def measure(wl, dev, steps: int, warmup: int, fence, order_hint_too=True):
         torch.cuda.synchronize()
         order_info["with_caller_supplied_order_ms_per_launch"] = float(np.mean([e0.elapsed_time(e1) for e0, e1 in given]))
         order_info["caller_supplied_order"] = "most step attempts first, exact counts of this batch (dyn_solve_batch_ordered): a side figure, not the headline"
-    return {"elapsed": elapsed, "kernel_ms": kern_ms, "out": out, "stats": stats, "kernel": kernel_name(), "dispatch_order": order_info}
+    return {"elapsed": elapsed, "kernel_ms": kern_ms, "out": out, "stats": stats, "kernel": kernel_name(), "dispatch_order": order_info,
+            "untimed": 2 + settle + warmup}
 
 
 def checksums(out, stats):
@@ -429,7 +439,7 @@ def main():
                 "trajectories_per_gpu": B,
                 "state_dim": m.state_dim,
                 "solver": "tsit5",
-                "untimed_launches_before_the_timed_region": SETTLE_LAUNCHES + args.warmup,
+                "untimed_launches_before_the_timed_region": res["untimed"],
                 "mean_steps_per_trajectory": steps_mean,
                 # static grid, trajectories dealt to waves in the given order: mean over waves of the most step attempts among
                 # a wave's trajectories (= its loop iterations; the wave's other trajectories idle for the difference)
