@@ -57,7 +57,7 @@ kernel = instance_name(stats["Name"]) if stats else None
 lines = [f"# rocprofv3 summary `{tag}` -- bench.py --workload {workload} (B={batch} per GPU)", "",
          f"- source revision: `{build_rev()}`", f"- dispatched instance: `{kernel}`", ""]
 if stats:
-    lines += ["## kernel-trace --stats (bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extra: 50 timed + 5 warm-up launches, the batch "
+    lines += ["## kernel-trace --stats (bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extra: 50 timed launches behind the untimed ones -- settle phase of >= 40 ms of work + 5 warm-up: `calls` counts them all --, the batch "
               "in its given order -- no forecast, nothing carried over between launches)", "",
               "| kernel | calls | avg ns | min ns | max ns | % of GPU time |", "|---|---|---|---|---|---|",
               f"| `{stats['Name'][:120]}` | {stats['Calls']} | {float(stats['AverageNs']):.0f} | {stats['MinNs']} | {stats['MaxNs']} | {stats['Percentage']} |"]
