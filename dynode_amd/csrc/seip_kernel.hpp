@@ -497,14 +497,13 @@ struct Seip {
         // ---- everything that needs no other wave goes here, between the mailbox writes and the barrier: it runs while the
         // writes land and the other waves arrive (one wave per SIMD: nobody else hides that wait)
 #pragma unroll
-        for (int v = 0; v < NS; ++v) dy[v] = T(0);
-#pragma unroll
         for (int sl = 0; sl < KL; ++sl) {
+            T wn_prev = T(0);   // waning chain: dy_m = wn_{m-1} - wn_m, the last state keeps its people
 #pragma unroll
-            for (int m = 0; m + 1 < M1; ++m) {
-                const T wn = omega[m] * y[sl * M1 + m];
-                dy[sl * M1 + m] -= wn;
-                dy[sl * M1 + m + 1] += wn;
+            for (int m = 0; m < M1; ++m) {
+                const T wn = m + 1 < M1 ? omega[m + 1 < M1 ? m : 0] * y[sl * M1 + m] : T(0);
+                dy[sl * M1 + m] = m == 0 ? (M1 > 1 ? -wn : T(0)) : (m + 1 < M1 ? wn_prev - wn : wn_prev);
+                wn_prev = wn;
             }
 #pragma unroll
             for (int l = 0; l < L; ++l) {
@@ -568,8 +567,9 @@ struct Seip {
             // tier s KT + tl - 1 (the lane below, same slot) -> s KT + tl; the last lane's tier -> lane 0 of the next slot
 #pragma unroll
             for (int sl = 0; sl < KL; ++sl) {
-                up[sl] += tl ? got[sl] : T(0);
-                if (sl + 1 < KL) up[sl + 1] += tl ? T(0) : got[sl];
+                const T same = tl ? got[sl] : T(0);
+                up[sl] = sl == 0 ? same : up[sl] + same;
+                if (sl + 1 < KL) up[sl + 1] = tl ? T(0) : got[sl];
             }
         } else {
 #pragma unroll
@@ -590,9 +590,8 @@ struct Seip {
             const int k = sl * KT + tl;
             const bool top = k == K;
             const int kc = k < K1 ? k : K;
+            // (sums start from their first term: `x = 0; x += a` is an add the compiler must keep, -0 + 0 is not -0)
             T inflow[L], moved = T(0);
-#pragma unroll
-            for (int l = 0; l < L; ++l) inflow[l] = T(0);
 #pragma unroll
             for (int m = 0; m < M1; ++m) {
                 const T S = y[sl * M1 + m];
@@ -600,13 +599,13 @@ struct Seip {
 #pragma unroll
                 for (int l = 0; l < L; ++l) {
                     const T f = (lam[l] * sus_at(sl, kc, m, l)) * S;
-                    inflow[l] += f;
-                    out += f;
+                    inflow[l] = m == 0 ? f : inflow[l] + f;
+                    out = l == 0 ? f : out + f;
                 }
                 dy[sl * M1 + m] -= out;
                 const T v = (top && m == 0) ? T(0) : rate[sl] * S; // the freshest state of the top tier stays
                 dy[sl * M1 + m] -= v;
-                moved += v;
+                moved = m == 0 ? v : moved + v;
             }
             dy[sl * M1] += (top ? moved : T(0)) + up[sl];   // top tier: refreshed in place; everyone: arrivals from below
 #pragma unroll
