@@ -44,8 +44,9 @@ namespace dyn {
 template <typename T, int METHOD, int GA, int L, int K1, int M1, int KT = 1, int NW = 1, int OPT = 0>
 struct Seip {
     // OPT bit 0 ("plain"): no seasonal forcing, no seasonal vaccination reset, no introduced strains, no recorded schedules,
-    // adaptive steps, no discontinuity points, dose splines of at most two knots -- as compile-time facts (enqueue() picks the variant when the call is that):
-    // their fields and branches leave the right-hand side and the stepping loop (the D = 960 kernel sits at its register line)
+    // adaptive steps, no discontinuity points, dose splines of at most two knots -- as compile-time facts (the entry point
+    // picks the variant when the call is that): their fields and branches leave the right-hand side and the stepping loop
+    // (the D = 960 kernel sat at its register line: docs/perf-log.md, "SEIP plain instances")
     static constexpr bool PLAIN = (OPT & 1) != 0;
     // ... and at most two knots per dose spline (the rows hold four: knots beyond the model's own are +inf with coefficient
     // 0, two truncated-power terms that add exactly zero to every evaluation)
