@@ -26,15 +26,13 @@ ERR_NAMES = {
 # every symbol include/dynode_hip.h declares (checked by tests/test_abi.py)
 EXPORTED_SYMBOLS = (
     "dyn_abi_version", "dyn_state_dim", "dyn_param_dim", "dyn_n_compartments",
-    "dyn_compartment_offsets", "dyn_is_supported", "dyn_trajectories_per_wave",
+    "dyn_compartment_offsets", "dyn_is_supported", "dyn_trajectories_per_wave", "dyn_trajectories_per_wave_for_batch",
     "dyn_last_error", "dyn_solve_batch", "dyn_solve_batch_jvp", "dyn_is_supported_jvp",
     "dyn_nuts_advance", "dyn_nuts_state_size", "dyn_philox4x32_10", "dyn_latent_sites",
     "dyn_solve_batch_loglik", "dyn_register_instance", "dyn_last_kernel_name", "dyn_solve_batch_record",
-    "dyn_solve_batch_replay", "dyn_latent_param_map", "dyn_potential_combine", "dyn_solve_batch_ordered", "dyn_cost_order",
-    "dyn_cost_order_capacity", "dyn_nuts_advance_mapped", "dyn_nuts_tail_size", "dyn_nuts_tail_pack",
+    "dyn_solve_batch_replay", "dyn_latent_param_map", "dyn_potential_combine", "dyn_solve_batch_ordered",
+    "dyn_nuts_advance_mapped", "dyn_nuts_tail_size", "dyn_nuts_tail_pack",
 )
-
-MAX_COST_FEATURES = 32
 
 MAX_SITES = 8
 DIST_NORMAL, DIST_UNIFORM, DIST_BETA, DIST_TRUNCNORMAL = 0, 1, 2, 3
@@ -62,6 +60,12 @@ class ModelDescC(ctypes.Structure):
                            ("family", ctypes.c_int32), ("seasonal_vax", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
+class DispatchHintsC(ctypes.Structure):
+    """dyn_dispatch_hints (ABI 9): all zero = the library's measured choices.  ``engine.dispatch_hints`` fills it."""
+    _fields_ = [(n, ctypes.c_int32) for n in ("pull", "pull_waves", "strains_per_lane", "replicas_log2", "producer_consumer",
+                                              "general_instance", "seip_tier_lanes", "seip_tier_waves")]
+
+
 class SolverOptsC(ctypes.Structure):
     _fields_ = [
         ("method", ctypes.c_int32),
@@ -74,6 +78,7 @@ class SolverOptsC(ctypes.Structure):
         ("n_jump", ctypes.c_int32),
         ("work_counter", ctypes.c_void_p),     # ABI 7: two zeroed int32 words on the device, or None (engine.work_counter)
         ("nuts_tail", ctypes.c_void_p),        # ABI 8: host blob of dyn_nuts_tail_pack, or None (infer/folded.py)
+        ("hints", DispatchHintsC),             # ABI 9: dispatch overrides of tests / tuning tools (engine.dispatch_hints)
     ]
 
 
@@ -182,6 +187,8 @@ def lib() -> ctypes.CDLL:
                      "dyn_trajectories_per_wave"):
             getattr(L, name).argtypes = [pm]
             getattr(L, name).restype = ctypes.c_int32
+        L.dyn_trajectories_per_wave_for_batch.argtypes = [pm, po, ctypes.c_int64]
+        L.dyn_trajectories_per_wave_for_batch.restype = ctypes.c_int32
         L.dyn_compartment_offsets.argtypes = [pm, ctypes.c_void_p]
         L.dyn_compartment_offsets.restype = ctypes.c_int32
         L.dyn_is_supported.argtypes = [pm, po]
@@ -213,12 +220,6 @@ def lib() -> ctypes.CDLL:
         L.dyn_nuts_tail_pack.restype = ctypes.c_int
         L.dyn_nuts_tail_pack.argtypes = ([ctypes.POINTER(NutsStateC), ctypes.POINTER(SiteDescC), ctypes.c_int32, ctypes.c_int32,
                                           ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32] + [ctypes.c_void_p] * 6)
-        L.dyn_cost_order_capacity.restype = ctypes.c_int32
-        L.dyn_cost_order_capacity.argtypes = [ctypes.c_int32]
-        L.dyn_cost_order.restype = ctypes.c_int
-        L.dyn_cost_order.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p,
-                                     ctypes.c_void_p, ctypes.c_double, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p,
-                                     ctypes.c_void_p, ctypes.c_void_p]
         L.dyn_is_supported_jvp.argtypes = [pm, po, ctypes.c_int32]
         L.dyn_is_supported_jvp.restype = ctypes.c_int32
         L.dyn_solve_batch_jvp.restype = ctypes.c_int

@@ -1,6 +1,8 @@
 // dynode_hip.hip -- C-ABI of libdynode_hip.so (see include/dynode_hip.h): argument
 // validation, shape dispatch and kernel enqueue.  No allocation, no synchronisation,
-// no global mutable state (the last-error text is thread-local).
+// no global mutable state (the last-error text is thread-local), nothing read from the
+// process environment: what tests and tuning tools want pinned travels in
+// dyn_solver_opts::hints.
 #include "../../include/dynode_hip.h"
 #include "solve_kernel.hpp"
 #include "seip_kernel.hpp"
@@ -163,11 +165,12 @@ static bool matches(const Entry &e, const dyn_model_desc *m, int G, int dtype, i
            e.W == m->n_wane && e.ND == nd && e.FEAT == model_features(m);
 }
 
-static const Entry *find_entry(const dyn_model_desc *m, int dtype, int method, int nd = 0) {
+static const dyn_dispatch_hints kNoHints = {0, 0, 0, 0, 0, 0, 0, 0};
+
+static const Entry *find_entry(const dyn_model_desc *m, int dtype, int method, int nd = 0, const dyn_dispatch_hints &h = kNoHints) {
     const int G = group_width(m->n_age);
-    // DYNODE_HIP_SPL=<n> (tuning aid): prefer the variant with n strains per lane
-    const char *env = getenv("DYNODE_HIP_SPL");
-    const int want_spl = env ? atoi(env) : 0;
+    // hints.strains_per_lane = n (tuning aid): prefer the variant with n strains per lane
+    const int want_spl = h.strains_per_lane;
     const Entry *first = nullptr;
     for (int i = 0; i < kNumEntries; ++i) {
         const Entry &e = kEntries[i];
@@ -194,14 +197,23 @@ static const Entry *find_entry(const dyn_model_desc *m, int dtype, int method, i
 // 0.46; B = 8192 0.55-0.58 / 0.54-0.57 / 0.63 (a wash: which of the first two wins changes from build to build and box to box);
 // B = 16384 (D = 136) 0.87-0.91 / 0.90 / 1.03; B = 65536 3.50 / 3.73 / 4.58.  Rule: when the default mapping fills at most half a
 // wave per SIMD, take the finest split compiled in that still fits two waves per SIMD; otherwise the first entry
-// (instances.def order).  DYNODE_HIP_SPL overrides.
-static const Entry *entry_for_batch(const Entry *e, const dyn_model_desc *m, int dtype, int method, int nd, int64_t B) {
-    if (getenv("DYNODE_HIP_SPL") || (e->FEAT & kSeip) || e->SPL == 1 || nd != 0) return e;
-    static thread_local int simds = 0;
-    if (simds == 0) {
-        int dev = 0, cus = 0;
-        simds = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) ? 4 * cus : -1;
-    }
+// (instances.def order).  hints.strains_per_lane overrides.
+// SIMDs of the current device (cached per thread AND device: a thread may move between GPUs)
+static int device_simds() {
+    static thread_local int c_dev = -1, c_simds = 0;
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return -1;
+    if (dev == c_dev) return c_simds;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return -1;
+    c_dev = dev;
+    c_simds = 4 * cus;
+    return c_simds;
+}
+
+static const Entry *entry_for_batch(const Entry *e, const dyn_model_desc *m, int dtype, int method, int nd, int64_t B,
+                                    const dyn_dispatch_hints &h) {
+    if (h.strains_per_lane > 0 || (e->FEAT & kSeip) || e->SPL == 1 || nd != 0) return e;
+    const int simds = device_simds();
     if (simds <= 0) return e;
     const int64_t waves = (B * entry_lanes(e) + 63) / 64;
     if (waves * 2 > simds) return e;   // (more than half a wave per SIMD: the widest per-lane state has the fewest instructions per trajectory)
@@ -235,35 +247,34 @@ static const Entry *find_variant(const Entry *e, int feat) {
 // SEIP: which lane mapping runs a model.  States that would spill (more than 32 values per lane) take the tiers dealt
 // over two lanes when that variant exists; it is also the fallback when only it is compiled in.  A lane group beyond a
 // wavefront (8 ages x 8 histories x 2 tier lanes; 16 histories) runs as a wave group: NW waves per trajectory.
-static const Entry *select_seip_entry(const dyn_model_desc *m, int dtype, int method, const Entry *e) {
+static const Entry *select_seip_entry(const dyn_model_desc *m, int dtype, int method, const Entry *e, const dyn_dispatch_hints &h = kNoHints) {
     Entry probe{dtype, method, group_width(m->n_age), m->n_strain, 1, 1, 1, m->n_wane, 0, 1, 0, nullptr};
     const int k1 = seip_tiers(m), lanes = group_width(m->n_age) << m->n_strain;
     const int per_tier = m->n_wane + 3 * m->n_strain, per_lane = k1 * per_tier;
-    const char *force = getenv("DYNODE_HIP_SEIP_TIER_LANES"); // tuning aid: 0 / 1
+    const int force = h.seip_tier_lanes; // tuning aid: 1 on, -1 off, 0 by state size
     // one tier per wave (K1 >= 3 tiers, a wavefront or more per tier): a third to a half of the state per lane, no padded tier
     // slot, two to three waves per SIMD instead of one -- measured on D = 2496: see DESIGN.md
-    const char *tw_env = getenv("DYNODE_HIP_SEIP_TIER_WAVES"); // tuning aid: 0 switches the mapping off
-    if (!(tw_env && atoi(tw_env) == 0)) {
+    if (h.seip_tier_waves >= 0) { // (hints.seip_tier_waves = -1 switches the mapping off)
         const Entry *tw = find_variant(&probe, kSeip | kSeipTierWaves | k1);
         if (tw) return tw;
     }
     if (lanes > 64) { // histories across waves: tier lanes on top (four waves) for big per-lane states, else two waves
         const Entry *w2 = find_variant(&probe, kSeip | kSeipWaves2 | k1);
         const Entry *w4 = find_variant(&probe, kSeip | kSeipTierLanes | kSeipWaves4 | k1);
-        if (w4 && (!w2 || (force ? atoi(force) != 0 : per_lane > 32))) return w4;
+        if (w4 && (!w2 || (force ? force > 0 : per_lane > 32))) return w4;
         return w2;
     }
     const Entry *two = find_variant(&probe, kSeip | kSeipTierLanes | k1);
     if (lanes == 64) { // tier lanes would need 128: a wave group of two
         const Entry *w2 = find_variant(&probe, kSeip | kSeipTierLanes | kSeipWaves2 | k1);
-        if (w2 && (!e || (force ? atoi(force) != 0 : per_lane > 32))) return w2;
+        if (w2 && (!e || (force ? force > 0 : per_lane > 32))) return w2;
         return e;
     }
     // ... and small float states: half the tiers per lane fit 256 registers, so two waves share a SIMD (measured on the
     // D = 960 shape: 6.5 vs 6.7 ms at 4096 trajectories, 23.3 vs 25.4 ms at 16384) -- only when the one-lane mapping is
     // down to two trajectories per wave: with 4 ages x 4 histories it keeps four per wave and wins (6.15 vs 6.70 ms at 8192)
     const bool small = dtype == DYN_F32 && k1 > 1 && ((k1 + 1) / 2) * per_tier <= 20 && lanes >= 32;
-    if (two && (!e || (force ? atoi(force) != 0 : (per_lane > 32 || small)))) return two;
+    if (two && (!e || (force ? force > 0 : (per_lane > 32 || small)))) return two;
     return e;
 }
 
@@ -336,6 +347,9 @@ static int enqueue(const Entry *e, const dyn_model_desc *m, const dyn_solver_opt
                    const LLArgs *ll = nullptr, const SchedArgs *sc = nullptr, const int32_t *order = nullptr) {
     KArgs<T> ka;
     ka.order = order;
+    const dyn_dispatch_hints &h = o->hints;
+    ka.pull_mode = h.pull;
+    ka.pull_waves = h.pull_waves > 0 ? h.pull_waves : 0;
     // work pulling (dyn_solver_opts::work_counter): the s/e/i/r/c kernels; launch() keeps it only for grids beyond one
     // resident round (the SEIP kernels have a static grid)
     ka.work = (e->FEAT & kSeip) ? nullptr : o->work_counter;
@@ -427,9 +441,8 @@ static int enqueue(const Entry *e, const dyn_model_desc *m, const dyn_solver_opt
         const int tpw = 64 / entry_lanes(e);
         const int64_t waves = (B + tpw - 1) / tpw;
         int r = 0;
-        const char *env = getenv("DYNODE_HIP_REPLICAS_LOG2");
-        if (env) {
-            r = atoi(env);
+        if (h.replicas_log2 > 0) {
+            r = h.replicas_log2 - 1;
         } else if (n_save >= 64) {
             // measured: tiny states (<= 5 values per lane: SIR, SEIRS) gain up to 4 waves per SIMD
             // (cfg 2: 0.37 -> 0.19 ms); register-heavy VALU-bound shapes do not (cfg 5: 0.72 -> 0.89 ms)
@@ -453,35 +466,23 @@ static int enqueue(const Entry *e, const dyn_model_desc *m, const dyn_solver_opt
     if (all_saved && ka.vec_ok && n_save > 0 && !ll && !(e->FEAT & kSaveAll)) {
         const Entry *fast = find_variant(e, e->FEAT | kSaveAll);
         // one trajectory-wave per SIMD or fewer, nothing replicated, the given order, no tangents: the two-wave kernel
-        // (DYNODE_HIP_PC=0 / 1 forces it off / on where the variant exists)
+        // (hints.producer_consumer = 1 runs it where the variant exists)
         const Entry *pc = find_variant(e, e->FEAT | kSaveAll | kProducerConsumer);
         if (pc && ka.rep_log2 == 0 && !order && !dparams) {
-            const int tpw = 64 / entry_lanes(e);
-            const int64_t waves = (B + tpw - 1) / tpw;
-            const char *env = getenv("DYNODE_HIP_PC");
-            static thread_local int simds = 0;
-            if (simds == 0) {
-                int dev = 0, cus = 0;
-                if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess)
-                    simds = 4 * cus;
-            }
-            const int nv = 1 + e->SPL * (e->E + 1 + e->W + e->C);
             // Measured (profiles/r03_producer_consumer_ab.md): it LOSES -- cfg 5's share 0.617 -> 0.68-0.75 ms, cfg 3 without the
             // bins axis at B = 8192 0.53-0.55 -> 0.58, cfg 2 0.233 -> 0.289 (replicated one-wave kernel: 0.148): two rendezvous
             // and 45 LDS writes per accepted step cost the stepping wave what the row arithmetic it sheds was worth.
-            // Off by default; DYNODE_HIP_PC=1 runs it (the bit-for-bit test does).
-            (void)waves; (void)simds; (void)nv;
-            if (env && atoi(env) != 0) fast = pc;
+            // Off by default; the bit-for-bit test asks for it.
+            if (h.producer_consumer > 0) fast = pc;
         }
         if (fast) e = fast;
         if ((e->FEAT & kSaveAll) && !(e->FEAT & kProducerConsumer)) {
-            // further compile-time facts of the call: adaptive steps without discontinuity points (bit 11; DYNODE_HIP_PLAIN=0
-            // keeps the general instance), a static grid (bit 10: launch() pulls only with a caller's queue on waves of more
-            // than two trajectories; DYNODE_HIP_PULL / _PULL_WAVES keep the pulling instances).  The most specific variant
-            // compiled in wins.
-            const char *env = getenv("DYNODE_HIP_PLAIN");
-            const bool nojump = ka.n_jump == 0 && !(o->constant_dt > 0.0) && !(env && atoi(env) == 0);
-            const bool stat = (64 / entry_lanes(e) <= 2 || !order) && !getenv("DYNODE_HIP_PULL") && !getenv("DYNODE_HIP_PULL_WAVES");
+            // further compile-time facts of the call: adaptive steps without discontinuity points (bit 11), a static grid
+            // (bit 10: launch() pulls only with a caller's queue on waves of more than two trajectories; hints.pull /
+            // .pull_waves keep the pulling instances); hints.general_instance keeps the general one.  The most specific
+            // variant compiled in wins.
+            const bool nojump = ka.n_jump == 0 && !(o->constant_dt > 0.0) && !h.general_instance;
+            const bool stat = (64 / entry_lanes(e) <= 2 || !order) && h.pull == 0 && h.pull_waves <= 0 && !h.general_instance;
             const int want[3] = {(nojump ? kAdaptiveNoJumps : 0) | (stat ? kStaticOnly : 0), stat ? kStaticOnly : 0,
                                  nojump ? kAdaptiveNoJumps : 0};
             for (int i = 0; i < 3; ++i) {
@@ -496,8 +497,7 @@ static int enqueue(const Entry *e, const dyn_model_desc *m, const dyn_solver_opt
     }
     if (ll && ll->slot == 3 && ll->mode == 1 && m->normalize && !m->seasonal && !m->has_intro && ka.n_jump == 0 &&
         !(o->constant_dt > 0.0) && !sc && !order && !(e->FEAT & kLean)) {
-        const char *env = getenv("DYNODE_HIP_LEAN");       // tuning aid: 0 keeps the general instance
-        const Entry *lean = (env && atoi(env) == 0) ? nullptr : find_variant(e, e->FEAT | kLean);
+        const Entry *lean = h.general_instance ? nullptr : find_variant(e, e->FEAT | kLean);
         if (lean) e = lean;
     }
     ka.nuts_tail = nullptr;
@@ -593,6 +593,15 @@ int32_t dyn_trajectories_per_wave(const dyn_model_desc *m) {
     return 64 / (dyn::group_width(m->n_age) * gs);
 }
 
+int32_t dyn_trajectories_per_wave_for_batch(const dyn_model_desc *m, const dyn_solver_opts *o, int64_t B) {
+    if (dyn::check_model(m) || !o) return 0;
+    if (m->family == 1) return dyn_trajectories_per_wave(m);
+    const dyn::Entry *e = dyn::find_entry(m, o->dtype, o->method, 0, o->hints);
+    if (!e) return 0;
+    e = dyn::entry_for_batch(e, m, o->dtype, o->method, 0, B, o->hints);
+    return 64 / dyn::entry_lanes(e);
+}
+
 int32_t dyn_is_supported(const dyn_model_desc *m, const dyn_solver_opts *o) {
     if (dyn::check_model(m) || !o) return 0;
     if (m->family == 1) // any lane mapping will do
@@ -640,18 +649,20 @@ static int solve_impl(const dyn_model_desc *m, const dyn_solver_opts *o, const v
                  "dyn_solve_batch_record + dyn_solve_batch_replay (central differences on the recorded step sequence)");
         return DYN_ERR_UNSUPPORTED;
     }
-    const dyn::Entry *e = dyn::find_entry(m, o->dtype, o->method, n_dir);
+    const dyn_dispatch_hints &h = o->hints;
+    if (h.replicas_log2 < 0 || h.replicas_log2 > 4 || h.pull_waves < 0 || h.strains_per_lane < 0) return DYN_ERR_OPTS;
+    const dyn::Entry *e = dyn::find_entry(m, o->dtype, o->method, n_dir, h);
     if (m->family == 1) {
-        e = dyn::select_seip_entry(m, o->dtype, o->method, e);
+        e = dyn::select_seip_entry(m, o->dtype, o->method, e, h);
         // a call with no seasonal term, no introduced strain, dose splines of at most two knots, no recorded schedule and adaptive
-        // steps without discontinuity points takes the variant compiled without them, when that shape has one (DYNODE_HIP_SEIP_PLAIN=0: tuning aid)
-        const char *pl = getenv("DYNODE_HIP_SEIP_PLAIN");
+        // steps without discontinuity points takes the variant compiled without them, when that shape has one
+        // (hints.general_instance keeps the general one)
         if (e && !m->seasonal && !m->seasonal_vax && !m->has_intro && m->n_vax_knots <= 2 && !sc && o->n_jump == 0 && !(o->constant_dt > 0) &&
-            !(pl && atoi(pl) == 0)) {
+            !h.general_instance) {
             const dyn::Entry *plain = dyn::find_variant(e, e->FEAT | dyn::kSeipPlain);
             if (plain) e = plain;
         }
-    } else if (e) e = dyn::entry_for_batch(e, m, o->dtype, o->method, n_dir, B);
+    } else if (e) e = dyn::entry_for_batch(e, m, o->dtype, o->method, n_dir, B, h);
     if (!e && m->family == 1) {
         snprintf(dyn::tl_error, sizeof(dyn::tl_error),
                  "no SEIP kernel compiled for A=%d strains=%d tiers=%d waning states=%d dtype=%d method=%d; to add it "

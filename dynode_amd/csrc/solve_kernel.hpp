@@ -94,6 +94,8 @@ struct KArgs {
     // trajectories belong to (HOST memory: launch() hands the struct to the kernel by value; the kernel only tests the
     // pointer), or nullptr.
     const dynnuts::Tail *nuts_tail;
+    // dyn_solver_opts::hints.pull / .pull_waves, for launch() (host side only; the kernels never read them)
+    int32_t pull_mode, pull_waves;
 };
 constexpr int kMaxJumps = 16;
 
@@ -1753,19 +1755,24 @@ solve_kernel_fused(const KArgs<T> ka, const dynnuts::Tail tail) {
     Stepper<Solver<T, METHOD, GA, ST, HAS_E, HAS_WANE, HAS_C, W, ND, SPL, FEAT>>::run(ka);
 }
 
-// waves of `kernel` the current device holds at once (occupancy x compute units); cached per (device, LDS size)
+// waves of `kernel` the current device holds at once (occupancy x compute units); cached per (kernel, device, LDS size).
+// Every instantiation of solve_kernel<T, ...> with the same T has the same function-pointer TYPE, so the kernel's address
+// is part of the key (a 256-register D = 136 kernel and the eight-waves-per-SIMD cfg 2 kernel must not read each other's
+// occupancy).
 template <typename K>
 static int64_t resident_waves(K kernel, size_t lds) {
+    static thread_local const void *c_kernel = nullptr;
     static thread_local int c_dev = -1;
     static thread_local size_t c_lds = 0;
     static thread_local int64_t c_val = 0;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 0;
-    if (dev == c_dev && lds == c_lds) return c_val;
+    if ((const void *)kernel == c_kernel && dev == c_dev && lds == c_lds) return c_val;
     int per_cu = 0, cus = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 64, lds) != hipSuccess ||
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
         return 0;
+    c_kernel = (const void *)kernel;
     c_dev = dev;
     c_lds = lds;
     c_val = (int64_t)per_cu * cus;
@@ -1820,11 +1827,10 @@ hipError_t launch(const KArgs<T> &ka_in, hipStream_t stream) {
         //   with the caller's exact order: static 2.24-2.28, pulling 2.30-2.40;  D = 136 B = 65536 in the caller's order:
         //   static 3.186, pulling 3.167;  cfg 5 B = 65536: 3.286 -> 3.259.
         // Default therefore: pull when the caller supplied the queue and a wave holds more than two trajectories.
-        // DYNODE_HIP_PULL=0 / 1 forces it off / on, DYNODE_HIP_PULL_WAVES=<n> sets the grid (tests, tuning).
-        const char *mode = getenv("DYNODE_HIP_PULL");
-        const char *forced = getenv("DYNODE_HIP_PULL_WAVES");
-        const bool want = mode ? atoi(mode) != 0 : (forced != nullptr || (TPW > 2 && ka.order != nullptr));
-        int64_t resident = forced ? atoll(forced) : resident_waves(kernel, lds);
+        // dyn_solver_opts::hints.pull = -1 / 1 forces it off / on, hints.pull_waves = <n> sets the grid (tests, tuning).
+        const bool forced = ka.pull_waves > 0;
+        const bool want = ka.pull_mode ? ka.pull_mode > 0 : (forced || (TPW > 2 && ka.order != nullptr));
+        int64_t resident = forced ? (int64_t)ka.pull_waves : resident_waves(kernel, lds);
         if (!want || ka.rep_log2 != 0 || resident <= 0 || blocks <= resident)
             ka.work = nullptr;
         else

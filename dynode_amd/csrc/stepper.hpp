@@ -494,7 +494,10 @@ struct Stepper {
                 const int nt = TPW >> kc.rep_log2;
                 const int64_t t0 = ((int64_t)blockIdx.x * TPW) >> kc.rep_log2;
                 const int64_t c = t0 / rows + lane;
-                if (lane < nt / rows && c < (int64_t)tl.st.n_chains) dynnuts::fused_tail(tl, (int)c, kc.ll_out, kc.dll_out);
+                // (tl.magic: the second argument really sits where kTailOffset says -- a kernarg layout this code did not expect
+                // makes the launch a plain gradient-solve whose chains stop advancing, instead of a corrupted sampler state)
+                if (tl.magic == dynnuts::kTailMagic && lane < nt / rows && c < (int64_t)tl.st.n_chains)
+                    dynnuts::fused_tail(tl, (int)c, kc.ll_out, kc.dll_out);
             }
         }
     }

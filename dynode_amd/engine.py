@@ -7,8 +7,9 @@ without ``libdynode_hip.so`` every call raises.
 
 from __future__ import annotations
 
+import contextlib
 import ctypes
-import os
+import threading
 from dataclasses import dataclass
 from typing import Optional, Sequence
 
@@ -89,21 +90,77 @@ def _dev(x, dtype, device) -> torch.Tensor:
     return torch.as_tensor(arr, dtype=dtype, device=device).contiguous()
 
 
+# ---- dispatch hints (dyn_solver_opts::hints, ABI 9).  Which compiled instance / lane mapping / grid shape runs a call is the
+# library's measured choice; tests and tuning tools pin one for the calls made inside a `with dispatch_hints(...)` block of
+# the calling thread.  (Up to ABI 8 these were DYNODE_HIP_* environment variables read inside the library.)
+_HINT_FIELDS = tuple(n for n, _ in _abi.DispatchHintsC._fields_)
+_HINTS = threading.local()
+
+
+def current_hints() -> dict:
+    return dict(getattr(_HINTS, "value", None) or {})
+
+
+@contextlib.contextmanager
+def dispatch_hints(**kw):
+    """Pin dispatch choices for the solves of this thread inside the block.  Keys = fields of ``dyn_dispatch_hints``
+    (include/dynode_hip.h): ``pull`` (1 / -1), ``pull_waves`` (n), ``strains_per_lane`` (n), ``replicas_log2`` (k: exactly
+    2^k replicas -- stored as k + 1), ``producer_consumer`` (1), ``general_instance`` (1), ``seip_tier_lanes`` (1 / -1),
+    ``seip_tier_waves`` (-1); plus ``work_min_batch`` (host side: the smallest batch that gets a work counter).  Nested
+    blocks merge; ``None`` removes a key."""
+    bad = set(kw) - set(_HINT_FIELDS) - {"work_min_batch"}
+    if bad:
+        raise TypeError(f"unknown dispatch hint(s) {sorted(bad)}; known: {_HINT_FIELDS + ('work_min_batch',)}")
+    before = getattr(_HINTS, "value", None)
+    merged = dict(before or {})
+    for k, v in kw.items():
+        if v is None:
+            merged.pop(k, None)
+        else:
+            merged[k] = int(v) + 1 if k == "replicas_log2" else int(v)
+    _HINTS.value = merged
+    try:
+        yield
+    finally:
+        _HINTS.value = before
+
+
+def set_dispatch_hints(**kw) -> None:
+    """`dispatch_hints` without a block: merge into this thread's hints until `clear_dispatch_hints` (test fixtures)."""
+    cm = dispatch_hints(**kw)
+    cm.__enter__()          # (never exited: the merged value stays)
+
+
+def clear_dispatch_hints() -> None:
+    _HINTS.value = None
+
+
+def _apply_hints(opts: "_abi.SolverOptsC") -> None:
+    for k, v in (getattr(_HINTS, "value", None) or {}).items():
+        if k in _HINT_FIELDS:
+            setattr(opts.hints, k, v)
+
+
 _WORK_COUNTERS: "dict[tuple, torch.Tensor]" = {}
-# fewer trajectories than the GPU has SIMDs can never exceed one resident round (DYNODE_WORK_MIN_BATCH: the tests pull small
-# batches through forced grids of a few waves)
+# fewer trajectories than the GPU has SIMDs can never exceed one resident round (dispatch_hints(work_min_batch=1): the tests
+# pull small batches through forced grids of a few waves)
 _WORK_MIN_BATCH = 1024
 
 
 def work_counter(B: int, device, stream) -> Optional[torch.Tensor]:
     """The two zeroed int32 words behind ``dyn_solver_opts.work_counter`` (work pulling, include/dynode_hip.h): one pair per
     (device, stream), created once -- the kernel leaves it zeroed, and launches of one stream cannot overlap.  While a HIP
-    graph is being captured the pair is a fresh one from the graph's own pool (replays of different graphs may overlap).
-    None for batches that can never exceed one resident round."""
-    if B < int(os.environ.get("DYNODE_WORK_MIN_BATCH", _WORK_MIN_BATCH)):
+    graph is being captured ON THAT STREAM the pair is a fresh one from the graph's own pool (replays of different graphs
+    may overlap).  None for batches that can never exceed one resident round.
+
+    A pulling launch that does not run to completion (a GPU fault, a reset) leaves the words non-zero, and the next launch
+    would start its tickets past the end of the queue: `drop_work_counters` forgets the cached pairs -- `solve_batch` calls
+    it whenever the library reports an error, and callers who catch a failed synchronize should too."""
+    if B < int(current_hints().get("work_min_batch", _WORK_MIN_BATCH)):
         return None
-    if torch.cuda.is_current_stream_capturing():
-        return torch.zeros(2, dtype=torch.int32, device=device)
+    with torch.cuda.stream(stream):
+        if torch.cuda.is_current_stream_capturing():
+            return torch.zeros(2, dtype=torch.int32, device=device)
     key = (str(device), int(stream.cuda_stream))
     t = _WORK_COUNTERS.get(key)
     if t is None:
@@ -112,6 +169,11 @@ def work_counter(B: int, device, stream) -> Optional[torch.Tensor]:
         with torch.cuda.stream(stream):
             t = _WORK_COUNTERS[key] = torch.zeros(2, dtype=torch.int32, device=device)
     return t
+
+
+def drop_work_counters() -> None:
+    """Forget the cached work-counter pairs (they are re-created zeroed on the next use)."""
+    _WORK_COUNTERS.clear()
 
 
 def save_mask_bytes(model: ModelDesc, save_mask: Optional[Sequence[bool]]):
@@ -149,13 +211,19 @@ def solve_batch(model: ModelDesc, y0, params, contact, t1: float, save_ts, *, t0
     ``leader[b]`` of ``steps`` (``leader=None``: row b) instead of controlling its own.  For this family ``dparams`` is
     served by `_replayed_tangents`: central differences of replayed solves on the primal's step sequence.
 
-    Large batches (more trajectory-waves than the GPU holds at once) run as a resident grid whose lane groups pull
-    trajectories from a queue as they finish (``dyn_solver_opts.work_counter``; csrc/solve_kernel.hpp ``Solver::run``).
+    Grid: one wave per ``trajectories_per_wave`` trajectories, started by the hardware as earlier waves retire (a static
+    grid).  The library launches a resident grid whose lane groups PULL trajectories from a queue as they finish
+    (``dyn_solver_opts.work_counter``; csrc/stepper.hpp) only where that was measured to pay: when the caller supplies the
+    queue (``order``) and a wave holds more than two trajectories.
 
     ``order``: the queue (``dyn_solve_batch_ordered``; it never changes a result).  ``None`` (default): the batch in its
     given order; an int32 device tensor [B]: that permutation -- a caller who knows which trajectories are expensive puts
-    them first; ``"forecast"``: opt-in, the step-count forecast of `schedule.py` learned from earlier launches of the same
-    model and settings (it needs thousands of trajectories of training and is keyed on the shared inputs' content).
+    them first.
+
+    float32 and the batch size: a batch that fills at most half a wave per SIMD takes a finer strain split (a shorter serial
+    instruction stream), whose summation order differs -- the same parameter row solved in a 3072-row and in a 65536-row
+    batch can differ in the last bits (and, rarely, in an accept / reject decision; float64 step counts do not).
+    ``with dispatch_hints(strains_per_lane=n)`` pins the mapping (include/dynode_hip.h, dyn_trajectories_per_wave_for_batch).
     """
     device = require_gpu()
     L = _abi.lib()
@@ -211,6 +279,7 @@ def solve_batch(model: ModelDesc, y0, params, contact, t1: float, save_ts, *, t0
         float(constant_dt),
         jt.ctypes.data_as(ctypes.POINTER(ctypes.c_double)) if jt.size else None, int(jt.size),
         work_t.data_ptr() if work_t is not None else None)
+    _apply_hints(opts)
     sched = sched_n = leader_t = None
     if record_steps and replay is not None:
         raise ValueError("record_steps and replay exclude each other")
@@ -229,30 +298,15 @@ def solve_batch(model: ModelDesc, y0, params, contact, t1: float, save_ts, *, t0
             raise ValueError("replay without a leader index needs one schedule row per trajectory")
 
     plain = n_dir == 0 and not record_steps and replay is None
-    order_t, cost = None, None
+    order_t = None
     if isinstance(order, torch.Tensor):
         if not plain:
             raise ValueError("a dispatch order goes with the plain solve (no tangents, no step schedules)")
         if order.dtype != torch.int32 or tuple(order.shape) != (B,) or not order.is_contiguous() or order.device != params_t.device:
             raise ValueError(f"order must be a contiguous int32 device tensor of shape ({B},)")
         order_t = order
-    elif order == "forecast":
-        from . import schedule
-
-        if (plain and B >= schedule.MIN_BATCH and B * D >= schedule.MIN_WORK and not constant_dt > 0.0 and schedule.enabled()
-                and not torch.cuda.is_current_stream_capturing()):
-            # the forecast belongs to a model, its settings AND the inputs every trajectory shares: a changed contact matrix
-            # or initial state starts a new one (small arrays: hashing them costs one device-to-host copy per call)
-            shared = (contact_t.detach().cpu().numpy().tobytes(), None if batched else y0_t.detach().cpu().numpy().tobytes(),
-                      tuple(float(v) for v in jump_ts), int(max_steps))
-            key = (model, dtype, method, float(rtol), float(atol), float(t0), float(t1), n_save > 0, str(device), hash(shared))
-            cost = schedule.model_for(key, P, device, schedule.strain_symmetry(model))
-            if cost.ready:
-                tpw = int(L.dyn_trajectories_per_wave(ctypes.byref(model.c())))
-                one_round = tpw > 0 and B % tpw == 0 and B // tpw <= schedule.ONE_ROUND_WAVES
-                order_t = cost.order(params_t, s, tpw if one_round else 0)
     elif order is not None:
-        raise ValueError('order must be None, "forecast" or an int32 tensor')
+        raise ValueError("order must be None or an int32 device tensor")
 
     def call():
         common = (ctypes.byref(model.c()), ctypes.byref(opts), y0_t.data_ptr(), int(batched),
@@ -282,14 +336,12 @@ def solve_batch(model: ModelDesc, y0, params, contact, t1: float, save_ts, *, t0
 
     rc = _call_with_jit(call, L, model, dtype, method, n_dir)
     if rc != 0:
+        drop_work_counters()
         raise SolveError(rc, L.dyn_last_error().decode())
     # keep inputs alive until the stream has consumed them
     for t in (y0_t, params_t, contact_t, ts_t, dparams_t, dy0_t, sched, sched_n, leader_t, order_t, work_t):
         if t is not None:
             t.record_stream(s)
-    if cost is not None and cost.training:      # learn the step-count forecast from what this launch returns (schedule.py)
-        with torch.cuda.stream(s):
-            cost.observe(params_t, n_acc + n_rej, status)
     return BatchResult(out, status, n_acc, n_rej, saved, sizes, dout, (sched, sched_n) if record_steps else None)
 
 
@@ -446,6 +498,7 @@ def solve_batch_loglik(model: ModelDesc, y0, params, contact, t1: float, save_ts
     opts = _abi.SolverOptsC(
         _METHODS[method], _DTYPES[dtype], float(rtol), float(atol), int(max_steps), float(constant_dt),
         jt.ctypes.data_as(ctypes.POINTER(ctypes.c_double)) if jt.size else None, int(jt.size))
+    _apply_hints(opts)
     if nuts_tail:
         opts.nuts_tail = int(nuts_tail)
     s = stream if stream is not None else torch.cuda.current_stream(device)

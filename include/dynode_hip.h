@@ -22,7 +22,8 @@
  *
  * Conventions: plain pointers and sizes only.  Every data pointer of dyn_solve_batch is a
  * DEVICE pointer (HBM) owned by the caller; the library allocates nothing user-visible,
- * keeps no mutable global state and never synchronises: work is enqueued on `stream`.
+ * keeps no mutable global state, reads nothing from the process environment and never
+ * synchronises: work is enqueued on `stream`.
  * Return value: 0 on success, negative DYN_ERR_* on argument errors (nothing enqueued).
  */
 #ifndef DYNODE_HIP_H
@@ -33,7 +34,7 @@
 extern "C" {
 #endif
 
-#define DYN_ABI_VERSION 8
+#define DYN_ABI_VERSION 9
 /* the save grid is staged in LDS: n_save * sizeof(real) must not exceed this */
 #define DYN_MAX_SAVE_BYTES 49152
 
@@ -123,6 +124,25 @@ typedef struct dyn_model_desc {
 enum { DYN_TSIT5 = 0, DYN_DOPRI5 = 1 };
 enum { DYN_F32 = 0, DYN_F64 = 1 };
 
+/* ABI 9.  Dispatch hints of ONE call.  Which compiled instance, lane mapping and grid shape runs a call is the library's
+ * measured choice when every field is 0 (what every ordinary caller passes).  Tests and tuning tools pin a choice here --
+ * up to ABI 8 these were DYNODE_HIP_* environment variables read inside the dispatch; the library now reads nothing from
+ * the process environment, so a call's result depends on its arguments alone.  None of them changes WHAT is computed;
+ * `strains_per_lane` and `replicas_log2` choose among lane mappings whose float32 summation orders differ in the last bits
+ * (see dyn_solve_batch on the batch-size rule). */
+typedef struct dyn_dispatch_hints {
+    int32_t pull;              /* work pulling (work_counter): 0 = where measured to pay, 1 = wherever the batch exceeds one
+                                  resident round, -1 = never */
+    int32_t pull_waves;        /* > 0: grid of a work-pulling launch in waves, instead of the waves the chip holds at once */
+    int32_t strains_per_lane;  /* > 0: take the instance with this many strains per lane (and skip the batch-size rule) */
+    int32_t replicas_log2;     /* 0 = by batch size; k + 1 = exactly 2^k lane groups per trajectory (k = 0..3) */
+    int32_t producer_consumer; /* 1 = the two-wave stepping / dense-output kernel where that variant is compiled (default off) */
+    int32_t general_instance;  /* 1 = keep the general instance: none of the variants with call facts compiled in (adaptive
+                                  steps without discontinuity points, static grid, lean gradient-solve, SEIP plain) */
+    int32_t seip_tier_lanes;   /* SEIP, tiers dealt over two lanes: 0 = by state size, 1 = on, -1 = off */
+    int32_t seip_tier_waves;   /* SEIP, one tier per wave: 0 = where compiled, -1 = off */
+} dyn_dispatch_hints;
+
 /* SolverParams (params.py:24-67).  jump_ts is a HOST pointer (tiny, read at enqueue). */
 typedef struct dyn_solver_opts {
     int32_t method;
@@ -141,7 +161,7 @@ typedef struct dyn_solver_opts {
      * streams) need pairs of their own.  The caller owns the memory, like every other buffer of this ABI.  Results never
      * depend on it.  The library pulls where that was measured to pay: when the caller supplies the queue
      * (dyn_solve_batch_ordered: longest-first needs dynamic assignment) and a wave holds more than two trajectories;
-     * DYNODE_HIP_PULL=1 pulls wherever the batch exceeds one resident round.  NULL, batches of one resident round, and the
+     * hints.pull = 1 pulls wherever the batch exceeds one resident round.  NULL, batches of one resident round, and the
      * SEIP family: a static grid, as before ABI 7. */
     int32_t *work_counter;
     /* Fused sampler iteration (ABI 8, dyn_solve_batch_loglik only): HOST pointer to a blob written by dyn_nuts_tail_pack,
@@ -156,6 +176,8 @@ typedef struct dyn_solver_opts {
      * otherwise the call returns DYN_ERR_UNSUPPORTED with nothing enqueued and the caller keeps its two launches
      * (DYN_ERR_OPTS: the pointer is not a packed blob). */
     const void *nuts_tail;
+    /* ABI 9: all zero = the library's choices (see dyn_dispatch_hints) */
+    dyn_dispatch_hints hints;
 } dyn_solver_opts;
 
 /* per-trajectory status */
@@ -183,6 +205,12 @@ int32_t dyn_compartment_offsets(const dyn_model_desc *m, int32_t *off);
 int32_t dyn_is_supported(const dyn_model_desc *m, const dyn_solver_opts *o);
 /* trajectories that share a 64-lane wavefront for this model (a wave group of the SEIP family: per workgroup of NW waves) */
 int32_t dyn_trajectories_per_wave(const dyn_model_desc *m);
+/* ... of the float32 / Tsit5 default mapping.  The mapping a call actually gets depends on its batch size: a batch that fills
+ * at most half a wave per SIMD takes the finest strain split compiled in (a shorter serial instruction stream per trajectory),
+ * so a trajectory's float32 summation order -- its last bits and, rarely, an accept / reject decision -- can differ between a
+ * 3072-row and a 65536-row batch (float64 step counts do not).  This query answers for (opts, B) what dyn_solve_batch will
+ * use; opts->hints.strains_per_lane pins the mapping for callers that need batch-size-independent bits. */
+int32_t dyn_trajectories_per_wave_for_batch(const dyn_model_desc *m, const dyn_solver_opts *opts, int64_t B);
 /* last launch-failure text of the calling thread ("" if none) */
 const char *dyn_last_error(void);
 /* name of the kernel instance the calling thread's last successful dyn_solve_batch* call enqueued, spelled the way
@@ -422,32 +450,14 @@ int dyn_nuts_tail_pack(const dyn_nuts_state *st, const dyn_site_desc *sites, int
  * no entry names stay unwritten).  Outputs are bit-identical for every permutation -- each trajectory is computed from its
  * own inputs and written to its own rows -- but the lane groups of a wave step in lock-step and waves start in index order, so
  * putting trajectories with similar step counts next to each other, the expensive ones first, shortens the launch by 10-15 %
- * (diffrax under vmap / pmap has no counterpart: XLA:CPU runs the samples one after another).
- * dyn_cost_order makes such an order from a cost model: predicted step attempts of trajectory b =
- *     coef[0] + sum_i coef[1 + i] l_i + sum_{i <= j} coef[1 + n + k(i, j)] l_i l_j,
- *     l_i = (f(params[b][c]) - coef[nq + i]) * coef[nq + n + i],   nq = 1 + n + n (n + 1) / 2,
- *     f = log and c = cols[i] if cols[i] >= 0, f = identity and c = -(cols[i] + 1) otherwise
- * (k runs over the upper triangle row by row), quantised to key_scale buckets per attempt, most expensive first.  The host fits
- * coef from the n_accept + n_reject the solve returned on earlier batches (dynode_amd/schedule.py).
- *   params [B][P] in dtype; cols [n_feat], coef [nq + 2 n] (float32), keys_ws [B], order [B]: DEVICE memory.
- * n_sym = S > 1: the first sym_blocks * S parameters are [quantity][strain] blocks of a model that treats its strains alike
- * (family 0: beta, gamma, sigma, omega); they are read in a canonical labelling -- strains sorted by block 0 / block 1 (r0),
- * largest first -- which makes the forecast a symmetric function of the strains.  n_sym <= 1: parameters are read as they are.
- * deal_waves_of = t > 0 (t = dyn_trajectories_per_wave, B a multiple of it): the sorted list is cut into waves of t trajectories
- * and the waves are dealt heavy, light, heavy, light ...: for launches whose waves all start at once (the waves sharing a SIMD
- * then carry about the same work); 0 = most expensive first throughout (launches of several residency rounds).
+ * (diffrax under vmap / pmap has no counterpart: XLA:CPU runs the samples one after another).  The learned step-count
+ * forecast of rounds 2-3 (dyn_cost_order, dynode_amd/schedule.py) bought nothing on top of the hardware's own wave dispatch
+ * and left the ABI with version 9; a caller who knows its batch passes its own order.
  */
-#define DYN_MAX_COST_FEATURES 32
-/* compiled feature capacities: n_feat must be one of 4, 8, 16, 24, 32 -- pad a smaller model with repeated columns and zero
- * coefficients / spreads (dyn_cost_order_capacity(n) = the capacity to pad n features to, -1 beyond the maximum) */
-int32_t dyn_cost_order_capacity(int32_t n_feat);
 int dyn_solve_batch_ordered(const dyn_model_desc *model, const dyn_solver_opts *opts, const void *y0, int32_t y0_is_batched,
                             const void *params, const void *contact, int64_t B, double t0, double t1, const void *save_ts,
                             int32_t n_save, const uint8_t *save_mask, void *ys_out, int32_t *status, int32_t *n_accept,
                             int32_t *n_reject, const int32_t *order, void *stream);
-int dyn_cost_order(const void *params, int32_t dtype, int64_t B, int32_t P, int32_t n_feat, const int32_t *cols,
-                   const float *coef, double key_scale, int32_t n_sym, int32_t sym_blocks, int32_t deal_waves_of,
-                   int32_t *keys_ws, int32_t *order, void *stream);
 
 
 #ifdef __cplusplus

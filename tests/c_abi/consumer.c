@@ -88,7 +88,7 @@ int main(void) {
         CHECK(hipDeviceSynchronize());
         CHECK(hipMemcpy(a, d_a, sizeof a, hipMemcpyDeviceToHost));
         CHECK(hipMemset(d_a, 0xff, sizeof a));
-        setenv("DYNODE_HIP_PULL_WAVES", "8", 1);
+        o.hints.pull_waves = 8;          /* ABI 9: dispatch hints travel in the call, not in the environment */
         o.work_counter = d_work;
         for (int rep = 0; rep < 2; ++rep) {     /* twice: the second launch finds the counters as the first one left them */
             rc = dyn_solve_batch(&m, &o, d_y0, 0, d_p2, d_c, B2, 0.0, 50.0, d_ts, NSAVE, NULL, d_a, d_stat2, d_stat2 + B2, d_stat2 + 2 * B2, NULL);
@@ -96,7 +96,7 @@ int main(void) {
             CHECK(hipDeviceSynchronize());
         }
         o.work_counter = NULL;
-        unsetenv("DYNODE_HIP_PULL_WAVES");
+        o.hints.pull_waves = 0;
         CHECK(hipMemcpy(b2, d_a, sizeof b2, hipMemcpyDeviceToHost));
         CHECK(hipMemcpy(work, d_work, sizeof work, hipMemcpyDeviceToHost));
         if (memcmp(a, b2, sizeof a) != 0) { fprintf(stderr, "work pulling changed the output\n"); return 10; }

@@ -34,6 +34,17 @@ def _no_silent_on_demand_builds(request, monkeypatch):
         monkeypatch.setenv("DYNODE_HIP_JIT", "0")
 
 
+@pytest.fixture
+def hints():
+    """Dispatch hints (dyn_solver_opts::hints through ``engine.dispatch_hints``) that last until the end of the test:
+    ``hints(seip_tier_lanes=1)``; ``hints(key=None)`` removes one."""
+    from dynode_amd import engine
+
+    engine.clear_dispatch_hints()
+    yield engine.set_dispatch_hints
+    engine.clear_dispatch_hints()
+
+
 @pytest.fixture(scope="session", autouse=True)
 def _built():
     """Build the HIP library and the oracle once per session (both are cheap no-ops when fresh)."""

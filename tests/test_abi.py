@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_abi.EXPORTED_SYMBOLS)
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.dyn_abi_version() == 8
+    assert lib.dyn_abi_version() == 9
 
 
 def test_no_torch_types_in_the_header():

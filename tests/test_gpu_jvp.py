@@ -153,14 +153,14 @@ LL_CASES = [
 
 @pytest.mark.parametrize("replicas", ["default", "0"])
 @pytest.mark.parametrize("m,nd,comp,inc", LL_CASES, ids=lambda v: str(v) if not isinstance(v, ModelDesc) else f"A{v.n_age}S{v.n_strain}e{int(v.has_e)}")
-def test_fused_poisson_likelihood_equals_scoring_the_saved_trajectory(m, nd, comp, inc, replicas, monkeypatch):
+def test_fused_poisson_likelihood_equals_scoring_the_saved_trajectory(m, nd, comp, inc, replicas, hints):
     """dyn_solve_batch_loglik == Poisson log-likelihood (and its tangents) computed from the output of
     dyn_solve_batch_jvp, in float64, for every compartment kind, both observation modes, and both
     kernel paths (in-order accumulation / LDS table of replicated trajectories)."""
     from dynode_amd.engine import solve_batch_loglik
 
     if replicas != "default":
-        monkeypatch.setenv("DYNODE_HIP_REPLICAS_LOG2", replicas)
+        hints(replicas_log2=int(replicas))
     B = 37
     y0, p, C, t1, ts = _workload(m, B, seed=11)
     rng = np.random.default_rng(1)

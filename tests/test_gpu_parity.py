@@ -200,7 +200,7 @@ def test_output_offsets_beyond_2_to_the_31():
     torch.cuda.empty_cache()
 
 
-# ------------------------------------------------------------------ dispatch order (dyn_solve_batch_ordered, dynode_amd/schedule.py)
+# ------------------------------------------------------------------ dispatch order (dyn_solve_batch_ordered)
 @pytest.mark.parametrize("wl", [synthetic.seirs_multi_strain(1536, seed=11, W=8), synthetic.sir_age_stratified(1100, seed=12),
                                 synthetic.seirs_multi_strain(1030, seed=13, seasonal=True), synthetic.seip(96, seed=14)],
                          ids=["cfg3_D360", "cfg2_replicated", "cfg5_ragged", "seip"])
@@ -240,7 +240,7 @@ def test_dispatch_order_never_changes_a_result(wl):
 @pytest.mark.parametrize("wl,waves", [(synthetic.seirs_multi_strain(1536, seed=31, W=8), 96), (synthetic.seirs_multi_strain(1301, seed=32), 24),
                                       (synthetic.sir_age_stratified(2050, seed=33), 5), (synthetic.seirs_multi_strain(1100, seed=34, seasonal=True), 64)],
                          ids=["cfg3_D360", "cfg3_D136_ragged", "cfg2", "cfg5"])
-def test_work_pulling_gives_the_bits_of_the_static_grid(wl, waves, monkeypatch):
+def test_work_pulling_gives_the_bits_of_the_static_grid(wl, waves):
     """dyn_solver_opts.work_counter: a batch beyond the resident grid (forced down to a few waves here) is integrated by lane
     groups that draw trajectories from a device queue as they finish.  Every output -- rows, status, step counts -- must be
     the static launch's bit for bit, in the given order, in a caller's order and with queue entries that are not
@@ -249,11 +249,15 @@ def test_work_pulling_gives_the_bits_of_the_static_grid(wl, waves, monkeypatch):
 
     m = wl.model
     args = (m, wl.y0, wl.params, wl.contact, wl.t1, wl.save_ts)
-    monkeypatch.setenv("DYNODE_HIP_REPLICAS_LOG2", "0")      # (small states are replicated at this batch size: static by construction)
-    monkeypatch.setenv("DYNODE_HIP_PULL", "0")
-    base = solve_batch(*args, dtype=F32)
-    monkeypatch.delenv("DYNODE_HIP_PULL")
-    monkeypatch.setenv("DYNODE_HIP_PULL_WAVES", str(waves))
+    # (replicas_log2=0: small states are replicated at this batch size -- static by construction)
+    with engine.dispatch_hints(replicas_log2=0, pull=-1):
+        base = solve_batch(*args, dtype=F32)
+        b64 = solve_batch(*args, dtype=F64)
+    with engine.dispatch_hints(replicas_log2=0, pull_waves=waves):
+        _pulled_equals_static(engine, wl, waves, args, base, b64)
+
+
+def _pulled_equals_static(engine, wl, waves, args, base, b64):
     g = torch.Generator().manual_seed(3)
     perm = torch.randperm(wl.B, generator=g).to(torch.int32).cuda()
     heavy_first = torch.argsort((base.n_accept + base.n_reject), descending=True, stable=True).to(torch.int32)
@@ -278,34 +282,32 @@ def test_work_pulling_gives_the_bits_of_the_static_grid(wl, waves, monkeypatch):
     assert bool((stats[:, skipped] == -5).all()) and torch.equal(stats[0, ~skipped], base.status[~skipped])
     assert next(iter(engine._WORK_COUNTERS.values())).tolist() == [0, 0]
     # float64 takes the same path: identical step counts to the oracle are checked elsewhere, here static == pulling
-    monkeypatch.setenv("DYNODE_HIP_PULL", "0")
-    b64 = solve_batch(*args, dtype=F64)
-    monkeypatch.delenv("DYNODE_HIP_PULL")
     r64 = solve_batch(*args, dtype=F64)
     assert torch.equal(r64.ys, b64.ys) and torch.equal(r64.n_accept, b64.n_accept) and torch.equal(r64.n_reject, b64.n_reject)
 
 
 @pytest.mark.parametrize("wl,budget", [(synthetic.seirs_multi_strain(1101, seed=51, seasonal=True), 97), (synthetic.seirs_multi_strain(777, seed=52), 97),
                                        (synthetic.sir_age_stratified(2050, seed=53), 40)], ids=["cfg5", "cfg3_D136", "cfg2"])
-def test_producer_consumer_waves_give_the_bits_of_the_one_wave_kernel(wl, budget, monkeypatch):
+def test_producer_consumer_waves_give_the_bits_of_the_one_wave_kernel(wl, budget):
     """FEAT bit 15: stepping on wave 0, dense output on wave 1 of a two-wave workgroup, every accepted step handed over through
     LDS.  Same polynomial, same operands, same instructions: rows, status and step counts are the one-wave kernel's bit for
     bit -- ragged batches, a trajectory that fails at once (NaN parameters: all rows +inf) and one that runs out of steps."""
-    from dynode_amd import _abi
+    from dynode_amd import _abi, engine
 
     m = wl.model
     params = wl.params.copy()
     params[5, 0] = np.nan                                          # fails before its first step
-    monkeypatch.setenv("DYNODE_HIP_REPLICAS_LOG2", "0")
-    if m.n_strain > 1:
-        monkeypatch.setenv("DYNODE_HIP_SPL", str(m.n_strain))      # (batches this small would take the strain-split mapping, which has no two-wave variant)
+    # (strains_per_lane: batches this small would take the strain-split mapping, which has no two-wave variant)
+    pin = dict(replicas_log2=0, strains_per_lane=m.n_strain if m.n_strain > 1 else None)
     args = (m, wl.y0, params, wl.contact, wl.t1, wl.save_ts)
-    monkeypatch.setenv("DYNODE_HIP_PC", "0")
-    base = solve_batch(*args, dtype=F32, max_steps=budget)         # (some trajectories stop at max_steps: their tails are +inf)
-    name0 = _abi.lib().dyn_last_kernel_name().decode()
-    monkeypatch.setenv("DYNODE_HIP_PC", "1")
-    r = solve_batch(*args, dtype=F32, max_steps=budget)
-    name1 = _abi.lib().dyn_last_kernel_name().decode()
+    with engine.dispatch_hints(**pin):
+        base = solve_batch(*args, dtype=F32, max_steps=budget)         # (some trajectories stop at max_steps: their tails are +inf)
+        name0 = _abi.lib().dyn_last_kernel_name().decode()
+        full0 = solve_batch(*args[:2], wl.params, *args[3:], dtype=F32)
+    with engine.dispatch_hints(producer_consumer=1, **pin):
+        r = solve_batch(*args, dtype=F32, max_steps=budget)
+        name1 = _abi.lib().dyn_last_kernel_name().decode()
+        full = solve_batch(*args[:2], wl.params, *args[3:], dtype=F32)                            # and a clean run, default step budget
     assert name0 != name1 and name1.endswith(", 49152>") and name0.endswith((", 16384>", ", 18432>", ", 19456>"))      # FEAT 0xC000 vs 0x4000 (or 0x4800: + adaptive, no jumps)
     assert int(base.status[5]) == 2 and int((base.status == 1).sum()) > 0 and int((base.status == 0).sum()) > 0
     for a, b in ((r.status, base.status), (r.n_accept, base.n_accept), (r.n_reject, base.n_reject)):
@@ -313,9 +315,6 @@ def test_producer_consumer_waves_give_the_bits_of_the_one_wave_kernel(wl, budget
     assert torch.equal(torch.isfinite(r.ys), torch.isfinite(base.ys))
     fin = torch.isfinite(base.ys)
     assert torch.equal(r.ys[fin], base.ys[fin]) and bool(torch.isinf(r.ys[5]).all())
-    full = solve_batch(*args[:2], wl.params, *args[3:], dtype=F32)                            # and a clean run, default step budget
-    monkeypatch.setenv("DYNODE_HIP_PC", "0")
-    full0 = solve_batch(*args[:2], wl.params, *args[3:], dtype=F32)
     assert int(full0.status.max()) == 0 and torch.equal(full.ys, full0.ys) and torch.equal(full.n_accept, full0.n_accept)
 
 
@@ -329,7 +328,7 @@ def _abi_lib_kernel_was_pulling(wl, waves) -> bool:
     return tpw > 0 and -(-wl.B // tpw) > waves
 
 
-def test_work_pulling_tangent_and_likelihood_kernels(monkeypatch):
+def test_work_pulling_tangent_and_likelihood_kernels():
     """The tangent kernels (dyn_solve_batch_jvp) and the fused likelihood take the same loop: a large gradient batch pulled
     through a small grid equals the static launch bit for bit."""
     wl = synthetic.sir_age_stratified(3000, seed=35)
@@ -337,79 +336,14 @@ def test_work_pulling_tangent_and_likelihood_kernels(monkeypatch):
     dp = np.zeros((wl.B, 2, m.param_dim))
     dp[:, 0, 0] = dp[:, 1, 1] = 1.0
     args = (m, wl.y0, wl.params, wl.contact, 100.0, wl.save_ts[:101])
-    monkeypatch.setenv("DYNODE_HIP_REPLICAS_LOG2", "0")
-    monkeypatch.setenv("DYNODE_HIP_PULL", "0")
-    base = solve_batch(*args, dtype=F32, dparams=dp)
-    monkeypatch.delenv("DYNODE_HIP_PULL")
-    monkeypatch.setenv("DYNODE_HIP_PULL_WAVES", "9")
-    r = solve_batch(*args, dtype=F32, dparams=dp)
+    from dynode_amd import engine
+
+    with engine.dispatch_hints(replicas_log2=0, pull=-1):
+        base = solve_batch(*args, dtype=F32, dparams=dp)
+    with engine.dispatch_hints(replicas_log2=0, pull_waves=9):
+        r = solve_batch(*args, dtype=F32, dparams=dp)
     for a, b in ((r.ys, base.ys), (r.dys, base.dys), (r.status, base.status), (r.n_accept, base.n_accept)):
         assert torch.equal(a, b)
-
-
-def test_learned_dispatch_order():
-    """schedule.py: the step-count forecast is learned from what the kernels return, `dyn_cost_order` turns it into a
-    permutation (most expensive first), and `order="forecast"` (opt-in) uses it from the second launch on without changing a bit."""
-    from dynode_amd import schedule
-
-    schedule.reset()
-    big = synthetic.seirs_multi_strain(32768, seed=21)
-    m, half = big.model, 16384           # 16384 x 136 state values: above schedule.MIN_WORK
-    train = (m, big.y0[:half], big.params[:half], big.contact, big.t1, big.save_ts[::73])
-    test = (m, big.y0[half:], big.params[half:], big.contact, big.t1, big.save_ts[::73])
-    first = solve_batch(*train, dtype=F32, order="forecast")    # trains (16384 rows >= 12 per coefficient)
-    (cm,) = schedule._MODELS.values()
-    assert cm.ready and int(cm.cols.numel()) == 16 and bool((cm.cols >= 0).all())      # 16 rates, all as logarithms
-    assert cm.best.sym == (4, 4)                                # exchangeable strains: the canonical labelling forecasts better
-    plain = solve_batch(*test, dtype=F32, order=None)
-    att = (plain.n_accept + plain.n_reject).double()
-    p_test = torch.as_tensor(big.params[half:], dtype=F32, device="cuda")
-    forecast = cm.forecast(p_test)
-    corr = float(torch.corrcoef(torch.stack([forecast, att]))[0, 1])
-    print(f"[dispatch order] forecast vs step attempts on unseen draws: correlation {corr:.3f}")
-    assert corr > 0.85
-    order = cm.order(p_test, torch.cuda.current_stream())
-    torch.cuda.synchronize()
-    assert torch.equal(torch.sort(order.long()).values, torch.arange(half, device="cuda"))       # a permutation
-    f_sorted = forecast[order.long()]
-    assert float((f_sorted[1:] - f_sorted[:-1]).max()) <= 1.0 / schedule.KEY_SCALE + 1e-3        # descending up to one bucket
-    # one residency round: waves of 8 dealt heavy, light, heavy, light ... (wave w of the descending list in slot 2 w / 2 (n - 1 - w) + 1)
-    dealt = cm.order(p_test, torch.cuda.current_stream(), 8)
-    torch.cuda.synchronize()
-    assert torch.equal(torch.sort(dealt.long()).values, torch.arange(half, device="cuda"))
-    n = half // 8
-    wave_cost = forecast[dealt.long()].reshape(n, 8).mean(1)
-    desc_cost = f_sorted.reshape(n, 8).mean(1)
-    slot = torch.tensor([2 * w if w < (n + 1) // 2 else 2 * (n - 1 - w) + 1 for w in range(n)], device="cuda")
-    assert float((wave_cost[slot] - desc_cost).abs().max()) <= 1.0 / schedule.KEY_SCALE + 1e-3
-    order64 = cm.order(p_test.double(), torch.cuda.current_stream())       # float64 parameter rows take the same kernel
-    torch.cuda.synchronize()
-    assert torch.equal(torch.sort(order64.long()).values, torch.arange(half, device="cuda"))
-    f64_sorted = forecast[order64.long()]
-    assert float((f64_sorted[1:] - f64_sorted[:-1]).max()) <= 1.0 / schedule.KEY_SCALE + 1e-3
-    auto = solve_batch(*test, dtype=F32, order="forecast")      # ordered by the forecast
-    for a, b in ((auto.ys, plain.ys), (auto.n_accept, plain.n_accept), (auto.n_reject, plain.n_reject), (auto.status, plain.status)):
-        assert torch.equal(a, b)
-    assert torch.equal(first.status, torch.zeros_like(first.status))
-    # constant steps: every trajectory costs the same, nothing is learned or ordered
-    schedule.reset()
-    solve_batch(*test, dtype=F32, constant_dt=0.5, order="forecast")
-    assert not schedule._MODELS
-    # the default never touches it, and the opt-in can be switched off
-    solve_batch(*test, dtype=F32)
-    assert not schedule._MODELS
-    os.environ["DYNODE_ORDER"] = "0"
-    try:
-        solve_batch(*test, dtype=F32, order="forecast")
-        assert not schedule._MODELS
-    finally:
-        del os.environ["DYNODE_ORDER"]
-    # a changed contact matrix starts a forecast of its own (keyed on the content of the shared inputs)
-    solve_batch(*train, dtype=F32, order="forecast")
-    other = (train[0], train[1], train[2], train[3] * 0.9) + train[4:]
-    solve_batch(*other, dtype=F32, order="forecast")
-    assert len(schedule._MODELS) == 2
-    schedule.reset()
 
 
 # ------------------------------------------------------------------ edge cases of the boundary
@@ -678,21 +612,13 @@ def fuzz_compare(case, dtype=F64):
     # ... and pulled through a grid of one or two waves (dyn_solver_opts.work_counter): every lane group reloads again and
     # again -- under discontinuity points, sub-save masks, constant steps, failing trajectories -- and not a bit may move
     if m.family == 0 and B > 2:
-        env = {"DYNODE_WORK_MIN_BATCH": "1", "DYNODE_HIP_PULL_WAVES": str(1 + B % 2), "DYNODE_HIP_REPLICAS_LOG2": "0"}
-        old = {k: os.environ.get(k) for k in env}
-        os.environ.update(env)
-        try:
+        from dynode_amd import engine
+
+        with engine.dispatch_hints(work_min_batch=1, pull_waves=1 + B % 2, replicas_log2=0):
             r_pull = solve_batch(m, y0, p, C, t1, ts, dtype=dtype, order=scr if B % 3 == 0 else None, **kw)
-            os.environ["DYNODE_HIP_PULL"] = "0"
-            r_stat = solve_batch(m, y0, p, C, t1, ts, dtype=dtype, **kw)          # same replica setting, static grid
+            with engine.dispatch_hints(pull=-1):
+                r_stat = solve_batch(m, y0, p, C, t1, ts, dtype=dtype, **kw)          # same replica setting, static grid
             torch.cuda.synchronize()
-        finally:
-            os.environ.pop("DYNODE_HIP_PULL", None)
-            for k, v in old.items():
-                if v is None:
-                    os.environ.pop(k, None)
-                else:
-                    os.environ[k] = v
         for a, b in ((r_pull.ys, r_stat.ys), (r_pull.status, r_stat.status), (r_pull.n_accept, r_stat.n_accept), (r_pull.n_reject, r_stat.n_reject),
                      (r_stat.status, r.status), (r_stat.n_accept, r.n_accept)):
             assert torch.equal(torch.nan_to_num(a, nan=-1.0), torch.nan_to_num(b, nan=-1.0)) if a.is_floating_point() else torch.equal(a, b)
@@ -910,25 +836,33 @@ def test_vaccination_shape_built_on_demand():
     assert _supported(m, F64, "tsit5")
 
 
-def test_batch_aware_lane_mapping_is_a_dispatch_choice_only(monkeypatch):
+def test_batch_aware_lane_mapping_is_a_dispatch_choice_only():
     """A batch that fills at most half a wave per SIMD runs on a strain-split instance (a trajectory over more lanes: a shorter
     instruction stream per wave on a mostly empty GPU; the finest split that still fits two waves per SIMD).  Which instance runs depends on the batch size; the trajectories do not,
     beyond float32 rounding of the sums over strains (another summation order) -- and in float64 every mapping gives the oracle's
     step counts (checked per mapping in the shape sweep)."""
-    from dynode_amd import _abi
+    import ctypes
+
+    from dynode_amd import _abi, engine
 
     wl = synthetic.seirs_multi_strain(3072, seed=61, seasonal=True)
     args = (wl.model, wl.y0, wl.params, wl.contact, wl.t1, wl.save_ts)
     small = solve_batch(*args, dtype=F32)
     name_small = _abi.lib().dyn_last_kernel_name().decode()
-    monkeypatch.setenv("DYNODE_HIP_SPL", "4")
-    base = solve_batch(*args, dtype=F32)
+    with engine.dispatch_hints(strains_per_lane=4):
+        base = solve_batch(*args, dtype=F32)
     name_base = _abi.lib().dyn_last_kernel_name().decode()
+    # the query that answers for (options, batch size) what a call gets: one lane group of 32 for the small batch, 8 lanes at full size
+    o = _abi.SolverOptsC(method=0, dtype=0, rtol=1e-5, atol=1e-6, max_steps=10**6)
+    tpw = lambda B: int(_abi.lib().dyn_trajectories_per_wave_for_batch(ctypes.byref(wl.model.c()), ctypes.byref(o), B))
+    if torch.cuda.get_device_properties(0).multi_processor_count == 256:
+        assert (tpw(3072), tpw(65536)) == (2, 8)
+    o.hints.strains_per_lane = 4
+    assert tpw(3072) == 8
     assert name_base.endswith(("1, 0, 4, 16384>", "1, 0, 4, 18432>", "1, 0, 4, 19456>")) and name_small.endswith("1, 0, 1, 16384>")
     assert int(small.status.max()) == 0 and int(base.status.max()) == 0
     scale = wl.population
     assert float((small.ys - base.ys).abs().max()) / scale < 1e-5
-    monkeypatch.delenv("DYNODE_HIP_SPL")
     wl2 = synthetic.seirs_multi_strain(8192, seed=62, seasonal=True)       # one wave per SIMD on 256 CUs: the default mapping stays
     mid = solve_batch(wl2.model, wl2.y0, wl2.params, wl2.contact, wl2.t1, wl2.save_ts[::30], dtype=F32)
     name_mid = _abi.lib().dyn_last_kernel_name().decode()

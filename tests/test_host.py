@@ -360,97 +360,6 @@ def test_monomial_parameter_maps_are_recognised_exactly_or_not_at_all():
     assert _fit_monomials(xn, torch.stack([xn[:, 2] * r0], dim=1)) is None
 
 
-def test_step_count_forecast_features_and_fit():
-    """schedule.CostModel on host tensors: which columns become features (logarithms of rates, plain values of anything that
-    reaches zero, nothing for constants), and that the ridge fit recovers a quadratic law of the logarithms."""
-    from dynode_amd import schedule
-
-    g = torch.Generator().manual_seed(3)
-    B = 6000
-    rate = torch.rand((B, 3), generator=g, dtype=torch.float64) * 0.4 + 0.1
-    amp = torch.rand((B, 1), generator=g, dtype=torch.float64) * 0.4          # reaches (almost) zero: stays linear
-    amp[0] = 0.0
-    const = torch.full((B, 1), 365.0, dtype=torch.float64)
-    params = torch.cat([rate, amp, const], dim=1)
-    l = torch.log(rate)
-    steps = 80.0 + 9.0 * l[:, 0] - 4.0 * l[:, 1] * l[:, 2] + 25.0 * amp[:, 0] + 3.0 * l[:, 0] ** 2
-    cm = schedule.CostModel(P=5, device=torch.device("cpu"))
-    assert cm.training and not cm.ready
-    cm.observe(params[:3000], steps[:3000], torch.zeros(3000, dtype=torch.int32))
-    assert cm.ready and cm.cols.tolist() == [0, 1, 2, -4]                    # dyn_cost_order's encoding: -(3 + 1) = column 3, linear
-    assert cm.best.coef.numel() == (1 + 4 + 10) + 2 * 4 and cm.best.cols_padded.numel() == 4 and schedule.capacity(5) == 8
-    pred = cm.forecast(params[3000:])
-    assert float((pred - steps[3000:]).abs().max()) < 0.05
-    # failed solves carry no weight
-    cm2 = schedule.CostModel(P=5, device=torch.device("cpu"))
-    bad = torch.zeros(3000, dtype=torch.int32)
-    bad[::2] = 1
-    wrong = steps[:3000].clone()
-    wrong[::2] = 1.0
-    cm2.observe(params[:3000], wrong, bad)
-    assert float((cm2.forecast(params[3000:]) - steps[3000:]).abs().max()) < 0.05
-    # a batch without a varying parameter has nothing to forecast with
-    cm3 = schedule.CostModel(P=5, device=torch.device("cpu"))
-    cm3.observe(params[:1].expand(2000, 5), steps[:1].expand(2000), torch.zeros(2000, dtype=torch.int32))
-    assert cm3.unusable and not cm3.ready and not cm3.training
-    # training stops after TRAIN_ROWS rows
-    rows = 0
-    cm4 = schedule.CostModel(P=5, device=torch.device("cpu"))
-    while cm4.training:
-        cm4.observe(params, steps, torch.zeros(B, dtype=torch.int32))
-        rows += B
-    assert rows >= schedule.TRAIN_ROWS and rows < schedule.TRAIN_ROWS + B
-
-
-def test_step_count_forecast_uses_the_strain_symmetry_when_it_is_there():
-    from dynode_amd import schedule
-
-    g = torch.Generator().manual_seed(4)
-    B, S = 8000, 3
-    beta = torch.rand((B, S), generator=g, dtype=torch.float64) * 0.3 + 0.2
-    gamma = torch.rand((B, S), generator=g, dtype=torch.float64) * 0.1 + 0.1
-    other = torch.rand((B, 1), generator=g, dtype=torch.float64) + 1.0
-    params = torch.cat([beta, gamma, other], dim=1)
-    r0 = beta / gamma
-    ok = torch.zeros(B, dtype=torch.int32)
-    # a symmetric law: the largest r0 and its gamma matter, whichever strain carries them
-    top = r0.argmax(1, keepdim=True)
-    sym_steps = 60.0 + 20.0 * torch.log(r0.gather(1, top))[:, 0] - 8.0 * torch.log(gamma.gather(1, top))[:, 0] + 5.0 * torch.log(other[:, 0])
-    cm = schedule.CostModel(P=2 * S + 1, device=torch.device("cpu"), sym=(S, 2))
-    cm.observe(params[:5000], sym_steps[:5000], ok[:5000])
-    assert cm.ready and cm.best.sym == (S, 2) and len(cm.variants) == 2
-    assert float((cm.forecast(params[5000:]) - sym_steps[5000:]).abs().max()) < 0.05
-    canon = cm.best.canonical(params)
-    assert bool((canon[:, 0] / canon[:, S] >= canon[:, 1] / canon[:, S + 1]).all()) and torch.equal(canon[:, -1], params[:, -1])
-    # a law that singles out strain 0: the plain regression wins
-    plain_steps = 60.0 + 20.0 * torch.log(r0[:, 0]) + 3.0 * torch.log(r0[:, 1]) * torch.log(gamma[:, 2])
-    cm2 = schedule.CostModel(P=2 * S + 1, device=torch.device("cpu"), sym=(S, 2))
-    cm2.observe(params[:5000], plain_steps[:5000], ok[:5000])
-    assert cm2.best.sym is None
-    assert float((cm2.forecast(params[5000:]) - plain_steps[5000:]).abs().max()) < 0.05
-    # more varying columns than the kernel takes: the ones that move with the step count are kept
-    wide = torch.cat([params, torch.rand((B, 40), generator=g, dtype=torch.float64) + 0.5], dim=1)
-    cm3 = schedule.CostModel(P=wide.shape[1], device=torch.device("cpu"))
-    cm3.observe(wide[:6000], plain_steps[:6000], torch.zeros(6000, dtype=torch.int32))
-    kept = set(int(c) if c >= 0 else -int(c) - 1 for c in cm3.cols.tolist())
-    assert len(kept) == 32 and {0, 3}.issubset(kept)          # beta_0 and gamma_0 carry the linear signal
-    from dynode_amd import ModelDesc
-
-    assert schedule.strain_symmetry(ModelDesc(n_age=8, n_strain=4, has_e=True, has_wane=True, has_c=True)) == (4, 4)
-    assert schedule.strain_symmetry(ModelDesc(n_age=8)) is None
-
-
-def test_a_forecast_that_explains_little_is_not_used():
-    from dynode_amd import schedule
-
-    g = torch.Generator().manual_seed(5)
-    params = torch.rand((6000, 3), generator=g, dtype=torch.float64) + 0.5
-    noise = torch.randn(6000, generator=g, dtype=torch.float64) * 10.0
-    cm = schedule.CostModel(P=3, device=torch.device("cpu"))
-    cm.observe(params, 100.0 + 2.0 * torch.log(params[:, 0]) + noise, torch.zeros(6000, dtype=torch.int32))
-    assert cm.fitted_rows == 6000 and not cm.ready          # R^2 of a few per cent: the batch keeps its given order
-
-
 def test_on_demand_seip_lane_mappings_follow_the_dispatch_rules():
     """jit._seip_wave_group / _features (host logic, no compiler): which SEIP lane mapping an on-demand build instantiates and
     the feature word it registers -- the words `select_seip_entry` (csrc/dynode_hip.hip) looks for."""

@@ -521,7 +521,7 @@ def _to_np(x):
                                         (dict(A=2, L=2, K1=3, M1=2, n_knots=2, intro=True), "f32"),
                                         (dict(A=4, L=3, K1=3, M1=4, n_knots=2, seasonal=True, seasonal_vax=True), "f32"),
                                         (dict(A=8, L=2, K1=3, M1=4, n_knots=2), "f32")], ids=lambda v: _ids(v) if isinstance(v, dict) else v)
-def test_tier_lanes_variant_matches_oracle(shape, prec, monkeypatch):
+def test_tier_lanes_variant_matches_oracle(shape, prec, hints):
     """The second lane mapping (tiers dealt over two lanes, `YT` entries): forced on, same bars as the first one;
     and both mappings agree with each other to rounding."""
     import torch
@@ -531,7 +531,7 @@ def test_tier_lanes_variant_matches_oracle(shape, prec, monkeypatch):
     wl = synthetic.seip(B=7, seed=41, t1=120.0, **shape)
     m, ts = wl.model, synthetic.save_grid(120.0)
     want, st, _, _ = O.solve(H.omodel(m), wl.y0, wl.params, wl.contact, 120.0, ts, dtype=npd, n_threads=8, constant_dt=0.5)
-    monkeypatch.setenv("DYNODE_HIP_SEIP_TIER_LANES", "1")
+    hints(seip_tier_lanes=1)
     two = solve_batch(m, wl.y0, wl.params, wl.contact, 120.0, ts, dtype=dtype, constant_dt=0.5)
     assert int(two.status.max()) == 0 and st.max() == 0
     assert np.abs(two.ys.cpu().numpy() - want).max() / 1000.0 < (1e-11 if prec == "f64" else 2e-5)
@@ -544,7 +544,7 @@ def test_tier_lanes_variant_matches_oracle(shape, prec, monkeypatch):
     wa, sa, na, nr = O.solve(H.omodel(m), wl.y0, wl.params, wl.contact, 120.0, ts, dtype=npd, n_threads=8)
     assert int(adaptive.status.max()) == 0 and np.abs(adaptive.ys.cpu().numpy() - wa).max() / 1000.0 < (5e-5 if prec == "f64" else 2e-4)
     if shape["A"] * (1 << shape["L"]) <= 32 or prec == "f32":
-        monkeypatch.setenv("DYNODE_HIP_SEIP_TIER_LANES", "0")
+        hints(seip_tier_lanes=-1)
         from dynode_amd.engine import SolveError
         try:
             one = solve_batch(m, wl.y0, wl.params, wl.contact, 120.0, ts, dtype=dtype, constant_dt=0.5)
@@ -648,7 +648,7 @@ def test_wave_groups_dispatch_sub_save_jumps_and_replay():
 
 
 @pytest.mark.gpu
-def test_one_tier_per_wave_and_tier_lanes_are_the_same_model(monkeypatch):
+def test_one_tier_per_wave_and_tier_lanes_are_the_same_model(hints):
     """8 ages x 3 strains x 3 tiers (D = 2496) has two lane mappings: two waves with the tiers dealt over two lanes and two
     slots per lane (`KT = 2`), and three waves with one tier each (`KT = K1 = 3`, the default).  Same right-hand side: under a
     constant step both agree with the oracle to float32 rounding, and adaptively with each other to the tolerance."""
@@ -661,7 +661,7 @@ def test_one_tier_per_wave_and_tier_lanes_are_the_same_model(monkeypatch):
     want, st, _, _ = O.solve(H.omodel(m), wl.y0, wl.params, wl.contact, 120.0, ts, dtype=np.float32, n_threads=8, constant_dt=0.5)
     got = {}
     for flag, name in (("1", "dyn::seip_kernel_wave_group<float, 0, 8, 3, 3, 4, 3, 3, 0>"), ("0", "dyn::seip_kernel_wave_group<float, 0, 8, 3, 3, 4, 2, 2, 0>")):
-        monkeypatch.setenv("DYNODE_HIP_SEIP_TIER_WAVES", flag)
+        hints(seip_tier_waves=None if flag == "1" else -1)
         rc = solve_batch(m, wl.y0, wl.params, wl.contact, 120.0, ts, constant_dt=0.5)
         assert _abi.lib().dyn_last_kernel_name().decode() == name
         assert int(rc.status.max()) == 0 and np.abs(rc.ys.cpu().numpy() - want).max() / 1000.0 < 2e-5
@@ -672,7 +672,7 @@ def test_one_tier_per_wave_and_tier_lanes_are_the_same_model(monkeypatch):
 
 
 @pytest.mark.gpu
-def test_packed_tier_waves_two_trajectories_per_wave_group(monkeypatch):
+def test_packed_tier_waves_two_trajectories_per_wave_group(hints):
     """4 ages x 8 histories is half a wavefront: with one tier per wave the planes of TWO trajectories sit side by side in
     each of the three waves (an odd batch leaves the last group half empty).  Against the oracle, against the tier-lane
     mapping, and through record / replay (every trajectory of a group has its own schedule rows in LDS)."""
@@ -685,14 +685,14 @@ def test_packed_tier_waves_two_trajectories_per_wave_group(monkeypatch):
     want, st, _, _ = O.solve(H.omodel(m), wl.y0, wl.params, wl.contact, 120.0, ts, dtype=np.float32, n_threads=8, constant_dt=0.5)
     got = {}
     for flag, name in (("1", "dyn::seip_kernel_wave_group<float, 0, 4, 3, 3, 4, 3, 3, 0>"), ("0", "dyn::seip_kernel<float, 0, 4, 3, 3, 4, 2, 0>")):
-        monkeypatch.setenv("DYNODE_HIP_SEIP_TIER_WAVES", flag)
+        hints(seip_tier_waves=None if flag == "1" else -1)
         rc = solve_batch(m, wl.y0, wl.params, wl.contact, 120.0, ts, constant_dt=0.5)
         assert _abi.lib().dyn_last_kernel_name().decode() == name
         assert int(rc.status.max()) == 0 and np.abs(rc.ys.cpu().numpy() - want).max() / 1000.0 < 2e-5
         got[flag] = solve_batch(m, wl.y0, wl.params, wl.contact, 120.0, ts, jump_ts=(40.25,))
         assert int(got[flag].status.max()) == 0
     assert float((got["1"].ys - got["0"].ys).abs().max()) / 1000.0 < 2e-4
-    monkeypatch.setenv("DYNODE_HIP_SEIP_TIER_WAVES", "1")
+    hints(seip_tier_waves=None)
     perm = np.random.default_rng(1).permutation(7)
     again = solve_batch(m, wl.y0[perm], wl.params[perm], wl.contact, 120.0, ts, jump_ts=(40.25,))
     assert torch.equal(again.ys, got["1"].ys[torch.as_tensor(perm, device="cuda")])          # bits do not depend on the neighbour in the wave
@@ -714,7 +714,7 @@ PLAIN_INSTANCES = [("seip", "dyn::seip_kernel_two_waves<float, 0, 8, 2, 3, 4, 2,
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,kernel", PLAIN_INSTANCES, ids=[n for n, _ in PLAIN_INSTANCES])
-def test_calls_without_seasonal_terms_take_the_plain_instance(name, kernel, monkeypatch):
+def test_calls_without_seasonal_terms_take_the_plain_instance(name, kernel, hints):
     """The bench shapes are compiled a second time with "no seasonal forcing, no seasonal vaccination, no introduced strains,
     no recorded schedule, adaptive steps, no discontinuity points, at most two knots per dose spline" as compile-time facts (seip_kernel.hpp `OPT` bit 0;
     `kSeipPlain` in dynode_hip.hip).  A call that uses none of them runs that instance, any other call the general one; the two
@@ -729,10 +729,10 @@ def test_calls_without_seasonal_terms_take_the_plain_instance(name, kernel, monk
     last = lambda: _abi.lib().dyn_last_kernel_name().decode()
     plain = solve_batch(m, wl.y0, wl.params, wl.contact, wl.t1, ts)
     assert last() == kernel % 1
-    monkeypatch.setenv("DYNODE_HIP_SEIP_PLAIN", "0")
+    hints(general_instance=1)
     general = solve_batch(m, wl.y0, wl.params, wl.contact, wl.t1, ts)
     assert last() == kernel % 0
-    monkeypatch.delenv("DYNODE_HIP_SEIP_PLAIN")
+    hints(general_instance=None)
     want, st, na, nr = O.solve(H.omodel(m), wl.y0, wl.params, wl.contact, wl.t1, ts, dtype=np.float32, n_threads=8)
     assert st.max() == 0
     for r, tag in ((plain, "plain"), (general, "general")):
