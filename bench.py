@@ -117,81 +117,134 @@ def cpu_baseline(wl, sample: int):
     }
 
 
-_CFG4_CDFS = None
+_CFG4 = {}
 
 
-def nuts_side_measurement(chains=128, warmup=1000, samples=1000, fused=True, adaptation="per_chain", more_seeds=()):
-    """cfg 4 at one GPU's share: NUTS on the 2-age SIR (tf=100, Poisson incidence), 1024 / 8 = 128 chains x
-    (1000 warm-up + 1000 draws), tree depth 10, with the KS test of the draws against tensor-grid quadrature of the
-    2-parameter posterior.  Unit of work = one gradient-solve (fused solve + tangents for every chain) per iteration.
-
-    The chains advance independently, so a run lasts as many gradient-solves as its SLOWEST chain needs leapfrogs -- with
-    per-chain adaptation 15.6 k to 26.8 k over eight sampler seeds (mean per chain: 9.4 k), i.e. the wall time is one chain's
-    luck while the time per gradient-solve is the engine's.  The posterior check is a realization too: the target has a flat
-    edge (the Beta(1/2, 1/2) prior of r0) holding about 1.5 % of the mass, which a run of 128 chains x 1000 draws either visits
-    (sd at or above quadrature, a few divergences) or not (sd 1-2 % low; KS p down to 1e-3 in one run of four).
-    ``more_seeds``: the same run under further sampler seeds, each with its own KS p and sd ratio; ``seconds`` and
-    ``posterior_vs_quadrature`` stay the reference's seed (8675314, src/dynode/infer/inference.py), ``seconds_median`` is
-    over all of them."""
+def cfg4_truth():
+    """Tensor-grid quadrature of cfg 4's two-parameter posterior (float64 HIP solves), once per bench run."""
     import torch
 
-    from dynode_amd.infer.inference import MCMCProcess, Potential, ks_against_quadrature
+    from dynode_amd.infer.checks import GridPosterior
+    from dynode_amd.infer.inference import Potential
     from dynode_amd.simulation import odes
     from examples import sir_infer_parameters as ex
 
-    data = ex.synthetic_incidence(100)
-    kw = dict(config=ex.get_config(), tf=100, obs_data=data)
+    if "truth" not in _CFG4:
+        data = ex.synthetic_incidence(100)
+        kw = dict(config=ex.get_config(), tf=100, obs_data=data)
+        odes.enable_x64(True)
+        try:
+            pot = Potential(ex.model, kw, 0, torch.device("cuda"))
+            _CFG4["truth"] = GridPosterior.from_potential(pot, [torch.linspace(-14.0, 14.0, 1401, dtype=torch.float64),
+                                                                torch.linspace(-6.0, 6.0, 601, dtype=torch.float64)]).refined(2)
+        finally:
+            odes.enable_x64(False)
+        _CFG4["kw"] = kw
+    return _CFG4["truth"], _CFG4["kw"]
+
+
+CFG4_TAILS = ((0, 2.0), (0, 4.0))     # z0 > 2: 0.74 % of the mass, 9 % of r0's variance; z0 > 4: 0.13 %
+
+
+def nuts_side_measurement(chains=128, warmup=1000, samples=1000, fused=True, adaptation="per_chain", seeds=(8675314,)):
+    """cfg 4 at one GPU's share: NUTS on the 2-age SIR (tf=100, Poisson incidence), 1024 / 8 = 128 chains x
+    (1000 warm-up + 1000 draws), tree depth 10, checked against tensor-grid quadrature of the 2-parameter posterior
+    (`dynode_amd/infer/checks.py`).  Unit of work = one gradient-solve (fused solve + tangents for every chain) per iteration.
+
+    The chains advance independently, so a run lasts as many gradient-solves as its SLOWEST chain needs leapfrogs: the wall
+    time is one chain's luck while the time per gradient-solve is the engine's.  The posterior figures of ONE run are a
+    realization too (the target's exponential tail along r0's unconstrained coordinate holds 9 % of the variance in 0.74 % of
+    the mass), so the run is repeated under ``seeds`` (the first is the reference's, 8675314, src/dynode/infer/inference.py:45)
+    and the verdict is the POOLED block: sd ratio over all chains with its across-chain standard error, z statistics of mean
+    and variance, Fisher's combination of the runs' KS p-values (thinning from the effective sample size of the squares).
+    ``seconds`` / ``gradient_solves`` are the first seed's, ``seconds_median`` over all."""
+    import numpy as np
+    import torch
+
+    from dynode_amd.infer import checks
+    from dynode_amd.infer.inference import MCMCProcess
+    from examples import sir_infer_parameters as ex
+
+    truth, kw = cfg4_truth()
+    model = ex.model_fused if fused else ex.model
     # one-off costs (lazy loading of the kernels, structure discovery of the potential, the caching allocator's first blocks)
     # are paid by a short untimed run of the same program: 16 chains x (20 + 20)
-    MCMCProcess(numpyro_model=ex.model_fused if fused else ex.model, num_warmup=20, num_samples=20, num_chains=16, nuts_max_tree_depth=10,
+    MCMCProcess(numpyro_model=model, num_warmup=20, num_samples=20, num_chains=16, nuts_max_tree_depth=10,
                 progress_bar=False, mcmc_kwargs={"adaptation": adaptation}).infer(**kw)
-    proc = MCMCProcess(numpyro_model=ex.model_fused if fused else ex.model, num_warmup=warmup, num_samples=samples, num_chains=chains,
-                       nuts_max_tree_depth=10, progress_bar=False, mcmc_kwargs={"adaptation": adaptation})
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    mcmc = proc.infer(**kw)
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
-    post = proc.get_samples(group_by_chain=True)
-    from dynode_amd.infer.inference import marginal_cdfs_by_quadrature
-
-    global _CFG4_CDFS
-    odes.enable_x64(True)
-    try:
-        pot = Potential(ex.model, kw, 0, torch.device("cuda"))
-        z0 = torch.linspace(-14.0, 14.0, 1001, dtype=torch.float64)
-        z1 = torch.linspace(-6.0, 6.0, 701, dtype=torch.float64)
-        if _CFG4_CDFS is None:      # the quadrature of the posterior: once per bench run (every cfg 4 entry has the same data)
-            _CFG4_CDFS = marginal_cdfs_by_quadrature(pot, [z0, z1])
-        ks = ks_against_quadrature(pot, post, [z0, z1], thin=10, cdfs=_CFG4_CDFS)
-    finally:
-        odes.enable_x64(False)
-    by_seed = {}
-    for seed in more_seeds:
-        p2 = MCMCProcess(numpyro_model=ex.model_fused if fused else ex.model, num_warmup=warmup, num_samples=samples, num_chains=chains,
-                         nuts_max_tree_depth=10, progress_bar=False, inference_prngkey=int(seed), mcmc_kwargs={"adaptation": adaptation})
+    runs, eps, imm, first = [], [], [], None
+    for seed in seeds:
+        proc = MCMCProcess(numpyro_model=model, num_warmup=warmup, num_samples=samples, num_chains=chains, nuts_max_tree_depth=10,
+                           progress_bar=False, inference_prngkey=int(seed), mcmc_kwargs={"adaptation": adaptation})
         torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        m2 = p2.infer(**kw)
+        t0 = time.perf_counter()
+        mcmc = proc.infer(**kw)
         torch.cuda.synchronize()
-        e2 = time.perf_counter() - t1
-        k2 = ks_against_quadrature(pot, p2.get_samples(group_by_chain=True), [z0, z1], thin=10, cdfs=_CFG4_CDFS)
-        by_seed[str(seed)] = {"seconds": e2, "gradient_solves": int(m2.nuts.potential_evals), "divergences": int(m2.nuts.diverging.sum()),
-                              "ks_p": {n: v["ks_p"] for n, v in k2.items()}, "sd_over_quadrature": {n: v["sd"] / v["quad_sd"] for n, v in k2.items()}}
-    extra = {}
-    if by_seed:
-        allsec = sorted([el] + [v["seconds"] for v in by_seed.values()])
-        extra = {"seconds_median": allsec[len(allsec) // 2], "other_sampler_seeds": by_seed}
-    return {**extra, "gradient_solves": int(mcmc.nuts.potential_evals), "us_per_gradient_solve": 1e6 * el / max(int(mcmc.nuts.potential_evals), 1),
-            "workload": f"cfg4 sir_infer_parameters: NUTS {chains} chains (one GPU's share of 1024) x ({warmup} warm-up + {samples} draws), "
+        el = time.perf_counter() - t0
+        st = checks.run_statistics(truth, mcmc.nuts.samples.cpu().numpy(), tails=CFG4_TAILS)
+        st.update(seed=int(seed), seconds=el, gradient_solves=int(mcmc.nuts.potential_evals), divergences=int(mcmc.nuts.diverging.sum()),
+                  mean_leapfrogs_per_transition=float(mcmc.nuts.num_steps.double().mean()))
+        runs.append(st)
+        eps.append(mcmc.nuts.step_size.cpu())
+        imm.append(mcmc.nuts.inverse_mass.cpu())
+        first = first or (el, mcmc)
+    el, mcmc = first
+    pooled = checks.pool_runs(truth, runs)
+    _CFG4[("kernels", fused, adaptation)] = (torch.cat(eps), torch.cat(imm))
+    secs = sorted(r["seconds"] for r in runs)
+    return {"workload": f"cfg4 sir_infer_parameters: NUTS {chains} chains (one GPU's share of 1024) x ({warmup} warm-up + {samples} draws), "
                         f"tree depth 10, warm-up adaptation {adaptation}"
-                        + (", Poisson likelihood fused into the solve kernel (examples model_fused)" if fused else ""),
-            "seconds": el, "transitions_per_s": chains * (warmup + samples) / el,
-            "gradient_solves_per_s": mcmc.nuts.potential_evals / el,
+                        + (", Poisson likelihood fused into the solve kernel (examples model_fused)" if fused else
+                           ", the reference-shaped model() (simulate -> diff(R) -> Poisson scored in torch)"),
+            "seconds": el, "seconds_median": secs[len(secs) // 2], "gradient_solves": int(mcmc.nuts.potential_evals),
+            "us_per_gradient_solve": 1e6 * el / max(int(mcmc.nuts.potential_evals), 1),
+            "transitions_per_s": chains * (warmup + samples) / el, "gradient_solves_per_s": mcmc.nuts.potential_evals / el,
             "chain_gradients_per_s": mcmc.nuts.potential_evals * chains / el,
             "mean_leapfrogs_per_transition": float(mcmc.nuts.num_steps.double().mean()),
             "divergences": int(mcmc.nuts.diverging.sum()),
-            "posterior_vs_quadrature": ks}
+            "posterior_vs_quadrature": {"pooled_over_sampler_seeds": pooled, "per_seed": runs}}
+
+
+def nuts_kernel_checks(fused: bool, chains: int, transitions: int = 100, decoupled_starts: int = 0):
+    """The calibrated checks of `dynode_amd/infer/checks.py` on the kernels the runs above adapted (per-chain adaptation):
+
+    stationarity  ``chains`` chains started at independent exact posterior draws, each with the (step size, mass matrix) of a
+                  random production chain, ``transitions`` transitions, nothing adapting: the end states are i.i.d. posterior
+                  draws if the transition kernel is invariant -- KS p-values exactly uniform, tail counts binomial.
+    decoupled     the same kernels, ``decoupled_starts`` exact starts each, 1000 draws: the production statistic (pooled sd
+                  ratio) without the coupling between a chain's adapted kernel and the state its own warm-up left it in."""
+    import numpy as np
+    import torch
+
+    from dynode_amd.infer import checks
+    from dynode_amd.infer.folded import discover
+    from dynode_amd.infer.inference import Potential
+    from dynode_amd.infer.nuts import KernelNUTS
+    from examples import sir_infer_parameters as ex
+
+    truth, kw = cfg4_truth()
+    eps, imm = _CFG4[("kernels", fused, "per_chain")]
+    rng = np.random.default_rng(20261004)
+
+    def sampler(seed):
+        pot = Potential(ex.model_fused if fused else ex.model, kw, seed, torch.device("cuda"))
+        folded = discover(pot, seed=seed)
+        return KernelNUTS(folded if folded is not None else pot.potential_and_grad, max_tree_depth=10, seed=seed)
+
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = {"stationarity": checks.stationarity(truth, sampler(4242), eps, imm, chains, transitions, rng, tails=CFG4_TAILS)}
+    torch.cuda.synchronize()
+    out["stationarity"]["seconds"] = time.perf_counter() - t0
+    out["stationarity"]["kernels"] = f"{eps.shape[0]} adapted (step size, dense mass matrix) pairs of the per-chain production runs above"
+    if decoupled_starts:
+        C = eps.shape[0] * decoupled_starts
+        pick = torch.arange(eps.shape[0]).repeat(decoupled_starts)
+        z0 = torch.from_numpy(truth.draws(C, rng)).cuda()
+        res = sampler(777).run(z0, 0, 1000, step_size=eps[pick].cuda(), inverse_mass=imm[pick].cuda())
+        st = checks.run_statistics(truth, res.samples.cpu().numpy(), thin=50, tails=CFG4_TAILS)
+        out["decoupled_start"] = {"chains": C, "draws": 1000, "divergences": int(res.diverging.sum()),
+                                  "pooled": checks.pool_runs(truth, [st])}
+    return out
 
 
 def kernel_name() -> str:
@@ -484,11 +537,16 @@ def main():
                     "all_status_ok": int(r2["stats"][0].max()) == 0}
                 del r2
             torch.cuda.empty_cache()
-            line["other_workloads"]["cfg4"] = nuts_side_measurement(more_seeds=(1, 2))     # numpyro's per-chain adaptation
+            # cfg 4.  numpyro's per-chain adaptation under eight sampler seeds, pooled (the fused-likelihood model), four for the
+            # program a drop-in user actually has -- the reference-shaped model() (simulate -> diff(R) -> Poisson scored in
+            # torch, examples/sir_infer_parameters.py:model; general autograd potential, same sampler kernel) --, the calibrated
+            # kernel checks on what those runs adapted, and the pooled-window variant's time
+            seeds = (8675314, 1001, 1002, 1003, 1004, 1005, 1006, 1007)
+            line["other_workloads"]["cfg4"] = nuts_side_measurement(seeds=seeds)
+            line["other_workloads"]["cfg4"]["kernel_checks"] = nuts_kernel_checks(True, 102400, decoupled_starts=4)
+            line["other_workloads"]["cfg4_reference_shaped_model"] = nuts_side_measurement(fused=False, seeds=seeds[:4])
+            line["other_workloads"]["cfg4_reference_shaped_model"]["kernel_checks"] = nuts_kernel_checks(False, 25600)
             line["other_workloads"]["cfg4_pooled_adaptation"] = nuts_side_measurement(adaptation="pooled")
-            # the program a drop-in user actually has: the reference-shaped model() (simulate -> diff(R) -> Poisson scored in torch,
-            # examples/sir_infer_parameters.py:model), general autograd potential, same sampler kernel
-            line["other_workloads"]["cfg4_reference_shaped_model"] = nuts_side_measurement(fused=False, more_seeds=(1, 2))
         if world == 1 and not args.no_cpu_baseline:
             sample = args.cpu_sample or (1024 if m.family == 1 else 8192 if m.state_dim >= 300 else 16384 if m.state_dim >= 100 else 65536)
             line["cpu_baseline"] = cpu_baseline(wl, min(sample, B))

@@ -101,6 +101,19 @@ def current_hints() -> dict:
     return dict(getattr(_HINTS, "value", None) or {})
 
 
+def _merged_hints(kw: dict) -> dict:
+    bad = set(kw) - set(_HINT_FIELDS) - {"work_min_batch"}
+    if bad:
+        raise TypeError(f"unknown dispatch hint(s) {sorted(bad)}; known: {_HINT_FIELDS + ('work_min_batch',)}")
+    merged = dict(getattr(_HINTS, "value", None) or {})
+    for k, v in kw.items():
+        if v is None:
+            merged.pop(k, None)
+        else:
+            merged[k] = int(v) + 1 if k == "replicas_log2" else int(v)
+    return merged
+
+
 @contextlib.contextmanager
 def dispatch_hints(**kw):
     """Pin dispatch choices for the solves of this thread inside the block.  Keys = fields of ``dyn_dispatch_hints``
@@ -108,17 +121,8 @@ def dispatch_hints(**kw):
     2^k replicas -- stored as k + 1), ``producer_consumer`` (1), ``general_instance`` (1), ``seip_tier_lanes`` (1 / -1),
     ``seip_tier_waves`` (-1); plus ``work_min_batch`` (host side: the smallest batch that gets a work counter).  Nested
     blocks merge; ``None`` removes a key."""
-    bad = set(kw) - set(_HINT_FIELDS) - {"work_min_batch"}
-    if bad:
-        raise TypeError(f"unknown dispatch hint(s) {sorted(bad)}; known: {_HINT_FIELDS + ('work_min_batch',)}")
     before = getattr(_HINTS, "value", None)
-    merged = dict(before or {})
-    for k, v in kw.items():
-        if v is None:
-            merged.pop(k, None)
-        else:
-            merged[k] = int(v) + 1 if k == "replicas_log2" else int(v)
-    _HINTS.value = merged
+    _HINTS.value = _merged_hints(kw)
     try:
         yield
     finally:
@@ -127,8 +131,7 @@ def dispatch_hints(**kw):
 
 def set_dispatch_hints(**kw) -> None:
     """`dispatch_hints` without a block: merge into this thread's hints until `clear_dispatch_hints` (test fixtures)."""
-    cm = dispatch_hints(**kw)
-    cm.__enter__()          # (never exited: the merged value stays)
+    _HINTS.value = _merged_hints(kw)
 
 
 def clear_dispatch_hints() -> None:

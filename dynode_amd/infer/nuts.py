@@ -165,6 +165,26 @@ class LockstepNUTS:
             eps = torch.where(active, eps * (2.0 ** direction), eps)
         return eps
 
+    def _initial_kernel(self, z, u, g, init_step_size, step_size, inverse_mass, gen):
+        """(eps, imm, mm_sqrt) a run starts from.  Default: identity metric and a line search from ``init_step_size``
+        (numpyro's ``find_reasonable_step_size``).  ``step_size`` ([C] or a float) / ``inverse_mass`` ([C, D, D] or [D, D])
+        start the run from a GIVEN kernel instead -- numpyro's ``NUTS(step_size=..., inverse_mass_matrix=...)``; with
+        ``num_warmup = 0`` nothing adapts and every transition uses exactly that kernel (the stationarity checks of
+        tests/test_gpu_infer.py start chains at exact posterior draws and need the kernel held fixed)."""
+        C, D = z.shape
+        dt, dev = z.dtype, z.device
+        eye = torch.eye(D, dtype=dt, device=dev).expand(C, D, D).contiguous()
+        imm, mm_sqrt = eye.clone(), eye.clone()
+        if inverse_mass is not None:
+            imm = torch.as_tensor(inverse_mass, dtype=dt, device=dev).expand(C, D, D).contiguous()
+            mm_sqrt = torch.linalg.cholesky(torch.linalg.inv(imm)).contiguous()
+        if step_size is not None:
+            eps = torch.as_tensor(step_size, dtype=dt, device=dev).expand(C).contiguous().clone()
+        else:
+            eps = self._find_reasonable_step_size(z, u, g, imm, mm_sqrt,
+                                                  torch.full((C,), float(init_step_size), dtype=dt, device=dev), gen)
+        return eps, imm, mm_sqrt
+
     # -------------------------------------------------------------- one transition for all chains
     def _transition(self, z, u, g, eps, imm, mm_sqrt, gen):
         C, D = z.shape
@@ -322,7 +342,7 @@ class BatchedNUTS(LockstepNUTS):
     """
 
     def run(self, z0: torch.Tensor, num_warmup: int, num_samples: int, init_step_size: float = 1.0,
-            progress: Optional[Callable] = None) -> NUTSResult:
+            progress: Optional[Callable] = None, step_size=None, inverse_mass=None) -> NUTSResult:
         C, D = z0.shape
         dev, dt = z0.device, torch.float64
         Dm = self.max_depth
@@ -335,10 +355,8 @@ class BatchedNUTS(LockstepNUTS):
 
         z = z0.clone().to(dt)
         eye = torch.eye(D, dtype=dt, device=dev).expand(C, D, D).contiguous()
-        imm, mm_sqrt = eye.clone(), eye.clone()
         u, g = self._eval(z)
-        eps = self._find_reasonable_step_size(z, u, g, imm, mm_sqrt,
-                                              torch.full((C,), float(init_step_size), dtype=dt, device=dev), gen)
+        eps, imm, mm_sqrt = self._initial_kernel(z, u, g, init_step_size, step_size, inverse_mass, gen)
         eps_avg = eps.clone()
         # dual averaging state, per chain
         da_mu, da_xbar, da_gbar = torch.log(10.0 * eps), torch.zeros(C, dtype=dt, device=dev), torch.zeros(C, dtype=dt, device=dev)
@@ -677,7 +695,7 @@ class GraphNUTS(LockstepNUTS):
 
     # ---------------------------------------------------------------- driver
     def run(self, z0: torch.Tensor, num_warmup: int, num_samples: int, init_step_size: float = 1.0,
-            progress: Optional[Callable] = None) -> NUTSResult:
+            progress: Optional[Callable] = None, step_size=None, inverse_mass=None) -> NUTSResult:
         C, D = z0.shape
         dev, dt, Dm = z0.device, torch.float64, self.max_depth
         total = num_warmup + num_samples
@@ -685,8 +703,7 @@ class GraphNUTS(LockstepNUTS):
         z = z0.clone().to(dt)
         eye = torch.eye(D, dtype=dt, device=dev).expand(C, D, D).contiguous()
         u, g = self._eval(z)
-        eps = self._find_reasonable_step_size(z, u, g, eye, eye,
-                                              torch.full((C,), float(init_step_size), dtype=dt, device=dev), gen)
+        eps, imm0, mms0 = self._initial_kernel(z, u, g, init_step_size, step_size, inverse_mass, gen)
         windows = _adaptation_windows(num_warmup)
         K = dict(C=C, D=D, total=total, num_warmup=num_warmup, num_samples=num_samples, eye=eye,
                  levels=torch.arange(Dm, device=dev),
@@ -695,12 +712,12 @@ class GraphNUTS(LockstepNUTS):
         zf = lambda *s: torch.zeros(s, dtype=dt, device=dev)
         zl_ = lambda *s: torch.zeros(s, dtype=torch.long, device=dev)
         zb = lambda *s: torch.zeros(s, dtype=torch.bool, device=dev)
-        r0 = torch.randn((C, D), dtype=dt, device=dev, generator=gen)
+        r0 = _mv(mms0, torch.randn((C, D), dtype=dt, device=dev, generator=gen))
         right = torch.rand(C, device=dev, generator=gen) < 0.5
         S = dict(z=z, u=u, g=g, eps=eps, eps_avg=eps.clone(), da_mu=torch.log(10.0 * eps), da_xbar=zf(C), da_gbar=zf(C),
-                 da_t=zf(C), imm=eye.clone(), mm_sqrt=eye.clone(), wi=zl_(C), wf_n=zf(C), wf_mean=zf(C, D), wf_m2=zf(C, D, D),
+                 da_t=zf(C), imm=imm0.clone(), mm_sqrt=mms0.clone(), wi=zl_(C), wf_n=zf(C), wf_mean=zf(C, D), wf_m2=zf(C, D, D),
                  it=zl_(C), pend_cov=eye.clone(), need_mm=zb(C),
-                 e0=u + 0.5 * (r0 * r0).sum(-1), zl=z.clone(), rl=r0.clone(), gl=g.clone(), zr=z.clone(), rr=r0.clone(),
+                 e0=u + self._kinetic(imm0, r0), zl=z.clone(), rl=r0.clone(), gl=g.clone(), zr=z.clone(), rr=r0.clone(),
                  gr=g.clone(), zp=z.clone(), up=u.clone(), gp=g.clone(), weight=zf(C), r_sum=r0.clone(), sum_acc=zf(C),
                  n_prop=zl_(C), depth=zl_(C), right=right,
                  sgn=torch.where(right, torch.ones(C, dtype=dt, device=dev), -torch.ones(C, dtype=dt, device=dev)),
@@ -807,7 +824,7 @@ class KernelNUTS(LockstepNUTS):
         self.recheck_blocks = (1, 3, 7)
 
     def run(self, z0: torch.Tensor, num_warmup: int, num_samples: int, init_step_size: float = 1.0,
-            progress: Optional[Callable] = None) -> NUTSResult:
+            progress: Optional[Callable] = None, step_size=None, inverse_mass=None) -> NUTSResult:
         import ctypes
 
         from .. import _abi
@@ -826,25 +843,23 @@ class KernelNUTS(LockstepNUTS):
         total = num_warmup + num_samples
         gen = torch.Generator(device=dev).manual_seed(self.seed)
         z = z0.clone().to(dt).contiguous()
-        eye = torch.eye(D, dtype=dt, device=dev).expand(C, D, D).contiguous()
         u, g = self._eval(z)
-        eps = self._find_reasonable_step_size(z, u, g, eye, eye,
-                                              torch.full((C,), float(init_step_size), dtype=dt, device=dev), gen)
+        eps, imm0, mms0 = self._initial_kernel(z, u, g, init_step_size, step_size, inverse_mass, gen)
         zf = lambda *s: torch.zeros(s, dtype=dt, device=dev)
         zi = lambda *s: torch.zeros(s, dtype=torch.int32, device=dev)
         W = max(len(windows), 1)
-        r0 = torch.randn((C, D), dtype=dt, device=dev, generator=gen)
+        r0 = _mv(mms0, torch.randn((C, D), dtype=dt, device=dev, generator=gen))
         right = torch.rand(C, device=dev, generator=gen) < 0.5
         sgn = torch.where(right, 1.0, -1.0).to(dt)
         r_half = r0 - 0.5 * (eps * sgn)[:, None] * g
         S = dict(z=z, u=u, g=g, eps=eps, eps_avg=eps.clone(), da_mu=torch.log(10.0 * eps), da_xbar=zf(C), da_gbar=zf(C),
-                 da_t=zf(C), imm=eye.clone(), mm_sqrt=eye.clone(), wf_n=zf(C), wf_mean=zf(C, D), wf_m2=zf(C, D, D),
-                 e0=u + 0.5 * (r0 * r0).sum(-1), zl=z.clone(), rl=r0.clone(), gl=g.clone(), zr=z.clone(), rr=r0.clone(),
+                 da_t=zf(C), imm=imm0.clone(), mm_sqrt=mms0.clone(), wf_n=zf(C), wf_mean=zf(C, D), wf_m2=zf(C, D, D),
+                 e0=u + self._kinetic(imm0, r0), zl=z.clone(), rl=r0.clone(), gl=g.clone(), zr=z.clone(), rr=r0.clone(),
                  gr=g.clone(), zp=z.clone(), up=u.clone(), gp=g.clone(), weight=zf(C), r_sum=r0.clone(), sum_acc=zf(C),
                  sgn=sgn, zc=z.clone(), rc=r0.clone(), gc=g.clone(), r_half=r_half, s_zp=z.clone(), s_up=u.clone(),
                  s_gp=g.clone(), s_weight=torch.full((C,), -math.inf, dtype=dt, device=dev), s_rsum=zf(C, D),
                  s_acc=zf(C), r_ck=zf(C, Dm, D), rs_ck=zf(C, Dm, D),
-                 z_eval=z + (eps * sgn)[:, None] * r_half, u_new=zf(C), g_new=zf(C, D),
+                 z_eval=z + (eps * sgn)[:, None] * _mv(imm0, r_half), u_new=zf(C), g_new=zf(C, D),
                  it=zi(C), wi=zi(C), n_prop=zi(C), depth=zi(C), right=right.to(torch.int32), leaf=zi(C), s_turn=zi(C),
                  s_div=zi(C), s_n=zi(C), rng_ctr=torch.zeros(C, dtype=torch.int64, device=dev),
                  pool=torch.zeros((W + 1, 1 + D + D * D), dtype=torch.int64, device=dev),

@@ -282,7 +282,7 @@ def truth_bars(m, got32, want32, y0, p, C, t1, ts, scale, label="", smooth=True,
     return err_hip, err_orc
 
 
-def oracle_sir_posterior_cdfs(obs, z_grids, tf=100.0):
+def oracle_sir_posterior_cdfs(obs, z_grids, tf=100.0, joint=False):
     """cfg 4's posterior oracle, INDEPENDENT of the HIP path and of the package's distributions: marginal CDFs of
     (r0, infectious_period) of the reference's model (examples/sir_infer_parameters.py:21-59) by tensor-grid quadrature in
     the unconstrained coordinates, with every likelihood term from float64 solves of the C oracle and every prior term from
@@ -290,7 +290,7 @@ def oracle_sir_posterior_cdfs(obs, z_grids, tf=100.0):
         r0 = 1.5 + sigmoid(z0),  r0 - 1.5 ~ Beta(0.5, 0.5);   T = 2 + 13 sigmoid(z1),  T ~ TruncNormal(8, 2, [2, 15])
         beta = r0 / T, gamma = 1 / T;  incidence = max(diff(R), 1e-6);  obs ~ Poisson(incidence)
     2-age SIR literal of sir_age_stratified.py:46-66,70,81-85.  Returns [(x_grid, cdf, pmf)] per site like
-    ``inference.marginal_cdfs_by_quadrature``."""
+    ``inference.marginal_cdfs_by_quadrature``; with ``joint`` also the joint cell masses [len(z0), len(z1)]."""
     from scipy import stats
     from scipy.special import expit, gammaln
 
@@ -317,4 +317,6 @@ def oracle_sir_posterior_cdfs(obs, z_grids, tf=100.0):
     for axis, grid in ((1, r0), (0, T)):
         marginal = p.sum(axis)
         out.append((grid, np.cumsum(marginal) - 0.5 * marginal, marginal))
+    if joint:
+        return out, p
     return out

@@ -102,63 +102,186 @@ def test_nuts_posterior_matches_grid_quadrature(data, sampler, adaptation):
 
 
 _ORACLE_CDFS = {}
+ORACLE_GRIDS = (np.linspace(-14.0, 14.0, 701), np.linspace(-6.0, 6.0, 501))
+SITES = ("strains_0_r0", "strains_0_infectious_period")
+TAILS = ((0, 2.0), (0, 4.0))          # z0 > 2: 0.74 % of the posterior mass and 9 % of r0's variance; z0 > 4: 0.13 %
+
+
+def _oracle_posterior(data):
+    """The posterior oracle of record: quadrature on a 701 x 501 grid with float64 solves of the C oracle and scipy.stats
+    priors (tests/helpers.py:oracle_sir_posterior_cdfs) -- nothing of the HIP path, nothing of dynode_amd.infer's likelihood
+    or priors.  (351,201 oracle solves: half a minute on the box's cores, once per session.)  Returns the marginals
+    [(x_grid, cdf, pmf)] and the same posterior as a `checks.GridPosterior` (joint cell masses: exact independent draws)."""
+    from scipy.special import expit
+
+    from dynode_amd.infer.checks import GridPosterior
+
+    key = data.numpy().tobytes()
+    if key not in _ORACLE_CDFS:
+        cdfs, joint = H.oracle_sir_posterior_cdfs(data.numpy(), list(ORACLE_GRIDS), joint=True)
+        post = GridPosterior(ORACLE_GRIDS, joint, [lambda z: 1.5 + expit(z), lambda z: 2.0 + 13.0 * expit(z)], SITES)
+        # (bicubic refinement of the log masses: what cuts the line -- tail masses, the core moment, the CDF between nodes,
+        # the uniform spread of `draws` inside a cell -- is second order in the spacing; see checks.GridPosterior.refined)
+        _ORACLE_CDFS[key] = (cdfs, post, post.refined(4))
+    return _ORACLE_CDFS[key]
 
 
 def _oracle_marginals(data):
-    """The posterior oracle of record: quadrature on a 701 x 501 grid with float64 solves of the C oracle and scipy.stats
-    priors (tests/helpers.py:oracle_sir_posterior_cdfs) -- nothing of the HIP path, nothing of dynode_amd.infer.
-    (351,201 oracle solves: half a minute on the box's cores, once per session.)"""
-    key = data.numpy().tobytes()
-    if key not in _ORACLE_CDFS:
-        _ORACLE_CDFS[key] = H.oracle_sir_posterior_cdfs(data.numpy(), [np.linspace(-14.0, 14.0, 701), np.linspace(-6.0, 6.0, 501)])
-    return _ORACLE_CDFS[key]
+    return _oracle_posterior(data)[0]
+
+
+def _oracle_truth(data):
+    """The refined grid (see `_oracle_posterior`): what the sampler checks compare with and draw their starts from."""
+    return _oracle_posterior(data)[2]
 
 
 def test_quadrature_from_the_c_oracle_equals_the_hip_built_one(data):
     """the quadrature behind the posterior checks was built from `Potential`, i.e. from HIP float64 solves -- it
     validated the sampler, not the likelihood.  The same quadrature from the C oracle + scipy priors must give the same
-    marginal CDFs: 1e-6 in CDF on identical grids (then the KS tests below run against the oracle's)."""
+    marginal CDFs: 1e-6 in CDF on identical grids (then the checks below run against the oracle's), and the same joint."""
+    from dynode_amd.infer.checks import GridPosterior
     from dynode_amd.infer.inference import marginal_cdfs_by_quadrature
 
-    zg = [torch.linspace(-14.0, 14.0, 701, dtype=torch.float64), torch.linspace(-6.0, 6.0, 501, dtype=torch.float64)]
+    zg = [torch.as_tensor(g, dtype=torch.float64) for g in ORACLE_GRIDS]
     odes.enable_x64(True)
     try:
         pot = Potential(ex.model, dict(config=ex.get_config(), tf=100, obs_data=data), 0, torch.device("cuda"))
         hip = marginal_cdfs_by_quadrature(pot, zg)
+        hip_joint = GridPosterior.from_potential(pot, zg)
     finally:
         odes.enable_x64(False)
-    want = _oracle_marginals(data)
+    want, post, _ = _oracle_posterior(data)
     for (g_h, c_h, m_h), (g_o, c_o, m_o), name in zip(hip, want, ("r0", "infectious_period")):
         assert np.abs(g_h - g_o).max() < 1e-12
         gap = float(np.abs(c_h - c_o).max())
         mean_h, mean_o = float((g_h * m_h).sum()), float((g_o * m_o).sum())
         print(f"{name}: max CDF gap HIP-built vs oracle-built {gap:.2e}, means {mean_h:.6f} / {mean_o:.6f}")
         assert gap < 1e-6 and abs(mean_h - mean_o) < 1e-6
+    assert float(np.abs(hip_joint.p - post.p).sum()) < 1e-6                       # total variation of the joint cell masses
+    for k in range(2):
+        assert abs(hip_joint.mean[k] - post.mean[k]) < 1e-6 and abs(hip_joint.sd[k] / post.sd[k] - 1.0) < 1e-6
 
 
-def test_nuts_posterior_high_power_ks_and_moments(data):
-    """cfg 4 at one GPU's share (128 chains), default per-chain adaptation as in numpyro, 12,800 thinned draws per
-    site (1000 + 1000 transitions, BASELINE cfg 4): KS p > 0.01 against the quadrature CDF, sample mean and standard
-    deviation within 3 of their Monte-Carlo standard errors of the quadrature moments."""
-    from dynode_amd.infer.inference import ks_against_quadrature
+_PRODUCTION = {}
 
+
+def _production_runs(data, kind: str, seeds):
+    """128 chains x (1000 + 1000), numpyro's per-chain adaptation, one run per sampler seed (cached per session): the pooled
+    statistics against the oracle's posterior, the runs', and the kernels (step size, dense mass matrix per chain) they adapted."""
+    from dynode_amd.infer import checks
+
+    post = _oracle_truth(data)
     kw = dict(config=ex.get_config(), tf=100, obs_data=data)
-    process = MCMCProcess(numpyro_model=ex.model_fused, num_warmup=1000, num_samples=1000, num_chains=128,
-                          nuts_max_tree_depth=10, progress_bar=False)
-    process.infer(**kw)
-    post = process.get_samples(group_by_chain=True)
-    pot = Potential(ex.model, kw, 0, torch.device("cuda"))      # (site names and order only: the CDFs are the C oracle's)
-    rep = ks_against_quadrature(pot, post, None, thin=10, cdfs=_oracle_marginals(data))
-    for name, r in rep.items():
-        print(name, {k: (round(v, 5) if isinstance(v, float) else v) for k, v in r.items()})
-        assert r["n"] >= 10_000 and r["ks_p"] > 0.01, (name, r)
-        # Moments: within 3 Monte-Carlo standard errors -- or, for the standard deviation, within 2.5 % (the mean: 0.1 %) of the
-        # quadrature value.  The posterior has a thin plateau towards r0 -> 2.5 (the Beta(1/2, 1/2) edge); a run of 128 chains x
-        # 1000 draws either has a chain wander onto it (sd a few per cent HIGH: round 2's library, 8 and 39 divergences) or not
-        # (sd 1-2 % LOW: every build of round 3, 0-3 divergences), and the effective-sample-size error bar does not see that
-        # mixture (docs/perf-log.md, "Posterior check note").  The KS test above is the distribution-level bar.
-        assert abs(r["mean_z"]) < 3.0 or abs(r["mean"] / r["quad_mean"] - 1.0) < 1e-3, (name, r)
-        assert abs(r["sd_z"]) < 3.0 or abs(r["sd"] / r["quad_sd"] - 1.0) < 0.025, (name, r)
+    for seed in seeds:
+        if (kind, seed) not in _PRODUCTION:
+            process = MCMCProcess(numpyro_model=getattr(ex, kind), num_warmup=1000, num_samples=1000, num_chains=128,
+                                  nuts_max_tree_depth=10, progress_bar=False, inference_prngkey=seed)
+            mcmc = process.infer(**kw)
+            st = checks.run_statistics(post, mcmc.nuts.samples.cpu().numpy(), tails=TAILS)
+            st.update(seed=seed, divergences=int(mcmc.nuts.diverging.sum()))
+            _PRODUCTION[(kind, seed)] = (st, mcmc.nuts.step_size.cpu(), mcmc.nuts.inverse_mass.cpu())
+    got = [_PRODUCTION[(kind, seed)] for seed in seeds]
+    runs = [g[0] for g in got]
+    return checks.pool_runs(post, runs, strip_runs=False), runs, torch.cat([g[1] for g in got]), torch.cat([g[2] for g in got])
+
+
+SEEDS = {"model_fused": (8675314, 1001, 1002, 1003, 1004, 1005, 1006, 1007), "model": (8675314, 1001, 1002, 1003)}
+
+
+def _kernel_sampler(data, kind: str, seed: int):
+    """The sampler `MCMCProcess.infer` builds for ``kind`` (folded potential + fused iteration where the model has the
+    structure, the general autograd potential otherwise), for runs from given states with given kernels."""
+    from dynode_amd.infer.folded import discover
+    from dynode_amd.infer.nuts import KernelNUTS
+
+    pot = Potential(getattr(ex, kind), dict(config=ex.get_config(), tf=100, obs_data=data), seed, torch.device("cuda"))
+    folded = discover(pot, seed=seed)
+    assert (folded is not None) == (kind == "model_fused")
+    return KernelNUTS(folded if folded is not None else pot.potential_and_grad, max_tree_depth=10, seed=seed)
+
+
+@pytest.mark.parametrize("kind,chains", [("model_fused", 102400), ("model", 25600)])
+def test_transition_kernel_leaves_the_posterior_invariant(data, kind, chains):
+    """THE calibrated posterior gate (north star: "KS-test agreement on posteriors"), for the fused-likelihood
+    model and for the reference-shaped un-fused ``model()`` (examples/sir_infer_parameters.py:21-39) at full power.
+
+    Chains start at INDEPENDENT EXACT posterior draws (the C oracle's quadrature), every chain gets the (step size, dense mass
+    matrix) a chain of a production run adapted, nothing adapts, 100 transitions.  If the transition kernel -- leapfrog on the
+    HIP gradient-solve, multinomial NUTS tree, U-turn checkpoints, divergence handling, Philox streams -- leaves the posterior
+    invariant, the states after any number of transitions are i.i.d. posterior draws: the KS p-values below are exactly
+    uniform (no thinning, no effective-sample-size estimate), the z statistics standard normal, the tail counts binomial.
+    Bars: every p > 1e-3, every |z| < 4 (the run is deterministic -- fixed start draws, counter-based randomness -- so this
+    is not a flaky test; under the null a bar fails in < 0.5 % of library builds).  tools/posterior_study.py runs the same
+    check with a million chains: every KS p in 0.18-0.99, every |z| < 2 after 1 ... 100 transitions."""
+    from dynode_amd.infer import checks
+
+    post = _oracle_truth(data)
+    _, _, eps, imm = _production_runs(data, kind, SEEDS[kind][:2])
+    rep = checks.stationarity(post, _kernel_sampler(data, kind, 4242), eps, imm, chains, 100, np.random.default_rng(20261004), tails=TAILS)
+    for t, row in rep["after"].items():
+        print(f"[{kind}] after {t:>3s}: " + ", ".join(f"{n[10:]} KS p {row[n]['ks_p']:.3f} mean z {row[n]['mean_z']:+.2f} var z {row[n]['var_z']:+.2f}" for n in SITES)
+              + "; " + ", ".join(f"{k[10:]} z {v['z']:+.2f}" for k, v in row.items() if ">z" in k))
+    assert rep["divergences"] <= 5e-4 * chains * 100
+    for t in ("10", "50", "100"):
+        row = rep["after"][t]
+        for n in SITES:
+            assert row[n]["ks_p"] > 1e-3 and abs(row[n]["mean_z"]) < 4.0 and abs(row[n]["var_z"]) < 4.0, (kind, t, n, row[n])
+        for k, v in row.items():
+            if ">z" in k:
+                assert abs(v["z"]) < 4.0, (kind, t, k, v)
+
+
+@pytest.mark.parametrize("kind", ["model_fused", "model"])
+def test_production_runs_pooled_over_sampler_seeds(data, kind):
+    """cfg 4 as the reference runs it -- 128 chains (one GPU's share of 1024) x (1000 warm-up + 1000 draws), numpyro's per-chain
+    windowed adaptation, init_to_median -- under eight sampler seeds (four for the slower un-fused ``model()``), POOLED: no
+    single seed decides.  Chains are independent, so the mean over all chains of a per-chain statistic has an honest
+    standard error whatever the autocorrelation inside a chain -- provided rare chains do not dominate the statistic.  The
+    plain variance's IS dominated (tools/posterior_study.py; docs/perf-log.md round 4; dynode_amd/infer/checks.py): the
+    posterior's exponential tail beyond z0 > 4 (r0 within 0.02 of its upper bound) holds 0.13 % of the mass, in the stationary
+    process a third of the draws found there belong to chains that sit there for their whole run, and such a chain carries
+    17 x the typical squared deviation.  A state that hard to leave is as hard to reach: 64 pooled production runs occupy
+    z0 > 4 at 0.69 x its mass and read sd 0.9956 +- 0.0015, single runs 0.976 ... 1.046 (median 0.995) -- while their CORE
+    sd ratio is 0.9998 +- 0.0004, the same kernels from exact starts give sd 0.9996 +- 0.0008, and the transition kernel
+    is invariant at the resolution of a million chains.  Gated therefore:
+      the CORE standard deviation (second moment within 3 sd of the mean: 90 % of the variance, bounded per-chain values)
+          within 1 % of the quadrature value and 4 across-chain standard errors
+      the mean within 4 across-chain standard errors
+      the runs' KS p-values (thinning = 2 x draws / ESS of the squares): Fisher's combination > 1e-3, none below 1e-4
+      the plain sd ratio within [0.97, 1.03] (reported; the band is what a missing or present tail chain moves it by)."""
+    pooled, runs, _, _ = _production_runs(data, kind, SEEDS[kind])
+    for r in runs:
+        print(f"[{kind}] seed {r['seed']}: divergences {r['divergences']}, " + ", ".join(
+            f"{n[10:]} sd ratio {r[n]['sd_ratio']:.4f} core {r[n]['core_sd_ratio']:.4f} KS p {r[n]['ks_p']:.3f} (thin {r[n]['thin']})" for n in SITES) + f", tails {r['tail_ratio']}")
+        assert r["divergences"] <= 20
+    print(f"[{kind}] pooled over {pooled['runs']} runs / {pooled['chains']} chains: " + ", ".join(
+        f"{n[10:]} core sd ratio {pooled[n]['core_sd_ratio']:.4f} +- {pooled[n]['core_sd_ratio_se']:.4f} (z {pooled[n]['core_z']:+.2f}), sd ratio {pooled[n]['sd_ratio']:.4f}, "
+        f"mean z {pooled[n]['mean_z']:+.2f}, Fisher p {pooled[n]['ks_fisher_p']:.3f}" for n in SITES) + f", tails {pooled['tail_ratio_mean']}")
+    for n in SITES:
+        assert abs(pooled[n]["core_sd_ratio"] - 1.0) < 0.01 and abs(pooled[n]["core_z"]) < 4.0, (n, pooled[n])
+        assert abs(pooled[n]["mean_z"]) < 4.0, (n, pooled[n])
+        assert pooled[n]["ks_fisher_p"] > 1e-3 and pooled[n]["ks_p_min"] > 1e-4, (n, pooled[n])
+        assert 0.97 <= pooled[n]["sd_ratio"] <= 1.03, (n, pooled[n])
+
+
+def test_adapted_kernels_from_exact_starts(data):
+    """The production runs' 1024 adapted kernels, four independent exact starts each, 1000 draws, nothing adapting: a
+    stationary process from its first draw, so every time average is unbiased -- the same gates as the production runs,
+    tighter (core sd ratio within 0.5 %), on 4096 chains."""
+    from dynode_amd.infer import checks
+
+    post = _oracle_truth(data)
+    _, _, eps, imm = _production_runs(data, "model_fused", SEEDS["model_fused"])
+    rng = np.random.default_rng(7)
+    reps = 4
+    pick = torch.arange(eps.shape[0]).repeat(reps)
+    z0 = torch.from_numpy(post.draws(pick.numel(), rng)).cuda()
+    res = _kernel_sampler(data, "model_fused", 777).run(z0, 0, 1000, step_size=eps[pick].cuda(), inverse_mass=imm[pick].cuda())
+    pooled = checks.pool_runs(post, [checks.run_statistics(post, res.samples.cpu().numpy(), thin=50, tails=TAILS)])
+    print("exact starts:", {n: {k: (round(v, 4) if isinstance(v, float) else v) for k, v in pooled[n].items() if k != "ks_p"} for n in SITES}, pooled["tail_ratio_mean"])
+    for n in SITES:
+        assert abs(pooled[n]["core_sd_ratio"] - 1.0) < 0.005 and abs(pooled[n]["core_z"]) < 3.5, (n, pooled[n])
+        assert abs(pooled[n]["mean_z"]) < 4.0 and pooled[n]["ks_p_min"] > 1e-3 and 0.98 <= pooled[n]["sd_ratio"] <= 1.02, (n, pooled[n])
 
 
 def test_get_samples_before_infer_raises():
