@@ -254,14 +254,23 @@ def kernel_name() -> str:
 
 
 def profiled_traffic(workload: str, B: int, name: str):
-    """HBM bytes per launch from the committed PMC passes (tools/profile.sh), only for the instance that ran."""
+    """HBM bytes per launch from the committed PMC passes (tools/profile.sh -> profiles/traffic.json) -- attached only when
+    the entry was profiled on the same kernel INSTANCE and the same kernel SOURCES as this run (`_abi.kernel_source_hash`: the
+    PMC passes need rocprofv3 around the whole process, so the line cannot sample them itself; a kernel edit that keeps the
+    instance's name must not keep its traffic).  Returns (bytes or None, provenance)."""
+    from dynode_amd import _abi
+
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    here = _abi.kernel_source_hash()
     if not os.path.exists(tpath):
-        return None
+        return None, {"kernel_source_hash": here, "profiled": None}
     rec = json.load(open(tpath)).get(f"{workload}:{B}")
-    if rec and rec.get("kernel") == name:
-        return rec["hbm_bytes_per_launch"]
-    return None
+    prov = {"kernel_source_hash": here, "profiled": None if not rec else {k: rec.get(k) for k in ("rev", "kernel_source_hash", "source")}}
+    if rec and rec.get("kernel") == name and rec.get("kernel_source_hash") == here:
+        return rec["hbm_bytes_per_launch"], prov
+    if rec:
+        prov["stale"] = "instance differs" if rec.get("kernel") != name else "kernel sources changed since the profile"
+    return None, prov
 
 
 def measure(wl, dev, steps: int, warmup: int, fence, order_hint_too=True):
@@ -364,8 +373,9 @@ def measured_device_bandwidth(dev, out_bytes: int):
 def roofline_block(wl, workload: str, res):
     bytes_traj = wl.bytes_per_trajectory(4)
     achieved = bytes_traj * wl.B / (res["kernel_ms"] * 1e-3) / 1e9  # GB/s per GPU, dominant (only) kernel
+    traffic, prov = profiled_traffic(workload, wl.B, res["kernel"])
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": profiled_traffic(workload, wl.B, res["kernel"]), "kernel": res["kernel"], "kernel_ms": res["kernel_ms"],
+            "traffic": traffic, "traffic_provenance": prov, "kernel": res["kernel"], "kernel_ms": res["kernel_ms"],
             "algorithmic_bytes_per_trajectory": bytes_traj, "trajectories_per_launch": wl.B, "dispatch_order": res["dispatch_order"]}
 
 
@@ -448,7 +458,14 @@ def main():
         wave_iters = float(attempts.amax(dim=1).float().mean())
 
     shards_match, shard_digests = None, None
+    ranks_seen, per_rank = 1, None
     if world > 1:
+        # what the process group itself says (not the environment), and every rank's own clock: a SCALE record checks itself
+        ranks_seen = int(dist.get_world_size())
+        mine_t = torch.tensor([float(rank), elapsed / args.steps * 1e3, kern_ms, float(torch.cuda.current_device())], dtype=torch.float64, device=cdev)
+        every_t = [torch.empty_like(mine_t) for _ in range(world)]
+        dist.all_gather(every_t, mine_t)
+        per_rank = [{"rank": int(e[0]), "ms_per_step": float(e[1]), "kernel_ms": float(e[2]), "device": int(e[3])} for e in (x.cpu() for x in every_t)]
         t = torch.tensor([elapsed, kern_ms], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kern_ms = float(t[0]), float(t[1])
@@ -500,6 +517,10 @@ def main():
                 "mean_loop_iterations_per_wave": wave_iters,
                 "all_status_ok": ok,
                 "parallelism": f"{world} x independent shards, no data-path collective",
+                # N > 1: dist.get_world_size() after init_process_group, the backend, and every rank's own timing (value uses the MAX)
+                "ranks_seen": ranks_seen,
+                "backend": (dist.get_backend() if world > 1 else None),
+                "per_rank": per_rank,
                 "shards_match_single_process": shards_match,
                 # per rank: [status sum, index-weighted accepted / rejected step counts, float64 sum of the output, of |last row|]
                 "shard_digests": shard_digests,

@@ -24,6 +24,23 @@ ERR_NAMES = {
 }
 
 # every symbol include/dynode_hip.h declares (checked by tests/test_abi.py)
+def kernel_source_hash() -> str:
+    """sha1 (12 hex digits) over the kernel sources the library is built from -- dynode_amd/csrc/*.{hip,hpp,inc,def}, its
+    Makefile and include/dynode_hip.h.  Computable wherever the tree is (the GPU box has no .git): a profile records it
+    (tools/summarize_prof.py -> profiles/traffic.json) and bench.py attaches profiled HBM traffic to its line only when the
+    sources it runs are the sources that were profiled."""
+    import hashlib
+
+    csrc = os.path.join(_HERE, "csrc")
+    files = sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".hpp", ".inc", ".def")) or f == "Makefile")
+    files.append(os.path.join(os.path.dirname(_HERE), "include", "dynode_hip.h"))
+    h = hashlib.sha1()
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:12]
+
+
 EXPORTED_SYMBOLS = (
     "dyn_abi_version", "dyn_state_dim", "dyn_param_dim", "dyn_n_compartments",
     "dyn_compartment_offsets", "dyn_is_supported", "dyn_trajectories_per_wave", "dyn_trajectories_per_wave_for_batch",

@@ -53,6 +53,10 @@ def test_bench_two_ranks_weak_scaling_rehearsal():
     assert d["value"] > 0 and d["config"]["trajectories_per_gpu"] == 16384
     # value = trajectories of BOTH ranks over the max-over-ranks wall clock
     assert abs(d["value"] - 2 * 16384 * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-9
+    # the line checks itself: the process group's own size and backend, and every rank's clock (the line's is their maximum)
+    assert d["config"]["ranks_seen"] == 2 and d["config"]["backend"] == "gloo"
+    per_rank = d["config"]["per_rank"]
+    assert [r["rank"] for r in per_rank] == [0, 1] and max(r["ms_per_step"] for r in per_rank) <= d["ms_per_step"] * (1 + 1e-9)
 
 
 def test_bench_two_ranks_strong_scaling_equals_one_process():

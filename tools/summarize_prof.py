@@ -37,6 +37,13 @@ def build_rev() -> str:
         return "unknown"
 
 
+def kernel_source_hash() -> str:
+    sys.path.insert(0, root)
+    from dynode_amd import _abi
+
+    return _abi.kernel_source_hash()
+
+
 def instance_name(raw: str) -> str:
     """rocprofv3 prints `void dyn::solve_kernel<...>(dyn::KArgs<float>)`; dyn_last_kernel_name() returns the middle part."""
     name = raw.strip().strip('"')
@@ -55,7 +62,7 @@ batch = batch or defaults[workload]
 
 kernel = instance_name(stats["Name"]) if stats else None
 lines = [f"# rocprofv3 summary `{tag}` -- bench.py --workload {workload} (B={batch} per GPU)", "",
-         f"- source revision: `{build_rev()}`", f"- dispatched instance: `{kernel}`", ""]
+         f"- source revision: `{build_rev()}` (kernel sources: `{kernel_source_hash()}`)", f"- dispatched instance: `{kernel}`", ""]
 if stats:
     lines += ["## kernel-trace --stats (bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extra: 50 timed launches behind the untimed ones -- settle phase of >= 40 ms of work + 5 warm-up: `calls` counts them all --, the batch "
               "in its given order -- no forecast, nothing carried over between launches)", "",
@@ -107,6 +114,7 @@ if hbm:
     tp = os.path.join(root, "profiles", "traffic.json")
     rec = json.load(open(tp)) if os.path.exists(tp) else {}
     rec[f"{workload}:{batch}"] = {"hbm_bytes_per_launch": hbm, "read_bytes": rd, "write_bytes": wr, "source": f"profiles/{tag}_rocprof_summary.md",
-                                  "kernel": kernel, "rev": build_rev(), "kernel_avg_ns": float(stats["AverageNs"]) if stats else None}
+                                  "kernel": kernel, "rev": build_rev(), "kernel_source_hash": kernel_source_hash(),
+                                  "kernel_avg_ns": float(stats["AverageNs"]) if stats else None}
     json.dump(rec, open(tp, "w"), indent=1, sort_keys=True)
 print("\n".join(lines))
