@@ -54,7 +54,8 @@ EXPORTED_SYMBOLS = (
 MAX_SITES = 8
 DIST_NORMAL, DIST_UNIFORM, DIST_BETA, DIST_TRUNCNORMAL = 0, 1, 2, 3
 
-NUTS_MAX_DIM, NUTS_MAX_DEPTH, NUTS_MAX_WINDOWS = 8, 10, 16
+NUTS_MAX_DIM, NUTS_MAX_DEPTH, NUTS_MAX_WINDOWS = 32, 10, 16
+NUTS_REG_DIM = 8        # up to here: pooled windows, the mapped / fused sampler forms (csrc/nuts_device.hpp kRegDim)
 # pointer members of dyn_nuts_state, in declaration order (include/dynode_hip.h)
 NUTS_POINTER_FIELDS = (
     "z_eval", "u_new", "g_new", "z", "u", "g", "eps", "eps_avg", "da_mu", "da_xbar", "da_gbar", "da_t",

@@ -49,9 +49,16 @@ __device__ inline double logaddexp(double a, double b) {
     return m + log1p(exp(-fabs(a - b)));
 }
 
-// y = M v for a row-major D x D matrix (D is a compile-time constant: everything stays in registers)
-template <int D>
-__device__ inline void matvec(const double *M, const double *v, double *y) {
+// The dimension of a chain is a compile-time constant up to kRegDim (DMAX = D: every loop unrolls, every vector lives in
+// registers) and a run-time number beyond (DMAX = DYN_NUTS_MAX_DIM: the same code with loops over st.dim and the per-chain
+// vectors / matrices in scratch and L2 -- one thread per chain still; at 32 dimensions a matrix-vector product is 1024
+// multiply-adds, about the cost of a tenth of a gradient-solve).  The helpers take D as an argument and are always inlined, so
+// a constant D propagates.
+constexpr int kRegDim = 8;
+
+// y = M v for a row-major D x D matrix
+template <int DMAX>
+__device__ __forceinline__ void matvec(const double *M, const double *v, double *y, const int D) {
 #pragma unroll
     for (int i = 0; i < D; ++i) {
         double a = 0;
@@ -60,27 +67,28 @@ __device__ inline void matvec(const double *M, const double *v, double *y) {
         y[i] = a;
     }
 }
-template <int D>
-__device__ inline double dot(const double *a, const double *b) {
+template <int DMAX>
+__device__ __forceinline__ double dot(const double *a, const double *b, const int D) {
     double s = 0;
 #pragma unroll
     for (int i = 0; i < D; ++i) s += a[i] * b[i];
     return s;
 }
-template <int D>
-__device__ inline bool is_turning(const double *imm, const double *rl, const double *rr, const double *rsum) {
-    double rs[D], vl[D], vr[D];
+template <int DMAX>
+__device__ __forceinline__ bool is_turning(const double *imm, const double *rl, const double *rr, const double *rsum, const int D) {
+    double rs[DMAX], vl[DMAX], vr[DMAX];
 #pragma unroll
     for (int i = 0; i < D; ++i) rs[i] = rsum[i] - 0.5 * (rl[i] + rr[i]);
-    matvec<D>(imm, rl, vl);
-    matvec<D>(imm, rr, vr);
-    return dot<D>(vl, rs) <= 0.0 || dot<D>(vr, rs) <= 0.0;
+    matvec<DMAX>(imm, rl, vl, D);
+    matvec<DMAX>(imm, rr, vr, D);
+    return dot<DMAX>(vl, rs, D) <= 0.0 || dot<DMAX>(vr, rs, D) <= 0.0;
 }
 
-// mm_sqrt = chol(inv(imm)) for a symmetric positive definite D x D (Gauss-Jordan + Cholesky)
-template <int D>
-__device__ inline void mass_sqrt(const double *imm, double *out) {
-    double a[D * D], inv[D * D];
+// mm_sqrt = chol(inv(imm)) for a symmetric positive definite D x D (Gauss-Jordan + Cholesky).  `a` and `inv`: D x D of
+// workspace each (local arrays below kRegDim; beyond, the chain's idle Welford accumulator and `out` itself -- the Cholesky
+// factor overwrites the lower triangle of the inverse in place, reading the symmetric partner from the upper one, and the
+// upper triangle is cleared at the end: the same operations in the same order either way).
+__device__ inline void mass_sqrt_into(const double *imm, double *out, double *a, double *inv, const int D) {
     for (int i = 0; i < D * D; ++i) a[i] = imm[i];
     for (int i = 0; i < D; ++i)
         for (int j = 0; j < D; ++j) inv[i * D + j] = i == j ? 1.0 : 0.0;
@@ -93,26 +101,34 @@ __device__ inline void mass_sqrt(const double *imm, double *out) {
             for (int j = 0; j < D; ++j) { a[r * D + j] -= f * a[c * D + j]; inv[r * D + j] -= f * inv[c * D + j]; }
         }
     }
-    for (int i = 0; i < D * D; ++i) out[i] = 0.0;
     for (int i = 0; i < D; ++i)
         for (int j = 0; j <= i; ++j) {
             double s = 0.5 * (inv[i * D + j] + inv[j * D + i]);
             for (int k = 0; k < j; ++k) s -= out[i * D + k] * out[j * D + k];
             out[i * D + j] = i == j ? sqrt(fmax(s, 1e-300)) : s / out[j * D + j];
         }
+    for (int i = 0; i < D; ++i)
+        for (int j = i + 1; j < D; ++j) out[i * D + j] = 0.0;
+}
+template <int DMAX>
+__device__ inline void mass_sqrt(const double *imm, double *out, const int D) {
+    double a[DMAX * DMAX], inv[DMAX * DMAX];
+    mass_sqrt_into(imm, out, a, inv, D);
 }
 
 // What the solve handed over for chain c: the likelihood side of the potential at z_eval.  `nuts_advance` reads it from the
 // buffers of the launch before it; the fused gradient-solve (solve_kernel.hpp, FEAT bit 12) from what its own wave just wrote.
-template <int D>
+template <int DMAX>
 struct Handed {
     double ll;
-    double dll[D];
+    double dll[DMAX];
 };
 
-// One sampler iteration of chain c (everything between two potential evaluations).
-template <int D, typename ST, typename MAP>
-__device__ __forceinline__ void advance_chain(const ST &st, const MAP &map, const int c, const Handed<D> &handed) {
+// One sampler iteration of chain c (everything between two potential evaluations).  RT: the dimension is st.dim (<= DMAX)
+// instead of DMAX itself (see kRegDim above).
+template <int DMAX, bool RT, typename ST, typename MAP>
+__device__ __forceinline__ void advance_chain(const ST &st, const MAP &map, const int c, const Handed<DMAX> &handed) {
+    const int D = RT ? (int)st.dim : DMAX;
     const int C = st.n_chains, Dm = st.max_depth;
     if (c >= C) return;
     const int total = st.num_warmup + st.num_samples;
@@ -178,7 +194,7 @@ __device__ __forceinline__ void advance_chain(const ST &st, const MAP &map, cons
     // ---- finish the leapfrog started by the previous launch: second momentum half step
     // the potential at z_eval: handed over as (u, g), or -- folded potential, infer/folded.py -- as its parts, combined here
     // instead of in a launch of their own: u = -(lp + ll + offset), g = -(dlp + dll)
-    double un, gn[D];
+    double un, gn[DMAX];
     if (st.pot_lp != nullptr) {
         un = -(st.pot_lp[c] + handed.ll + st.pot_offset);
         for (int i = 0; i < D; ++i) gn[i] = -(st.pot_dlp[(int64_t)c * D + i] + handed.dll[i]);
@@ -187,12 +203,12 @@ __device__ __forceinline__ void advance_chain(const ST &st, const MAP &map, cons
         for (int i = 0; i < D; ++i) gn[i] = st.g_new[(int64_t)c * D + i];
     }
     const double *zn = st.z_eval + (int64_t)c * D;
-    double rn[D], tmp[D];
+    double rn[DMAX], tmp[DMAX];
     bool bad = !isfinite(un);
     for (int i = 0; i < D; ++i) bad = bad || !isfinite(gn[i]);
     for (int i = 0; i < D; ++i) rn[i] = p_r_half[i] - 0.5 * eps_signed * (bad ? 0.0 : gn[i]);
-    matvec<D>(imm, rn, tmp);
-    double de = (bad ? INFINITY : un) + 0.5 * dot<D>(rn, tmp) - L_e0;
+    matvec<DMAX>(imm, rn, tmp, D);
+    double de = (bad ? INFINITY : un) + 0.5 * dot<DMAX>(rn, tmp, D) - L_e0;
     if (isnan(de)) de = INFINITY;
     const double lw = -de;
     const bool div = de > st.max_delta_energy;
@@ -225,9 +241,9 @@ __device__ __forceinline__ void advance_chain(const ST &st, const MAP &map, cons
         for (int i = 0; i < D; ++i) { r_ck[idx_max * D + i] = rn[i]; rs_ck[idx_max * D + i] = s_rsum[i]; }
     } else {
         for (int l = idx_max; l >= idx_min; --l) {
-            double sub[D];
+            double sub[DMAX];
             for (int i = 0; i < D; ++i) sub[i] = s_rsum[i] - rs_ck[l * D + i] + r_ck[l * D + i];
-            s_turn = s_turn || is_turning<D>(imm, r_ck + l * D, rn, sub);
+            s_turn = s_turn || is_turning<DMAX>(imm, r_ck + l * D, rn, sub, D);
         }
     }
     ++leaf;
@@ -250,7 +266,7 @@ __device__ __forceinline__ void advance_chain(const ST &st, const MAP &map, cons
         L_sum_acc += s_acc;
         L_n_prop += s_n;
         ++depth;
-        stop = s_turn || s_div || is_turning<D>(imm, p_rl, p_rr, p_r_sum) || depth >= Dm;
+        stop = s_turn || s_div || is_turning<DMAX>(imm, p_rl, p_rr, p_r_sum, D) || depth >= Dm;
     }
 
     double eps = L_eps;
@@ -271,19 +287,19 @@ __device__ __forceinline__ void advance_chain(const ST &st, const MAP &map, cons
             L_da_t = t1; L_da_gbar = gbar; L_da_xbar = xbar;
             eps = exp(x);
             L_eps_avg = exp(xbar);
-            if (st.pooled && L_pend > 0) {
+            if constexpr (!RT) if (st.pooled && L_pend > 0) {   // (pooled windows: up to kRegDim dimensions, dyn_nuts_advance checks)
                 // pooled window statistics of every chain that has closed this window so far
                 // (pool_ro = the pool as it stood after the previous launch: no concurrent writers)
                 const int64_t *pw = st.pool_ro + (int64_t)(L_pend - 1) * (1 + D + D * D);
                 const double N = (double)pw[0], nn = fmax(N, 2.0);
-                double mu[D], cand[D * D], chol[D * D];
+                double mu[DMAX], cand[DMAX * DMAX], chol[DMAX * DMAX];
                 for (int i = 0; i < D; ++i) mu[i] = (double)pw[1 + i] / POOL_SCALE / N;
                 for (int i = 0; i < D; ++i)
                     for (int j = 0; j < D; ++j) {
                         const double cov = ((double)pw[1 + D + i * D + j] / POOL_SCALE - N * mu[i] * mu[j]) / (nn - 1.0);
                         cand[i * D + j] = (nn / (nn + 5.0)) * cov + (i == j ? 1e-3 * (5.0 / (nn + 5.0)) : 0.0);
                     }
-                mass_sqrt<D>(cand, chol);
+                mass_sqrt<DMAX>(cand, chol, D);
                 bool good = N >= 2.0;
                 for (int i = 0; i < D * D; ++i) good = good && isfinite(cand[i]) && isfinite(chol[i]);
                 for (int i = 0; i < D; ++i) good = good && chol[i * D + i] > 0.0 && cand[i * D + i] > 0.0;
@@ -299,7 +315,7 @@ __device__ __forceinline__ void advance_chain(const ST &st, const MAP &map, cons
             const int wi = L_wi;
             if (wi < st.n_windows && it >= st.w_start[wi] && it < st.w_end[wi]) {
                 const double n1 = L_wf_n + 1.0;
-                double d0[D];
+                double d0[DMAX];
                 double *mean = p_wf_mean, *m2 = p_wf_m2;
                 for (int i = 0; i < D; ++i) { d0[i] = z[i] - mean[i]; mean[i] += d0[i] / n1; }
                 for (int i = 0; i < D; ++i)
@@ -325,7 +341,8 @@ __device__ __forceinline__ void advance_chain(const ST &st, const MAP &map, cons
                             for (int j = 0; j < D; ++j)
                                 imm[i * D + j] = (nn / (nn + 5.0)) * m2[i * D + j] / (nn - 1.0) +
                                                  (i == j ? 1e-3 * (5.0 / (nn + 5.0)) : 0.0);
-                        mass_sqrt<D>(imm, mms);
+                        if constexpr (RT) mass_sqrt_into(imm, mms, m2, mms, D);   // (m2 is cleared below; the inverse is built in mms itself)
+                        else mass_sqrt<DMAX>(imm, mms, D);
                         eps = L_eps_avg; // restart dual averaging around the running average
                         L_da_mu = log(10.0 * eps);
                         L_da_t = 0.0; L_da_gbar = 0.0; L_da_xbar = 0.0;
@@ -361,11 +378,11 @@ __device__ __forceinline__ void advance_chain(const ST &st, const MAP &map, cons
         L_eps = eps;
         L_it = ++it;
         // fresh momentum r0 = chol(M) * normal, new trajectory = the single point (z, r0)
-        double nrm[D], r0[D];
+        double nrm[DMAX], r0[DMAX];
         for (int i = 0; i < D; ++i) nrm[i] = rng.normal();
-        matvec<D>(mms, nrm, r0);
-        matvec<D>(imm, r0, tmp);
-        L_e0 = L_u + 0.5 * dot<D>(r0, tmp);
+        matvec<DMAX>(mms, nrm, r0, D);
+        matvec<DMAX>(imm, r0, tmp, D);
+        L_e0 = L_u + 0.5 * dot<DMAX>(r0, tmp, D);
         for (int i = 0; i < D; ++i) {
             p_zl[i] = p_zr[i] = p_zp[i] = z[i];
             p_rl[i] = p_rr[i] = p_r_sum[i] = r0[i];
@@ -402,10 +419,10 @@ __device__ __forceinline__ void advance_chain(const ST &st, const MAP &map, cons
 
     // ---- first half of the next leapfrog: r_half, and the position the potential is needed at
     const double es = eps * (go_right ? 1.0 : -1.0);
-    double rh[D];
+    double rh[DMAX];
     for (int i = 0; i < D; ++i) rh[i] = rc[i] - 0.5 * es * gc[i];
-    matvec<D>(imm, rh, tmp);
-    double ze[D];
+    matvec<DMAX>(imm, rh, tmp, D);
+    double ze[DMAX];
     for (int i = 0; i < D; ++i) {
         p_r_half[i] = rh[i];
         ze[i] = (it >= total) ? z[i] : zc[i] + es * tmp[i];
@@ -473,7 +490,7 @@ __device__ __forceinline__ void tail_chain(const TL &tl, const int c, const doub
     Handed<D> handed;
     handed.ll = load_written(ll_out + (int64_t)c * tl.rows_per_chain);
     for (int i = 0; i < D; ++i) handed.dll[i] = load_written(dll_out + (int64_t)c * D + i); // [C rows][D / rows] flat == [C][D]
-    advance_chain<D>(tl.st, tl.map, c, handed);
+    advance_chain<D, false>(tl.st, tl.map, c, handed);
 }
 
 constexpr int kFusedMaxDim = 4;

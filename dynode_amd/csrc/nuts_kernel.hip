@@ -32,7 +32,17 @@ __global__ void __launch_bounds__(64) nuts_advance(const dyn_nuts_state st, cons
         handed.ll = st.pot_ll[(int64_t)c * st.pot_ll_stride];
         for (int i = 0; i < D; ++i) handed.dll[i] = st.pot_dll[(int64_t)c * D + i];
     }
-    advance_chain<D>(st, map, c, handed);
+    advance_chain<D, false>(st, map, c, handed);
+}
+
+// ... beyond kRegDim dimensions: the same state machine with the dimension a run-time number (nuts_device.hpp).  The
+// potential arrives as (u_new, g_new) -- the mapped / folded forms stop at DYN_MAX_SITES = kRegDim sites.
+__global__ void __launch_bounds__(64) nuts_advance_any_dim(const dyn_nuts_state st, const dynlat::MapArgs map) {
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= st.n_chains) return;
+    Handed<DYN_NUTS_MAX_DIM> handed;
+    handed.ll = 0.0;
+    advance_chain<DYN_NUTS_MAX_DIM, true>(st, map, c, handed);
 }
 
 } // namespace dynnuts
@@ -55,9 +65,16 @@ static int advance(const dyn_nuts_state *st, const dynlat::MapArgs &map, void *s
     const unsigned blocks = (unsigned)((st->n_chains + 63) / 64);
     if (st->pooled && (!st->pool || !st->pool_ro || !st->pend)) return DYN_ERR_NULL;
     using Kern = void (*)(const dyn_nuts_state, const dynlat::MapArgs);
-    static const Kern kernels[DYN_NUTS_MAX_DIM] = {
+    static_assert(dynnuts::kRegDim == 8, "one compile-time instance per dimension up to kRegDim");
+    static const Kern kernels[dynnuts::kRegDim] = {
         dynnuts::nuts_advance<1>, dynnuts::nuts_advance<2>, dynnuts::nuts_advance<3>, dynnuts::nuts_advance<4>,
         dynnuts::nuts_advance<5>, dynnuts::nuts_advance<6>, dynnuts::nuts_advance<7>, dynnuts::nuts_advance<8>};
+    if (st->dim > dynnuts::kRegDim) {
+        // the run-time-dimension instance: plain (u_new, g_new) potential, per-chain adaptation
+        if (st->pooled || st->pot_lp != nullptr || map.enabled) return DYN_ERR_UNSUPPORTED;
+        hipLaunchKernelGGL(dynnuts::nuts_advance_any_dim, dim3(blocks), dim3(64), 0, (hipStream_t)stream, *st, map);
+        return hipGetLastError() == hipSuccess ? 0 : DYN_ERR_LAUNCH;
+    }
     hipLaunchKernelGGL(kernels[st->dim - 1], dim3(blocks), dim3(64), 0, (hipStream_t)stream, *st, map);
     if (hipGetLastError() != hipSuccess) return DYN_ERR_LAUNCH;
     if (st->pooled) {

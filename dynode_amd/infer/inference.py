@@ -442,8 +442,20 @@ class MCMCProcess(InferenceProcess):
             self._inference_complete, self._inferer, self._inference_state = True, out, out.last_state
             self._inferer_kwargs = kwargs
             return out
-        if kind == "kernel" and (pot.dim > 8 or self.nuts_max_tree_depth > 10):
+        from .. import _abi
+
+        if kind == "kernel" and (pot.dim > _abi.NUTS_MAX_DIM or self.nuts_max_tree_depth > _abi.NUTS_MAX_DEPTH):
+            # beyond what the sampler kernel is compiled for: the torch-op sampler under a HIP graph -- the same algorithm,
+            # ~400 small launches per iteration instead of one.  Said out loud: it is a different performance class.
+            import warnings
+
+            warnings.warn(f"MCMCProcess: {pot.dim} sampled dimensions / tree depth {self.nuts_max_tree_depth} exceed the sampler kernel's "
+                          f"limits ({_abi.NUTS_MAX_DIM} / {_abi.NUTS_MAX_DEPTH}, include/dynode_hip.h): running the torch-op sampler "
+                          f"(mcmc_kwargs={{'sampler': 'graph'}}) instead of dyn_nuts_advance", RuntimeWarning, stacklevel=2)
             kind = "graph"
+        if kind == "kernel" and pot.dim > _abi.NUTS_REG_DIM and self.mcmc_kwargs.get("adaptation", "per_chain") == "pooled":
+            raise NotImplementedError(f"adaptation='pooled' is compiled for up to {_abi.NUTS_REG_DIM} sampled dimensions (this model: {pot.dim}); "
+                                      "use the default per-chain adaptation")
         cls = {"kernel": KernelNUTS, "graph": GraphNUTS, "eager": BatchedNUTS}[kind]
         extra = {"adaptation": self.mcmc_kwargs.get("adaptation", "per_chain"),
                  "fuse": bool(self.mcmc_kwargs.get("fuse", True))} if kind == "kernel" else {}
@@ -494,6 +506,9 @@ class MCMCProcess(InferenceProcess):
             res.samples, res.accept_prob = res.samples[:, keep].contiguous(), res.accept_prob[:, keep].contiguous()
             res.num_steps, res.diverging = res.num_steps[:, keep].contiguous(), res.diverging[:, keep].contiguous()
         out = MCMCResult(pot, res, local)
+        # which sampler ran (a class name of infer/nuts.py) and, for the kernel sampler, launches per iteration (1: fused into the
+        # gradient-solve; 2: gradient-solve + dyn_nuts_advance_mapped; None: a general potential's launches + dyn_nuts_advance)
+        out.sampler, out.launches_per_iteration = type(sampler).__name__, getattr(sampler, "launches_per_iteration", None)
         self._inference_complete, self._inferer, self._inference_state = True, out, out.last_state
         self._inferer_kwargs = kwargs
         return out

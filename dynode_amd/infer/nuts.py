@@ -794,7 +794,8 @@ class KernelNUTS(LockstepNUTS):
     thread per chain: leapfrog halves, tree, adaptation incl. the mass-matrix Cholesky, recording,
     counter-based Philox randomness), captured together in one HIP graph.  The host replays the
     graph and looks at the per-chain transition counters every `block` iterations.  Needs the HIP
-    library and device tensors (no CPU form); dimension <= 8, tree depth <= 10.
+    library and device tensors (no CPU form); dimension <= 32 (one compiled instance per dimension up to 8, a run-time-dimension
+    instance beyond), tree depth <= 10.
 
     ``adaptation="per_chain"`` is numpyro's behaviour: every chain estimates its own dense mass
     matrix from its own window.  ``"pooled"`` merges the window statistics of all chains of this
@@ -839,6 +840,8 @@ class KernelNUTS(LockstepNUTS):
         windows = _adaptation_windows(num_warmup, 25 if early else 75)
         if D > _abi.NUTS_MAX_DIM or Dm > _abi.NUTS_MAX_DEPTH or len(windows) > _abi.NUTS_MAX_WINDOWS:
             raise ValueError(f"KernelNUTS supports dim <= {_abi.NUTS_MAX_DIM}, max_tree_depth <= {_abi.NUTS_MAX_DEPTH}")
+        if D > _abi.NUTS_REG_DIM and self.adaptation == "pooled":
+            raise ValueError(f"pooled adaptation windows are compiled for dim <= {_abi.NUTS_REG_DIM}")
         L = _abi.lib()
         total = num_warmup + num_samples
         gen = torch.Generator(device=dev).manual_seed(self.seed)

@@ -333,11 +333,13 @@ int32_t dyn_is_supported_jvp(const dyn_model_desc *m, const dyn_solver_opts *o, 
  * every call costs every unfinished chain exactly one gradient.  All arrays are device arrays,
  * row-major with the chain index first; real = float64.
  */
-#define DYN_NUTS_MAX_DIM 8
+#define DYN_NUTS_MAX_DIM 32 /* up to 8: one compiled instance per dimension, a chain's vectors in registers; 9..32: one instance with
+                               the dimension a run-time number (plain u_new / g_new potential, per-chain adaptation: pooled windows
+                               and the mapped / fused forms stop at 8 -- DYN_ERR_UNSUPPORTED beyond) */
 #define DYN_NUTS_MAX_DEPTH 10
 #define DYN_NUTS_MAX_WINDOWS 16
 typedef struct dyn_nuts_state {
-    int32_t n_chains, dim, max_depth;  /* dim <= DYN_NUTS_MAX_DIM, max_depth <= DYN_NUTS_MAX_DEPTH */
+    int32_t n_chains, dim, max_depth;  /* dim <= DYN_NUTS_MAX_DIM (32), max_depth <= DYN_NUTS_MAX_DEPTH */
     int32_t num_warmup, num_samples;
     int32_t n_windows;                 /* slow adaptation windows [w_start, w_end) in transitions */
     int32_t pooled;                    /* 0: every chain adapts its own mass matrix (numpyro);

@@ -136,8 +136,12 @@ def test_sampler_entry_validates_before_launching():
     lib = _abi.lib()
     assert lib.dyn_nuts_advance(None, None) == -1
     st = _abi.NutsStateC()
-    st.n_chains, st.dim, st.max_depth = 4, 9, 5           # dimension above DYN_NUTS_MAX_DIM
+    st.n_chains, st.dim, st.max_depth = 4, 33, 5          # dimension above DYN_NUTS_MAX_DIM
     assert lib.dyn_nuts_advance(ctypes.byref(st), None) == -3
+    st.dim, st.pooled = 9, 1                              # pooled windows stop at 8 dimensions: refused before any pointer is read
+    st.pool = st.pool_ro = st.pend = 8                    # (non-null)
+    assert lib.dyn_nuts_advance(ctypes.byref(st), None) == -7
+    st.pooled = 0
     st.dim, st.max_depth = 2, 11
     assert lib.dyn_nuts_advance(ctypes.byref(st), None) == -3
     st.max_depth, st.n_chains = 5, 0                      # no chains: nothing to do, no launch

@@ -897,3 +897,75 @@ def test_default_nuts_fits_the_seip_model_with_adaptive_steps():
         chi.mean(), chi.std(), r0.mean(), r0.std(), float(mcmc.nuts.accept_prob.mean()), float(mcmc.nuts.num_steps.double().mean())))
     assert abs(chi.mean() - 0.45) < max(3 * chi.std(), 0.02) and abs(r0.mean() - 2.4) < max(3 * r0.std(), 0.01)
     assert chi.std() < 0.05 and r0.std() < 0.02 and float(mcmc.nuts.accept_prob.mean()) > 0.6
+
+
+@pytest.mark.parametrize("sites", [6, 9])
+def test_kernel_sampler_on_the_multi_strain_model_agrees_with_the_gradient_free_sampler(sites):
+    """the reference's 2-age x 3-strain model (examples/seirs_multi_strain_age_stratified.py:46-49,187-209)
+    with priors on every strain's r0 and infectious period (6 sampled dimensions) and, second case, latent period (9: beyond the
+    eight per-dimension instances, `dyn_nuts_advance`'s run-time-dimension instance).  The sampler kernel must be what runs --
+    no torch-op downgrade -- and its posterior must agree, site by site, with the gradient-free ensemble sampler's
+    (infer/ensemble.py: stretch moves, no tangents, no mass matrix): two-sample KS p > 0.01 on thinned draws."""
+    from dynode_amd import _abi
+    from examples import infer_multi_strain as ex_m
+
+    obs = ex_m.synthetic_incidence(120)
+    assert obs.shape == (120, 2, 3)
+    kw = dict(config=ex_m.get_config(sites), tf=120, obs_data=obs)
+    nuts = MCMCProcess(numpyro_model=ex_m.model, num_warmup=400, num_samples=400, num_chains=64, nuts_max_tree_depth=8, progress_bar=False)
+    mcmc = nuts.infer(**kw)
+    assert mcmc.sampler == "KernelNUTS" and mcmc.potential.dim == sites
+    if sites <= 8:          # folded potential: the gradient-solve (one tangent direction per trajectory row) + dyn_nuts_advance_mapped
+        assert mcmc.launches_per_iteration == 2
+        assert _abi.lib().dyn_last_kernel_name().decode().startswith("dyn::solve_kernel<float, 0, 2, 3, true, true, true, 1, 1, 3")
+    post = nuts.get_samples(group_by_chain=True)
+    assert len(post) == sites and int(mcmc.nuts.diverging.sum()) <= 20
+    ens = MCMCProcess(numpyro_model=ex_m.model, num_warmup=3000, num_samples=3000, num_chains=128, nuts_max_tree_depth=8, progress_bar=False,
+                      mcmc_kwargs={"sampler": "ensemble"})
+    ens.infer(**kw)
+    post_e = ens.get_samples(group_by_chain=True)
+    truth = dict(zip((f"strains_{k}_r0" for k in range(3)), ex_m.TRUTH["r0s"]))
+    truth.update(zip((f"strains_{k}_infectious_period" for k in range(3)), ex_m.TRUTH["infectious_periods"]))
+    for name in post:
+        a = post[name][:, ::8].reshape(-1).cpu().numpy()            # 64 x 50
+        b = post_e[name][:, ::300].reshape(-1).cpu().numpy()        # 128 x 10: stretch moves decorrelate slowly
+        ks = stats.ks_2samp(a, b)
+        print(f"[{sites} sites] {name}: NUTS {a.mean():.4f} +- {a.std():.4f}, ensemble {b.mean():.4f} +- {b.std():.4f}, KS p {ks.pvalue:.3f}")
+        assert ks.pvalue > 0.01, (name, ks)
+        if name in truth:                                            # noiseless data: the posterior sits on the generating values
+            assert abs(a.mean() - truth[name]) < max(4 * a.std(), 0.02 * truth[name]), (name, a.mean(), truth[name])
+
+
+def test_sampler_kernel_beyond_eight_dimensions_on_a_correlated_gaussian():
+    """The run-time-dimension instance of dyn_nuts_advance (9 .. 32 dimensions; csrc/nuts_device.hpp `advance_chain<DMAX, RT>`)
+    on an analytic 12-dimensional target, and the 8-dimensional compiled instance beside it on the leading 8 x 8 block: moments,
+    per-coordinate KS tests, adapted mass matrices, reproducibility; pooled windows are refused beyond eight dimensions."""
+    from dynode_amd.infer.nuts import KernelNUTS
+
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(5)
+    A = torch.randn(12, 12, generator=g, dtype=torch.float64)
+    cov12 = (A @ A.T / 12.0 + torch.diag(torch.linspace(0.2, 2.0, 12, dtype=torch.float64))).to(dev)
+    for D in (12, 8):
+        cov = cov12[:D, :D].contiguous()
+        prec = torch.linalg.inv(cov)
+
+        def pg(z):
+            gr = z @ prec
+            return 0.5 * (z * gr).sum(-1), gr
+
+        z0 = torch.randn(96, D, generator=g, dtype=torch.float64).to(dev)
+        res = KernelNUTS(pg, max_tree_depth=8, seed=2).run(z0, num_warmup=400, num_samples=400)
+        x = res.samples.reshape(-1, D)
+        assert res.samples.shape == (96, 400, D) and int(res.diverging.sum()) == 0 and 0.6 < float(res.accept_prob.mean()) < 0.95
+        sd = torch.sqrt(torch.diagonal(cov))
+        assert float((x.mean(0) / sd).abs().max()) < 0.06
+        assert float(((torch.cov(x.T) - cov) / (sd[:, None] * sd[None, :])).abs().max()) < 0.08
+        assert float(((res.inverse_mass.mean(0) - cov) / (sd[:, None] * sd[None, :])).abs().max()) < 0.25
+        for d in range(D):
+            thin = res.samples[:, ::10, d].reshape(-1).cpu().numpy()
+            assert stats.kstest(thin, "norm", args=(0.0, float(sd[d]))).pvalue > 1e-3, (D, d)
+        again = KernelNUTS(pg, max_tree_depth=8, seed=2).run(z0, num_warmup=400, num_samples=400)
+        assert torch.equal(again.samples, res.samples)
+    with pytest.raises(ValueError, match="pooled"):
+        KernelNUTS(pg, max_tree_depth=8, seed=2, adaptation="pooled").run(torch.zeros(4, 12, dtype=torch.float64, device=dev), 50, 50)
