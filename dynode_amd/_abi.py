@@ -81,7 +81,7 @@ class ModelDescC(ctypes.Structure):
 class DispatchHintsC(ctypes.Structure):
     """dyn_dispatch_hints (ABI 9): all zero = the library's measured choices.  ``engine.dispatch_hints`` fills it."""
     _fields_ = [(n, ctypes.c_int32) for n in ("pull", "pull_waves", "strains_per_lane", "replicas_log2", "producer_consumer",
-                                              "general_instance", "seip_tier_lanes", "seip_tier_waves")]
+                                              "general_instance", "seip_tier_lanes", "seip_tier_waves", "strict_control")]
 
 
 class SolverOptsC(ctypes.Structure):

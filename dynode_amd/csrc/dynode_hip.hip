@@ -34,7 +34,10 @@ namespace dyn {
     extern template hipError_t launch_seip<T, METHOD, GA, L, K1, M1, KT, NW>(const KArgs<T> &, hipStream_t);
 #define YP(T, METHOD, GA, L, K1, M1, KT, NW) \
     extern template hipError_t launch_seip<T, METHOD, GA, L, K1, M1, KT, NW, 1>(const KArgs<T> &, hipStream_t);
+#define YS(T, METHOD, GA, L, K1, M1, KT, NW) \
+    extern template hipError_t launch_seip<T, METHOD, GA, L, K1, M1, KT, NW, 3>(const KArgs<T> &, hipStream_t);
 #include "seip_instances.def"
+#undef YS
 #undef YP
 #undef YW
 #undef YT
@@ -65,6 +68,10 @@ constexpr int kSeipTierWaves = 0x200; // ... or one tier per tier lane with whol
 // and fourth knot (Seip OPT bit 0);
 // enqueue swaps it in for a call that uses none of them
 constexpr int kSeipPlain = 0x1000;
+// ... a plain instance with the step controller in the oracle's arithmetic (Seip OPT bit 1; test-only, hints.strict_control)
+constexpr int kSeipStrict = 0x2000;
+// FEAT bit 16 (solve_kernel.hpp STRICT_CONTROL): the same for the s/e/i/r/c kernels
+constexpr int kStrictControl = 0x10000;
 // FEAT bit 14 (solve_kernel.hpp SAVE_ALL): variant without the per-round save-offset / store-width tests, picked by
 // enqueue when every compartment is saved into 16-byte aligned rows
 constexpr int kSaveAll = 0x4000;
@@ -116,7 +123,13 @@ static const Entry kEntries[] = {
      kSeip | kSeipPlain |                                                                                        \
          (KT > 2 ? kSeipTierWaves : ((KT == 2 ? kSeipTierLanes : 0) | (NW == 2 ? kSeipWaves2 : (NW == 4 ? kSeipWaves4 : 0)))) | K1, \
      (void *)(hipError_t(*)(const KArgs<T> &, hipStream_t)) & launch_seip<T, METHOD, GA, L, K1, M1, KT, NW, 1>},
+#define YS(T, METHOD, GA, L, K1, M1, KT, NW)                                                                     \
+    {DType<T>::id, METHOD, GA, L, 1, 1, 1, M1, 0, 1,                                                             \
+     kSeip | kSeipPlain | kSeipStrict |                                                                          \
+         (KT > 2 ? kSeipTierWaves : ((KT == 2 ? kSeipTierLanes : 0) | (NW == 2 ? kSeipWaves2 : (NW == 4 ? kSeipWaves4 : 0)))) | K1, \
+     (void *)(hipError_t(*)(const KArgs<T> &, hipStream_t)) & launch_seip<T, METHOD, GA, L, K1, M1, KT, NW, 3>},
 #include "seip_instances.def"
+#undef YS
 #undef YP
 #undef YW
 #undef YT
@@ -165,7 +178,7 @@ static bool matches(const Entry &e, const dyn_model_desc *m, int G, int dtype, i
            e.W == m->n_wane && e.ND == nd && e.FEAT == model_features(m);
 }
 
-static const dyn_dispatch_hints kNoHints = {0, 0, 0, 0, 0, 0, 0, 0};
+static const dyn_dispatch_hints kNoHints = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 
 static const Entry *find_entry(const dyn_model_desc *m, int dtype, int method, int nd = 0, const dyn_dispatch_hints &h = kNoHints) {
     const int G = group_width(m->n_age);
@@ -289,7 +302,7 @@ static void note_kernel(const Entry *e) {
         const int nv = ((k1 + kt - 1) / kt) * (e->W + 3 * e->S);
         if (entry_waves(e) > 1)
             snprintf(tl_kernel, sizeof(tl_kernel), "dyn::seip_kernel_wave_group<%s, %d, %d, %d, %d, %d, %d, %d, %d>", t, e->method, e->G,
-                     e->S, k1, e->W, kt, entry_waves(e), (e->FEAT & kSeipPlain) ? 1 : 0);
+                     e->S, k1, e->W, kt, entry_waves(e), ((e->FEAT & kSeipPlain) ? 1 : 0) | ((e->FEAT & kSeipStrict) ? 2 : 0));
         else
             snprintf(tl_kernel, sizeof(tl_kernel), "dyn::%s<%s, %d, %d, %d, %d, %d, %d, %d>",
                      (e->dtype == DYN_F32 && nv <= 20) ? "seip_kernel_two_waves" : "seip_kernel", t, e->method, e->G, e->S, k1,
@@ -500,6 +513,10 @@ static int enqueue(const Entry *e, const dyn_model_desc *m, const dyn_solver_opt
         const Entry *lean = h.general_instance ? nullptr : find_variant(e, e->FEAT | kLean);
         if (lean) e = lean;
     }
+    if (h.strict_control && !(e->FEAT & kSeip)) {   // test-only twin with the oracle's controller arithmetic, where compiled
+        const Entry *strict = find_variant(e, e->FEAT | kStrictControl);
+        if (strict) e = strict;
+    }
     ka.nuts_tail = nullptr;
     if (o->nuts_tail) {
         // one launch per sampler iteration: only where the wave <-> chain correspondence holds (include/dynode_hip.h)
@@ -661,6 +678,10 @@ static int solve_impl(const dyn_model_desc *m, const dyn_solver_opts *o, const v
             !h.general_instance) {
             const dyn::Entry *plain = dyn::find_variant(e, e->FEAT | dyn::kSeipPlain);
             if (plain) e = plain;
+            if (plain && h.strict_control) {   // test-only twin with the oracle's controller arithmetic, where compiled
+                const dyn::Entry *strict = dyn::find_variant(e, e->FEAT | dyn::kSeipStrict);
+                if (strict) e = strict;
+            }
         }
     } else if (e) e = dyn::entry_for_batch(e, m, o->dtype, o->method, n_dir, B, h);
     if (!e && m->family == 1) {

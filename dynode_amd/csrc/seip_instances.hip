@@ -10,7 +10,9 @@ namespace dyn {
 #define YT(T, METHOD, GA, L, K1, M1) template hipError_t launch_seip<T, METHOD, GA, L, K1, M1, 2>(const KArgs<T> &, hipStream_t);
 #define YW(T, METHOD, GA, L, K1, M1, KT, NW) template hipError_t launch_seip<T, METHOD, GA, L, K1, M1, KT, NW>(const KArgs<T> &, hipStream_t);
 #define YP(T, METHOD, GA, L, K1, M1, KT, NW) template hipError_t launch_seip<T, METHOD, GA, L, K1, M1, KT, NW, 1>(const KArgs<T> &, hipStream_t);
+#define YS(T, METHOD, GA, L, K1, M1, KT, NW) template hipError_t launch_seip<T, METHOD, GA, L, K1, M1, KT, NW, 3>(const KArgs<T> &, hipStream_t);
 #include "seip_instances.def"
+#undef YS
 #undef YP
 #undef YW
 #undef YT

@@ -48,6 +48,8 @@ struct Seip {
     // picks the variant when the call is that): their fields and branches leave the right-hand side and the stepping loop
     // (the D = 960 kernel sat at its register line: docs/perf-log.md, "SEIP plain instances")
     static constexpr bool PLAIN = (OPT & 1) != 0;
+    // OPT bit 1 (test-only instances): the step controller in the oracle's arithmetic -- IEEE division, powf (stepper.hpp)
+    static constexpr bool STRICT_CONTROL = (OPT & 2) != 0;
     // ... and at most two knots per dose spline (the rows hold four: knots beyond the model's own are +inf with coefficient
     // 0, two truncated-power terms that add exactly zero to every evaluation)
     static constexpr int NKC = PLAIN ? 2 : 4;

@@ -408,17 +408,25 @@ template <typename T>
 struct Control {
     using M = Mth<T>;
     // second half of the starting-step heuristic: h1 from max(d1, d2)
+    template <bool STRICT = false>
     static __device__ __forceinline__ T initial_h1(T max_d, T h0) {
-        return (max_d <= T(1e-15)) ? M::max(T(1e-6), h0 * T(1e-3)) : M::pow_fast(T(0.01) / max_d, T(0.2));
+        if constexpr (STRICT && sizeof(T) == 4) return (max_d <= T(1e-15)) ? M::max(T(1e-6), h0 * T(1e-3)) : powf(T(0.01) / max_d, T(0.2));
+        else return (max_d <= T(1e-15)) ? M::max(T(1e-6), h0 * T(1e-3)) : M::pow_fast(T(0.01) / max_d, T(0.2));
     }
     // error norm -> accept?, can the solve go on?, next step factor.  A NaN / inf estimate is a rejected step with
     // infinite error (diffeqsolve replaces NaN by inf before the controller); the solve only fails when the step cannot
     // shrink any further.  factor = clip(safety * err^(-1/order), keep ? 1 : factormin, factormax); err == 0 -> factormax
+    // STRICT (test-only instances, FEAT bit 16 / Seip OPT bit 1): the oracle's float32 arithmetic to the letter -- libm's
+    // correctly rounded powf instead of v_log_f32 / v_exp_f32 -- so that what the fast controller arithmetic costs in
+    // accept / reject decisions can be measured (tests/test_gpu_parity.py)
+    template <bool STRICT = false>
     static __device__ __forceinline__ void decide(T err, T tprev, T dt, bool &keep, bool &finite, T &factor) {
         if (!(err == err)) err = M::inf();
         keep = err < T(1);
         finite = !(err == M::inf() && !(tprev + T(0.2) * dt > tprev));
-        T f = T(0.9) * M::pow_fast(err, T(-0.2));
+        T f;
+        if constexpr (STRICT && sizeof(T) == 4) f = T(0.9) * powf(err, T(-0.2));
+        else f = T(0.9) * M::pow_fast(err, T(-0.2));
         f = M::max(f, keep ? T(1) : T(0.2));
         factor = M::min(f, T(10));
     }
@@ -537,6 +545,8 @@ struct Solver {
     // those trajectories belong to (nuts_device.hpp) -- the sampler iteration as one launch.  Static grids only.
     static constexpr bool FUSED = (FEAT & 0x1000) != 0;
     static_assert(!FUSED || LEAN, "the fused sampler tail rides on the lean instance");
+    // FEAT bit 16 (test-only instances): the step controller in the oracle's arithmetic -- IEEE division, sqrtf, powf (stepper.hpp)
+    static constexpr bool STRICT_CONTROL = (FEAT & 0x10000) != 0;
     // where solve_kernel_fused's second argument (dynnuts::Tail, by value) sits in the kernel-argument segment
     static constexpr size_t kTailOffset = (sizeof(KArgs<T>) + alignof(dynnuts::Tail) - 1) / alignof(dynnuts::Tail) * alignof(dynnuts::Tail);
     static_assert(KV == 0 || ((KV == 2 || KV == 4) && GA % KV == 0), "vaccination tiers: 2 or 4 lanes per age");
@@ -1735,7 +1745,7 @@ namespace dyn {
 // compiler's default range.
 template <typename T, int METHOD, int GA, int ST, int W, int ND, int SPL, int FEAT>
 constexpr int waves_per_simd(bool upper) {
-    return (sizeof(T) == 4 && METHOD == 0 && GA == 8 && ST == 4 && ND == 0 && (FEAT & ~0x4C00) == 0 &&
+    return (sizeof(T) == 4 && METHOD == 0 && GA == 8 && ST == 4 && ND == 0 && (FEAT & ~0x14C00) == 0 &&
             ((W == 8 && SPL == 1) || (W == 1 && SPL == 2))) ? 3 : (upper ? 8 : 1);
 }
 

