@@ -273,6 +273,32 @@ def profiled_traffic(workload: str, B: int, name: str):
     return None, prov
 
 
+def latency_floor(workload: str, B: int, name: str, stats, tpw: int, rep_log2: int = 0):
+    """A launch of at most two waves per SIMD ends when its SLOWEST wave's instruction stream does, however idle the HBM is:
+    floor = (vector instructions of the slowest wave) x 4 cycles (a wave issues at most one vector instruction per four
+    cycles) / clock.  The slowest wave's count = the profiled mean per wave (SQ_INSTS_VALU / SQ_WAVES of this instance,
+    profiles/traffic.json, same kernel sources) x (its loop iterations / the mean over waves), iterations of a wave = the most
+    step attempts among its trajectories.  None without a matching profile entry."""
+    from dynode_amd import _abi
+
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(tpath) or tpw <= 0 or B % tpw:
+        return None
+    rec = json.load(open(tpath)).get(f"{workload}:{B}")
+    if not rec or rec.get("kernel") != name or rec.get("kernel_source_hash") != _abi.kernel_source_hash() or not rec.get("valu_insts_per_wave"):
+        return None
+    # trajectories that share a wave: B / waves of the profiled launch (replicated small states: fewer than `tpw`)
+    g = max(1, int(round(B / rec["waves_per_launch"]))) if rec.get("waves_per_launch") else tpw
+    if B % g:
+        return None
+    iters = (stats[1] + stats[2]).reshape(B // g, g).amax(dim=1).float()
+    slowest = rec["valu_insts_per_wave"] * float(iters.max() / iters.mean())
+    clock = rec.get("clock_ghz") or 2.4
+    return {"latency_floor_ms": slowest * 4.0 / (clock * 1e9) * 1e3, "valu_insts_slowest_wave": slowest, "clock_ghz": clock,
+            "iterations_slowest_over_mean": float(iters.max() / iters.mean()),
+            "model": "slowest wave's vector instructions x 4 cycles / clock (profiles/traffic.json: SQ_INSTS_VALU / SQ_WAVES of this instance)"}
+
+
 def measure(wl, dev, steps: int, warmup: int, fence, order_hint_too=True):
     """Resident inputs, `warmup` untimed launches, then `steps` launches with a HIP event pair around each -- the batch in its
     GIVEN order, nothing learned or cached between launches (`solve_batch(order=None)`, the default).  ``order_hint_too``:
@@ -330,6 +356,35 @@ def measure(wl, dev, steps: int, warmup: int, fence, order_hint_too=True):
         torch.cuda.synchronize()
         order_info["with_caller_supplied_order_ms_per_launch"] = float(np.mean([e0.elapsed_time(e1) for e0, e1 in given]))
         order_info["caller_supplied_order"] = "most step attempts first, exact counts of this batch (dyn_solve_batch_ordered): a side figure, not the headline"
+    pipelined = None
+    if order_hint_too and 2 * out.numel() * 4 < 0.5 * torch.cuda.get_device_properties(dev).total_memory:
+        # What an ensemble driver that issues batch after batch would see: launches alternating between TWO streams (own output
+        # buffers), so that the head of launch i + 1 fills the SIMDs the tail of launch i leaves idle (8192 waves over 3072
+        # resident slots = 2.67 rounds: the last round is a third empty).  Sustained ms per launch; a side figure, never `value`.
+        out2, stats2 = torch.empty_like(out), torch.empty_like(stats)
+        streams = (torch.cuda.Stream(), torch.cuda.Stream())
+        bufs = ((out, stats), (out2, stats2))
+        torch.cuda.synchronize()
+        n = 2 * min(steps, 10)
+
+        def both(count):
+            for i in range(count):
+                o, st_ = bufs[i % 2]
+                with torch.cuda.stream(streams[i % 2]):
+                    solve_batch(m, y0, params, contact, wl.t1, ts, dtype=f32, out=o, stats_out=(st_[0], st_[1], st_[2]), stream=streams[i % 2])
+
+        both(4)
+        torch.cuda.synchronize()
+        t_p = time.perf_counter()
+        both(n)
+        torch.cuda.synchronize()
+        pipelined = (time.perf_counter() - t_p) / n * 1e3
+        same = bool(torch.equal(out2, out))
+        order_info["two_stream_pipelined_ms_per_launch"] = pipelined
+        order_info["two_stream_pipelined"] = ("launches alternate between two HIP streams with their own output buffers: launch i + 1's first waves "
+                                              "overlap launch i's last round (sustained wall-clock per launch over %d launches; outputs identical: %s)" % (n, same))
+        del out2, stats2
+        torch.cuda.empty_cache()
     return {"elapsed": elapsed, "kernel_ms": kern_ms, "out": out, "stats": stats, "kernel": kernel_name(), "dispatch_order": order_info,
             "untimed": 2 + settle + warmup}
 
@@ -555,7 +610,15 @@ def main():
                     "workload": describe(w2, name) + f", B={w2.B}", "trajectories_per_s": w2.B / (r2["kernel_ms"] * 1e-3),
                     "ms_per_launch": r2["kernel_ms"], "hbm_frac": blk["frac"], "kernel": blk["kernel"],
                     "with_caller_supplied_order_ms_per_launch": r2["dispatch_order"].get("with_caller_supplied_order_ms_per_launch"),
+                    "two_stream_pipelined_ms_per_launch": r2["dispatch_order"].get("two_stream_pipelined_ms_per_launch"),
                     "all_status_ok": int(r2["stats"][0].max()) == 0}
+                if name in ("cfg2", "cfg5"):
+                    # launches of one or two waves per SIMD: the bound is the slowest wave's instruction stream, not HBM
+                    tpw2 = int(_abi.lib().dyn_trajectories_per_wave(ctypes.byref(w2.model.c())))
+                    lf = latency_floor(name, w2.B, blk["kernel"], r2["stats"], tpw2)
+                    if lf:
+                        lf["frac_of_latency_floor"] = lf["latency_floor_ms"] / r2["kernel_ms"]
+                        line["other_workloads"][name].update(lf)
                 del r2
             torch.cuda.empty_cache()
             # cfg 4.  numpyro's per-chain adaptation under eight sampler seeds, pooled (the fused-likelihood model), four for the

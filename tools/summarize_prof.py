@@ -115,6 +115,9 @@ if hbm:
     rec = json.load(open(tp)) if os.path.exists(tp) else {}
     rec[f"{workload}:{batch}"] = {"hbm_bytes_per_launch": hbm, "read_bytes": rd, "write_bytes": wr, "source": f"profiles/{tag}_rocprof_summary.md",
                                   "kernel": kernel, "rev": build_rev(), "kernel_source_hash": kernel_source_hash(),
+                                  "valu_insts_per_wave": (mean["SQ_INSTS_VALU"] / mean["SQ_WAVES"]) if "SQ_INSTS_VALU" in mean and mean.get("SQ_WAVES") else None,
+                                  "waves_per_launch": mean.get("SQ_WAVES"),
+                                  "clock_ghz": (mean["GRBM_GUI_ACTIVE"] / 8 / float(stats["AverageNs"])) if "GRBM_GUI_ACTIVE" in mean and stats else None,
                                   "kernel_avg_ns": float(stats["AverageNs"]) if stats else None}
     json.dump(rec, open(tp, "w"), indent=1, sort_keys=True)
 print("\n".join(lines))
