@@ -13,8 +13,8 @@ from .infer import (InferenceProcess, MCMCProcess, SVIProcess, checkpoint_compar
 from .simulation import AbstractODEParams, PoissonObservation, Solution, SolverError, simulate  # noqa: F401
 from .typing import (CompartmentGradients, CompartmentState, CompartmentTimeseries, DynodeName,  # noqa: F401
                      ObservedData, ODE_Eqns, UnitIntervalFloat)
-from .utils import (base_equation, conditional_knots, date_to_epi_week, date_to_sim_day,  # noqa: F401
+from .utils import (base_equation, conditional_knots, date_to_sim_day,  # noqa: F401
                     drop_keys_with_substring, evaluate_cubic_spline, flatten_list_parameters,
-                    identify_distribution_indexes, sim_day_to_date, sim_day_to_epiweek, vectorize_objects)
+                    identify_distribution_indexes, sim_day_to_date, vectorize_objects)
 
 __version__ = "0.1.0"

@@ -1,7 +1,7 @@
 """Host helpers of ``dynode.utils`` (reference src/dynode/utils/{utils,splines,datetime_utils}.py).
 
 Only ``vectorize_objects`` and the simulation-day helpers sit on the simulate/infer path
-(``get_odeparams`` uses the former); the spline evaluators, key helpers and epiweek conversions are
+(``get_odeparams`` uses the former); the spline evaluators and key helpers are
 what the reference's post-processing and vaccination-rate code call.  Everything here is plain
 NumPy / Python, accepts torch tensors where arrays are expected, and has no plotting or logging.
 """
@@ -122,51 +122,3 @@ def date_to_sim_day(date: datetime.date, init_date: datetime.date) -> int:
 def sim_day_to_date(sim_day: int, init_date: datetime.date) -> datetime.date:
     """The calendar date of simulation day ``sim_day`` (day 0 = ``init_date``)."""
     return init_date + datetime.timedelta(days=int(sim_day))
-
-
-class EpiWeek:
-    """CDC / MMWR epidemiological week (what ``epiweeks.Week`` provides to the reference; that
-    package is not a dependency here).  Weeks run Sunday-Saturday; week 1 of a year is the week
-    that has at least four of its days in that year."""
-
-    __slots__ = ("year", "week")
-
-    def __init__(self, year: int, week: int):
-        self.year, self.week = int(year), int(week)
-
-    @staticmethod
-    def _first_week_start(year: int) -> datetime.date:
-        jan4 = datetime.date(year, 1, 4)                       # always inside week 1
-        return jan4 - datetime.timedelta(days=(jan4.weekday() + 1) % 7)   # back to Sunday
-
-    @classmethod
-    def fromdate(cls, date: datetime.date) -> "EpiWeek":
-        year = date.year + 1 if date >= cls._first_week_start(date.year + 1) else date.year
-        if date < cls._first_week_start(year):
-            year -= 1
-        return cls(year, (date - cls._first_week_start(year)).days // 7 + 1)
-
-    def startdate(self) -> datetime.date:
-        return self._first_week_start(self.year) + datetime.timedelta(weeks=self.week - 1)
-
-    def enddate(self) -> datetime.date:
-        return self.startdate() + datetime.timedelta(days=6)
-
-    def __eq__(self, other):
-        return isinstance(other, EpiWeek) and (self.year, self.week) == (other.year, other.week)
-
-    def __hash__(self):
-        return hash((self.year, self.week))
-
-    def __repr__(self):
-        return f"EpiWeek(year={self.year}, week={self.week})"
-
-
-def date_to_epi_week(date: datetime.date) -> EpiWeek:
-    """CDC epiweek containing ``date`` (datetime_utils.py:91-106)."""
-    return EpiWeek.fromdate(date)
-
-
-def sim_day_to_epiweek(sim_day: int, init_date: datetime.date) -> EpiWeek:
-    """CDC epiweek containing simulation day ``sim_day`` (datetime_utils.py:36-61)."""
-    return EpiWeek.fromdate(sim_day_to_date(sim_day, init_date))

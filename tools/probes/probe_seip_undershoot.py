@@ -13,7 +13,7 @@ from helpers import O
 wl = synthetic.WORKLOADS["seip83"](768)
 m = wl.model
 for flag in ("1", "0"):
-    os.environ["DYNODE_HIP_SEIP_PLAIN"] = flag
+    pass  # (round 4: pin the instance with engine.dispatch_hints(general_instance=1) instead of the old environment switch)
     r = solve_batch(m, wl.y0, wl.params, wl.contact, wl.t1, wl.save_ts)
     ys = r.ys
     mn = ys.reshape(768, -1).min(1).values
@@ -24,7 +24,7 @@ truth, st, _, _ = O.solve(H.omodel(m), wl.y0[b:b + 1], wl.params[b:b + 1], wl.co
 o32, st, na, nr = O.solve(H.omodel(m), wl.y0[b:b + 1], wl.params[b:b + 1], wl.contact, wl.t1, wl.save_ts, dtype=np.float32, n_threads=8)
 print("float32 oracle: min", o32.min(), "max err", np.abs(o32 - truth).max(), "steps", na, nr)
 for flag in ("1", "0"):
-    os.environ["DYNODE_HIP_SEIP_PLAIN"] = flag
+    pass  # (round 4: pin the instance with engine.dispatch_hints(general_instance=1) instead of the old environment switch)
     r = solve_batch(m, wl.y0[b:b + 1], wl.params[b:b + 1], wl.contact, wl.t1, wl.save_ts)
     y = r.ys[0].cpu().numpy()
     k = np.unravel_index(y.argmin(), y.shape)
