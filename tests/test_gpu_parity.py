@@ -943,6 +943,21 @@ def test_what_the_fast_controller_arithmetic_costs_in_step_decisions(name, B, B_
               f"(p99.9 relative {100 * rep[tag]['attempts_rel_p999']:.1f} %), |hip - oracle| / scale median {rep[tag]['err_median']:.2e} "
               f"p99 {rep[tag]['err_p99']:.2e} p99.9 {rep[tag]['err_p999']:.2e} max {rep[tag]['err_max']:.2e}")
     print(f"[controller study {name}] ms per launch at B = {B_timing}: fast {fast_ms:.4f}, strict {strict_ms:.4f} ({100 * (strict_ms / fast_ms - 1):+.2f} %)")
-    # the strict arithmetic must not make parity WORSE, and neither instance may leave the bars the suite holds elsewhere
-    assert rep["strict"]["same_counts"] >= rep["fast"]["same_counts"] - 0.05
-    assert rep["fast"]["err_max"] < 5e-4 and rep["strict"]["err_max"] < 5e-4
+    # Measured (MI355X, round 4; DESIGN.md section 7 has the table):
+    #   cfg 3, D = 360, 2048 trajectories: fast 80.8 % / strict 80.2 % take the oracle's exact (accepted, rejected) counts;
+    #     |d attempts| mean 0.31 / 0.33, p99 4, max 7; |hip - oracle| / scale max 9.2e-7 / 7.9e-7; strict costs +23 % per launch
+    #   SEIP D = 2496 (kinks: dose caps), 1024 trajectories: 0.9 % / 0.7 % identical counts (of ~270 attempts), |d attempts| mean
+    #     8.6 / 8.3, p99 26, max 34 (p99.9: 12 % of the trajectory's attempts); |hip - oracle| / scale p99.9 1.7e-4 / 1.6e-4,
+    #     max 2.9e-4 / 2.8e-4; strict costs +30 %
+    # i.e. the fast controller arithmetic accounts for NONE of the float32 step-decision differences -- they are summation order
+    # (lane reductions, packed FMAs, the interpolant as a polynomial) -- and the oracle's arithmetic would cost a quarter of the
+    # launch.  The fast arithmetic stays; the bars below hold both instances to the measured distribution.
+    assert abs(rep["strict"]["same_counts"] - rep["fast"]["same_counts"]) < 0.05
+    assert abs(rep["strict"]["d_attempts_mean"] - rep["fast"]["d_attempts_mean"]) < 0.15 * max(rep["fast"]["d_attempts_mean"], 1.0)
+    assert strict_ms > 1.1 * fast_ms
+    for tag in ("fast", "strict"):
+        if name == "cfg3":
+            assert rep[tag]["same_counts"] > 0.7 and rep[tag]["d_attempts_max"] <= 12 and rep[tag]["err_max"] < 2e-6, rep[tag]
+        else:       # 2 x the measured p99.9 (value) / the measured maximum + a third (attempts)
+            assert rep[tag]["err_p999"] < 3.5e-4 and rep[tag]["err_max"] < 6e-4 and rep[tag]["d_attempts_max"] <= 45, rep[tag]
+            assert rep[tag]["attempts_rel_p999"] < 0.25, rep[tag]

@@ -737,7 +737,7 @@ def test_calls_without_seasonal_terms_take_the_plain_instance(name, kernel, hint
     assert st.max() == 0
     for r, tag in ((plain, "plain"), (general, "general")):
         got = r.ys.cpu().numpy()
-        assert int(r.status.max()) == 0 and np.abs(got - want).max() / 1000.0 < 5e-4
+        assert int(r.status.max()) == 0 and np.abs(got - want).max() / 1000.0 < 3.5e-4   # (2 x the measured p99.9: see test_north_star_sizes_properties)
         H.truth_bars(m, got, want, wl.y0, wl.params, wl.contact, wl.t1, ts, 1000.0, f"{name} {tag}", smooth=False, rtol=1e-9)
         assert np.abs((r.n_accept + r.n_reject).cpu().numpy() - (na + nr)).max() <= max(8, 0.2 * (na + nr).max())
     assert float((plain.ys - general.ys).abs().max()) / 1000.0 < 2e-4
@@ -762,7 +762,7 @@ def test_calls_without_seasonal_terms_take_the_plain_instance(name, kernel, hint
     r3 = solve_batch(w3.model, w3.y0, w3.params, w3.contact, 90.0, t3)
     assert last() == kernel % 0
     want3, st3, _, _ = O.solve(H.omodel(w3.model), w3.y0, w3.params, w3.contact, 90.0, t3, dtype=np.float32, n_threads=8)
-    assert int(r3.status.max()) == 0 and st3.max() == 0 and np.abs(r3.ys.cpu().numpy() - want3).max() / 1000.0 < 5e-4
+    assert int(r3.status.max()) == 0 and st3.max() == 0 and np.abs(r3.ys.cpu().numpy() - want3).max() / 1000.0 < 3.5e-4
 
 
 @pytest.mark.gpu
@@ -823,9 +823,13 @@ def test_north_star_sizes_properties(name, B):
     idx = np.arange(0, B, max(B // 6, 1))[:6]
     want, st, na, nr = O.solve(H.omodel(m), wl.y0[idx], wl.params[idx], wl.contact, wl.t1, wl.save_ts, dtype=np.float32, n_threads=8)
     got = r.ys[torch.as_tensor(idx, device="cuda")].cpu().numpy()
-    assert st.max() == 0 and np.abs(got - want).max() / 1000.0 < 5e-4          # adaptive float32: step decisions differ near the dose-cap kinks
+    # adaptive float32: step decisions differ near the dose-cap kinks.  Bar = 2 x the p99.9 of |hip - oracle| / scale measured over
+    # 1024 trajectories of the D = 2496 shape (1.7e-4; maximum 2.9e-4: tests/test_gpu_parity.py, controller study -- the strict-control
+    # twin reads the same, so the width is summation order at the kinks, not the controller's fast arithmetic)
+    assert st.max() == 0 and np.abs(got - want).max() / 1000.0 < 3.5e-4
     # (secondary to:) against a float64 rtol 1e-9 solve of the same six trajectories the HIP solution is as accurate as the oracle's
     H.truth_bars(m, got, want, wl.y0[idx], wl.params[idx], wl.contact, wl.t1, wl.save_ts, 1000.0, f"{name} north-star size", smooth=False, rtol=1e-9)
-    assert np.abs((r.n_accept + r.n_reject).cpu().numpy()[idx] - (na + nr)).max() <= max(8, 0.2 * (na + nr).max())   # (the bar of test_hip_matches_oracle)
+    # (step attempts: 2 x the measured p99.9 of the relative difference, 12 % of a trajectory's ~270 attempts)
+    assert np.abs((r.n_accept + r.n_reject).cpu().numpy()[idx] - (na + nr)).max() <= max(8, 0.25 * (na + nr).max())
     del r, r2, rp
     torch.cuda.empty_cache()
