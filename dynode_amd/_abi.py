@@ -25,15 +25,16 @@ ERR_NAMES = {
 
 # every symbol include/dynode_hip.h declares (checked by tests/test_abi.py)
 def kernel_source_hash() -> str:
-    """sha1 (12 hex digits) over the kernel sources the library is built from -- dynode_amd/csrc/*.{hip,hpp,inc,def}, its
-    Makefile and include/dynode_hip.h.  Computable wherever the tree is (the GPU box has no .git): a profile records it
-    (tools/summarize_prof.py -> profiles/traffic.json) and bench.py attaches profiled HBM traffic to its line only when the
-    sources it runs are the sources that were profiled."""
+    """sha1 (12 hex digits) over the DEVICE code the solve kernels are built from -- the kernel headers of dynode_amd/csrc
+    (solve_kernel.hpp, stepper.hpp and its includes, seip_kernel.hpp, nuts_device.hpp, latent_device.hpp), the instance lists
+    and the Makefile (per-unit compiler flags).  Host-side dispatch (dynode_hip.hip) is not in it: which instance ran is
+    checked by name.  Computable wherever the tree is (the GPU box has no .git): a profile records it (tools/summarize_prof.py
+    -> profiles/traffic.json) and bench.py attaches profiled HBM traffic to its line only when the device code it runs is the
+    device code that was profiled."""
     import hashlib
 
     csrc = os.path.join(_HERE, "csrc")
-    files = sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".hpp", ".inc", ".def")) or f == "Makefile")
-    files.append(os.path.join(os.path.dirname(_HERE), "include", "dynode_hip.h"))
+    files = sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hpp", ".inc", ".def")) or f == "Makefile")
     h = hashlib.sha1()
     for f in files:
         h.update(os.path.basename(f).encode())
@@ -42,7 +43,7 @@ def kernel_source_hash() -> str:
 
 
 EXPORTED_SYMBOLS = (
-    "dyn_abi_version", "dyn_state_dim", "dyn_param_dim", "dyn_n_compartments",
+    "dyn_abi_version", "dyn_model_desc_size", "dyn_solver_opts_size", "dyn_state_dim", "dyn_param_dim", "dyn_n_compartments",
     "dyn_compartment_offsets", "dyn_is_supported", "dyn_trajectories_per_wave", "dyn_trajectories_per_wave_for_batch",
     "dyn_last_error", "dyn_solve_batch", "dyn_solve_batch_jvp", "dyn_is_supported_jvp",
     "dyn_nuts_advance", "dyn_nuts_state_size", "dyn_philox4x32_10", "dyn_latent_sites",
@@ -201,6 +202,11 @@ def lib() -> ctypes.CDLL:
         L = ctypes.CDLL(LIB_PATH)
         pm, po = ctypes.POINTER(ModelDescC), ctypes.POINTER(SolverOptsC)
         L.dyn_abi_version.restype = ctypes.c_int32
+        for name, struct in (("dyn_model_desc_size", ModelDescC), ("dyn_solver_opts_size", SolverOptsC)):
+            getattr(L, name).restype = ctypes.c_int32
+            if getattr(L, name)() != ctypes.sizeof(struct):      # a stale library next to newer Python (or the reverse): refuse, loudly
+                raise ImportError(f"{LIB_PATH}: {name}() = {getattr(L, name)()} but the binding's struct has {ctypes.sizeof(struct)} bytes "
+                                  "(rebuild: make -C dynode_amd/csrc)")
         for name in ("dyn_state_dim", "dyn_param_dim", "dyn_n_compartments",
                      "dyn_trajectories_per_wave"):
             getattr(L, name).argtypes = [pm]

@@ -548,6 +548,8 @@ static int enqueue(const Entry *e, const dyn_model_desc *m, const dyn_solver_opt
 extern "C" {
 
 int32_t dyn_abi_version(void) { return DYN_ABI_VERSION; }
+int32_t dyn_model_desc_size(void) { return (int32_t)sizeof(dyn_model_desc); }
+int32_t dyn_solver_opts_size(void) { return (int32_t)sizeof(dyn_solver_opts); }
 
 int32_t dyn_n_compartments(const dyn_model_desc *m) {
     if (m->family == 1) return 4; /* s e i c */

@@ -200,6 +200,9 @@ enum {
 };
 
 int32_t dyn_abi_version(void);
+/* sizeof(dyn_model_desc), sizeof(dyn_solver_opts): a binding checks its own struct layouts against these before the first call */
+int32_t dyn_model_desc_size(void);
+int32_t dyn_solver_opts_size(void);
 int32_t dyn_state_dim(const dyn_model_desc *m);
 int32_t dyn_param_dim(const dyn_model_desc *m);
 int32_t dyn_n_compartments(const dyn_model_desc *m);

@@ -192,3 +192,41 @@ def test_trajectories_per_wave_follows_the_seip_lane_mapping():
     assert lib.dyn_trajectories_per_wave(ctypes.byref(seip(n_age=4, n_strain=2, n_wane=4, n_vax_tiers=3).c())) == 4
     assert lib.dyn_trajectories_per_wave(ctypes.byref(seip(n_age=4, n_strain=3, n_wane=4, n_vax_tiers=3).c())) == 2
     assert lib.dyn_trajectories_per_wave(ctypes.byref(seip(n_age=2, n_strain=2, n_wane=2, n_vax_tiers=2).c())) == 8
+
+
+def test_struct_layouts_of_the_binding_match_the_header():
+    """ctypes mirrors of dyn_model_desc / dyn_solver_opts / dyn_dispatch_hints: sizes against the library's own sizeof, field
+    names and order of the hints against the header text (a binding that drifts from the header would pass garbage hints)."""
+    lib = _abi.lib()
+    assert lib.dyn_model_desc_size() == ctypes.sizeof(_abi.ModelDescC) and lib.dyn_solver_opts_size() == ctypes.sizeof(_abi.SolverOptsC)
+    text = open(os.path.join(H.ROOT, "include", "dynode_hip.h")).read()
+    body = re.sub(r"/\*.*?\*/", "", text[text.index("typedef struct dyn_dispatch_hints"):text.index("} dyn_dispatch_hints;")], flags=re.S)
+    assert tuple(re.findall(r"int32_t\s+(\w+);", body)) == tuple(n for n, _ in _abi.DispatchHintsC._fields_)
+    opts = re.sub(r"/\*.*?\*/", "", text[text.index("typedef struct dyn_solver_opts"):text.index("} dyn_solver_opts;")], flags=re.S)
+    assert tuple(re.findall(r"[\w\s\*]+?[\s\*](\w+);", opts)) == tuple(n for n, _ in _abi.SolverOptsC._fields_)
+
+
+def test_dispatch_hints_context_sets_exactly_the_fields_it_names():
+    from dynode_amd import engine
+
+    o = _opts()
+    with engine.dispatch_hints(pull=-1, replicas_log2=0, strains_per_lane=2, strict_control=1):
+        with engine.dispatch_hints(pull=None, seip_tier_waves=-1):
+            engine._apply_hints(o)
+    h = o.hints
+    assert (h.pull, h.replicas_log2, h.strains_per_lane, h.strict_control, h.seip_tier_waves, h.pull_waves) == (0, 1, 2, 1, -1, 0)
+    assert engine.current_hints() == {}
+    with pytest.raises(TypeError):
+        with engine.dispatch_hints(no_such_hint=1):
+            pass
+    # out-of-range hints are an argument error of the call, before anything is enqueued
+    o2 = _opts()
+    o2.hints.replicas_log2 = 9
+    m = ModelDesc(n_age=8)
+    assert lib_call_rc(m, o2) == -4
+
+
+def lib_call_rc(m, o):
+    lib = _abi.lib()
+    one = ctypes.c_void_p(8)            # non-null placeholders: the argument checks come before any pointer is read
+    return lib.dyn_solve_batch(ctypes.byref(m.c()), ctypes.byref(o), one, 0, one, one, 4, 0.0, 10.0, one, 3, None, one, one, one, one, None)
