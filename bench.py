@@ -247,6 +247,17 @@ def nuts_kernel_checks(fused: bool, chains: int, transitions: int = 100, decoupl
     return out
 
 
+def trajectories_per_wave(model, B: int) -> int:
+    """Trajectories that share a wavefront in the mapping a float32 Tsit5 call of B rows actually gets (the library takes a finer
+    strain split for batches that fill at most half a wave per SIMD: dyn_trajectories_per_wave_for_batch)."""
+    import ctypes
+
+    from dynode_amd import _abi
+
+    o = _abi.SolverOptsC(method=_abi.DYN_TSIT5, dtype=_abi.DYN_F32, rtol=1e-5, atol=1e-6, max_steps=10**6)
+    return int(_abi.lib().dyn_trajectories_per_wave_for_batch(ctypes.byref(model.c()), ctypes.byref(o), int(B)))
+
+
 def kernel_name() -> str:
     from dynode_amd import _abi
 
@@ -506,7 +517,7 @@ def main():
     # lock-step cost of a static grid: a wave's loop runs until the slowest of its trajectories is through
     import ctypes
     from dynode_amd import _abi
-    tpw = int(_abi.lib().dyn_trajectories_per_wave(ctypes.byref(m.c())))
+    tpw = trajectories_per_wave(m, B)
     wave_iters = None
     if tpw > 0 and B % tpw == 0:
         attempts = (res["stats"][1] + res["stats"][2]).reshape(B // tpw, tpw)
@@ -614,7 +625,7 @@ def main():
                     "all_status_ok": int(r2["stats"][0].max()) == 0}
                 if name in ("cfg2", "cfg5"):
                     # launches of one or two waves per SIMD: the bound is the slowest wave's instruction stream, not HBM
-                    tpw2 = int(_abi.lib().dyn_trajectories_per_wave(ctypes.byref(w2.model.c())))
+                    tpw2 = trajectories_per_wave(w2.model, w2.B)
                     lf = latency_floor(name, w2.B, blk["kernel"], r2["stats"], tpw2)
                     if lf:
                         lf["frac_of_latency_floor"] = lf["latency_floor_ms"] / r2["kernel_ms"]
