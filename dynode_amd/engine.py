@@ -337,6 +337,11 @@ def solve_batch(model: ModelDesc, y0, params, contact, t1: float, save_ts, *, t0
             int(dy0_t is not None and dy0_t.dim() == 3), out.data_ptr(), dout.data_ptr(),
             status.data_ptr(), n_acc.data_ptr(), n_rej.data_ptr(), ctypes.c_void_p(s.cuda_stream))
 
+    if work_t is not None and (order_t is not None or current_hints().get("pull", 0) > 0 or current_hints().get("pull_waves", 0) > 0):
+        # a launch that may pull: rows the queue never hands out (counters left non-zero by a launch that did not run to its
+        # end) must not read as solved -- every row starts at status -1 and the kernel overwrites it with 0 / 1 / 2
+        with torch.cuda.stream(s):
+            status.fill_(-1)
     rc = _call_with_jit(call, L, model, dtype, method, n_dir)
     if rc != 0:
         drop_work_counters()
