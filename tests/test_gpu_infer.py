@@ -912,23 +912,25 @@ def test_kernel_sampler_on_the_multi_strain_model_agrees_with_the_gradient_free_
     obs = ex_m.synthetic_incidence(120)
     assert obs.shape == (120, 2, 3)
     kw = dict(config=ex_m.get_config(sites), tf=120, obs_data=obs)
-    nuts = MCMCProcess(numpyro_model=ex_m.model, num_warmup=300, num_samples=300, num_chains=48, nuts_max_tree_depth=8, progress_bar=False)
+    # (9 sites run the general autograd potential, nine tangent launches per gradient: a smaller run keeps the suite short)
+    chains, draws, thin_n, ens_draws, thin_e = (48, 300, 6, 1500, 150) if sites == 6 else (32, 200, 4, 1000, 100)
+    nuts = MCMCProcess(numpyro_model=ex_m.model, num_warmup=draws, num_samples=draws, num_chains=chains, nuts_max_tree_depth=8, progress_bar=False)
     mcmc = nuts.infer(**kw)
     assert mcmc.sampler == "KernelNUTS" and mcmc.potential.dim == sites
     if sites <= 8:          # folded potential: the gradient-solve (one tangent direction per trajectory row) + dyn_nuts_advance_mapped
         assert mcmc.launches_per_iteration == 2
         assert _abi.lib().dyn_last_kernel_name().decode().startswith("dyn::solve_kernel<float, 0, 2, 3, true, true, true, 1, 1, 3")
     post = nuts.get_samples(group_by_chain=True)
-    assert len(post) == sites and int(mcmc.nuts.diverging.sum()) <= 0.005 * 48 * 300        # (9 sites: the flat priors of the latent periods have edges)
-    ens = MCMCProcess(numpyro_model=ex_m.model, num_warmup=1500, num_samples=1500, num_chains=128, nuts_max_tree_depth=8, progress_bar=False,
+    assert len(post) == sites and int(mcmc.nuts.diverging.sum()) <= 0.005 * chains * draws  # (9 sites: the flat priors of the latent periods have edges)
+    ens = MCMCProcess(numpyro_model=ex_m.model, num_warmup=ens_draws, num_samples=ens_draws, num_chains=128, nuts_max_tree_depth=8, progress_bar=False,
                       mcmc_kwargs={"sampler": "ensemble"})
     ens.infer(**kw)
     post_e = ens.get_samples(group_by_chain=True)
     truth = dict(zip((f"strains_{k}_r0" for k in range(3)), ex_m.TRUTH["r0s"]))
     truth.update(zip((f"strains_{k}_infectious_period" for k in range(3)), ex_m.TRUTH["infectious_periods"]))
     for name in post:
-        a = post[name][:, ::6].reshape(-1).cpu().numpy()            # 48 x 50
-        b = post_e[name][:, ::150].reshape(-1).cpu().numpy()        # 128 x 10: stretch moves decorrelate slowly
+        a = post[name][:, ::thin_n].reshape(-1).cpu().numpy()       # chains x 50
+        b = post_e[name][:, ::thin_e].reshape(-1).cpu().numpy()     # 128 x 10: stretch moves decorrelate slowly
         ks = stats.ks_2samp(a, b)
         print(f"[{sites} sites] {name}: NUTS {a.mean():.4f} +- {a.std():.4f}, ensemble {b.mean():.4f} +- {b.std():.4f}, KS p {ks.pvalue:.3f}")
         assert ks.pvalue > 0.01, (name, ks)
