@@ -1005,9 +1005,9 @@ def test_dimensions_beyond_the_sampler_kernel_fall_back_loudly_and_twenty_run_on
         assert abs(d.mean() - mean) < 5 * sd / np.sqrt(1500) and abs(d.std() / sd - 1) < 0.1, (i, d.mean(), mean, d.std(), sd)
     model, y = make(34)
     with pytest.warns(RuntimeWarning, match="exceed the sampler kernel's limits"):
-        proc = MCMCProcess(numpyro_model=model, num_samples=40, num_chains=4, num_warmup=40, progress_bar=False, nuts_max_tree_depth=5)
+        proc = MCMCProcess(numpyro_model=model, num_samples=8, num_chains=4, num_warmup=8, progress_bar=False, nuts_max_tree_depth=3)
         mcmc = proc.infer(y=y)
-    assert mcmc.sampler == "GraphNUTS" and proc.get_samples()["loc_33"].shape == (160,)
+    assert mcmc.sampler == "GraphNUTS" and proc.get_samples()["loc_33"].shape == (32,)
     with pytest.raises(NotImplementedError, match="pooled"):
         MCMCProcess(numpyro_model=make(12)[0], num_samples=10, num_chains=4, num_warmup=10, progress_bar=False, nuts_max_tree_depth=5,
                     mcmc_kwargs={"adaptation": "pooled"}).infer(y=make(12)[1])
