@@ -623,6 +623,15 @@ def main():
                     "with_caller_supplied_order_ms_per_launch": r2["dispatch_order"].get("with_caller_supplied_order_ms_per_launch"),
                     "two_stream_pipelined_ms_per_launch": r2["dispatch_order"].get("two_stream_pipelined_ms_per_launch"),
                     "all_status_ok": int(r2["stats"][0].max()) == 0}
+                if w2.model.family == 1:
+                    # the bench call runs a "plain" instance (no seasonal terms / introductions / schedules / discontinuity points
+                    # compiled in); the general instance of the same shape, for a call that uses any of them, beside it
+                    from dynode_amd import engine
+
+                    with engine.dispatch_hints(general_instance=1):
+                        r3 = measure(w2, dev, 10, 2, torch.cuda.synchronize, order_hint_too=False)
+                    line["other_workloads"][name].update(general_instance_ms_per_launch=r3["kernel_ms"], general_instance_kernel=r3["kernel"])
+                    del r3
                 if name in ("cfg2", "cfg5"):
                     # launches of one or two waves per SIMD: the bound is the slowest wave's instruction stream, not HBM
                     tpw2 = trajectories_per_wave(w2.model, w2.B)
