@@ -42,6 +42,15 @@ def test_bench_line_has_every_field_of_the_contract():
     assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-12 and 0.2 < roof["frac"] < 0.8
     assert roof["traffic"] is None or roof["traffic"] > 3e9
+    # profiled traffic is attached only for the instance AND the device code that were profiled: the line says which it compared
+    from dynode_amd import _abi
+
+    prov = roof["traffic_provenance"]
+    assert prov["kernel_source_hash"] == _abi.kernel_source_hash()
+    if roof["traffic"] is not None:
+        assert prov["profiled"]["kernel_source_hash"] == prov["kernel_source_hash"] and "stale" not in prov
+    elif prov["profiled"] is not None:
+        assert prov.get("stale")
     # lock-step cost of the static grid, reported next to the mean: a wave loops as long as its slowest trajectory needs
     cfg = d["config"]
     assert cfg["trajectories_per_wave"] == 2 and cfg["mean_steps_per_trajectory"] <= cfg["mean_loop_iterations_per_wave"] < 1.2 * cfg["mean_steps_per_trajectory"]
