@@ -913,7 +913,7 @@ def test_kernel_sampler_on_the_multi_strain_model_agrees_with_the_gradient_free_
     assert obs.shape == (120, 2, 3)
     kw = dict(config=ex_m.get_config(sites), tf=120, obs_data=obs)
     # (9 sites run the general autograd potential, nine tangent launches per gradient: a smaller run keeps the suite short)
-    chains, draws, thin_n, ens_draws, thin_e = (48, 300, 6, 1500, 150) if sites == 6 else (32, 200, 4, 1000, 100)
+    chains, draws, thin_n, ens_draws, thin_e = (48, 300, 6, 1500, 150) if sites == 6 else (24, 150, 3, 800, 80)
     nuts = MCMCProcess(numpyro_model=ex_m.model, num_warmup=draws, num_samples=draws, num_chains=chains, nuts_max_tree_depth=8, progress_bar=False)
     mcmc = nuts.infer(**kw)
     assert mcmc.sampler == "KernelNUTS" and mcmc.potential.dim == sites
@@ -995,14 +995,14 @@ def test_dimensions_beyond_the_sampler_kernel_fall_back_loudly_and_twenty_run_on
     model, y = make(20)
     with warnings.catch_warnings():
         warnings.simplefilter("error", RuntimeWarning)                       # no downgrade warning here
-        proc = MCMCProcess(numpyro_model=model, num_samples=300, num_chains=16, num_warmup=300, progress_bar=False, nuts_max_tree_depth=6)
+        proc = MCMCProcess(numpyro_model=model, num_samples=150, num_chains=16, num_warmup=150, progress_bar=False, nuts_max_tree_depth=5)
         mcmc = proc.infer(y=y)
     assert mcmc.sampler == "KernelNUTS" and mcmc.potential.dim == 20
     post = proc.get_samples()
     for i in (0, 7, 19):        # conjugate: precision 1/4 + 24, mean = sum(y_i) / (24 + 1/4)
         mean, sd = float(y[i].sum()) / 24.25, 24.25 ** -0.5
         d = post[f"loc_{i}"].cpu().numpy()
-        assert abs(d.mean() - mean) < 5 * sd / np.sqrt(1500) and abs(d.std() / sd - 1) < 0.1, (i, d.mean(), mean, d.std(), sd)
+        assert abs(d.mean() - mean) < 5 * sd / np.sqrt(800) and abs(d.std() / sd - 1) < 0.12, (i, d.mean(), mean, d.std(), sd)
     model, y = make(34)
     with pytest.warns(RuntimeWarning, match="exceed the sampler kernel's limits"):
         proc = MCMCProcess(numpyro_model=model, num_samples=8, num_chains=4, num_warmup=8, progress_bar=False, nuts_max_tree_depth=3)
