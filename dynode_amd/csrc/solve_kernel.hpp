@@ -66,7 +66,7 @@ struct KArgs {
     int32_t dy0_batched;
     // discontinuity_points (ClipStepSizeController jump_ts), passed by value in the kernarg
     int32_t n_jump;
-    T jump_ts[16];
+    T jump_ts[64];
     // Step schedules (SEIP family, dyn_solve_batch_record / _replay): an adaptive solve can write down the (t_prev, t_next)
     // of every accepted step, and a later launch can make other parameter rows take exactly those steps -- the discrete
     // map is then smooth in the parameters, which is what differentiating through the reference's solve assumes (the
@@ -97,7 +97,7 @@ struct KArgs {
     // dyn_solver_opts::hints.pull / .pull_waves, for launch() (host side only; the kernels never read them)
     int32_t pull_mode, pull_waves;
 };
-constexpr int kMaxJumps = 16;
+constexpr int kMaxJumps = 64;   // (a year of weekly interventions: 52)
 
 // ---------------------------------------------------------------- math per precision
 template <typename T>

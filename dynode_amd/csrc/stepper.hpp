@@ -73,9 +73,9 @@ struct Stepper {
         // discontinuity points follow the save grid in LDS (per-group index into the table)
         T *const jt_tab = ts_tab + n_save;
         const int n_jump = F::ADAPTIVE_NO_JUMPS ? 0 : ka.n_jump;
-        if (n_jump > 0 && lane == 0) {
-#pragma unroll
-            for (int j = 0; j < kMaxJumps; ++j) jt_tab[j] = ka.jump_ts[j];
+        if (n_jump > 0) {   // one per lane, straight from the kernel-argument segment (no unrolled copy through scalar registers)
+            static_assert(kMaxJumps == 64, "the discontinuity points are staged one per lane");
+            jt_tab[lane] = cold_args<T>()->jump_ts[lane];
         }
         // the family's own tables follow (Solver: likelihood table, parked rates, the two-wave hand-over; Seip: susceptibility
         // tables and dose splines per trajectory slot, recorded schedules, the mailbox of a wave group)

@@ -460,7 +460,15 @@ def test_unsupported_shape_fails_loudly(monkeypatch):
     with pytest.raises(SolveError, match=r"UNSUPPORTED.*X\(float, 0, 8, 7, false, false, false, 1, 0, 7\)"):
         solve_batch(ModelDesc(n_age=8, n_strain=7), np.zeros(8 * 15), np.zeros((1, 14)), np.eye(8), 10.0, [0.0, 10.0])
     with pytest.raises(SolveError, match="UNSUPPORTED"):       # more jump points than the LDS table holds
-        solve_batch(SIR1, [0.9, 0.1, 0], [[0.3, 0.1]], [[1.0]], 100.0, [0.0, 100.0], jump_ts=list(np.arange(1.0, 40.0, 2.0)))
+        solve_batch(SIR1, [0.9, 0.1, 0], [[0.3, 0.1]], [[1.0]], 100.0, [0.0, 100.0], jump_ts=list(np.arange(1.0, 99.0, 1.5)))       # 66 > 64
+    # ... and a year of weekly discontinuity points (52) is inside it: float64 equals the oracle with identical step counts
+    weekly = list(np.arange(7.0, 365.0, 7.0))[:52]
+    m8 = ModelDesc(n_age=8)
+    y0, p, C, t1, ts = random_workload(m8, 9, seed=77)
+    got, st, na, nr = hip(m8, y0, p, C, 365.0, synthetic.save_grid(365.0), dtype=F64, jump_ts=weekly)
+    want, st_o, na_o, nr_o = O.solve(H.omodel(m8), y0, p, C, 365.0, synthetic.save_grid(365.0), dtype=np.float64, n_threads=8, jump_ts=weekly)
+    assert st.max() == 0 and st_o.max() == 0 and np.abs(got - want).max() / 1000.0 < 1e-11
+    assert np.array_equal(na, na_o) and np.array_equal(nr, nr_o)
     with pytest.raises(SolveError, match="JUMP"):               # must be strictly increasing
         solve_batch(SIR1, [0.9, 0.1, 0], [[0.3, 0.1]], [[1.0]], 100.0, [0.0, 100.0], jump_ts=[50.0, 20.0])
 
