@@ -113,7 +113,7 @@ class NutsStateC(ctypes.Structure):
                    ("seed", ctypes.c_uint64), ("target_accept", ctypes.c_double), ("max_delta_energy", ctypes.c_double)]
                 + [(n, ctypes.c_void_p) for n in NUTS_POINTER_FIELDS]
                 + [(n, ctypes.c_void_p) for n in ("pot_lp", "pot_dlp", "pot_ll", "pot_dll")]
-                + [("pot_offset", ctypes.c_double), ("pot_ll_stride", ctypes.c_int32), ("pot_reserved", ctypes.c_int32)])
+                + [("pot_offset", ctypes.c_double), ("pot_ll_stride", ctypes.c_int32), ("pot_dll_stride", ctypes.c_int32)])
 
 
 @dataclass(frozen=True)

@@ -309,7 +309,7 @@ static void note_kernel(const Entry *e) {
                      e->W, kt, (e->FEAT & kSeipPlain) ? 1 : 0);
         return;
     }
-    snprintf(tl_kernel, sizeof(tl_kernel), "dyn::solve_kernel<%s, %d, %d, %d, %s, %s, %s, %d, %d, %d, %d>", t, e->method,
+    snprintf(tl_kernel, sizeof(tl_kernel), "dyn::solve_kernel%s<%s, %d, %d, %d, %s, %s, %s, %d, %d, %d, %d>", (e->FEAT & kFused) ? "_fused" : "", t, e->method,
              e->G, e->S, e->E ? "true" : "false", e->WN ? "true" : "false", e->C ? "true" : "false", e->W, e->ND, e->SPL,
              e->FEAT);
 }
@@ -523,9 +523,16 @@ static int enqueue(const Entry *e, const dyn_model_desc *m, const dyn_solver_opt
         const dynnuts::Tail *const t = static_cast<const dynnuts::Tail *>(o->nuts_tail);
         if (t->magic != dynnuts::kTailMagic) return DYN_ERR_OPTS; // not a dyn_nuts_tail_pack blob
         const int rows = t->rows_per_chain;
-        const Entry *fused = (e->FEAT & kLean) ? find_variant(e, e->FEAT | kFused) : nullptr;
+        // (a lean instance carries the state machine up to four dimensions; beyond, the general instance of the shape takes the call)
+        if ((e->FEAT & kLean) && t->st.dim > dynnuts::kFusedLeanMaxDim) {
+            const Entry *general = find_variant(e, e->FEAT & ~kLean);
+            if (general) e = general;
+        }
+        const Entry *fused = e->ND > 0 ? find_variant(e, e->FEAT | kFused) : nullptr;
         const int nt = (64 / entry_lanes(e)) >> ka.rep_log2; // trajectories per wave
-        if (!fused || rows < 1 || nt < rows || nt % rows != 0 || B != (int64_t)t->st.n_chains * rows || rows * e->ND != t->st.dim ||
+        // directions split over the rows of a chain (one each; rows beyond the sites are padding) or all in its one row
+        const bool dirs_ok = t->map.split ? (e->ND == 1 && rows >= t->st.dim) : (rows == 1 && e->ND == t->st.dim);
+        if (!fused || !ll || order || rows < 1 || nt < rows || nt % rows != 0 || B != (int64_t)t->st.n_chains * rows || !dirs_ok ||
             (t->map.f64 != 0) != (sizeof(T) == 8) || t->map.params != params || t->map.seeds != dparams) {
             snprintf(tl_error, sizeof(tl_error), "nuts_tail: this call cannot carry the sampler's side (see dyn_solver_opts::nuts_tail)");
             return DYN_ERR_UNSUPPORTED;
@@ -707,7 +714,7 @@ static int solve_impl(const dyn_model_desc *m, const dyn_solver_opts *o, const v
                                 (sc && sc->in ? (size_t)2 * sc->cap : 0); /* replayed schedule */
         const int nw = dyn::entry_waves(e), ktl = dyn::entry_tier_lanes(e), kl = (dyn::seip_tiers(m) + ktl - 1) / ktl;
         const size_t mailbox = nw > 1 ? (size_t)2 * nw * 64 * (m->n_strain + kl * 4 + m->n_wane + 2 * m->n_strain) : 0; /* >= 2 NW NSLOT 64 */
-        const size_t bytes = ((size_t)n_save + dyn::kMaxJumps + (64 / dyn::entry_lanes(e)) * per_traj + mailbox) * (o->dtype == DYN_F64 ? 8 : 4);
+        const size_t bytes = ((size_t)n_save + (o->n_jump > 0 ? dyn::kMaxJumps : 0) /* as launch_seip sizes it */ + (64 / dyn::entry_lanes(e)) * per_traj + mailbox) * (o->dtype == DYN_F64 ? 8 : 4);
         const size_t limit = nw > 1 ? 160 * 1024 : 64 * 1024; /* a wave group is alone (or two) on its CU */
         if (bytes > limit) {
             snprintf(dyn::tl_error, sizeof(dyn::tl_error), "SEIP tables need %zu bytes of LDS per workgroup (limit %zu)", bytes, limit);

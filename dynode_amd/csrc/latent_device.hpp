@@ -110,10 +110,11 @@ __device__ inline void map_chain(const TAB &tab, int64_t C, int64_t c, const dou
             __builtin_memcpy(&site, &tab.s[i], sizeof(site));
             return q * eval_site(site, zrow[i]).dx;
         };
-        if (split) { // one direction per trajectory: chain c becomes rows c n .. c n + n - 1 of an n C batch with one seed row each
-            for (int i = 0; i < n; ++i) {     // (neighbours: the copies of a chain take the same steps, so they share a wave for free)
-                params[(c * n + i) * P + j] = (T)p;
-                seeds[(c * n + i) * P + j] = (T)seed(i);
+        if (split) { // one direction per trajectory: chain c becomes rows c R .. c R + n - 1 of an R C batch with one seed row each
+            const int64_t R = split;          // (R >= n rows per chain: rows beyond the sites are padding -- the chain's parameters, zero seeds)
+            for (int i = 0; i < R; ++i) {     // (neighbours: the copies of a chain take the same steps, so they share a wave for free)
+                params[(c * R + i) * P + j] = (T)p;
+                seeds[(c * R + i) * P + j] = i < n ? (T)seed(i) : (T)0;
             }
         } else {
             params[c * P + j] = (T)p;
@@ -125,7 +126,7 @@ __device__ inline void map_chain(const TAB &tab, int64_t C, int64_t c, const dou
 // what dyn_nuts_advance_mapped hands to the sampler kernel (by value)
 struct MapArgs {
     SiteTable tab;
-    int32_t enabled, P, f64, split;      // f64: params / seeds are double (else float)
+    int32_t enabled, P, f64, split;      // f64: params / seeds are double (else float); split: rows per chain (0: all directions in one row)
     const double *coef, *expo;
     double *x, *lp, *dlp_dz;
     void *params, *seeds;

@@ -51,11 +51,20 @@ __global__ void __launch_bounds__(64) potential_combine(int64_t C, int n, const 
                                                         double *__restrict__ u, double *__restrict__ g) {
     const int64_t c = (int64_t)blockIdx.x * 64 + threadIdx.x;
     if (c >= C) return;
-    u[c] = -(lp[c] + ll[split ? c * n : c] + offset);   // (split: the n copies of a chain carry the same log-likelihood; the first is read)
-    for (int i = 0; i < n; ++i) g[c * n + i] = -(dlp_dz[c * n + i] + dll[c * n + i]);    // (split: row c n + i holds direction i)
+    // (split = rows per chain: the copies of a chain carry the same log-likelihood, the first is read; row c rows + i holds direction i)
+    u[c] = -(lp[c] + ll[split ? c * split : c] + offset);
+    for (int i = 0; i < n; ++i) g[c * n + i] = -(dlp_dz[c * n + i] + dll[c * (split ? split : n) + i]);
 }
 
 } // namespace dynlat
+
+// dyn_latent_param_map's split_directions as rows per chain: 0 = all directions in one row, 1 = n_sites rows, r >= 2 = r rows
+// (the chains padded to r >= n_sites trajectories); -1 = invalid
+int dynlat_rows_per_chain(int32_t split_directions, int32_t n_sites) {
+    if (split_directions == 0) return 0;
+    if (split_directions == 1) return n_sites;
+    return split_directions >= n_sites && split_directions <= 64 ? split_directions : -1;
+}
 
 static int fill_table(dynlat::SiteTable &tab, const dyn_site_desc *sites, int32_t n_sites) {
     if (n_sites < 1 || n_sites > DYN_MAX_SITES) return DYN_ERR_SIZE;
@@ -89,14 +98,16 @@ extern "C" int dyn_latent_param_map(const dyn_site_desc *sites, int32_t n_sites,
     if (dtype != DYN_F32 && dtype != DYN_F64) return DYN_ERR_OPTS;
     dynlat::SiteTable tab;
     if (int rc = fill_table(tab, sites, n_sites)) return rc;
+    const int rows = dynlat_rows_per_chain(split_directions, n_sites);
+    if (rows < 0) return DYN_ERR_SIZE;
     if (C == 0) return 0;
     const dim3 grid((unsigned)((C + 63) / 64)), block(64);
     if (dtype == DYN_F32)
         hipLaunchKernelGGL(dynlat::latent_param_map<float>, grid, block, 0, (hipStream_t)stream, tab, C, z, x, lp, dlp_dz,
-                           (int)P, coef, expo, (float *)params, (float *)seeds, (int)(split_directions != 0));
+                           (int)P, coef, expo, (float *)params, (float *)seeds, rows);
     else
         hipLaunchKernelGGL(dynlat::latent_param_map<double>, grid, block, 0, (hipStream_t)stream, tab, C, z, x, lp, dlp_dz,
-                           (int)P, coef, expo, (double *)params, (double *)seeds, (int)(split_directions != 0));
+                           (int)P, coef, expo, (double *)params, (double *)seeds, rows);
     return hipGetLastError() == hipSuccess ? 0 : DYN_ERR_LAUNCH;
 }
 
@@ -104,8 +115,10 @@ extern "C" int dyn_potential_combine(int64_t C, int32_t n, const double *lp, con
                                      const double *dll, double offset, int32_t split_directions, double *u, double *g, void *stream) {
     if (C > 0 && (!lp || !dlp_dz || !ll || !dll || !u || !g)) return DYN_ERR_NULL;
     if (C < 0 || n < 1 || n > DYN_MAX_SITES) return DYN_ERR_SIZE;
+    const int rows = dynlat_rows_per_chain(split_directions, n);
+    if (rows < 0) return DYN_ERR_SIZE;
     if (C == 0) return 0;
     hipLaunchKernelGGL(dynlat::potential_combine, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, (hipStream_t)stream, C,
-                       (int)n, lp, dlp_dz, ll, dll, offset, (int)(split_directions != 0), u, g);
+                       (int)n, lp, dlp_dz, ll, dll, offset, rows, u, g);
     return hipGetLastError() == hipSuccess ? 0 : DYN_ERR_LAUNCH;
 }

@@ -477,7 +477,7 @@ struct Tail {
     uint64_t magic;
     dyn_nuts_state st;
     dynlat::MapArgs map;
-    int32_t rows_per_chain; // trajectories of one chain in the solve's batch (n_sites when directions are split, else 1)
+    int32_t rows_per_chain; // trajectories of one chain in the solve's batch (directions split: >= n_sites, rows beyond the sites are padding; else 1)
 };
 
 __device__ inline double load_written(const double *p) { // what this wave stored a moment ago (past the vector L1)
@@ -489,22 +489,37 @@ template <int D, typename TL>
 __device__ __forceinline__ void tail_chain(const TL &tl, const int c, const double *ll_out, const double *dll_out) {
     Handed<D> handed;
     handed.ll = load_written(ll_out + (int64_t)c * tl.rows_per_chain);
-    for (int i = 0; i < D; ++i) handed.dll[i] = load_written(dll_out + (int64_t)c * D + i); // [C rows][D / rows] flat == [C][D]
+    // directions split: [C rows][1], row r of a chain carries direction r (rows beyond D are padding); else [C][D]
+    const int64_t first = (int64_t)c * (tl.map.split ? tl.rows_per_chain : D);
+    for (int i = 0; i < D; ++i) handed.dll[i] = load_written(dll_out + first + i);
     advance_chain<D, false>(tl.st, tl.map, c, handed);
 }
 
-constexpr int kFusedMaxDim = 4;
+constexpr int kFusedMaxDim = kRegDim;   // every compile-time-dimension instance of the state machine ...
+constexpr int kFusedLeanMaxDim = 4;     // ... in a general tangent instance; a lean one (solve_kernel.hpp) stops here: the cases beyond
+                                        // cost the cfg 4 kernel 116 bytes of scratch per lane and twice the spilled scalars
 
 // Chain c's iteration inside the gradient-solve launch (solve_kernel.hpp): called by ONE lane per chain, after the wave's
 // stores of ll_out / dll_out have completed.  TL: `Tail` in the address space the caller reads it from (the kernarg segment).
-template <typename TL>
+template <int MAXD, typename TL>
 __device__ __forceinline__ void fused_tail(const TL &tl, const int c, const double *ll_out, const double *dll_out) {
+    static_assert(MAXD == kFusedLeanMaxDim || MAXD == kFusedMaxDim, "fused tail: four or eight dimensions");
     switch (tl.st.dim) {
     case 1: tail_chain<1>(tl, c, ll_out, dll_out); break;
     case 2: tail_chain<2>(tl, c, ll_out, dll_out); break;
     case 3: tail_chain<3>(tl, c, ll_out, dll_out); break;
     case 4: tail_chain<4>(tl, c, ll_out, dll_out); break;
-    default: break; // (dyn_nuts_tail_pack refuses other sizes)
+    default:
+        if constexpr (MAXD > 4) {
+            switch (tl.st.dim) {
+            case 5: tail_chain<5>(tl, c, ll_out, dll_out); break;
+            case 6: tail_chain<6>(tl, c, ll_out, dll_out); break;
+            case 7: tail_chain<7>(tl, c, ll_out, dll_out); break;
+            case 8: tail_chain<8>(tl, c, ll_out, dll_out); break;
+            default: break; // (dyn_nuts_tail_pack refuses other sizes)
+            }
+        }
+        break; // (enqueue() never hands a lean instance more than kFusedLeanMaxDim)
     }
 }
 

@@ -19,6 +19,8 @@
 
 #include <string.h>
 
+int dynlat_rows_per_chain(int32_t split_directions, int32_t n_sites);   // latent_kernel.hip
+
 namespace dynnuts {
 
 template <int D>
@@ -30,7 +32,8 @@ __global__ void __launch_bounds__(64) nuts_advance(const dyn_nuts_state st, cons
     for (int i = 0; i < D; ++i) handed.dll[i] = 0.0;
     if (st.pot_lp != nullptr) {
         handed.ll = st.pot_ll[(int64_t)c * st.pot_ll_stride];
-        for (int i = 0; i < D; ++i) handed.dll[i] = st.pot_dll[(int64_t)c * D + i];
+        const int64_t first = (int64_t)c * (st.pot_dll_stride > 0 ? st.pot_dll_stride : D);
+        for (int i = 0; i < D; ++i) handed.dll[i] = st.pot_dll[first + i];
     }
     advance_chain<D, false>(st, map, c, handed);
 }
@@ -107,7 +110,8 @@ static int build_map(const dyn_nuts_state *st, const dyn_site_desc *sites, int32
     map.enabled = 1;
     map.P = P;
     map.f64 = dtype == DYN_F64;
-    map.split = split_directions != 0;
+    map.split = dynlat_rows_per_chain(split_directions, n_sites);
+    if (map.split < 0) return DYN_ERR_SIZE;
     map.coef = coef;
     map.expo = expo;
     map.x = x;
@@ -148,7 +152,7 @@ extern "C" int dyn_nuts_tail_pack(const dyn_nuts_state *st, const dyn_site_desc 
     t.st = *st;
     t.st.pot_ll = nullptr; // (the fused launch reads its own outputs)
     t.st.pot_dll = nullptr;
-    t.rows_per_chain = split_directions ? n_sites : 1;
+    t.rows_per_chain = t.map.split ? t.map.split : 1;
     memcpy(blob, &t, sizeof(t));
     return 0;
 }

@@ -541,10 +541,11 @@ struct Solver {
     // instruction stream (128 chains on 1024 SIMDs): every switch the wave does not have to evaluate is latency.
     static constexpr bool LEAN = (FEAT & 0x2000) != 0;
     static_assert(!LEAN || (ND > 0 && KV == 0 && !INTRO), "lean instance: tangent kernels of the plain family");
-    // FEAT bit 12: a lean instance whose waves, once their trajectories are scored, run the NUTS state machine of the chains
-    // those trajectories belong to (nuts_device.hpp) -- the sampler iteration as one launch.  Static grids only.
+    // FEAT bit 12: a tangent instance (lean or general: any observed compartment / likelihood mode the fused likelihood takes)
+    // whose waves, once their trajectories are scored, run the NUTS state machine of the chains those trajectories belong to
+    // (nuts_device.hpp) -- the sampler iteration as one launch.  Static grids only.
     static constexpr bool FUSED = (FEAT & 0x1000) != 0;
-    static_assert(!FUSED || LEAN, "the fused sampler tail rides on the lean instance");
+    static_assert(!FUSED || (ND > 0 && KV == 0), "the fused sampler tail rides on a gradient-solve (tangent instance)");
     // FEAT bit 16 (test-only instances): the step controller in the oracle's arithmetic -- IEEE division, sqrtf, powf (stepper.hpp)
     static constexpr bool STRICT_CONTROL = (FEAT & 0x10000) != 0;
     // where solve_kernel_fused's second argument (dynnuts::Tail, by value) sits in the kernel-argument segment
@@ -1521,7 +1522,7 @@ struct Solver {
     static constexpr bool ROOTLESS_NORM = KV == 0;  // the controller works on the mean square of the error (Control::decide_ms); not with the dose cap's kinks
     // FEAT bit 10: a static-grid-only instance -- prologue in front of the stepping loop, write-off behind it, nothing of the
     // queue in between (Stepper: PULLS = false).  For shapes whose launches are static anyway (launch(): two trajectories per wave).
-    static constexpr bool PULLS = (FEAT & 0x0400) == 0 && !LEAN;   // slots may draw further trajectories from KArgs::work (a lean instance is only dispatched without a caller's queue: a static grid)
+    static constexpr bool PULLS = (FEAT & 0x0400) == 0 && !LEAN && !FUSED;   // slots may draw further trajectories from KArgs::work (a lean instance is only dispatched without a caller's queue: a static grid)
     static constexpr bool REPLAYS = false;          // (recorded step schedules: the SEIP family)
     static constexpr bool IDLE_SLOTS_LOAD = false;  // a slot beyond the batch idles without data
     int a, as;            // age lane; (age, first global strain of this lane) = a ST + s0: the lane's place in a compartment

@@ -121,15 +121,32 @@ class FoldedPotential:
                                     and _supported_nd(self.call["model"], method, self.dtype, 1))
         return hit
 
+    def rows_per_chain(self, C: int) -> int:
+        """Trajectories a chain occupies in the gradient-solve's batch: 1 with every direction in one row, else -- one direction
+        per row -- the number of sites rounded up to a power of two (the rows beyond the sites are padding: the chain's
+        parameters, zero seeds).  A wave holds a power of two of trajectories, so whole chains then fall into waves: what the
+        one-launch sampler iteration needs (`dyn_solver_opts::nuts_tail`), six sites included."""
+        if not self.split_directions(C):
+            return 1
+        rows = 1
+        while rows < self.n:
+            rows <<= 1
+        return rows
+
+    def _split_arg(self, C: int) -> int:
+        """``split_directions`` of the C ABI: 0, or the rows per chain."""
+        return self.rows_per_chain(C) if self.split_directions(C) else 0
+
     def _buffers(self, C: int):
         b = self._buf.get(C)
         if b is None:
             dev, f64 = self.pot.device, torch.float64
-            rows = C * self.n if self.split_directions(C) else C                 # split: every chain once per direction
+            split = self.split_directions(C)
+            rows = C * self.rows_per_chain(C)                                    # split: every chain once per direction (+ padding)
             b = self._buf[C] = dict(x=torch.empty((C, self.n), dtype=f64, device=dev), lp=torch.empty(C, dtype=f64, device=dev),
                                     dlp=torch.empty((C, self.n), dtype=f64, device=dev),
                                     params=torch.empty((rows, self.P), dtype=self.dtype, device=dev),
-                                    seeds=torch.empty((rows, (self.n * C) // rows, self.P), dtype=self.dtype, device=dev))
+                                    seeds=torch.empty((rows, 1 if split else self.n, self.P), dtype=self.dtype, device=dev))
         return b
 
     def into(self, z: torch.Tensor, u_out: torch.Tensor, g_out: torch.Tensor) -> None:
@@ -141,15 +158,15 @@ class FoldedPotential:
             raise ValueError(f"shapes: z, g [C, {self.n}], u [C]")
         lp, dlp, ll, dll, stride = self.parts(z)
         rc = _abi.lib().dyn_potential_combine(C, self.n, lp.data_ptr(), dlp.data_ptr(), ll.data_ptr(), dll.data_ptr(), self.offset,
-                                              int(stride > 1), u_out.data_ptr(), g_out.data_ptr(),
+                                              self._split_arg(C), u_out.data_ptr(), g_out.data_ptr(),
                                               ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
         if rc:
             raise RuntimeError(f"dyn_potential_combine: {_abi.ERR_NAMES.get(rc, rc)}")
 
     def parts(self, z: torch.Tensor):
-        """The two launches in front of the combine: ``(lp [C], dlp [C, n], ll, dll [C, n], ll_stride)`` with
-        ``u = -(lp + ll[::ll_stride] + offset)``, ``g = -(dlp + dll)`` -- `dyn_nuts_advance` forms these itself
-        (`dyn_nuts_state.pot_*`)."""
+        """The two launches in front of the combine: ``(lp [C], dlp [C, n], ll, dll [C, rows >= n], ll_stride)`` with
+        ``u = -(lp + ll[::ll_stride] + offset)``, ``g = -(dlp + dll[:, :n])`` -- `dyn_nuts_advance` forms these itself
+        (`dyn_nuts_state.pot_*`; ``pot_dll_stride = dll.shape[1]``)."""
         self.map_now(z)
         return self.solve_current(z.shape[0])
 
@@ -164,7 +181,7 @@ class FoldedPotential:
         arr, n = self.pot.site_table
         rc = _abi.lib().dyn_latent_param_map(arr, n, C, z.data_ptr(), b["x"].data_ptr(), b["lp"].data_ptr(), b["dlp"].data_ptr(),
                                              self.P, self.coef.data_ptr(), self.expo.data_ptr(), _DTYPES[self.dtype],
-                                             int(self.split_directions(C)), b["params"].data_ptr(), b["seeds"].data_ptr(),
+                                             self._split_arg(C), b["params"].data_ptr(), b["seeds"].data_ptr(),
                                              ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
         if rc:
             raise RuntimeError(f"dyn_latent_param_map: {_abi.ERR_NAMES.get(rc, rc)}")
@@ -177,7 +194,7 @@ class FoldedPotential:
         b = self._buffers(C)
         arr, n = self.pot.site_table
         return _abi.lib().dyn_nuts_advance_mapped(ctypes.byref(st), arr, n, self.P, self.coef.data_ptr(), self.expo.data_ptr(),
-                                                  _DTYPES[self.dtype], int(self.split_directions(C)), b["x"].data_ptr(),
+                                                  _DTYPES[self.dtype], self._split_arg(C), b["x"].data_ptr(),
                                                   b["lp"].data_ptr(), b["dlp"].data_ptr(), b["params"].data_ptr(),
                                                   b["seeds"].data_ptr(), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
 
@@ -185,7 +202,7 @@ class FoldedPotential:
         """`dyn_nuts_tail_pack`: the (host) blob that lets the gradient-solve run the sampler's side of an iteration itself
         (``solve_current(C, nuts_tail=...)``: ONE launch per iteration).  ``st`` must carry this potential's prior-side
         buffers in ``pot_lp`` / ``pot_dlp``.  Returns the blob (keep it alive for as long as launches use it), or None when
-        the library refuses (more than four sampled sites)."""
+        the library refuses (more than eight sampled sites)."""
         from ..engine import _DTYPES
 
         L = _abi.lib()
@@ -193,7 +210,7 @@ class FoldedPotential:
         arr, n = self.pot.site_table
         blob = ctypes.create_string_buffer(int(L.dyn_nuts_tail_size()))
         rc = L.dyn_nuts_tail_pack(ctypes.byref(st), arr, n, self.P, self.coef.data_ptr(), self.expo.data_ptr(),
-                                  _DTYPES[self.dtype], int(self.split_directions(C)), b["x"].data_ptr(), b["lp"].data_ptr(),
+                                  _DTYPES[self.dtype], self._split_arg(C), b["x"].data_ptr(), b["lp"].data_ptr(),
                                   b["dlp"].data_ptr(), b["params"].data_ptr(), b["seeds"].data_ptr(), blob)
         if rc == -7:
             return None
@@ -210,7 +227,7 @@ class FoldedPotential:
         b, c = self._buffers(C), self.call
         split = self.split_directions(C)
         method = c["kw"].get("method", "tsit5")
-        if split:      # n C trajectories with one direction each: ll [n C], dll [n C, 1]
+        if split:      # rows C trajectories with one direction each (rows >= n per chain): ll [rows C], dll [rows C, 1]
             ll, dll, *_ = solve_batch_loglik(c["model"], c["y0"], b["params"], c["contact"], c["t1"], c["save_ts"], c["obs"],
                                              c["comp"], dparams=b["seeds"], increments=c["increments"], floor=c["floor"],
                                              nuts_tail=None if nuts_tail is None else ctypes.addressof(nuts_tail), **c["kw"])
@@ -230,7 +247,8 @@ class FoldedPotential:
                 grads.append(dlp_)
                 start += nd
             dll = grads[0] if len(grads) == 1 else torch.cat(grads, dim=1)
-        return b["lp"], b["dlp"], ll, dll.reshape(C, self.n), (self.n if split else 1)
+        rows = self.rows_per_chain(C)
+        return b["lp"], b["dlp"], ll, dll.reshape(C, rows if split else self.n), rows
 
     def deviation(self, z: torch.Tensor):
         """(max |du| / (1 + |u|), max |dg| / (1 + |g|), rows finite in the general potential but not in the folded one) at the

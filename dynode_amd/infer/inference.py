@@ -349,7 +349,7 @@ class MCMCProcess(InferenceProcess):
                                     of its sampled sites and whose only likelihood is the solve's (``infer/folded.py``: the
                                     reference's own inference example is one) is evaluated in three launches per gradient
                                     instead of ~26; any other model silently keeps the general potential (``"verbose"`` says why)
-                     ``fuse``       ``True`` (default) / ``False``: with a folded potential of at most four sites, the
+                     ``fuse``       ``True`` (default) / ``False``: with a folded potential (at most eight sites), the
                                     gradient-solve's waves also run the sampler's side for the chains they scored
                                     (``dyn_solver_opts::nuts_tail``): a sampler iteration is ONE launch, same draws
     """

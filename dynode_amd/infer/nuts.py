@@ -892,7 +892,7 @@ class KernelNUTS(LockstepNUTS):
             folded.map_now(S["z_eval"])
 
         # ... and where the library can fuse the sampler's side into the gradient-solve (dyn_solver_opts::nuts_tail: whole
-        # chains inside a wave, at most four sites), an iteration is that ONE launch.  DYNODE_NUTS_FUSE=0 keeps the two.
+        # chains inside a wave, at most eight sites), an iteration is that ONE launch.  DYNODE_NUTS_FUSE=0 keeps the two.
         tail = {"blob": None}
         if folded is not None and self.fuse and hasattr(folded, "pack_tail") and os.environ.get("DYNODE_NUTS_FUSE", "1") != "0":
             b = folded._buffers(C)
@@ -919,7 +919,7 @@ class KernelNUTS(LockstepNUTS):
                 lp_, dlp_, ll_, dll_, stride = folded.solve_current(C)
                 keep_alive[:] = [lp_, dlp_, ll_, dll_]
                 st.pot_lp, st.pot_dlp, st.pot_ll, st.pot_dll = lp_.data_ptr(), dlp_.data_ptr(), ll_.data_ptr(), dll_.data_ptr()
-                st.pot_offset, st.pot_ll_stride = float(folded.offset), int(stride)
+                st.pot_offset, st.pot_ll_stride, st.pot_dll_stride = float(folded.offset), int(stride), int(dll_.shape[1])
                 rc = folded.advance_mapped(st, C)
             else:
                 u_, g_ = self.pg(S["z_eval"])

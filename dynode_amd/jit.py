@@ -139,10 +139,19 @@ def _seip_plain(model, dtype) -> bool:
             and model.n_vax_knots <= 2)
 
 
+_FUSED = 0x1000          # csrc/dynode_hip.hip kFused
+
+
+def _fused_twin(model, dtype, n_dir) -> bool:
+    """An on-demand tangent build of the s/e/i/r/c family carries the fused-sampler twin too (float32, the sampler's dtype for the
+    solve; one or two directions per trajectory; no vaccination-tier lanes: solve_kernel.hpp FUSED)."""
+    return model.family == 0 and dtype == torch.float32 and n_dir in (1, 2) and model.vax_lanes == 0
+
+
 def _name(model, dtype, method, n_dir, spl) -> str:
     return (f"{'f64' if dtype == torch.float64 else 'f32'}_m{method}_g{_group_width(model.n_age)}_s{model.n_strain}"
             f"_e{int(model.has_e)}w{int(model.has_wane)}c{int(model.has_c)}_W{model.n_wane}_nd{n_dir}_spl{spl}"
-            f"_f{_features(model, dtype)}{'p' if _seip_plain(model, dtype) else ''}_{_stamp()}")
+            f"_f{_features(model, dtype)}{'p' if _seip_plain(model, dtype) else ''}{'t' if _fused_twin(model, dtype, n_dir) else ''}_{_stamp()}")
 
 
 def _source(model, dtype, method, n_dir, spl) -> str:
@@ -166,12 +175,21 @@ def _source(model, dtype, method, n_dir, spl) -> str:
                     f'extern "C" void *dyn_extra_launch_plain(void) {{\n'
                     f"    return (void *)(hipError_t(*)(const dyn::KArgs<{t}> &, hipStream_t)) & dyn::launch_seip<{full}>;\n}}\n")
         return src
-    args = (f"{t}, {method}, {_group_width(model.n_age)}, {model.n_strain}, {b(model.has_e)}, {b(model.has_wane)}, "
-            f"{b(model.has_c)}, {model.n_wane}, {n_dir}, {spl}, {_features(model)}")
-    return (f'#include "{os.path.join(_CSRC, "solve_kernel.hpp")}"\n'
-            f"namespace dyn {{ template hipError_t launch<{args}>(const KArgs<{t}> &, hipStream_t); }}\n"
-            f'extern "C" void *dyn_extra_launch(void) {{\n'
-            f"    return (void *)(hipError_t(*)(const dyn::KArgs<{t}> &, hipStream_t)) & dyn::launch<{args}>;\n}}\n")
+    head = (f"{t}, {method}, {_group_width(model.n_age)}, {model.n_strain}, {b(model.has_e)}, {b(model.has_wane)}, "
+            f"{b(model.has_c)}, {model.n_wane}, {n_dir}, {spl}")
+    args = f"{head}, {_features(model)}"
+    src = (f'#include "{os.path.join(_CSRC, "solve_kernel.hpp")}"\n'
+           f"namespace dyn {{ template hipError_t launch<{args}>(const KArgs<{t}> &, hipStream_t); }}\n"
+           f'extern "C" void *dyn_extra_launch(void) {{\n'
+           f"    return (void *)(hipError_t(*)(const dyn::KArgs<{t}> &, hipStream_t)) & dyn::launch<{args}>;\n}}\n")
+    if _fused_twin(model, dtype, n_dir):
+        # ... and the same gradient-solve with the sampler's side of a NUTS iteration behind it (FEAT bit 12; dynode_hip.hip
+        # kFused): what a call that carries dyn_solver_opts::nuts_tail is dispatched to -- one launch per iteration
+        full = f"{head}, {_features(model) | _FUSED}"
+        src += (f"namespace dyn {{ template hipError_t launch<{full}>(const KArgs<{t}> &, hipStream_t); }}\n"
+                f'extern "C" void *dyn_extra_launch_fused(void) {{\n'
+                f"    return (void *)(hipError_t(*)(const dyn::KArgs<{t}> &, hipStream_t)) & dyn::launch<{full}>;\n}}\n")
+    return src
 
 
 def ensure_kernel(model: _abi.ModelDesc, dtype=torch.float32, method: str = "tsit5", n_dir: int = 0) -> bool:
@@ -236,5 +254,12 @@ def ensure_kernel(model: _abi.ModelDesc, dtype=torch.float32, method: str = "tsi
                                          _features(model, dtype) | _SEIP_PLAIN, ctypes.c_void_p(extra.dyn_extra_launch_plain()))
             if rc:
                 raise RuntimeError(f"dyn_register_instance (plain): {_abi.ERR_NAMES.get(rc, rc)}")
+        if _fused_twin(model, dtype, n_dir) and hasattr(extra, "dyn_extra_launch_fused"):
+            extra.dyn_extra_launch_fused.restype = ctypes.c_void_p
+            rc = L.dyn_register_instance(opts.dtype, mid, _group_width(model.n_age), model.n_strain, int(model.has_e),
+                                         int(model.has_wane), int(model.has_c), model.n_wane, n_dir, spl,
+                                         _features(model, dtype) | _FUSED, ctypes.c_void_p(extra.dyn_extra_launch_fused()))
+            if rc:
+                raise RuntimeError(f"dyn_register_instance (fused): {_abi.ERR_NAMES.get(rc, rc)}")
         _LOADED[name] = extra
     return True

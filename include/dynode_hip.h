@@ -175,10 +175,13 @@ typedef struct dyn_solver_opts {
      * next positions in `params` / `dparams` (which must be the blob's buffers) for the next call: one launch per sampler
      * iteration instead of two, the same draws bit for bit.  The blob is read during the call (it travels as a kernel
      * argument), so a captured HIP graph holds its own copy.  Needs the chain-major batch of dyn_nuts_advance_mapped (chain c
-     * = trajectories c*rows .. c*rows + rows - 1), every chain's trajectories inside one wave, no caller order, at most 4
-     * sampled dimensions and the likelihood options of the reference's inference example (poisson on slot 3 increments);
-     * otherwise the call returns DYN_ERR_UNSUPPORTED with nothing enqueued and the caller keeps its two launches
-     * (DYN_ERR_OPTS: the pointer is not a packed blob). */
+     * = trajectories c*rows .. c*rows + rows - 1), every chain's trajectories inside one wave (rows divides the trajectories
+     * per wave, dyn_trajectories_per_wave_for_batch: pad the chains to a power of two of rows, dyn_latent_param_map), no
+     * caller order, at most 8 sampled dimensions -- either one per row or all in a chain's single row -- and a shape whose
+     * tangent instance was compiled with the sampler behind it (ABI 9: any observed compartment / likelihood mode of
+     * dyn_solve_batch_loglik; csrc/instances.def units 28, 33, 34, and every float32 shape built on demand); otherwise the
+     * call returns DYN_ERR_UNSUPPORTED with nothing enqueued and the caller keeps its two launches (DYN_ERR_OPTS: the pointer
+     * is not a packed blob). */
     const void *nuts_tail;
     /* ABI 9: all zero = the library's choices (see dyn_dispatch_hints) */
     dyn_dispatch_hints hints;
@@ -378,11 +381,13 @@ typedef struct dyn_nuts_state {
     double *out_z, *out_acc;           /* [C][num_samples][D], [C][num_samples] */
     int32_t *out_n, *out_div;          /* [C][num_samples] leapfrogs per draw, divergence flag */
     /* ABI 6, optional: the potential at z_eval in parts instead of (u_new, g_new) -- when pot_lp != NULL the kernel forms
-     * u = -(pot_lp[c] + pot_ll[c * pot_ll_stride] + pot_offset), g[c][i] = -(pot_dlp[c][i] + pot_dll[c][i]) itself
-     * (what dyn_potential_combine would write; saves that launch in every sampler iteration) */
+     * u = -(pot_lp[c] + pot_ll[c * pot_ll_stride] + pot_offset), g[c][i] = -(pot_dlp[c][i] + pot_dll[c * pot_dll_stride + i])
+     * itself (what dyn_potential_combine would write; saves that launch in every sampler iteration).  pot_dll_stride = 0
+     * means D (a dense [C][D]); a gradient-solve with one direction per trajectory and padded chains (dyn_latent_param_map,
+     * split_directions > n_sites) leaves [C][rows] */
     const double *pot_lp, *pot_dlp, *pot_ll, *pot_dll;
     double pot_offset;
-    int32_t pot_ll_stride, pot_reserved;
+    int32_t pot_ll_stride, pot_dll_stride;
 } dyn_nuts_state;
 int dyn_nuts_advance(const dyn_nuts_state *st, void *stream);
 /* sizeof(dyn_nuts_state), for binding checks */
@@ -430,6 +435,9 @@ int dyn_latent_sites(const dyn_site_desc *sites, int32_t n_sites, int64_t C, con
  *     one -- params [C][n_sites][P] (chain c repeated n_sites times), seeds [C][n_sites][1][P], to be solved as a batch of
  *     n_sites C rows with n_dir = 1 (a third less work on the serial path of every trajectory at n_sites = 2; same bits); the
  *     combine then reads ll [C n_sites] at c n_sites and dll [C n_sites][1] as [c][i].
+ *   split_directions = r >= 2 (n_sites <= r <= 64): the same with r rows per chain -- rows n_sites .. r - 1 of a chain are
+ *     padding (its parameters, zero seeds; their outputs are never read): params [C][r][P], seeds [C][r][1][P], ll [C r],
+ *     dll [C r][1].  With r a power of two whole chains fall into waves, which dyn_solver_opts::nuts_tail needs.
  */
 int dyn_latent_param_map(const dyn_site_desc *sites, int32_t n_sites, int64_t C, const double *z, double *x, double *lp,
                          double *dlp_dz, int32_t P, const double *coef, const double *expo, int32_t dtype,
@@ -447,7 +455,7 @@ int dyn_nuts_advance_mapped(const dyn_nuts_state *st, const dyn_site_desc *sites
  * dyn_nuts_tail_size() bytes, owned by the caller).  st->pot_lp / pot_dlp / pot_offset must be set (= lp, dlp_dz);
  * st->pot_ll / pot_dll are not used -- the fused launch reads what it wrote itself.  The device buffers named inside must stay
  * valid and unmoved for as long as launches use the blob (a sampler run: the state buffers never move).  DYN_ERR_UNSUPPORTED:
- * more than 4 sampled dimensions. */
+ * more than 8 sampled dimensions (where the site table and the compile-time-dimension state machines stop too). */
 int32_t dyn_nuts_tail_size(void);
 int dyn_nuts_tail_pack(const dyn_nuts_state *st, const dyn_site_desc *sites, int32_t n_sites, int32_t P, const double *coef,
                        const double *expo, int32_t dtype, int32_t split_directions, double *x, double *lp, double *dlp_dz,

@@ -148,6 +148,27 @@ def test_sampler_entry_validates_before_launching():
     assert lib.dyn_nuts_advance(ctypes.byref(st), None) == 0
 
 
+def test_rows_per_chain_of_the_latent_map_are_validated():
+    """`split_directions` of dyn_latent_param_map / dyn_potential_combine: 0 = every direction in the chain's one row, 1 = n_sites
+    rows, r >= 2 = r rows with r >= n_sites (the rest padding; include/dynode_hip.h) -- anything else is a size error, found
+    before any launch (C = 0: nothing runs, no GPU needed)."""
+    lib = _abi.lib()
+    sites = (_abi.SiteDescC * 3)()
+    for sd in sites:                                       # Normal(0, 1), identity transform
+        sd.dist, sd.aff_scale, sd.lo, sd.hi = 0, 1.0, -1e300, 1e300
+        sd.p[0], sd.p[1] = 0.0, 1.0
+    dummy = (ctypes.c_double * 16)()
+    addr = ctypes.addressof(dummy)
+
+    def rc(split, n=3):
+        return lib.dyn_latent_param_map(sites, n, 0, None, None, None, None, 2, addr, addr, _abi.DYN_F32, split, None, None, None)
+
+    assert rc(0) == 0 and rc(1) == 0 and rc(3) == 0 and rc(4) == 0 and rc(64) == 0
+    assert rc(2) == -3 and rc(65) == -3 and rc(-1) == -3   # fewer rows than sites, more than a wavefront, negative
+    assert lib.dyn_potential_combine(0, 3, None, None, None, None, 0.0, 2, None, None, None) == -3
+    assert lib.dyn_potential_combine(0, 3, None, None, None, None, 0.0, 8, None, None, None) == 0
+
+
 @pytest.mark.on_demand_build
 def test_on_demand_kernel_build_and_registration():
     """dynode_amd/jit.py without a GPU: lane mapping choices, and a full build + dyn_register_instance
