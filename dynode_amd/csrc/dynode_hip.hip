@@ -854,4 +854,11 @@ int32_t dyn_is_supported_jvp(const dyn_model_desc *m, const dyn_solver_opts *o, 
     return dyn::find_entry(m, o->dtype, o->method, n_dir) ? 1 : 0;
 }
 
+int32_t dyn_fused_twin(const dyn_model_desc *m, const dyn_solver_opts *o, int32_t n_dir) {
+    if (dyn::check_model(m) || !o || n_dir < 1 || m->family != 0) return 0;
+    const dyn::Entry *e = dyn::find_entry(m, o->dtype, o->method, n_dir);
+    if (!e) return 0;
+    return dyn::find_variant(e, e->FEAT | dyn::kFused) ? 1 : -e->SPL;
+}
+
 } // extern "C"

@@ -205,9 +205,16 @@ class FoldedPotential:
         the library refuses (more than eight sampled sites)."""
         from ..engine import _DTYPES
 
+        from .. import jit
+
         L = _abi.lib()
         b = self._buffers(C)
         arr, n = self.pot.site_table
+        # the gradient-solve's instance needs its twin with the sampler behind it: built in for the inference examples' shapes,
+        # built on first use for any other float32 shape (dynode_amd/jit.py)
+        n_dir = 1 if self.split_directions(C) else self.n
+        if n > _abi.NUTS_REG_DIM or not jit.ensure_fused_twin(self.call["model"], self.dtype, self.call["kw"].get("method", "tsit5"), n_dir):
+            return None
         blob = ctypes.create_string_buffer(int(L.dyn_nuts_tail_size()))
         rc = L.dyn_nuts_tail_pack(ctypes.byref(st), arr, n, self.P, self.coef.data_ptr(), self.expo.data_ptr(),
                                   _DTYPES[self.dtype], self._split_arg(C), b["x"].data_ptr(), b["lp"].data_ptr(),

@@ -192,6 +192,84 @@ def _source(model, dtype, method, n_dir, spl) -> str:
     return src
 
 
+def _build(name: str, source, entry: str, what: str) -> str:
+    """``lib/jit/<name>.so`` from ``source()`` unless it is there already (callers hold ``_LOCK``); ``entry``: a symbol the
+    finished library must export."""
+    os.makedirs(_OUT, exist_ok=True)
+    so = os.path.join(_OUT, name + ".so")
+    if not os.path.exists(so):
+        if not os.path.exists(HIPCC):
+            raise RuntimeError(f"{HIPCC} not found: cannot build the kernel for {what}; add it to csrc/instances.def "
+                               "on a machine with ROCm and rebuild")
+        # one builder per shape across processes (torchrun ranks miss the same shape at the same moment): the others
+        # wait on the lock file and then find the finished library
+        import fcntl
+
+        with open(os.path.join(_OUT, name + ".lock"), "w") as lock:
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            try:
+                if not os.path.exists(so):
+                    tag = f"{name}.{os.getpid()}"
+                    src, tmp = os.path.join(_OUT, tag + ".hip"), os.path.join(_OUT, tag + ".tmp.so")
+                    with open(src, "w") as f:          # a source file of this process's own: never rewritten under a reader
+                        f.write(source())
+                    print(f"[dynode_amd] building the kernel for {name} (one-off, ~15 s) ...", file=sys.stderr, flush=True)
+                    try:
+                        flags = ["-fno-slp-vectorize"]      # as csrc/Makefile (SOLVE_FLAGS, SEIP_FLAGS)
+                        subprocess.run([HIPCC, "-O3", "-std=c++17", "-fPIC", "-shared", "--offload-arch=gfx950", *flags, src, "-o", tmp],
+                                       check=True)
+                        probe = ctypes.CDLL(tmp)           # refuse to publish a library without its entry point
+                        getattr(probe, entry)
+                        os.replace(tmp, so)                # atomic: nobody ever loads a half-written file
+                    finally:
+                        for leftover in (src, tmp):
+                            if os.path.exists(leftover):
+                                os.remove(leftover)
+            finally:
+                fcntl.flock(lock, fcntl.LOCK_UN)
+    return so
+
+
+def ensure_fused_twin(model: _abi.ModelDesc, dtype=torch.float32, method: str = "tsit5", n_dir: int = 1) -> bool:
+    """Make sure the tangent kernel of (model shape, dtype, method, n_dir) has the twin that carries the sampler's side of a
+    NUTS iteration (``dyn_solver_opts::nuts_tail``, FEAT bit 12): shapes of ``csrc/instances.def`` other than the inference
+    examples' have the tangent kernel built in without it.  True when the twin exists afterwards (built in, loaded or built now);
+    False when it cannot (no tangent kernel, another family / dtype, no hipcc, JIT disabled) -- the sampler then keeps two
+    launches per iteration."""
+    mid = {"tsit5": _abi.DYN_TSIT5, "dopri5": _abi.DYN_DOPRI5}[method]
+    L = _abi.lib()
+    opts = _abi.SolverOptsC(mid, _abi.DYN_F64 if dtype == torch.float64 else _abi.DYN_F32, 1e-5, 1e-6, 10**6, 0.0, None, 0)
+    mc = model.c()
+    have = int(L.dyn_fused_twin(ctypes.byref(mc), ctypes.byref(opts), n_dir))
+    if have >= 0:
+        return have == 1
+    if not (enabled() and _fused_twin(model, dtype, n_dir) and os.path.exists(HIPCC)):
+        return False
+    spl = -have
+    name = _name(model, dtype, mid, n_dir, spl) + "_twin"
+    with _LOCK:
+        if name in _LOADED:
+            return True
+        t = "float"
+        b = lambda v: "true" if v else "false"   # noqa: E731
+        full = (f"{t}, {mid}, {_group_width(model.n_age)}, {model.n_strain}, {b(model.has_e)}, {b(model.has_wane)}, "
+                f"{b(model.has_c)}, {model.n_wane}, {n_dir}, {spl}, {_features(model) | _FUSED}")
+        text = (f'#include "{os.path.join(_CSRC, "solve_kernel.hpp")}"\n'
+                f"namespace dyn {{ template hipError_t launch<{full}>(const KArgs<{t}> &, hipStream_t); }}\n"
+                f'extern "C" void *dyn_extra_launch_fused(void) {{\n'
+                f"    return (void *)(hipError_t(*)(const dyn::KArgs<{t}> &, hipStream_t)) & dyn::launch<{full}>;\n}}\n")
+        so = _build(name, lambda: text, "dyn_extra_launch_fused", f"{model} (fused sampler twin)")
+        extra = ctypes.CDLL(so)
+        extra.dyn_extra_launch_fused.restype = ctypes.c_void_p
+        rc = L.dyn_register_instance(opts.dtype, mid, _group_width(model.n_age), model.n_strain, int(model.has_e),
+                                     int(model.has_wane), int(model.has_c), model.n_wane, n_dir, spl,
+                                     _features(model, dtype) | _FUSED, ctypes.c_void_p(extra.dyn_extra_launch_fused()))
+        if rc:
+            raise RuntimeError(f"dyn_register_instance (fused twin): {_abi.ERR_NAMES.get(rc, rc)}")
+        _LOADED[name] = extra
+    return True
+
+
 def ensure_kernel(model: _abi.ModelDesc, dtype=torch.float32, method: str = "tsit5", n_dir: int = 0) -> bool:
     """Make sure a kernel for (model shape, dtype, method, n_dir) exists; returns True if one had to be
     built or loaded.  Raises if hipcc is missing or the shape cannot be mapped to lanes."""
@@ -208,38 +286,7 @@ def ensure_kernel(model: _abi.ModelDesc, dtype=torch.float32, method: str = "tsi
     with _LOCK:
         if name in _LOADED:
             return False
-        os.makedirs(_OUT, exist_ok=True)
-        so = os.path.join(_OUT, name + ".so")
-        if not os.path.exists(so):
-            if not os.path.exists(HIPCC):
-                raise RuntimeError(f"{HIPCC} not found: cannot build the kernel for {model}; add it to csrc/instances.def "
-                                   "on a machine with ROCm and rebuild")
-            # one builder per shape across processes (torchrun ranks miss the same shape at the same moment): the others
-            # wait on the lock file and then find the finished library
-            import fcntl
-
-            with open(os.path.join(_OUT, name + ".lock"), "w") as lock:
-                fcntl.flock(lock, fcntl.LOCK_EX)
-                try:
-                    if not os.path.exists(so):
-                        tag = f"{name}.{os.getpid()}"
-                        src, tmp = os.path.join(_OUT, tag + ".hip"), os.path.join(_OUT, tag + ".tmp.so")
-                        with open(src, "w") as f:          # a source file of this process's own: never rewritten under a reader
-                            f.write(_source(model, dtype, mid, n_dir, spl))
-                        print(f"[dynode_amd] building the kernel for {name} (one-off, ~15 s) ...", file=sys.stderr, flush=True)
-                        try:
-                            flags = ["-fno-slp-vectorize"]      # as csrc/Makefile (SOLVE_FLAGS, SEIP_FLAGS)
-                            subprocess.run([HIPCC, "-O3", "-std=c++17", "-fPIC", "-shared", "--offload-arch=gfx950", *flags, src, "-o", tmp],
-                                           check=True)
-                            probe = ctypes.CDLL(tmp)           # refuse to publish a library without its entry point
-                            probe.dyn_extra_launch
-                            os.replace(tmp, so)                # atomic: nobody ever loads a half-written file
-                        finally:
-                            for leftover in (src, tmp):
-                                if os.path.exists(leftover):
-                                    os.remove(leftover)
-                finally:
-                    fcntl.flock(lock, fcntl.LOCK_UN)
+        so = _build(name, lambda: _source(model, dtype, mid, n_dir, spl), "dyn_extra_launch", f"{model}")
         extra = ctypes.CDLL(so)
         extra.dyn_extra_launch.restype = ctypes.c_void_p
         rc = L.dyn_register_instance(opts.dtype, mid, _group_width(model.n_age), model.n_strain, int(model.has_e),

@@ -328,6 +328,11 @@ int dyn_register_instance(int32_t dtype, int32_t method, int32_t ga, int32_t n_s
                           int32_t features, void *launch_fn);
 /* 1 if a tangent kernel for (model shape, method, dtype, n_dir) is compiled in */
 int32_t dyn_is_supported_jvp(const dyn_model_desc *m, const dyn_solver_opts *o, int32_t n_dir);
+/* Does that tangent kernel have the twin that also runs the sampler's side of a NUTS iteration (dyn_solver_opts::nuts_tail)?
+ * 1: yes.  0: there is no tangent kernel for the shape at all.  -spl (< 0): the kernel exists without the twin; a builder adds
+ * it as dyn_register_instance(..., n_dir, spl, features | 0x1000, launch<..., spl, features | 0x1000>) -- dynode_amd/jit.py does
+ * on first use. */
+int32_t dyn_fused_twin(const dyn_model_desc *m, const dyn_solver_opts *o, int32_t n_dir);
 
 /*
  * One NUTS sampler iteration for n_chains independent chains (one GPU thread per chain).

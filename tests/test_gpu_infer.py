@@ -5,6 +5,8 @@ quadrature of the 2-parameter posterior on a fine grid (one batched solve), agai
 NUTS marginals must pass a KS test -- the north star's "KS-test agreement on posteriors".
 """
 
+import ctypes
+
 import numpy as np
 import pytest
 import torch
@@ -668,6 +670,64 @@ def test_one_launch_per_iteration_beyond_the_inference_example(data, case):
     for a, b_ in zip(runs[True][:4], runs[False][:4]):
         assert torch.equal(a, b_)
     assert bool(torch.isfinite(runs[True][0]).all()) and float(runs[True][0].std()) > 0
+
+
+@pytest.mark.on_demand_build
+def test_fused_twin_of_a_built_in_tangent_kernel_is_built_on_first_use():
+    """Shapes other than the inference examples' have their tangent kernels built in WITHOUT the sampler behind them
+    (`dyn_fused_twin` < 0); the first sampler run on such a model builds the twin (`jit.ensure_fused_twin`, hipcc) and
+    registers it.  The reference's 1-bin SEIRS (examples/seirs.py) with priors on r0, the infectious and the latent
+    period: three sites, chains padded to four trajectory rows, one launch per iteration, same draws as with two."""
+    from dynode_amd import PoissonObservation, _abi, jit, simulate
+    from dynode_amd.infer import distributions as dist
+    from dynode_amd.infer import folded, sample_then_resolve
+    from dynode_amd.infer.nuts import KernelNUTS
+    from dynode_amd.rhs import SEIRS_ODEParams, seirs_ode
+    from examples import seirs as ex_s
+
+    def solve(config, tf, observe=None):
+        tp = config.parameters.transmission_params
+        one = torch.ones((), dtype=torch.float64)
+        r0, t_inf, t_lat = (torch.as_tensor(v, dtype=torch.float64) * one for v in (tp.strains[0].r0, tp.strains[0].infectious_period, tp.latent_period))
+        par = SEIRS_ODEParams(beta=r0 / t_inf, gamma=1.0 / t_inf, sigma=1.0 / t_lat, omega=np.array(1.0 / tp.waning_period))
+        return simulate(ode=seirs_ode, duration_days=tf, initial_state=config.initializer.get_initial_state(), ode_parameters=par,
+                        solver_parameters=config.parameters.solver_params, observe=observe)
+
+    def model(config, tf, obs_data):
+        config = config.model_copy(deep=False)
+        config.parameters = config.parameters.model_copy(deep=False)
+        config.parameters.transmission_params = sample_then_resolve(config.parameters.transmission_params)
+        sol = solve(config, tf, observe=PoissonObservation(compartment=config.idx.i, data=obs_data, increments=False, floor=1e-9))
+        handlers.factor("prevalence", sol.log_likelihood)
+        return sol
+
+    truth = ex_s.get_config()
+    obs = solve(truth, 90).ys[truth.idx.i].cpu()                  # prevalence (a fraction: the example's population is 1)
+    config = ex_s.get_config()
+    tp = config.parameters.transmission_params
+    tp.strains[0].r0 = dist.TransformedDistribution(dist.Beta(2.0, 2.0), dist.transforms.AffineTransform(1.2, 2.0))
+    tp.strains[0].infectious_period = dist.TruncatedNormal(loc=7.0, scale=2.0, low=3.0, high=12.0)
+    tp.latent_period = dist.Uniform(1.0, 6.0)
+
+    pot = Potential(model, dict(config=config, tf=90, obs_data=obs), 0, torch.device("cuda"))
+    f = folded.discover(pot)
+    assert f is not None and f.n == 3 and f.rows_per_chain(16) == 4
+    mc, opts = f.call["model"].c(), _abi.SolverOptsC(_abi.DYN_TSIT5, _abi.DYN_F32, 1e-5, 1e-6, 10**6, 0.0, None, 0)
+    had = int(_abi.lib().dyn_fused_twin(ctypes.byref(mc), ctypes.byref(opts), 1))
+    assert had in (-1, 1)                                         # -1: built-in tangent kernel (one strain per lane), no twin yet
+    z0 = pot.initial(16, init_to_median, 3)
+    runs = {}
+    for fuse in (True, False):
+        f = folded.discover(pot)
+        sampler = KernelNUTS(f, max_tree_depth=6, target_accept=0.8, seed=11, fuse=fuse, block=16)
+        sampler.recheck_blocks = ()
+        res = sampler.run(z0, 64, 32)
+        runs[fuse] = (res.samples.clone(), res.num_steps.clone(), res.step_size.clone(), sampler.launches_per_iteration)
+    assert int(_abi.lib().dyn_fused_twin(ctypes.byref(mc), ctypes.byref(opts), 1)) == 1
+    assert runs[True][3] == 1 and runs[False][3] == 2
+    for a, b_ in zip(runs[True][:3], runs[False][:3]):
+        assert torch.equal(a, b_)
+    assert jit.ensure_fused_twin(f.call["model"], torch.float32, "tsit5", 1) and not jit.ensure_fused_twin(f.call["model"], torch.float64, "tsit5", 1)
 
 
 def test_a_call_that_cannot_carry_the_sampler_is_refused(data):
