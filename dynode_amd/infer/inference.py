@@ -54,33 +54,47 @@ class Potential:
                                   if s["type"] == "sample" and not s["is_observed"])
         if not self.latent:
             raise ValueError("the model has no latent sample sites")
-        for n, s in tr.sites.items():
-            if s["type"] == "sample" and not s["is_observed"] and tuple(s["value"].shape) not in ((), (1,)):
-                raise ValueError(f"latent site {n!r} is not scalar; vector-valued latents are not supported yet")
+        # a site may be vector- (tensor-) valued with element-wise independent distributions (numpyro: a distribution with a
+        # batch shape): its elements take consecutive unconstrained coordinates, and the model sees a [chains, *shape] value
+        self.shapes = OrderedDict((n, tuple(tr.sites[n]["value"].shape)) for n in self.latent)
+        self.slices, offset = OrderedDict(), 0
+        for n, shape in self.shapes.items():
+            if tuple(self.latent[n].batch_shape) != shape:
+                raise ValueError(f"latent site {n!r}: value shape {shape} is not the distribution's batch shape {tuple(self.latent[n].batch_shape)}")
+            k = int(np.prod(shape)) if shape else 1
+            self.slices[n] = (offset, k)
+            offset += k
         self.deterministic = [n for n, s in tr.sites.items() if s["type"] == "deterministic"]
         self.bij = OrderedDict((n, biject_to(d.support)) for n, d in self.latent.items())
-        self.dim = len(self.latent)
+        self.dim = offset
+        self.scalar_sites = all(shape == () for shape in self.shapes.values())
         # bijections + log priors + log-Jacobians of all latent sites as one kernel launch, when every
-        # site is in the fused families (fused_sites.py); otherwise the generic torch path below
+        # site is a scalar in the fused families (fused_sites.py); otherwise the generic torch path below
         self.site_table = None
         self._ones: dict = {}
-        if torch.device(device).type == "cuda":
+        if torch.device(device).type == "cuda" and self.scalar_sites:
             from . import fused_sites
 
             self.site_table = fused_sites.build_table(self.latent.values())
 
+    def _coords(self, z: torch.Tensor, name: str) -> torch.Tensor:
+        """The unconstrained coordinates of site ``name``: [..., *shape]."""
+        o, k = self.slices[name]
+        shape = self.shapes[name]
+        return z[..., o] if shape == () else z[..., o:o + k].reshape(tuple(z.shape[:-1]) + shape)
+
     def constrain(self, z: torch.Tensor) -> "OrderedDict[str, torch.Tensor]":
-        return OrderedDict((n, b(z[..., i])) for i, (n, b) in enumerate(self.bij.items()))
+        return OrderedDict((n, b(self._coords(z, n))) for n, b in self.bij.items())
 
     def initial(self, chains: int, strategy, seed: int) -> torch.Tensor:
         gen = torch.Generator().manual_seed(seed)
         kind, n = strategy if isinstance(strategy, tuple) else strategy()
         cols = []
         for name, d in self.latent.items():
-            draws = d.sample(gen, (chains, n)).reshape(chains, n)
+            draws = d.sample(gen, (chains, n)).reshape((chains, n) + self.shapes[name])
             x = draws.median(dim=1).values if kind == "median" else draws[:, 0]
-            cols.append(self.bij[name].inv(x))
-        return torch.stack(cols, dim=1).to(self.device)
+            cols.append(self.bij[name].inv(x).reshape(chains, -1))
+        return torch.cat(cols, dim=1).to(self.device)
 
     def log_joint(self, z: torch.Tensor):
         """(log p(x, obs) + log|dx/dz|) per chain, and the trace."""
@@ -97,8 +111,9 @@ class Potential:
             with handlers.substitute(x), handlers.trace() as tr:
                 self.model(**self.kwargs)
             total = torch.zeros(C, dtype=torch.float64, device=z.device)
-            for i, (name, b) in enumerate(self.bij.items()):
-                total = total + self.latent[name].log_prob(x[name]) + b.log_abs_det_jacobian(z[:, i])
+            for name, b in self.bij.items():
+                lp = self.latent[name].log_prob(x[name]) + b.log_abs_det_jacobian(self._coords(z, name))
+                total = total + (lp if lp.dim() == 1 else lp.reshape(C, -1).sum(-1))
         for name, s in tr.sites.items():
             if s["type"] == "sample" and s["is_observed"]:
                 lp = s["fn"].log_prob(s["value"].to(z.device))
@@ -195,8 +210,8 @@ class MCMCResult:
         self.num_samples = int(nuts.samples.shape[1])       # numpyro's MCMC.num_samples
 
     def get_samples(self, group_by_chain: bool = False) -> dict:
-        x = self.potential.constrain(self.nuts.samples)            # [C, N] per site
-        return {n: (v if group_by_chain else v.reshape(-1)) for n, v in x.items()}
+        x = self.potential.constrain(self.nuts.samples)            # [C, N, *shape] per site
+        return {n: (v if group_by_chain else v.reshape((-1,) + tuple(v.shape[2:]))) for n, v in x.items()}
 
     @property
     def last_state(self):
@@ -204,13 +219,19 @@ class MCMCResult:
 
     def summary(self) -> dict:
         """site -> {mean, std, median, 5.0%, 95.0%, n_eff, r_hat}: the columns of numpyro's ``MCMC.print_summary``
-        (effective sample size and split R-hat from ``infer/diagnostics.py``), scalar sites only."""
+        (effective sample size and split R-hat from ``infer/diagnostics.py``); a vector-valued site has a row per element,
+        ``name[i]`` (``name[i,j]`` ...), as numpyro prints them."""
         from .diagnostics import effective_sample_size, split_rhat
 
-        out = {}
+        flat = {}
         for n, v in self.get_samples(group_by_chain=True).items():
-            if v.dim() != 2:
-                continue
+            if v.dim() == 2:
+                flat[n] = v
+            else:
+                for idx in np.ndindex(*v.shape[2:]):
+                    flat[f"{n}[{','.join(map(str, idx))}]"] = v[(slice(None), slice(None)) + idx]
+        out = {}
+        for n, v in flat.items():
             x = v.detach().double().cpu().numpy()
             q = np.quantile(x, [0.05, 0.5, 0.95])
             out[n] = {"mean": float(x.mean()), "std": float(x.std(ddof=1)), "median": float(q[1]), "5.0%": float(q[0]),

@@ -1060,6 +1060,53 @@ def test_kernel_sampler_on_the_multi_strain_model_agrees_with_the_gradient_free_
             assert abs(a.mean() - truth[name]) < max(4 * a.std(), 0.02 * truth[name]), (name, a.mean(), truth[name])
 
 
+def test_vector_valued_sites_sample_the_same_posterior_as_scalar_ones():
+    """The 2-age x 3-strain model with ONE site per parameter kind -- ``r0 ~ shape (3,)``, ``infectious_period ~ shape (3,)``,
+    the way a numpyro model would declare per-strain priors as a distribution with a batch shape -- against the six scalar
+    sites of examples/infer_multi_strain.py (same priors, same data): six unconstrained coordinates either way, the sampler
+    kernel on the general autograd potential, per-element two-sample KS p > 0.01 and means within three standard errors."""
+    from dynode_amd import PoissonObservation, simulate
+    from dynode_amd.infer import distributions as dist
+    from dynode_amd.rhs import SEIRS_MultiStrain_ODEParams, seirs_multi_strain_ode
+    from examples import infer_multi_strain as ex_m
+    from examples import seirs_multi_strain_age_stratified as base
+
+    obs = ex_m.synthetic_incidence(120)
+    static = base.get_config(**ex_m.TRUTH)
+    tp = static.parameters.transmission_params
+    t_lat = torch.tensor(ex_m.TRUTH["latent_periods"], dtype=torch.float64)
+
+    def model(tf, obs_data, t_lat):        # (tensors among the keyword arguments live on the device from the start: no copy per evaluation)
+        r0 = handlers.sample("r0", dist.TransformedDistribution(dist.Beta(torch.full((3,), 2.0), 2.0), dist.transforms.AffineTransform(1.2, 2.0)))
+        t_inf = handlers.sample("infectious_period", dist.TruncatedNormal(loc=torch.full((3,), 7.0), scale=2.0, low=3.0, high=12.0))
+        par = SEIRS_MultiStrain_ODEParams(beta=r0 / t_inf, gamma=1.0 / t_inf, sigma=(1.0 / t_lat).to(r0.device) * torch.ones_like(r0),   # (a no-op on the device; the first trace runs on prior draws on the host)
+                                          omega=1.0 / np.array(tp.waning_period, dtype=float), contact_matrix=tp.contact_matrix, idx=static.idx)
+        sol = simulate(ode=seirs_multi_strain_ode, duration_days=tf, initial_state=ex_m.initial_state(static), ode_parameters=par,
+                       solver_parameters=static.parameters.solver_params,
+                       observe=PoissonObservation(compartment=static.idx.c, data=obs_data, increments=True, floor=1e-6))
+        handlers.factor("incidence", sol.log_likelihood)
+        return sol
+
+    chains, draws = 32, 250
+    vec = MCMCProcess(numpyro_model=model, num_warmup=draws, num_samples=draws, num_chains=chains, nuts_max_tree_depth=8, progress_bar=False)
+    mcmc = vec.infer(tf=120, obs_data=obs, t_lat=t_lat)
+    assert mcmc.sampler == "KernelNUTS" and mcmc.potential.dim == 6 and mcmc.potential.shapes == {"r0": (3,), "infectious_period": (3,)}
+    post = vec.get_samples(group_by_chain=True)
+    assert tuple(post["r0"].shape) == (chains, draws, 3) and tuple(vec.get_samples()["r0"].shape) == (chains * draws, 3)
+    assert set(mcmc.summary()) == {f"{n}[{k}]" for n in ("r0", "infectious_period") for k in range(3)}
+    ref = MCMCProcess(numpyro_model=ex_m.model, num_warmup=draws, num_samples=draws, num_chains=chains, nuts_max_tree_depth=8, progress_bar=False)
+    ref.infer(config=ex_m.get_config(6), tf=120, obs_data=obs)
+    post_s = ref.get_samples(group_by_chain=True)
+    for name in ("r0", "infectious_period"):
+        for k in range(3):
+            a = post[name][:, ::5, k].reshape(-1).cpu().numpy()
+            b = post_s[f"strains_{k}_{name}"][:, ::5].reshape(-1).cpu().numpy()
+            ks = stats.ks_2samp(a, b)
+            print(f"{name}[{k}]: vector site {a.mean():.4f} +- {a.std():.4f}, scalar sites {b.mean():.4f} +- {b.std():.4f}, KS p {ks.pvalue:.3f}")
+            assert ks.pvalue > 0.01, (name, k, ks)
+            assert abs(a.mean() - b.mean()) < 3.0 * np.hypot(a.std(), b.std()) / np.sqrt(a.size / 4.0), (name, k, a.mean(), b.mean())
+
+
 def test_sampler_kernel_beyond_eight_dimensions_on_a_correlated_gaussian():
     """The run-time-dimension instance of dyn_nuts_advance (9 .. 32 dimensions; csrc/nuts_device.hpp `advance_chain<DMAX, RT>`)
     on an analytic 12-dimensional target, and the 8-dimensional compiled instance beside it on the leading 8 x 8 block: moments,

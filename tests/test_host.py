@@ -304,6 +304,49 @@ def _proc(**kw):
                        progress_bar=False, **kw)
 
 
+def test_vector_valued_latent_sites_take_consecutive_coordinates():
+    """A latent site may be tensor-valued with element-wise independent distributions (numpyro: a distribution with a
+    batch shape, e.g. one prior per strain): its elements are consecutive unconstrained coordinates, the model sees
+    ``[chains, *shape]``, the log joint sums the elements.  Checked against the densities written out chain by chain."""
+    from dynode_amd.infer.inference import Potential, init_to_median
+
+    gen = torch.Generator().manual_seed(0)
+    y = torch.tensor([1.0, -2.0, 0.5], dtype=torch.float64) + 0.5 * torch.randn(40, 3, dtype=torch.float64, generator=gen)
+
+    def model(y):
+        mu = handlers.sample("mu", dist.Normal(torch.zeros(3), 10.0))
+        s = handlers.sample("s", dist.Uniform(0.1, 2.0))
+        w = handlers.sample("w", dist.TruncatedNormal(torch.tensor([[1.0, 2.0], [3.0, 4.0]]), 1.0, low=0.0, high=9.0))
+        handlers.sample("y", dist.Normal(mu[..., None, :] + 0.0 * w.sum((-1, -2))[..., None, None], s[..., None, None]), obs=y)
+
+    pot = Potential(model, dict(y=y), 0, torch.device("cpu"))
+    assert pot.dim == 8 and pot.shapes == {"mu": (3,), "s": (), "w": (2, 2)} and dict(pot.slices) == {"mu": (0, 3), "s": (3, 1), "w": (4, 4)}
+    assert not pot.scalar_sites and pot.site_table is None
+    z = pot.initial(5, init_to_median, 1)
+    assert tuple(z.shape) == (5, 8)
+    x = pot.constrain(z)
+    assert {k: tuple(v.shape) for k, v in x.items()} == {"mu": (5, 3), "s": (5,), "w": (5, 2, 2)}
+    assert torch.equal(x["mu"], z[:, :3]) and bool(((x["w"] > 0) & (x["w"] < 9)).all())
+    u, g = pot.potential_and_grad(z)
+    assert tuple(u.shape) == (5,) and tuple(g.shape) == (5, 8) and bool(torch.isfinite(g).all())
+    for c in range(5):
+        want = (dist.Normal(0.0, 10.0).log_prob(x["mu"][c]).sum() + dist.Uniform(0.1, 2.0).log_prob(x["s"][c])
+                + pot.bij["s"].log_abs_det_jacobian(z[c, 3])
+                + dist.TruncatedNormal(torch.tensor([[1.0, 2.0], [3.0, 4.0]]), 1.0, low=0.0, high=9.0).log_prob(x["w"][c]).sum()
+                + pot.bij["w"].log_abs_det_jacobian(z[c, 4:]).sum() + dist.Normal(x["mu"][c], x["s"][c]).log_prob(y).sum())
+        assert abs(float(want) + float(u[c])) < 1e-9 * abs(float(want))
+    # a value whose shape is not the distribution's batch shape is refused at construction
+    with pytest.raises(ValueError, match="batch shape"):
+        Potential(lambda: handlers.sample("a", _Odd()), {}, 0, torch.device("cpu"))
+
+
+class _Odd(dist.Normal):
+    """A distribution whose draws do not have its batch shape (for the refusal above)."""
+
+    def sample(self, rng, sample_shape=()):
+        return torch.zeros(tuple(sample_shape) + (2,), dtype=torch.float64)
+
+
 def test_nuts_kwargs_the_reference_sets_itself_raise_like_numpyro_would():
     # reference: NUTS(model, dense_mass=True, max_tree_depth=..., init_strategy=..., **nuts_kwargs) -> duplicate keyword
     for key in ("dense_mass", "max_tree_depth", "init_strategy"):
