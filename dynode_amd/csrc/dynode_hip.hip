@@ -462,6 +462,14 @@ static int enqueue(const Entry *e, const dyn_model_desc *m, const dyn_solver_opt
             const int nv = 1 + e->SPL * (e->E + 1 + e->W + e->C);
             if (nv <= 5 && !(e->FEAT & kSeip))
                 while (r < 3 && (waves << (r + 1)) <= 2048) ++r;
+            // ... and a gradient-solve scored in the kernel is its rows (one Poisson term per saved value and plane), whatever
+            // the state's size: up to eight lane groups while the launch stays at half a wave per SIMD (the six-site 2-age x
+            // 3-strain model, 128 chains x 8 rows = 32 trajectory-waves: 310 us unreplicated, 239 / 229 with four / eight;
+            // two do not fit their likelihood table into LDS).  A call that carries the sampler (nuts_tail) is refused below
+            // when whole chains no longer fit a wave at this replication -- the six-site model's eight rows at eight lane
+            // groups: two launches per iteration at 229 us beat one at 239 (1.44 against 1.57 s for 128 chains x 200)
+            else if (ll && !(e->FEAT & kSeip))
+                while (r < 3 && (waves << (r + 1)) <= 512) ++r;
         }
         ka.rep_log2 = r < 0 ? 0 : (r > 3 ? 3 : r);
         if (ll) { // the replicas of a trajectory must share a wave (LDS table, lane reductions)

@@ -6,7 +6,8 @@ inference example attaches them to one strain (examples/sir_infer_parameters.py:
 daily incidence by age and strain (increments of the cumulative-infection compartment ``c``), scored inside the solve kernel.
 
 ``get_config(sites=6)``: r0 and infectious period of the three strains (6 sampled dimensions: the sampler kernel's
-per-dimension instances, folded potential, the sampler's side fused into the gradient-solve -- one launch per iteration).  ``sites=9`` adds the three latent periods: beyond
+per-dimension instances, folded potential: the gradient-solve, eight lane groups per trajectory, and the sampler kernel -- two
+launches per iteration; `dyn_solver_opts::nuts_tail` would make it one at four lane groups, which measured slower).  ``sites=9`` adds the three latent periods: beyond
 eight dimensions the sampler kernel's run-time-dimension instance (``dyn_nuts_advance``, include/dynode_hip.h) and the general
 autograd potential.  The initial infections are split evenly over the strains here (the reference splits them in proportion
 to r0, :153-167, which would make the initial state a function of the sampled values).

@@ -613,14 +613,16 @@ def test_one_launch_per_iteration_draws_the_same_chains(data, adaptation, chains
 
 
 @pytest.mark.parametrize("case", ["prevalence", "multi_strain"])
-def test_one_launch_per_iteration_beyond_the_inference_example(data, case):
+def test_one_launch_per_iteration_beyond_the_inference_example(data, case, hints):
     """The one-launch iteration is not tied to the inference example's shape (VERDICT r03 "missing" 3): general tangent
     instances carry the sampler's side too (csrc/instances.def units 33, 34; FEAT bit 12 without bit 13).
     ``prevalence``: the 2-age SIR scored on the infectious compartment's daily VALUES instead of diff(R) -- another slot,
     another likelihood mode.  ``multi_strain``: the reference's 2-age x 3-strain model with six sampled sites, one tangent
     direction per trajectory, every chain padded from six to eight rows so that whole chains fall into waves
     (`dyn_latent_param_map`, split_directions = 8).  Same draws as the two-launch iteration bit for bit; the folded
-    potential with padded chains equals the general autograd potential."""
+    potential with padded chains equals the general autograd potential.  (The library's own choice for the six-site model
+    is eight lane groups per trajectory, at which a chain's eight rows no longer share a wave and the call keeps its two
+    launches -- faster than fusing at four groups; the test pins four to exercise the fused path.)"""
     from dynode_amd import PoissonObservation, _abi
     from dynode_amd.infer import folded
     from dynode_amd.infer.nuts import KernelNUTS
@@ -644,6 +646,7 @@ def test_one_launch_per_iteration_beyond_the_inference_example(data, case):
 
         pot = Potential(ex_m.model, dict(config=ex_m.get_config(6), tf=120, obs_data=ex_m.synthetic_incidence(120)), 0, dev)
         chains, rows, name = 32, 8, "dyn::solve_kernel_fused<float, 0, 2, 3, true, true, true, 1, 1, 3, 4096>"
+        hints(replicas_log2=2)      # four lane groups per trajectory: eight trajectories = one chain per wave
     f = folded.discover(pot)
     assert f is not None and f.split_directions(chains) and f.rows_per_chain(chains) == rows
     z0 = pot.initial(chains, init_to_median, 3)
@@ -1037,8 +1040,10 @@ def test_kernel_sampler_on_the_multi_strain_model_agrees_with_the_gradient_free_
     nuts = MCMCProcess(numpyro_model=ex_m.model, num_warmup=draws, num_samples=draws, num_chains=chains, nuts_max_tree_depth=8, progress_bar=False)
     mcmc = nuts.infer(**kw)
     assert mcmc.sampler == "KernelNUTS" and mcmc.potential.dim == sites
-    if sites <= 8:          # folded potential, one tangent direction per trajectory row, chains padded to eight rows: the
-        assert mcmc.launches_per_iteration == 1          # gradient-solve's waves run the sampler's side (one launch per iteration)
+    if sites <= 8:          # folded potential, one tangent direction per trajectory row, chains padded to eight rows, eight lane
+        # groups per trajectory (the library's choice for a scored gradient-solve this small): a chain's rows span two waves,
+        # so the gradient-solve and dyn_nuts_advance_mapped stay two launches (measured faster than fusing at four groups)
+        assert mcmc.launches_per_iteration == 2
         # (the last launch of infer() is the general gradient-solve that re-scores the final positions; the fused instance's
         # name is asserted in test_one_launch_per_iteration_beyond_the_inference_example)
         assert _abi.lib().dyn_last_kernel_name().decode().startswith("dyn::solve_kernel<float, 0, 2, 3, true, true, true, 1, 1, 3")
