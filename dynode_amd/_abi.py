@@ -52,11 +52,11 @@ EXPORTED_SYMBOLS = (
     "dyn_nuts_advance_mapped", "dyn_nuts_tail_size", "dyn_nuts_tail_pack", "dyn_fused_twin",
 )
 
-MAX_SITES = 8
+MAX_SITES = 16          # sites of a folded potential / of the fused prior kernel (include/dynode_hip.h DYN_MAX_SITES)
 DIST_NORMAL, DIST_UNIFORM, DIST_BETA, DIST_TRUNCNORMAL = 0, 1, 2, 3
 
 NUTS_MAX_DIM, NUTS_MAX_DEPTH, NUTS_MAX_WINDOWS = 32, 10, 16
-NUTS_REG_DIM = 8        # up to here: pooled windows, the mapped / fused sampler forms (csrc/nuts_device.hpp kRegDim)
+NUTS_REG_DIM = 8        # up to here: pooled windows, the one-launch sampler iteration (csrc/nuts_device.hpp kRegDim)
 # pointer members of dyn_nuts_state, in declaration order (include/dynode_hip.h)
 NUTS_POINTER_FIELDS = (
     "z_eval", "u_new", "g_new", "z", "u", "g", "eps", "eps_avg", "da_mu", "da_xbar", "da_gbar", "da_t",

@@ -67,12 +67,14 @@ __device__ inline SiteValue eval_site(const dyn_site_desc &d, double zi) {
 
 // One chain of `latent_param_map`: sites, log prior, parameter row(s) and tangent seeds of the monomial parameter map
 // p_j = coef_j prod_i x_i^expo[j][i] at the unconstrained position `zrow` (comments at the kernel in latent_kernel.hip).
-template <typename T, typename TAB>   // TAB: SiteTable in whatever address space the caller holds it (kernel argument, kernarg segment)
+// NMAX: the most sites the caller can have (the arrays below are sized by it: a compile-time-dimension sampler instance passes
+// its dimension, so that an eight-dimension kernel does not carry sixteen-element arrays)
+template <typename T, int NMAX = DYN_MAX_SITES, typename TAB>   // TAB: SiteTable in whatever address space the caller holds it (kernel argument, kernarg segment)
 __device__ inline void map_chain(const TAB &tab, int64_t C, int64_t c, const double *zrow, double *__restrict__ x_out,
                                  double *__restrict__ lp_out, double *__restrict__ dlp_dz, int P, const double *__restrict__ coef,
                                  const double *__restrict__ expo, T *__restrict__ params, T *__restrict__ seeds, int split) {
-    const int n = tab.n;
-    double total = 0.0, x[DYN_MAX_SITES], rel[DYN_MAX_SITES];   // rel_i = (dx_i/dz_i) / x_i (0 where x_i == 0: see the seeds below)
+    const int n = tab.n < NMAX ? tab.n : NMAX;
+    double total = 0.0, x[NMAX], rel[NMAX];   // rel_i = (dx_i/dz_i) / x_i (0 where x_i == 0: see the seeds below)
     for (int i = 0; i < n; ++i) {
         dyn_site_desc site;
         __builtin_memcpy(&site, &tab.s[i], sizeof(site));

@@ -433,10 +433,10 @@ __device__ __forceinline__ void advance_chain(const ST &st, const MAP &map, cons
     // top of this call were consumed above, so their buffers can take the next position's values now)
     if (map.enabled) {
         if (map.f64)
-            dynlat::map_chain<double>(map.tab, st.n_chains, c, ze, map.x, map.lp, map.dlp_dz, map.P, map.coef, map.expo,
+            dynlat::map_chain<double, (RT ? DYN_MAX_SITES : DMAX)>(map.tab, st.n_chains, c, ze, map.x, map.lp, map.dlp_dz, map.P, map.coef, map.expo,
                                       (double *)map.params, (double *)map.seeds, map.split);
         else
-            dynlat::map_chain<float>(map.tab, st.n_chains, c, ze, map.x, map.lp, map.dlp_dz, map.P, map.coef, map.expo,
+            dynlat::map_chain<float, (RT ? DYN_MAX_SITES : DMAX)>(map.tab, st.n_chains, c, ze, map.x, map.lp, map.dlp_dz, map.P, map.coef, map.expo,
                                      (float *)map.params, (float *)map.seeds, map.split);
     }
     st.rng_ctr[c] = (int64_t)rng.ctr;

