@@ -146,7 +146,7 @@ def cfg4_truth():
 CFG4_TAILS = ((0, 2.0), (0, 4.0))     # z0 > 2: 0.74 % of the mass, 9 % of r0's variance; z0 > 4: 0.13 %
 
 
-def nuts_side_measurement(chains=128, warmup=1000, samples=1000, fused=True, adaptation="per_chain", seeds=(8675314,)):
+def nuts_side_measurement(chains=128, warmup=1000, samples=1000, fused=True, adaptation="per_chain", seeds=(8675314,), fold=True):
     """cfg 4 at one GPU's share: NUTS on the 2-age SIR (tf=100, Poisson incidence), 1024 / 8 = 128 chains x
     (1000 warm-up + 1000 draws), tree depth 10, checked against tensor-grid quadrature of the 2-parameter posterior
     (`dynode_amd/infer/checks.py`).  Unit of work = one gradient-solve (fused solve + tangents for every chain) per iteration.
@@ -167,14 +167,15 @@ def nuts_side_measurement(chains=128, warmup=1000, samples=1000, fused=True, ada
 
     truth, kw = cfg4_truth()
     model = ex.model_fused if fused else ex.model
+    own = {"adaptation": adaptation, "fold": fold}
     # one-off costs (lazy loading of the kernels, structure discovery of the potential, the caching allocator's first blocks)
     # are paid by a short untimed run of the same program: 16 chains x (20 + 20)
     MCMCProcess(numpyro_model=model, num_warmup=20, num_samples=20, num_chains=16, nuts_max_tree_depth=10,
-                progress_bar=False, mcmc_kwargs={"adaptation": adaptation}).infer(**kw)
+                progress_bar=False, mcmc_kwargs=own).infer(**kw)
     runs, eps, imm, first = [], [], [], None
     for seed in seeds:
         proc = MCMCProcess(numpyro_model=model, num_warmup=warmup, num_samples=samples, num_chains=chains, nuts_max_tree_depth=10,
-                           progress_bar=False, inference_prngkey=int(seed), mcmc_kwargs={"adaptation": adaptation})
+                           progress_bar=False, inference_prngkey=int(seed), mcmc_kwargs=own)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         mcmc = proc.infer(**kw)
@@ -194,7 +195,10 @@ def nuts_side_measurement(chains=128, warmup=1000, samples=1000, fused=True, ada
     return {"workload": f"cfg4 sir_infer_parameters: NUTS {chains} chains (one GPU's share of 1024) x ({warmup} warm-up + {samples} draws), "
                         f"tree depth 10, warm-up adaptation {adaptation}"
                         + (", Poisson likelihood fused into the solve kernel (examples model_fused)" if fused else
-                           ", the reference-shaped model() (simulate -> diff(R) -> Poisson scored in torch)"),
+                           ", the reference-shaped model() (simulate -> diff(R) -> Poisson scored in torch)"
+                           + (": its likelihood recognised as the solve's fused one (infer/folded.py), one launch per iteration" if fold else
+                              " on the general autograd potential (mcmc_kwargs fold=False)")),
+            "launches_per_iteration": getattr(mcmc, "launches_per_iteration", None),
             "seconds": el, "seconds_median": secs[len(secs) // 2], "gradient_solves": int(mcmc.nuts.potential_evals),
             "us_per_gradient_solve": 1e6 * el / max(int(mcmc.nuts.potential_evals), 1),
             "transitions_per_s": chains * (warmup + samples) / el, "gradient_solves_per_s": mcmc.nuts.potential_evals / el,
@@ -227,7 +231,7 @@ def nuts_kernel_checks(fused: bool, chains: int, transitions: int = 100, decoupl
 
     def sampler(seed):
         pot = Potential(ex.model_fused if fused else ex.model, kw, seed, torch.device("cuda"))
-        folded = discover(pot, seed=seed)
+        folded = discover(pot, seed=seed) if fused else None      # (not fused: the general autograd potential, the independent check)
         return KernelNUTS(folded if folded is not None else pot.potential_and_grad, max_tree_depth=10, seed=seed)
 
     torch.cuda.synchronize()
@@ -648,8 +652,11 @@ def main():
             seeds = (8675314, 1001, 1002, 1003, 1004, 1005, 1006, 1007)
             line["other_workloads"]["cfg4"] = nuts_side_measurement(seeds=seeds)
             line["other_workloads"]["cfg4"]["kernel_checks"] = nuts_kernel_checks(True, 102400, decoupled_starts=4)
-            line["other_workloads"]["cfg4_reference_shaped_model"] = nuts_side_measurement(fused=False, seeds=seeds[:4])
-            line["other_workloads"]["cfg4_reference_shaped_model"]["kernel_checks"] = nuts_kernel_checks(False, 25600)
+            # (round 4: by default the model's torch-written likelihood is recognised and folded -- the first block; the second
+            # keeps the general autograd potential, whose posterior checks are the independent ones)
+            line["other_workloads"]["cfg4_reference_shaped_model"] = nuts_side_measurement(fused=False, seeds=seeds[:2])
+            line["other_workloads"]["cfg4_reference_shaped_model_general_potential"] = nuts_side_measurement(fused=False, seeds=seeds[:4], fold=False)
+            line["other_workloads"]["cfg4_reference_shaped_model_general_potential"]["kernel_checks"] = nuts_kernel_checks(False, 25600)
             line["other_workloads"]["cfg4_pooled_adaptation"] = nuts_side_measurement(adaptation="pooled")
         if world == 1 and not args.no_cpu_baseline:
             sample = args.cpu_sample or (1024 if m.family == 1 else 8192 if m.state_dim >= 300 else 16384 if m.state_dim >= 100 else 65536)

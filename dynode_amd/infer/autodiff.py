@@ -224,6 +224,7 @@ def solve_batch_diff(model, y0, params: torch.Tensor, contact, t1, save_ts, **kw
     """Like ``engine.solve_batch`` but differentiable with respect to ``params`` ([B, P] tensor)."""
     from ..engine import BatchResult, save_mask_bytes
 
+    seen = dict(plain=True, model=model, y0=y0, params=params, contact=contact, t1=t1, save_ts=save_ts, kw=dict(kw))
     params = _joined(params, y0)          # [params | y0] when the initial state carries a graph of its own
     y0 = y0.detach() if isinstance(y0, torch.Tensor) else y0
     leaf = _rowwise_leaf(params)
@@ -233,7 +234,13 @@ def solve_batch_diff(model, y0, params: torch.Tensor, contact, t1, save_ts, **kw
     else:
         ys, status, n_acc, n_rej = _DiffSolve.apply(params, model, y0, contact, t1, save_ts, kw)
     _, saved, sizes = save_mask_bytes(model, kw.get("save_mask"))
-    return BatchResult(ys, status, n_acc, n_rej, saved, sizes)
+    res = BatchResult(ys, status, n_acc, n_rej, saved, sizes)
+    from . import folded
+
+    # only inside `folded.recording()` (structure discovery of a sampler's potential: a model that scores the saved rows in
+    # torch, like the reference's own inference example, may be the solve's fused likelihood written out)
+    folded.note(dict(seen, result=res))
+    return res
 
 
 class _DiffLogLik(torch.autograd.Function):
