@@ -202,6 +202,23 @@ class _FiniteDifferenceLogJoint(torch.autograd.Function):
         return -(g * grad_out[:, None]), None, None
 
 
+class _FoldedLogJoint(torch.autograd.Function):
+    """log density of a batch of unconstrained points through a `folded.FoldedPotential` (three launches: sites and parameter
+    map, the gradient-solve with its fused likelihood, the combine) as a differentiable tensor -- SVI's ELBO on models with the
+    structure, instead of the model's torch program and its backward pass."""
+
+    @staticmethod
+    def forward(ctx, z, folded):
+        u, g = folded(z)
+        ctx.save_for_backward(g)
+        return -u
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (g,) = ctx.saved_tensors
+        return -(g * grad_out[:, None]), None
+
+
 class MCMCResult:
     """What ``infer`` returns: the sampler output plus numpyro-style accessors."""
 
@@ -707,12 +724,24 @@ class SVIProcess(InferenceProcess):
         o = self.optimizer
         opt = torch.optim.Adam(guide.parameters(), lr=o.step_size, betas=(o.b1, o.b2), eps=o.eps)
         gen = torch.Generator(device=device).manual_seed(self.inference_prngkey)
-        losses = torch.empty(self.num_iterations, dtype=torch.float64)
+        losses = torch.empty(self.num_iterations, dtype=torch.float64, device=device)    # (read once, at the end: no host sync per step)
+        fd = self.svi_kwargs.get("gradient", "autograd") == "finite_difference"
+        # a model with the structure (infer/folded.py: monomial parameter map, the solve's own likelihood -- also written out
+        # in torch, like the reference's model()) is scored by three launches per step; ``svi_kwargs={"fold": False}`` keeps
+        # the model's torch program
+        folded = None
+        if not fd and self.svi_kwargs.get("fold", True):
+            from .folded import discover
+
+            folded = discover(pot, seed=self.inference_prngkey, verbose=self.svi_kwargs.get("fold") == "verbose")
+        self._folded_potential = folded is not None
         for it in range(self.num_iterations):
             opt.zero_grad()
             z, _ = guide.sample(self.num_particles, gen)
-            if self.svi_kwargs.get("gradient", "autograd") == "finite_difference":
+            if fd:
                 lj = _FiniteDifferenceLogJoint.apply(z, pot, float(self.svi_kwargs.get("fd_step", 1e-4)))
+            elif folded is not None:
+                lj = _FoldedLogJoint.apply(z, folded)
             else:
                 lj, _ = pot.log_joint(z)
             finite = torch.isfinite(lj)
@@ -720,9 +749,10 @@ class SVIProcess(InferenceProcess):
             loss = -(lj.sum() / finite.sum().clamp_min(1) + guide.entropy())      # -ELBO, reparameterised
             loss.backward()
             opt.step()
-            losses[it] = float(loss.detach())
+            losses[it] = loss.detach()
             if self.progress_bar and (it + 1) % max(1, self.num_iterations // 10) == 0:
                 print(f"[svi] {it + 1}/{self.num_iterations} loss {float(loss):.3f}", flush=True)
+        losses = losses.cpu()
         out = SVIResult(pot, guide, losses)
         self._inference_complete, self._inferer, self._inference_state = True, out, out.params
         self._inferer_kwargs = kwargs

@@ -318,9 +318,25 @@ def test_svi_gaussian_fit_lands_on_the_posterior(data):
     """reference inference.py:244-302 (SVIProcess: AutoMultivariateNormal + Adam(0.1) + ELBO)."""
     from dynode_amd.infer.inference import SVIProcess
 
+    import time
+
     proc = SVIProcess(numpyro_model=ex.model, num_iterations=400, num_samples=2000, num_particles=16, progress_bar=False)
+    t0 = time.perf_counter()
     res = proc.infer(config=ex.get_config(), tf=100, obs_data=data)
+    t_folded = time.perf_counter() - t0
+    assert proc._folded_potential is True            # the ELBO through the folded potential (three launches per step)
     assert float(res.losses[-50:].mean()) < float(res.losses[:20].mean())          # the ELBO improved
+    # ... and the same fit through the model's own torch program (same particles: the guide's generator is seeded alike)
+    slow = SVIProcess(numpyro_model=ex.model, num_iterations=400, num_samples=2000, num_particles=16, progress_bar=False, svi_kwargs={"fold": False})
+    t0 = time.perf_counter()
+    res_slow = slow.infer(config=ex.get_config(), tf=100, obs_data=data)
+    t_general = time.perf_counter() - t0
+    assert slow._folded_potential is False
+    print(f"SVI 400 steps x 16 particles: folded potential {t_folded:.2f} s, the model's torch program {t_general:.2f} s")
+    for name in ("strains_0_r0", "strains_0_infectious_period"):
+        a, b = proc.get_samples()[name], slow.get_samples()[name]
+        assert abs(float(a.median()) - float(b.median())) < 0.05 * float(b.std()) + 1e-3, (name, float(a.median()), float(b.median()))
+    assert abs(float(res.losses[-50:].mean()) - float(res_slow.losses[-50:].mean())) < 0.05
     post = proc.get_samples()
     assert set(post) == {"strains_0_r0", "strains_0_infectious_period"} and post["strains_0_r0"].shape == (2000,)
     # a Gaussian in the unconstrained space cannot match the ridge exactly; its centre must
