@@ -1847,6 +1847,12 @@ hipError_t launch(const KArgs<T> &ka_in, hipStream_t stream) {
         else
             grid = resident;
     }
+    if (lds > 65536) {
+        // a save grid beyond the default 64 KB of dynamic LDS (hourly saves over a year in float64 are 70 KB): the kernel
+        // attribute has to allow it -- up to the CU's 160 KB, at one or two waves per CU instead of a full complement
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
     hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(PC ? 128 : 64), lds, stream, ka);
     return hipGetLastError();
     }

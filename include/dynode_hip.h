@@ -35,8 +35,9 @@ extern "C" {
 #endif
 
 #define DYN_ABI_VERSION 9
-/* the save grid is staged in LDS: n_save * sizeof(real) must not exceed this */
-#define DYN_MAX_SAVE_BYTES 49152
+/* the save grid is staged in LDS: n_save * sizeof(real) must not exceed this (128 KB of a CU's 160: 32 k float32 or 16 k
+ * float64 save times; beyond 48 KB -- the limit up to round 3 -- a launch keeps only one or two waves per CU resident) */
+#define DYN_MAX_SAVE_BYTES 131072
 
 /*
  * One member of the compartmental RHS family (the examples of the reference).

@@ -471,6 +471,16 @@ def test_unsupported_shape_fails_loudly(monkeypatch):
     assert np.array_equal(na, na_o) and np.array_equal(nr, nr_o)
     with pytest.raises(SolveError, match="JUMP"):               # must be strictly increasing
         solve_batch(SIR1, [0.9, 0.1, 0], [[0.3, 0.1]], [[1.0]], 100.0, [0.0, 100.0], jump_ts=[50.0, 20.0])
+    # a save grid beyond the default 64 KB of dynamic LDS -- hourly saves over a year in float64: 8761 x 8 = 70 KB -- runs (the
+    # launch raises the kernel's LDS attribute) and equals the oracle; beyond 128 KB the call is refused by name
+    hourly = np.linspace(0.0, 365.0, 365 * 24 + 1)
+    y0, p, C, t1, ts = random_workload(SIR1, 5, seed=12)
+    got, st, na, nr = hip(SIR1, y0, p, C, 365.0, hourly, dtype=F64)
+    want, st_o, na_o, nr_o = O.solve(H.omodel(SIR1), y0, p, C, 365.0, hourly, dtype=np.float64)
+    assert got.shape == (5, 8761, 3) and st.max() == 0 and np.abs(got - want).max() < 1e-11 * max(1.0, np.abs(want).max())
+    assert np.array_equal(na, na_o) and np.array_equal(nr, nr_o)
+    with pytest.raises(SolveError, match="UNSUPPORTED.*save grid"):
+        solve_batch(SIR1, [0.9, 0.1, 0], [[0.3, 0.1]], [[1.0]], 365.0, np.linspace(0.0, 365.0, 20000), dtype=torch.float64)
 
 
 @pytest.mark.parametrize("m", [ModelDesc(n_age=1, has_e=True, has_wane=True, seasonal=True), ModelDesc(n_age=8),
