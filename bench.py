@@ -481,7 +481,11 @@ def main():
     rehearsal = os.environ.get("DYNODE_BENCH_REHEARSAL") == "1"
     torch.cuda.set_device(0 if rehearsal else local_rank)
     dev = torch.device("cuda", 0 if rehearsal else local_rank)
-    if world > 1:
+    # DYNODE_BENCH_SINGLE_RANK_GROUP=1 under `torch.distributed.run --nproc-per-node 1`: the RCCL process group and every
+    # collective of the N > 1 path with ONE rank -- the backend a one-GPU box can run for real (tests/test_gpu_multirank.py).
+    # Never set by the driver.
+    grouped = world > 1 or (os.environ.get("DYNODE_BENCH_SINGLE_RANK_GROUP") == "1" and "RANK" in os.environ)
+    if grouped:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if rehearsal:
             dist.init_process_group("gloo")
@@ -510,7 +514,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if grouped:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -529,7 +533,7 @@ def main():
 
     shards_match, shard_digests = None, None
     ranks_seen, per_rank = 1, None
-    if world > 1:
+    if grouped:
         # what the process group itself says (not the environment), and every rank's own clock: a SCALE record checks itself
         ranks_seen = int(dist.get_world_size())
         mine_t = torch.tensor([float(rank), elapsed / args.steps * 1e3, kern_ms, float(torch.cuda.current_device())], dtype=torch.float64, device=cdev)
@@ -589,7 +593,7 @@ def main():
                 "parallelism": f"{world} x independent shards, no data-path collective",
                 # N > 1: dist.get_world_size() after init_process_group, the backend, and every rank's own timing (value uses the MAX)
                 "ranks_seen": ranks_seen,
-                "backend": (dist.get_backend() if world > 1 else None),
+                "backend": (dist.get_backend() if grouped else None),
                 "per_rank": per_rank,
                 "shards_match_single_process": shards_match,
                 # per rank: [status sum, index-weighted accepted / rejected step counts, float64 sum of the output, of |last row|]
@@ -662,7 +666,7 @@ def main():
             sample = args.cpu_sample or (1024 if m.family == 1 else 8192 if m.state_dim >= 300 else 16384 if m.state_dim >= 100 else 65536)
             line["cpu_baseline"] = cpu_baseline(wl, min(sample, B))
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if grouped:
         dist.destroy_process_group()
 
 

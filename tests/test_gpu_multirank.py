@@ -59,6 +59,26 @@ def test_bench_two_ranks_weak_scaling_rehearsal():
     assert [r["rank"] for r in per_rank] == [0, 1] and max(r["ms_per_step"] for r in per_rank) <= d["ms_per_step"] * (1 + 1e-9)
 
 
+def test_bench_rccl_process_group_with_one_rank():
+    """The backend the 8-GPU node runs, as far as a one-GPU box can: `bench.py` under `torch.distributed.run` with ONE rank and
+    `DYNODE_BENCH_SINGLE_RANK_GROUP=1` initialises the RCCL ("nccl") process group on its device and runs every collective of
+    the N > 1 path on it -- the barrier around the timed region, the all-gather of the ranks' own clocks, the max / min
+    all-reduces, the all-gather of the shard digests (float64 on the device)."""
+    env = dict(os.environ, DYNODE_BENCH_SINGLE_RANK_GROUP="1", MASTER_ADDR="127.0.0.1")
+    env.pop("DYNODE_BENCH_REHEARSAL", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(H.ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+           "--no-cpu-baseline", "--no-extra", "--workload", "cfg3d136"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=H.ROOT)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["config"]["backend"] == "nccl" and d["config"]["ranks_seen"] == 1
+    assert [q["rank"] for q in d["config"]["per_rank"]] == [0] and d["config"]["per_rank"][0]["ms_per_step"] == pytest.approx(d["ms_per_step"], rel=1e-9)
+    assert len(d["config"]["shard_digests"]) == 1 and d["config"]["all_status_ok"] is True and d["value"] > 0
+
+
 def test_bench_two_ranks_strong_scaling_equals_one_process():
     """Strong scaling: ONE global batch of 65536 draws split by shard_bounds.  Each rank's digests must be those of the same
     rows of a single-process solve of the whole batch, bit for bit (the kernel is deterministic and batch-position invariant,
