@@ -208,6 +208,32 @@ def nuts_side_measurement(chains=128, warmup=1000, samples=1000, fused=True, ada
             "posterior_vs_quadrature": {"pooled_over_sampler_seeds": pooled, "per_seed": runs}}
 
 
+def nuts_multi_strain_side(sites: int, chains=128, warmup=300, samples=300):
+    """NUTS beyond the inference example's shape: every strain's r0 / infectious (/ latent) period of the
+    reference's 2-age x 3-strain model (examples/infer_multi_strain.py), six or nine sampled sites, default settings."""
+    import torch
+
+    from dynode_amd.infer.inference import MCMCProcess
+    from examples import infer_multi_strain as ex_m
+
+    kw = dict(config=ex_m.get_config(sites), tf=120, obs_data=ex_m.synthetic_incidence(120))
+    MCMCProcess(numpyro_model=ex_m.model, num_warmup=20, num_samples=20, num_chains=16, nuts_max_tree_depth=8, progress_bar=False).infer(**kw)
+    proc = MCMCProcess(numpyro_model=ex_m.model, num_warmup=warmup, num_samples=samples, num_chains=chains, nuts_max_tree_depth=8, progress_bar=False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    mcmc = proc.infer(**kw)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    post = proc.get_samples()
+    truth = dict(zip((f"strains_{k}_r0" for k in range(3)), ex_m.TRUTH["r0s"]))
+    return {"workload": f"NUTS on the 2-age x 3-strain model, {sites} sampled sites, {chains} chains x ({warmup} + {samples}), tree depth 8, per-chain adaptation",
+            "seconds": el, "sampler": mcmc.sampler, "folded_potential": bool(proc._folded_potential),
+            "launches_per_iteration": mcmc.launches_per_iteration, "gradient_solves": int(mcmc.nuts.potential_evals),
+            "us_per_gradient_solve": 1e6 * el / max(int(mcmc.nuts.potential_evals), 1),
+            "mean_leapfrogs_per_transition": float(mcmc.nuts.num_steps.double().mean()), "divergences": int(mcmc.nuts.diverging.sum()),
+            "r0_posterior_mean_sd_truth": {k: [float(post[k].mean()), float(post[k].std()), float(v)] for k, v in truth.items()}}
+
+
 def nuts_kernel_checks(fused: bool, chains: int, transitions: int = 100, decoupled_starts: int = 0):
     """The calibrated checks of `dynode_amd/infer/checks.py` on the kernels the runs above adapted (per-chain adaptation):
 
@@ -662,6 +688,8 @@ def main():
             line["other_workloads"]["cfg4_reference_shaped_model_general_potential"] = nuts_side_measurement(fused=False, seeds=seeds[:4], fold=False)
             line["other_workloads"]["cfg4_reference_shaped_model_general_potential"]["kernel_checks"] = nuts_kernel_checks(False, 25600)
             line["other_workloads"]["cfg4_pooled_adaptation"] = nuts_side_measurement(adaptation="pooled")
+            for sites in (6, 9):
+                line["other_workloads"][f"nuts_multi_strain_{sites}_sites"] = nuts_multi_strain_side(sites)
         if world == 1 and not args.no_cpu_baseline:
             sample = args.cpu_sample or (1024 if m.family == 1 else 8192 if m.state_dim >= 300 else 16384 if m.state_dim >= 100 else 65536)
             line["cpu_baseline"] = cpu_baseline(wl, min(sample, B))
