@@ -32,15 +32,18 @@ __global__ void __launch_bounds__(64) latent_sites(const SiteTable tab, int64_t 
 // p_j = coef_j * prod_i x_i^expo[j][i] (the reference's get_odeparams family, SURVEY rows A6: beta = r0 / T_inf,
 // gamma = 1 / T_inf, sigma = 1 / T_lat, omega = 1 / T_wane).  Writes the parameter rows and the tangent seeds
 // d p_j / d z_i = expo[j][i] p_j / x_i * dx_i/dz_i in the solve's dtype: what `dyn_solve_batch_loglik` reads next.
-template <typename T>
+template <typename T, int NS>   // NS lanes per chain: 1, 2, 4, 8 or DYN_MAX_SITES, the smallest power of two that holds the model's sites
 __global__ void __launch_bounds__(64) latent_param_map(const SiteTable tab, int64_t C, const double *__restrict__ z,
                                                        double *__restrict__ x_out, double *__restrict__ lp_out,
                                                        double *__restrict__ dlp_dz, int P, const double *__restrict__ coef,
                                                        const double *__restrict__ expo, T *__restrict__ params,
                                                        T *__restrict__ seeds, int split) {
-    const int64_t c = (int64_t)blockIdx.x * 64 + threadIdx.x;
-    if (c >= C) return;
-    map_chain<T>(tab, C, c, z + c * tab.n, x_out, lp_out, dlp_dz, P, coef, expo, params, seeds, split);
+    const int64_t t = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const int64_t c = t / NS;
+    const int sub = (int)(t % NS);
+    if (c >= C) return;                 // (whole lane groups: NS divides the wavefront)
+    const double z_sub = sub < tab.n ? z[c * tab.n + sub] : 0.0;
+    map_chain_lanes<T, NS>(tab, c, sub, (int)(threadIdx.x & 63) - sub, z_sub, x_out, lp_out, dlp_dz, P, coef, expo, params, seeds, split);
 }
 
 // u = -(lp + ll + offset), g = -(dlp_dz + dll): the potential and its gradient from the prior side and the solve's
@@ -101,13 +104,23 @@ extern "C" int dyn_latent_param_map(const dyn_site_desc *sites, int32_t n_sites,
     const int rows = dynlat_rows_per_chain(split_directions, n_sites);
     if (rows < 0) return DYN_ERR_SIZE;
     if (C == 0) return 0;
-    const dim3 grid((unsigned)((C + 63) / 64)), block(64);
-    if (dtype == DYN_F32)
-        hipLaunchKernelGGL(dynlat::latent_param_map<float>, grid, block, 0, (hipStream_t)stream, tab, C, z, x, lp, dlp_dz,
-                           (int)P, coef, expo, (float *)params, (float *)seeds, rows);
-    else
-        hipLaunchKernelGGL(dynlat::latent_param_map<double>, grid, block, 0, (hipStream_t)stream, tab, C, z, x, lp, dlp_dz,
-                           (int)P, coef, expo, (double *)params, (double *)seeds, rows);
+    const int ns = n_sites <= 1 ? 1 : n_sites <= 2 ? 2 : n_sites <= 4 ? 4 : n_sites <= 8 ? 8 : DYN_MAX_SITES;
+    const dim3 grid((unsigned)((C * ns + 63) / 64)), block(64);
+#define DYN_LAUNCH_MAP(T, NS)                                                                                              \
+    hipLaunchKernelGGL((dynlat::latent_param_map<T, NS>), grid, block, 0, (hipStream_t)stream, tab, C, z, x, lp, dlp_dz, \
+                       (int)P, coef, expo, (T *)params, (T *)seeds, rows)
+#define DYN_LAUNCH_MAP_N(T)                                                                                                \
+    do {                                                                                                                   \
+        if (ns == 1) DYN_LAUNCH_MAP(T, 1);                                                                                 \
+        else if (ns == 2) DYN_LAUNCH_MAP(T, 2);                                                                            \
+        else if (ns == 4) DYN_LAUNCH_MAP(T, 4);                                                                            \
+        else if (ns == 8) DYN_LAUNCH_MAP(T, 8);                                                                            \
+        else DYN_LAUNCH_MAP(T, DYN_MAX_SITES);                                                                             \
+    } while (0)
+    if (dtype == DYN_F32) DYN_LAUNCH_MAP_N(float);
+    else DYN_LAUNCH_MAP_N(double);
+#undef DYN_LAUNCH_MAP_N
+#undef DYN_LAUNCH_MAP
     return hipGetLastError() == hipSuccess ? 0 : DYN_ERR_LAUNCH;
 }
 

@@ -126,13 +126,16 @@ struct Handed {
 
 // One sampler iteration of chain c (everything between two potential evaluations).  RT: the dimension is st.dim (<= DMAX)
 // instead of DMAX itself (see kRegDim above).
-template <int DMAX, bool RT, typename ST, typename MAP>
-__device__ __forceinline__ void advance_chain(const ST &st, const MAP &map, const int c, const Handed<DMAX> &handed) {
+// INLINE_MAP: this thread also does the map of the position it hands out (dyn_nuts_advance_mapped; the fused launch's tail).
+// Without it the caller does -- nuts_kernel.hip spreads that over the lanes of a chain (dynlat::map_chain_lanes) -- and takes
+// the position from `ze_out`.  Returns whether a position was handed out (false: no such chain, or a finished one).
+template <int DMAX, bool RT, bool INLINE_MAP = true, typename ST, typename MAP>
+__device__ __forceinline__ bool advance_chain(const ST &st, const MAP &map, const int c, const Handed<DMAX> &handed, double *ze_out = nullptr) {
     const int D = RT ? (int)st.dim : DMAX;
     const int C = st.n_chains, Dm = st.max_depth;
-    if (c >= C) return;
+    if (c >= C) return false;
     const int total = st.num_warmup + st.num_samples;
-    if (st.it[c] >= total) return; // finished chains idle
+    if (st.it[c] >= total) return false; // finished chains idle
     // Scalars of this chain live in registers for the whole call (loaded here, stored at the end);
     // the per-chain vectors are disjoint, which the restrict qualifiers tell the compiler, so loads
     // are not serialised behind the stores of earlier phases.
@@ -427,11 +430,12 @@ __device__ __forceinline__ void advance_chain(const ST &st, const MAP &map, cons
         p_r_half[i] = rh[i];
         ze[i] = (it >= total) ? z[i] : zc[i] + es * tmp[i];
         st.z_eval[(int64_t)c * D + i] = ze[i];
+        if constexpr (!INLINE_MAP) ze_out[i] = ze[i];
     }
     // dyn_nuts_advance_mapped: the prior side of the potential at that position and the parameter rows / tangent seeds of
     // the solve that comes next -- what dyn_latent_param_map would do in a launch of its own (the potential parts read at the
     // top of this call were consumed above, so their buffers can take the next position's values now)
-    if (map.enabled) {
+    if constexpr (INLINE_MAP) if (map.enabled) {
         if (map.f64)
             dynlat::map_chain<double, (RT ? DYN_MAX_SITES : DMAX)>(map.tab, st.n_chains, c, ze, map.x, map.lp, map.dlp_dz, map.P, map.coef, map.expo,
                                       (double *)map.params, (double *)map.seeds, map.split);
@@ -466,6 +470,7 @@ __device__ __forceinline__ void advance_chain(const ST &st, const MAP &map, cons
     st.s_div[c] = L_s_div;
     st.s_n[c] = L_s_n;
     if (st.pooled) st.pend[c] = L_pend;
+    return true;
 }
 
 
@@ -524,3 +529,5 @@ __device__ __forceinline__ void fused_tail(const TL &tl, const int c, const doub
 }
 
 } // namespace dynnuts
+
+#pragma clang fp contract(fast)   // (back to hipcc's default: see latent_device.hpp)

@@ -23,36 +23,74 @@ int dynlat_rows_per_chain(int32_t split_directions, int32_t n_sites);   // laten
 
 namespace dynnuts {
 
-template <int D>
-__global__ void __launch_bounds__(64) nuts_advance(const dyn_nuts_state st, const dynlat::MapArgs map) {
-    const int c = blockIdx.x * 64 + threadIdx.x;
-    if (c >= st.n_chains) return;
-    Handed<D> handed;
-    handed.ll = 0.0;
-    for (int i = 0; i < D; ++i) handed.dll[i] = 0.0;
-    if (st.pot_lp != nullptr) {
-        handed.ll = st.pot_ll[(int64_t)c * st.pot_ll_stride];
-        const int64_t first = (int64_t)c * (st.pot_dll_stride > 0 ? st.pot_dll_stride : D);
-        for (int i = 0; i < D; ++i) handed.dll[i] = st.pot_dll[first + i];
+// NS lanes per chain: lane 0 of the group runs the chain's state machine; with a map behind it (dyn_nuts_advance_mapped) the NS
+// lanes then share the map of the position handed out, one site each (dynlat::map_chain_lanes).  NS = 1: one thread per chain.
+template <int NS, typename MAP>
+__device__ __forceinline__ void map_lanes(const MAP &map, bool go, const double *ze, int dim, int c, int sub) {
+    const int leader = (int)(threadIdx.x & 63) - sub;
+    go = __shfl((int)go, leader) != 0;
+    double z_sub = 0.0;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        const double zi = __shfl(ze[i], leader);
+        if (i == sub) z_sub = zi;
     }
-    advance_chain<D, false>(st, map, c, handed);
+    if (!go) return;
+    if (map.f64)
+        dynlat::map_chain_lanes<double, NS>(map.tab, c, sub, leader, z_sub, map.x, map.lp, map.dlp_dz, map.P, map.coef, map.expo,
+                                            (double *)map.params, (double *)map.seeds, map.split);
+    else
+        dynlat::map_chain_lanes<float, NS>(map.tab, c, sub, leader, z_sub, map.x, map.lp, map.dlp_dz, map.P, map.coef, map.expo,
+                                           (float *)map.params, (float *)map.seeds, map.split);
+}
+
+template <int D, int NS>
+__global__ void __launch_bounds__(64) nuts_advance(const dyn_nuts_state st, const dynlat::MapArgs map) {
+    const int t = blockIdx.x * 64 + threadIdx.x;
+    const int c = t / NS, sub = t % NS;
+    bool go = false;
+    double ze[NS > D ? NS : D];
+#pragma unroll
+    for (int i = 0; i < (NS > D ? NS : D); ++i) ze[i] = 0.0;
+    if (sub == 0 && c < st.n_chains) {
+        Handed<D> handed;
+        handed.ll = 0.0;
+        for (int i = 0; i < D; ++i) handed.dll[i] = 0.0;
+        if (st.pot_lp != nullptr) {
+            handed.ll = st.pot_ll[(int64_t)c * st.pot_ll_stride];
+            const int64_t first = (int64_t)c * (st.pot_dll_stride > 0 ? st.pot_dll_stride : D);
+            for (int i = 0; i < D; ++i) handed.dll[i] = st.pot_dll[first + i];
+        }
+        go = advance_chain<D, false, NS == 1>(st, map, c, handed, ze);
+    }
+    if constexpr (NS > 1)
+        if (map.enabled) map_lanes<NS>(map, go, ze, D, c, sub);     // (wave-uniform)
 }
 
 // ... beyond kRegDim dimensions: the same state machine with the dimension a run-time number (nuts_device.hpp).  The
 // potential arrives as (u_new, g_new) or -- up to DYN_MAX_SITES dimensions -- in the parts of a folded potential (pot_*),
 // with the map of the next position behind it (dyn_nuts_advance_mapped).
+template <int NS>
 __global__ void __launch_bounds__(64) nuts_advance_any_dim(const dyn_nuts_state st, const dynlat::MapArgs map) {
-    const int c = blockIdx.x * 64 + threadIdx.x;
-    if (c >= st.n_chains) return;
-    Handed<DYN_NUTS_MAX_DIM> handed;
-    handed.ll = 0.0;
-    if (st.pot_lp != nullptr) {
-        const int D = st.dim;
-        handed.ll = st.pot_ll[(int64_t)c * st.pot_ll_stride];
-        const int64_t first = (int64_t)c * (st.pot_dll_stride > 0 ? st.pot_dll_stride : D);
-        for (int i = 0; i < D; ++i) handed.dll[i] = st.pot_dll[first + i];
+    const int t = blockIdx.x * 64 + threadIdx.x;
+    const int c = t / NS, sub = t % NS;
+    bool go = false;
+    double ze[DYN_NUTS_MAX_DIM];
+    if constexpr (NS > 1)
+        for (int i = 0; i < NS; ++i) ze[i] = 0.0;
+    if (sub == 0 && c < st.n_chains) {
+        Handed<DYN_NUTS_MAX_DIM> handed;
+        handed.ll = 0.0;
+        if (st.pot_lp != nullptr) {
+            const int D = st.dim;
+            handed.ll = st.pot_ll[(int64_t)c * st.pot_ll_stride];
+            const int64_t first = (int64_t)c * (st.pot_dll_stride > 0 ? st.pot_dll_stride : D);
+            for (int i = 0; i < D; ++i) handed.dll[i] = st.pot_dll[first + i];
+        }
+        go = advance_chain<DYN_NUTS_MAX_DIM, true, NS == 1>(st, map, c, handed, ze);
     }
-    advance_chain<DYN_NUTS_MAX_DIM, true>(st, map, c, handed);
+    if constexpr (NS > 1)
+        if (map.enabled) map_lanes<NS>(map, go, ze, st.dim, c, sub);
 }
 
 } // namespace dynnuts
@@ -72,20 +110,31 @@ static int advance(const dyn_nuts_state *st, const dynlat::MapArgs &map, void *s
         st->max_depth > DYN_NUTS_MAX_DEPTH || st->n_windows < 0 || st->n_windows > DYN_NUTS_MAX_WINDOWS)
         return DYN_ERR_SIZE;
     if (st->n_chains == 0) return 0;
-    const unsigned blocks = (unsigned)((st->n_chains + 63) / 64);
     if (st->pooled && (!st->pool || !st->pool_ro || !st->pend)) return DYN_ERR_NULL;
     using Kern = void (*)(const dyn_nuts_state, const dynlat::MapArgs);
     static_assert(dynnuts::kRegDim == 8, "one compile-time instance per dimension up to kRegDim");
-    static const Kern kernels[dynnuts::kRegDim] = {
-        dynnuts::nuts_advance<1>, dynnuts::nuts_advance<2>, dynnuts::nuts_advance<3>, dynnuts::nuts_advance<4>,
-        dynnuts::nuts_advance<5>, dynnuts::nuts_advance<6>, dynnuts::nuts_advance<7>, dynnuts::nuts_advance<8>};
+    // one thread per chain; with a map behind the state machine, the next power of two of lanes per chain (they share the map)
+    static const Kern plain[dynnuts::kRegDim] = {
+        dynnuts::nuts_advance<1, 1>, dynnuts::nuts_advance<2, 1>, dynnuts::nuts_advance<3, 1>, dynnuts::nuts_advance<4, 1>,
+        dynnuts::nuts_advance<5, 1>, dynnuts::nuts_advance<6, 1>, dynnuts::nuts_advance<7, 1>, dynnuts::nuts_advance<8, 1>};
+    static const Kern mapped[dynnuts::kRegDim] = {
+        dynnuts::nuts_advance<1, 1>, dynnuts::nuts_advance<2, 2>, dynnuts::nuts_advance<3, 4>, dynnuts::nuts_advance<4, 4>,
+        dynnuts::nuts_advance<5, 8>, dynnuts::nuts_advance<6, 8>, dynnuts::nuts_advance<7, 8>, dynnuts::nuts_advance<8, 8>};
+    static const int lanes_of[dynnuts::kRegDim] = {1, 2, 4, 4, 8, 8, 8, 8};
     if (st->dim > dynnuts::kRegDim) {
         // the run-time-dimension instance: per-chain adaptation; (u_new, g_new), or a folded potential's parts and map
         if (st->pooled) return DYN_ERR_UNSUPPORTED;
-        hipLaunchKernelGGL(dynnuts::nuts_advance_any_dim, dim3(blocks), dim3(64), 0, (hipStream_t)stream, *st, map);
+        const int ns = map.enabled ? DYN_MAX_SITES : 1;
+        const unsigned blocks = (unsigned)(((int64_t)st->n_chains * ns + 63) / 64);
+        if (map.enabled)
+            hipLaunchKernelGGL(dynnuts::nuts_advance_any_dim<DYN_MAX_SITES>, dim3(blocks), dim3(64), 0, (hipStream_t)stream, *st, map);
+        else
+            hipLaunchKernelGGL(dynnuts::nuts_advance_any_dim<1>, dim3(blocks), dim3(64), 0, (hipStream_t)stream, *st, map);
         return hipGetLastError() == hipSuccess ? 0 : DYN_ERR_LAUNCH;
     }
-    hipLaunchKernelGGL(kernels[st->dim - 1], dim3(blocks), dim3(64), 0, (hipStream_t)stream, *st, map);
+    const int ns = map.enabled ? lanes_of[st->dim - 1] : 1;
+    const unsigned blocks = (unsigned)(((int64_t)st->n_chains * ns + 63) / 64);
+    hipLaunchKernelGGL((map.enabled ? mapped : plain)[st->dim - 1], dim3(blocks), dim3(64), 0, (hipStream_t)stream, *st, map);
     if (hipGetLastError() != hipSuccess) return DYN_ERR_LAUNCH;
     if (st->pooled) {
         // readers of the next launch see the pool as it stands now, never a half-updated one

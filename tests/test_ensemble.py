@@ -31,7 +31,7 @@ def test_affine_invariance_and_rejection_of_failed_points():
         return torch.where(z[:, 0] > 2e-3, torch.full_like(lp, float("nan")), lp)       # a forbidden half-space
 
     s = EnsembleSampler(logp, seed=5)
-    z0 = torch.randn((40, 2), dtype=torch.float64) * scale * 0.1
+    z0 = torch.randn((40, 2), dtype=torch.float64, generator=torch.Generator().manual_seed(3)) * scale * 0.1    # (own stream: not whatever the tests before left of the global one)
     res = s.run(z0, 300, 700)
     x = res.samples.reshape(-1, 2)
     assert float(x[:, 0].max()) <= 2e-3

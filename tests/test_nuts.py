@@ -31,7 +31,7 @@ def test_correlated_gaussian_moments_and_marginals(sampler):
     torch.manual_seed(0)
     cov = torch.tensor([[4.0, 1.8], [1.8, 1.0]], dtype=torch.float64)    # strongly correlated, unequal scales
     nuts = sampler(gaussian_target(cov), max_tree_depth=8, seed=1)
-    res = nuts.run(torch.randn(32, 2, dtype=torch.float64), num_warmup=300, num_samples=300)
+    res = nuts.run(torch.randn(32, 2, dtype=torch.float64, generator=torch.Generator().manual_seed(23)), num_warmup=300, num_samples=300)
     x = res.samples.reshape(-1, 2)
     assert res.samples.shape == (32, 300, 2) and int(res.diverging.sum()) == 0
     assert 0.6 < float(res.accept_prob.mean()) < 0.95                      # dual averaging towards 0.8
