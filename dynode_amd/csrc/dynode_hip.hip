@@ -82,6 +82,7 @@ constexpr int kProducerConsumer = 0x8000;
 // (normalised, no seasonal forcing, no discontinuity points, adaptive steps, Poisson likelihood of the increments of r) fixed at
 // compile time; picked by enqueue when the call is exactly that
 constexpr int kLean = 0x2000;
+constexpr int kLeanC = 0x20000;   // (with kLean) the lean instance that scores the increments of c (solve_kernel.hpp LEAN_SLOT)
 // FEAT bit 11 (solve_kernel.hpp ADAPTIVE_NO_JUMPS): adaptive steps and no discontinuity points as compile-time facts; picked
 // by enqueue on top of a SAVE_ALL variant when the call has neither
 constexpr int kAdaptiveNoJumps = 0x0800;
@@ -516,9 +517,9 @@ static int enqueue(const Entry *e, const dyn_model_desc *m, const dyn_solver_opt
             }
         }
     }
-    if (ll && ll->slot == 3 && ll->mode == 1 && m->normalize && !m->seasonal && !m->has_intro && ka.n_jump == 0 &&
+    if (ll && (ll->slot == 3 || ll->slot == 4) && ll->mode == 1 && m->normalize && !m->seasonal && !m->has_intro && ka.n_jump == 0 &&
         !(o->constant_dt > 0.0) && !sc && !order && !(e->FEAT & kLean)) {
-        const Entry *lean = h.general_instance ? nullptr : find_variant(e, e->FEAT | kLean);
+        const Entry *lean = h.general_instance ? nullptr : find_variant(e, e->FEAT | kLean | (ll->slot == 4 ? kLeanC : 0));
         if (lean) e = lean;
     }
     if (h.strict_control && !(e->FEAT & kSeip)) {   // test-only twin with the oracle's controller arithmetic, where compiled
@@ -532,8 +533,10 @@ static int enqueue(const Entry *e, const dyn_model_desc *m, const dyn_solver_opt
         if (t->magic != dynnuts::kTailMagic) return DYN_ERR_OPTS; // not a dyn_nuts_tail_pack blob
         const int rows = t->rows_per_chain;
         // (a lean instance carries the state machine up to four dimensions; beyond, the general instance of the shape takes the call)
-        if ((e->FEAT & kLean) && t->st.dim > dynnuts::kFusedLeanMaxDim) {
-            const Entry *general = find_variant(e, e->FEAT & ~kLean);
+        // (... and so does it where the lean instance has no twin that carries the sampler)
+        const int lean_dims = (e->FEAT & kLeanC) ? dynnuts::kFusedMaxDim : dynnuts::kFusedLeanMaxDim;   // (solve_kernel.hpp kTailMaxDim)
+        if ((e->FEAT & kLean) && (t->st.dim > lean_dims || !find_variant(e, e->FEAT | kFused))) {
+            const Entry *general = find_variant(e, e->FEAT & ~(kLean | kLeanC));
             if (general) e = general;
         }
         const Entry *fused = e->ND > 0 ? find_variant(e, e->FEAT | kFused) : nullptr;

@@ -541,11 +541,17 @@ struct Solver {
     // instruction stream (128 chains on 1024 SIMDs): every switch the wave does not have to evaluate is latency.
     static constexpr bool LEAN = (FEAT & 0x2000) != 0;
     static_assert(!LEAN || (ND > 0 && KV == 0 && !INTRO), "lean instance: tangent kernels of the plain family");
+    // bit 17 (with bit 13): the same with the increments of the cumulative-infection compartment c scored instead of r's -- the
+    // multi-strain inference example's likelihood (examples/infer_multi_strain.py)
+    static constexpr int LEAN_SLOT = (FEAT & 0x20000) != 0 ? 4 : 3;
+    static_assert((FEAT & 0x20000) == 0 || (LEAN && HAS_C), "bit 17 qualifies a lean instance of a model with a c compartment");
     // FEAT bit 12: a tangent instance (lean or general: any observed compartment / likelihood mode the fused likelihood takes)
     // whose waves, once their trajectories are scored, run the NUTS state machine of the chains those trajectories belong to
     // (nuts_device.hpp) -- the sampler iteration as one launch.  Static grids only.
     static constexpr bool FUSED = (FEAT & 0x1000) != 0;
     static_assert(!FUSED || (ND > 0 && KV == 0), "the fused sampler tail rides on a gradient-solve (tangent instance)");
+    // ... with the state machines up to eight dimensions, except on the cfg 4 lean instance (four: nuts_device.hpp)
+    static constexpr int kTailMaxDim = LEAN && LEAN_SLOT == 3 ? dynnuts::kFusedLeanMaxDim : dynnuts::kFusedMaxDim;
     // FEAT bit 16 (test-only instances): the step controller in the oracle's arithmetic -- IEEE division, sqrtf, powf (stepper.hpp)
     static constexpr bool STRICT_CONTROL = (FEAT & 0x10000) != 0;
     // where solve_kernel_fused's second argument (dynnuts::Tail, by value) sits in the kernel-argument segment
@@ -1232,7 +1238,7 @@ struct Solver {
     __device__ __forceinline__ static void ll_row(const KArgs<T> &ka, const Poly &d, const State (&y)[NC],
                                                   const State (&k)[7][NC], LL &ll, int j, int a, int as, bool lead,
                                                   T *tab_row) {
-        switch (LEAN ? 3 : ka.ll_slot) {
+        switch (LEAN ? LEAN_SLOT : ka.ll_slot) {
         case 0:
             if (lead) ll_block<IS, 1>(ka, d, y, k, ll, j, a, tab_row);
             break;
@@ -1253,7 +1259,7 @@ struct Solver {
     // table mode, after the solve: replica `rep` scores observation rows rep, rep + R, ...
     __device__ __forceinline__ static void ll_from_table(const KArgs<T> &ka, LL &ll, const T *tab_lane, int row_stride,
                                                          int n_save, int rep, int R, int a, int as, bool lead) {
-        const int slot = LEAN ? 3 : ka.ll_slot, ll_mode = LEAN ? 1 : ka.ll_mode;
+        const int slot = LEAN ? LEAN_SLOT : ka.ll_slot, ll_mode = LEAN ? 1 : ka.ll_mode;
         const int cnt = slot == 0 ? 1 : (slot == 3 ? S * W : S);
         const int off = slot == 0 ? a : (slot == 3 ? as * W : as);
         if (slot == 0 && !lead) return;
@@ -1585,7 +1591,7 @@ struct Solver {
         tb.rate_tab = reinterpret_cast<V4 *>(
             ts_tab + (((n_save + (n_jump > 0 ? kMaxJumps : 0) + (tb.ll_table ? (64 >> ka.rep_log2) * n_save * LLMAX * NC : 0)) + 3) & ~3));
         if (tb.fused_ll) {
-            const int slot = LEAN ? 3 : ka.ll_slot;
+            const int slot = LEAN ? LEAN_SLOT : ka.ll_slot;
             tb.pairs = pairs_of(slot == 0, slot == 1, slot == 2, slot == 3, slot == 4);
         } else {
             tb.pairs = pairs_of(ka.save_off[0] >= 0, ka.save_off[1] >= 0, ka.save_off[2] >= 0, ka.save_off[3] >= 0, ka.save_off[4] >= 0);
@@ -1669,7 +1675,8 @@ struct Solver {
         }
     }
     __device__ __forceinline__ static void dense_begin(const Tables &tb, T dt, const State (&y)[NC], const State (&y1)[NC], State (&k)[7][NC]) {
-        if constexpr (LEAN) dense_coefficients<IR / 2, (IR + S * W - 1) / 2 + 1>(dt, y, y1, k);   // rows = the likelihood of the increments of r
+        if constexpr (LEAN && LEAN_SLOT == 3) dense_coefficients<IR / 2, (IR + S * W - 1) / 2 + 1>(dt, y, y1, k);   // rows = the likelihood of the increments of r
+        else if constexpr (LEAN) dense_coefficients<IC / 2, (IC + S - 1) / 2 + 1>(dt, y, y1, k);                     // ... of c
         else if constexpr (SAVE_ALL) dense_coefficients(dt, y, y1, k);
         else dense_coefficients(dt, y, y1, k, tb.pairs);
     }

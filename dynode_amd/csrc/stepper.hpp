@@ -499,7 +499,7 @@ struct Stepper {
                 // (tl.magic: the second argument really sits where kTailOffset says -- a kernarg layout this code did not expect
                 // makes the launch a plain gradient-solve whose chains stop advancing, instead of a corrupted sampler state)
                 if (tl.magic == dynnuts::kTailMagic && lane < nt / rows && c < (int64_t)tl.st.n_chains)
-                    dynnuts::fused_tail<F::LEAN ? dynnuts::kFusedLeanMaxDim : dynnuts::kFusedMaxDim>(tl, (int)c, kc.ll_out, kc.dll_out);
+                    dynnuts::fused_tail<F::kTailMaxDim>(tl, (int)c, kc.ll_out, kc.dll_out);
             }
         }
     }
