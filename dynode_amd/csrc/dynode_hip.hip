@@ -522,6 +522,14 @@ static int enqueue(const Entry *e, const dyn_model_desc *m, const dyn_solver_opt
         const Entry *lean = h.general_instance ? nullptr : find_variant(e, e->FEAT | kLean | (ll->slot == 4 ? kLeanC : 0));
         if (lean) e = lean;
     }
+    // Tangent instances: gradient-solves are small batches in the given order, so the static grid (bit 10) and -- without
+    // discontinuity points or constant steps -- "adaptive, no jumps" (bit 11) can be compile-time facts where the twin is
+    // compiled: the general 2-age x 3-strain tangent instance spills 120 scalars, this twin 68 (the lean ones 16)
+    if (e->ND > 0 && !(e->FEAT & (kLean | kSeip | kStaticOnly | kAdaptiveNoJumps)) && !order && !sc && h.pull == 0 && h.pull_waves <= 0 &&
+        !h.general_instance && ka.n_jump == 0 && !(o->constant_dt > 0.0)) {
+        const Entry *v = find_variant(e, e->FEAT | kStaticOnly | kAdaptiveNoJumps);
+        if (v) e = v;
+    }
     if (h.strict_control && !(e->FEAT & kSeip)) {   // test-only twin with the oracle's controller arithmetic, where compiled
         const Entry *strict = find_variant(e, e->FEAT | kStrictControl);
         if (strict) e = strict;
@@ -538,6 +546,10 @@ static int enqueue(const Entry *e, const dyn_model_desc *m, const dyn_solver_opt
         if ((e->FEAT & kLean) && (t->st.dim > lean_dims || !find_variant(e, e->FEAT | kFused))) {
             const Entry *general = find_variant(e, e->FEAT & ~(kLean | kLeanC));
             if (general) e = general;
+        }
+        if ((e->FEAT & kStaticOnly) && !find_variant(e, e->FEAT | kFused)) {   // (the static twin above: its base may have the fused one)
+            const Entry *base = find_variant(e, e->FEAT & ~(kStaticOnly | kAdaptiveNoJumps));
+            if (base) e = base;
         }
         const Entry *fused = e->ND > 0 ? find_variant(e, e->FEAT | kFused) : nullptr;
         const int nt = (64 / entry_lanes(e)) >> ka.rep_log2; // trajectories per wave

@@ -148,10 +148,18 @@ def _fused_twin(model, dtype, n_dir) -> bool:
     return model.family == 0 and dtype == torch.float32 and n_dir in (1, 2) and model.vax_lanes == 0
 
 
+_STATIC_ADAPTIVE = 0x0C00          # csrc/dynode_hip.hip kStaticOnly | kAdaptiveNoJumps
+
+
+def _static_twin(model, dtype, n_dir) -> bool:
+    """An on-demand float32 tangent build carries the static-grid / adaptive-only twin too (10 % on the 2-age x 3-strain shape)."""
+    return model.family == 0 and dtype == torch.float32 and n_dir > 0
+
+
 def _name(model, dtype, method, n_dir, spl) -> str:
     return (f"{'f64' if dtype == torch.float64 else 'f32'}_m{method}_g{_group_width(model.n_age)}_s{model.n_strain}"
             f"_e{int(model.has_e)}w{int(model.has_wane)}c{int(model.has_c)}_W{model.n_wane}_nd{n_dir}_spl{spl}"
-            f"_f{_features(model, dtype)}{'p' if _seip_plain(model, dtype) else ''}{'t' if _fused_twin(model, dtype, n_dir) else ''}_{_stamp()}")
+            f"_f{_features(model, dtype)}{'p' if _seip_plain(model, dtype) else ''}{'t' if _fused_twin(model, dtype, n_dir) else ''}{'s' if _static_twin(model, dtype, n_dir) else ''}_{_stamp()}")
 
 
 def _source(model, dtype, method, n_dir, spl) -> str:
@@ -182,6 +190,13 @@ def _source(model, dtype, method, n_dir, spl) -> str:
            f"namespace dyn {{ template hipError_t launch<{args}>(const KArgs<{t}> &, hipStream_t); }}\n"
            f'extern "C" void *dyn_extra_launch(void) {{\n'
            f"    return (void *)(hipError_t(*)(const dyn::KArgs<{t}> &, hipStream_t)) & dyn::launch<{args}>;\n}}\n")
+    if _static_twin(model, dtype, n_dir):
+        # ... the tangent instance with a static grid and adaptive steps without discontinuity points as compile-time facts (FEAT
+        # bits 10 + 11; dynode_hip.hip: what a gradient-solve without a caller's order or discontinuity points is dispatched to)
+        stat = f"{head}, {_features(model) | _STATIC_ADAPTIVE}"
+        src += (f"namespace dyn {{ template hipError_t launch<{stat}>(const KArgs<{t}> &, hipStream_t); }}\n"
+                f'extern "C" void *dyn_extra_launch_static(void) {{\n'
+                f"    return (void *)(hipError_t(*)(const dyn::KArgs<{t}> &, hipStream_t)) & dyn::launch<{stat}>;\n}}\n")
     if _fused_twin(model, dtype, n_dir):
         # ... and the same gradient-solve with the sampler's side of a NUTS iteration behind it (FEAT bit 12; dynode_hip.hip
         # kFused): what a call that carries dyn_solver_opts::nuts_tail is dispatched to -- one launch per iteration
@@ -308,5 +323,12 @@ def ensure_kernel(model: _abi.ModelDesc, dtype=torch.float32, method: str = "tsi
                                          _features(model, dtype) | _FUSED, ctypes.c_void_p(extra.dyn_extra_launch_fused()))
             if rc:
                 raise RuntimeError(f"dyn_register_instance (fused): {_abi.ERR_NAMES.get(rc, rc)}")
+        if _static_twin(model, dtype, n_dir) and hasattr(extra, "dyn_extra_launch_static"):
+            extra.dyn_extra_launch_static.restype = ctypes.c_void_p
+            rc = L.dyn_register_instance(opts.dtype, mid, _group_width(model.n_age), model.n_strain, int(model.has_e),
+                                         int(model.has_wane), int(model.has_c), model.n_wane, n_dir, spl,
+                                         _features(model, dtype) | _STATIC_ADAPTIVE, ctypes.c_void_p(extra.dyn_extra_launch_static()))
+            if rc:
+                raise RuntimeError(f"dyn_register_instance (static twin): {_abi.ERR_NAMES.get(rc, rc)}")
         _LOADED[name] = extra
     return True
