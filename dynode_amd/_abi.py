@@ -49,7 +49,7 @@ EXPORTED_SYMBOLS = (
     "dyn_nuts_advance", "dyn_nuts_state_size", "dyn_philox4x32_10", "dyn_latent_sites",
     "dyn_solve_batch_loglik", "dyn_register_instance", "dyn_last_kernel_name", "dyn_solve_batch_record",
     "dyn_solve_batch_replay", "dyn_latent_param_map", "dyn_potential_combine", "dyn_solve_batch_ordered",
-    "dyn_nuts_advance_mapped", "dyn_nuts_tail_size", "dyn_nuts_tail_pack", "dyn_fused_twin",
+    "dyn_nuts_advance_mapped", "dyn_nuts_tail_size", "dyn_nuts_tail_pack", "dyn_fused_twin", "dyn_lean_twin",
 )
 
 MAX_SITES = 16          # sites of a folded potential / of the fused prior kernel (include/dynode_hip.h DYN_MAX_SITES)
@@ -248,6 +248,8 @@ def lib() -> ctypes.CDLL:
         L.dyn_is_supported_jvp.restype = ctypes.c_int32
         L.dyn_fused_twin.argtypes = [pm, po, ctypes.c_int32]
         L.dyn_fused_twin.restype = ctypes.c_int32
+        L.dyn_lean_twin.argtypes = [pm, po, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]
+        L.dyn_lean_twin.restype = ctypes.c_int32
         L.dyn_solve_batch_jvp.restype = ctypes.c_int
         L.dyn_solve_batch_jvp.argtypes = [
             pm, po, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,

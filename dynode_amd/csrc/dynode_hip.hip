@@ -82,7 +82,12 @@ constexpr int kProducerConsumer = 0x8000;
 // (normalised, no seasonal forcing, no discontinuity points, adaptive steps, Poisson likelihood of the increments of r) fixed at
 // compile time; picked by enqueue when the call is exactly that
 constexpr int kLean = 0x2000;
-constexpr int kLeanC = 0x20000;   // (with kLean) the lean instance that scores the increments of c (solve_kernel.hpp LEAN_SLOT)
+constexpr int kLeanFacts = 0x1E0000;   // (with kLean) bits 17-19: which compartment the lean instance scores, bit 20: its values (solve_kernel.hpp LEAN_CODE / LEAN_MODE)
+// the FEAT bits of the lean instance that scores compartment `slot` (0 s .. 4 c) in `mode` (0 values, 1 increments)
+static int lean_bits(int slot, int mode) {
+    const int code = slot == 3 ? 0 : slot == 4 ? 1 : slot == 2 ? 2 : slot == 1 ? 3 : 4;
+    return kLean | (code << 17) | (mode == 0 ? 0x100000 : 0);
+}
 // FEAT bit 11 (solve_kernel.hpp ADAPTIVE_NO_JUMPS): adaptive steps and no discontinuity points as compile-time facts; picked
 // by enqueue on top of a SAVE_ALL variant when the call has neither
 constexpr int kAdaptiveNoJumps = 0x0800;
@@ -517,9 +522,9 @@ static int enqueue(const Entry *e, const dyn_model_desc *m, const dyn_solver_opt
             }
         }
     }
-    if (ll && (ll->slot == 3 || ll->slot == 4) && ll->mode == 1 && m->normalize && !m->seasonal && !m->has_intro && ka.n_jump == 0 &&
-        !(o->constant_dt > 0.0) && !sc && !order && !(e->FEAT & kLean)) {
-        const Entry *lean = h.general_instance ? nullptr : find_variant(e, e->FEAT | kLean | (ll->slot == 4 ? kLeanC : 0));
+    if (ll && ll->slot >= 0 && ll->slot <= 4 && (ll->mode == 0 || ll->mode == 1) && m->normalize && !m->seasonal && !m->has_intro &&
+        ka.n_jump == 0 && !(o->constant_dt > 0.0) && !sc && !order && !(e->FEAT & kLean)) {
+        const Entry *lean = h.general_instance ? nullptr : find_variant(e, e->FEAT | lean_bits(ll->slot, ll->mode));
         if (lean) e = lean;
     }
     // Tangent instances: gradient-solves are small batches in the given order, so the static grid (bit 10) and -- without
@@ -542,9 +547,9 @@ static int enqueue(const Entry *e, const dyn_model_desc *m, const dyn_solver_opt
         const int rows = t->rows_per_chain;
         // (a lean instance carries the state machine up to four dimensions; beyond, the general instance of the shape takes the call)
         // (... and so does it where the lean instance has no twin that carries the sampler)
-        const int lean_dims = (e->FEAT & kLeanC) ? dynnuts::kFusedMaxDim : dynnuts::kFusedLeanMaxDim;   // (solve_kernel.hpp kTailMaxDim)
+        const int lean_dims = (e->FEAT & kLeanFacts) ? dynnuts::kFusedMaxDim : dynnuts::kFusedLeanMaxDim;   // (solve_kernel.hpp kTailMaxDim)
         if ((e->FEAT & kLean) && (t->st.dim > lean_dims || !find_variant(e, e->FEAT | kFused))) {
-            const Entry *general = find_variant(e, e->FEAT & ~(kLean | kLeanC));
+            const Entry *general = find_variant(e, e->FEAT & ~(kLean | kLeanFacts));
             if (general) e = general;
         }
         if ((e->FEAT & kStaticOnly) && !find_variant(e, e->FEAT | kFused)) {   // (the static twin above: its base may have the fused one)
@@ -875,6 +880,23 @@ int dyn_register_instance(int32_t dtype, int32_t method, int32_t ga, int32_t n_s
 int32_t dyn_is_supported_jvp(const dyn_model_desc *m, const dyn_solver_opts *o, int32_t n_dir) {
     if (dyn::check_model(m) || !o) return 0;
     return dyn::find_entry(m, o->dtype, o->method, n_dir) ? 1 : 0;
+}
+
+int32_t dyn_lean_twin(const dyn_model_desc *m, const dyn_solver_opts *o, int32_t n_dir, int32_t obs_compartment, int32_t obs_mode,
+                      int32_t *spl, int32_t *features) {
+    if (dyn::check_model(m) || !o || !spl || !features || n_dir < 1 || m->family != 0 || obs_mode < 0 || obs_mode > 1) return 0;
+    if (!m->normalize || m->seasonal || m->has_intro) return 0;      // (what a lean instance takes as facts)
+    // compartment index (reference order s, (e), i, r, (c)) -> kernel slot 0 s, 1 e, 2 i, 3 r, 4 c, as dyn_solve_batch_loglik
+    const int slots[5] = {0, m->has_e ? 1 : -1, 2, 3, m->has_c ? 4 : -1};
+    int slot = -1, idx = 0;
+    for (int k = 0; k < 5; ++k)
+        if (slots[k] >= 0 && idx++ == obs_compartment) slot = slots[k];
+    if (slot < 0) return 0;
+    const dyn::Entry *e = dyn::find_entry(m, o->dtype, o->method, n_dir);
+    if (!e || (e->FEAT & dyn::kSeip)) return 0;
+    *spl = e->SPL;
+    *features = e->FEAT | dyn::lean_bits(slot, obs_mode);
+    return dyn::find_variant(e, *features) ? 1 : -1;
 }
 
 int32_t dyn_fused_twin(const dyn_model_desc *m, const dyn_solver_opts *o, int32_t n_dir) {

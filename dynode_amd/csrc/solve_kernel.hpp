@@ -541,17 +541,22 @@ struct Solver {
     // instruction stream (128 chains on 1024 SIMDs): every switch the wave does not have to evaluate is latency.
     static constexpr bool LEAN = (FEAT & 0x2000) != 0;
     static_assert(!LEAN || (ND > 0 && KV == 0 && !INTRO), "lean instance: tangent kernels of the plain family");
-    // bit 17 (with bit 13): the same with the increments of the cumulative-infection compartment c scored instead of r's -- the
-    // multi-strain inference example's likelihood (examples/infer_multi_strain.py)
-    static constexpr int LEAN_SLOT = (FEAT & 0x20000) != 0 ? 4 : 3;
-    static_assert((FEAT & 0x20000) == 0 || (LEAN && HAS_C), "bit 17 qualifies a lean instance of a model with a c compartment");
+    // bits 17-19 (with bit 13): WHICH compartment the lean instance scores -- 0: r (the reference's inference example), 1: c
+    // (the multi-strain inference example, examples/infer_multi_strain.py), 2: i, 3: e, 4: s -- and bit 20: its VALUES at the
+    // save times instead of its increments between them.  Twins other than the two examples' are built on first use
+    // (dynode_amd/jit.py ensure_lean_twin).
+    static constexpr int LEAN_CODE = (FEAT >> 17) & 0x7;
+    static constexpr int LEAN_SLOT = LEAN_CODE == 0 ? 3 : LEAN_CODE == 1 ? 4 : LEAN_CODE == 2 ? 2 : LEAN_CODE == 3 ? 1 : 0;
+    static constexpr int LEAN_MODE = (FEAT & 0x100000) != 0 ? 0 : 1;
+    static_assert((FEAT & 0x1E0000) == 0 || LEAN, "bits 17-20 qualify a lean instance");
+    static_assert(LEAN_CODE <= 4 && (LEAN_SLOT != 4 || HAS_C) && (LEAN_SLOT != 1 || HAS_E), "lean instance: the scored compartment exists");
     // FEAT bit 12: a tangent instance (lean or general: any observed compartment / likelihood mode the fused likelihood takes)
     // whose waves, once their trajectories are scored, run the NUTS state machine of the chains those trajectories belong to
     // (nuts_device.hpp) -- the sampler iteration as one launch.  Static grids only.
     static constexpr bool FUSED = (FEAT & 0x1000) != 0;
     static_assert(!FUSED || (ND > 0 && KV == 0), "the fused sampler tail rides on a gradient-solve (tangent instance)");
     // ... with the state machines up to eight dimensions, except on the cfg 4 lean instance (four: nuts_device.hpp)
-    static constexpr int kTailMaxDim = LEAN && LEAN_SLOT == 3 ? dynnuts::kFusedLeanMaxDim : dynnuts::kFusedMaxDim;
+    static constexpr int kTailMaxDim = LEAN && LEAN_CODE == 0 && LEAN_MODE == 1 ? dynnuts::kFusedLeanMaxDim : dynnuts::kFusedMaxDim;
     // FEAT bit 16 (test-only instances): the step controller in the oracle's arithmetic -- IEEE division, sqrtf, powf (stepper.hpp)
     static constexpr bool STRICT_CONTROL = (FEAT & 0x10000) != 0;
     // where solve_kernel_fused's second argument (dynnuts::Tail, by value) sits in the kernel-argument segment
@@ -1208,7 +1213,7 @@ struct Solver {
     template <int FIRST, int CNT>
     __device__ __forceinline__ static void ll_block(const KArgs<T> &ka, const Poly &d, const State (&y)[NC],
                                                     const State (&k)[7][NC], LL &ll, int j, int off, T *tab_row) {
-        const int ll_mode = LEAN ? 1 : ka.ll_mode;
+        const int ll_mode = LEAN ? LEAN_MODE : ka.ll_mode;
         const bool have = ll_mode == 0 || j > 0;
         const T *orow = ka.obs + (int64_t)(ll_mode == 0 ? j : (j > 0 ? j - 1 : 0)) * ka.ll_row + off;
 #pragma unroll
@@ -1259,7 +1264,7 @@ struct Solver {
     // table mode, after the solve: replica `rep` scores observation rows rep, rep + R, ...
     __device__ __forceinline__ static void ll_from_table(const KArgs<T> &ka, LL &ll, const T *tab_lane, int row_stride,
                                                          int n_save, int rep, int R, int a, int as, bool lead) {
-        const int slot = LEAN ? LEAN_SLOT : ka.ll_slot, ll_mode = LEAN ? 1 : ka.ll_mode;
+        const int slot = LEAN ? LEAN_SLOT : ka.ll_slot, ll_mode = LEAN ? LEAN_MODE : ka.ll_mode;
         const int cnt = slot == 0 ? 1 : (slot == 3 ? S * W : S);
         const int off = slot == 0 ? a : (slot == 3 ? as * W : as);
         if (slot == 0 && !lead) return;
@@ -1675,8 +1680,12 @@ struct Solver {
         }
     }
     __device__ __forceinline__ static void dense_begin(const Tables &tb, T dt, const State (&y)[NC], const State (&y1)[NC], State (&k)[7][NC]) {
-        if constexpr (LEAN && LEAN_SLOT == 3) dense_coefficients<IR / 2, (IR + S * W - 1) / 2 + 1>(dt, y, y1, k);   // rows = the likelihood of the increments of r
-        else if constexpr (LEAN) dense_coefficients<IC / 2, (IC + S - 1) / 2 + 1>(dt, y, y1, k);                     // ... of c
+        // (a lean instance's rows are the likelihood of ONE compartment: coefficients for its register pairs only)
+        if constexpr (LEAN && LEAN_SLOT == 3) dense_coefficients<IR / 2, (IR + S * W - 1) / 2 + 1>(dt, y, y1, k);
+        else if constexpr (LEAN && LEAN_SLOT == 4) dense_coefficients<IC / 2, (IC + S - 1) / 2 + 1>(dt, y, y1, k);
+        else if constexpr (LEAN && LEAN_SLOT == 2) dense_coefficients<II / 2, (II + S - 1) / 2 + 1>(dt, y, y1, k);
+        else if constexpr (LEAN && LEAN_SLOT == 1) dense_coefficients<IE / 2, (IE + S - 1) / 2 + 1>(dt, y, y1, k);
+        else if constexpr (LEAN) dense_coefficients<IS / 2, IS / 2 + 1>(dt, y, y1, k);
         else if constexpr (SAVE_ALL) dense_coefficients(dt, y, y1, k);
         else dense_coefficients(dt, y, y1, k, tb.pairs);
     }

@@ -32,6 +32,7 @@ from __future__ import annotations
 import contextlib
 import ctypes
 import os
+import sys
 import threading
 from typing import Optional
 
@@ -105,6 +106,24 @@ class FoldedPotential:
         self.dtype = call["kw"].get("dtype", torch.float32)
         self._buf: dict = {}
         self._split: dict = {}
+        self._lean: set = set()
+
+    def _ensure_lean(self, n_dir: int) -> None:
+        """A sampler is about to take thousands of gradient-solves on this model: have the lean twin of its tangent kernel
+        built (`jit.ensure_lean_twin`; a no-op for the shapes compiled in and where no lean instance applies)."""
+        if n_dir in self._lean:
+            return
+        self._lean.add(n_dir)
+        kw = self.call["kw"]
+        jumps = kw.get("jump_ts")
+        if self.call["model"].family != 0 or (jumps is not None and len(jumps) > 0) or float(kw.get("constant_dt", 0.0) or 0.0) > 0.0:
+            return
+        from .. import jit
+
+        try:
+            jit.ensure_lean_twin(self.call["model"], self.dtype, kw.get("method", "tsit5"), n_dir, self.call["comp"], self.call["increments"])
+        except Exception as err:  # pragma: no cover - a failed build must not stop the run: the general instance is there
+            print(f"[dynode_amd] lean twin not built ({type(err).__name__}: {str(err)[:120]}); the general tangent instance runs", file=sys.stderr, flush=True)
 
     SPLIT_MAX_ROWS = int(os.environ.get("DYNODE_FOLD_SPLIT_ROWS", "2048"))   # chains x directions up to which the GPU is far from full (cfg 4: 128 x 2)
 
@@ -234,6 +253,7 @@ class FoldedPotential:
         b, c = self._buffers(C), self.call
         split = self.split_directions(C)
         method = c["kw"].get("method", "tsit5")
+        self._ensure_lean(1 if split else min(self.n, 2))
         if split:      # rows C trajectories with one direction each (rows >= n per chain): ll [rows C], dll [rows C, 1]
             ll, dll, *_ = solve_batch_loglik(c["model"], c["y0"], b["params"], c["contact"], c["t1"], c["save_ts"], c["obs"],
                                              c["comp"], dparams=b["seeds"], increments=c["increments"], floor=c["floor"],

@@ -285,6 +285,51 @@ def ensure_fused_twin(model: _abi.ModelDesc, dtype=torch.float32, method: str = 
     return True
 
 
+def ensure_lean_twin(model: _abi.ModelDesc, dtype, method: str, n_dir: int, obs_compartment: int, increments: bool) -> bool:
+    """Make sure the tangent kernel of (model shape, dtype, method, n_dir) has its LEAN twin for a fused likelihood on
+    ``obs_compartment`` (values or increments) -- the instance with the scored compartment, the likelihood mode and the model's
+    run-time switches as compile-time facts (`dyn_lean_twin`; FEAT bit 13 + bits 17-20) -- and that twin's sampler-carrying
+    twin (bit 12).  Built in for the two inference examples; for any other model a sampler is about to take thousands of
+    gradient-solves on, built here on first use (one-off, ~40 s, kept in lib/jit).  True when the twin exists afterwards; False
+    where no lean instance applies (seasonal forcing, introduced strains, float64, no hipcc, JIT disabled): the call keeps the
+    general tangent instance."""
+    mid = {"tsit5": _abi.DYN_TSIT5, "dopri5": _abi.DYN_DOPRI5}[method]
+    L = _abi.lib()
+    opts = _abi.SolverOptsC(mid, _abi.DYN_F64 if dtype == torch.float64 else _abi.DYN_F32, 1e-5, 1e-6, 10**6, 0.0, None, 0)
+    mc = model.c()
+    spl, feat = ctypes.c_int32(0), ctypes.c_int32(0)
+    have = int(L.dyn_lean_twin(ctypes.byref(mc), ctypes.byref(opts), n_dir, int(obs_compartment), int(bool(increments)),
+                               ctypes.byref(spl), ctypes.byref(feat)))
+    if have >= 0:
+        return have == 1
+    if not (enabled() and dtype == torch.float32 and n_dir in (1, 2) and model.vax_lanes == 0 and os.path.exists(HIPCC)):
+        return False
+    name = _name(model, dtype, mid, n_dir, spl.value) + f"_lean{feat.value:x}"
+    with _LOCK:
+        if name in _LOADED:
+            return True
+        t = "float"
+        b = lambda v: "true" if v else "false"   # noqa: E731
+        head = (f"{t}, {mid}, {_group_width(model.n_age)}, {model.n_strain}, {b(model.has_e)}, {b(model.has_wane)}, "
+                f"{b(model.has_c)}, {model.n_wane}, {n_dir}, {spl.value}")
+        text = f'#include "{os.path.join(_CSRC, "solve_kernel.hpp")}"\n'
+        for sym, f_ in (("dyn_extra_launch_lean", feat.value), ("dyn_extra_launch_lean_fused", feat.value | _FUSED)):
+            text += (f"namespace dyn {{ template hipError_t launch<{head}, {f_}>(const KArgs<{t}> &, hipStream_t); }}\n"
+                     f'extern "C" void *{sym}(void) {{\n'
+                     f"    return (void *)(hipError_t(*)(const dyn::KArgs<{t}> &, hipStream_t)) & dyn::launch<{head}, {f_}>;\n}}\n")
+        so = _build(name, lambda: text, "dyn_extra_launch_lean", f"{model} (lean twin, features {feat.value:#x})")
+        extra = ctypes.CDLL(so)
+        for sym, f_ in (("dyn_extra_launch_lean", feat.value), ("dyn_extra_launch_lean_fused", feat.value | _FUSED)):
+            fn = getattr(extra, sym)
+            fn.restype = ctypes.c_void_p
+            rc = L.dyn_register_instance(opts.dtype, mid, _group_width(model.n_age), model.n_strain, int(model.has_e),
+                                         int(model.has_wane), int(model.has_c), model.n_wane, n_dir, spl.value, f_, ctypes.c_void_p(fn()))
+            if rc:
+                raise RuntimeError(f"dyn_register_instance (lean twin): {_abi.ERR_NAMES.get(rc, rc)}")
+        _LOADED[name] = extra
+    return True
+
+
 def ensure_kernel(model: _abi.ModelDesc, dtype=torch.float32, method: str = "tsit5", n_dir: int = 0) -> bool:
     """Make sure a kernel for (model shape, dtype, method, n_dir) exists; returns True if one had to be
     built or loaded.  Raises if hipcc is missing or the shape cannot be mapped to lanes."""

@@ -334,6 +334,16 @@ int32_t dyn_is_supported_jvp(const dyn_model_desc *m, const dyn_solver_opts *o, 
  * it as dyn_register_instance(..., n_dir, spl, features | 0x1000, launch<..., spl, features | 0x1000>) -- dynode_amd/jit.py does
  * on first use. */
 int32_t dyn_fused_twin(const dyn_model_desc *m, const dyn_solver_opts *o, int32_t n_dir);
+/* Is there a LEAN twin of that tangent kernel for a likelihood on `obs_compartment` in `obs_mode` (the arguments of
+ * dyn_solve_batch_loglik) -- the instance with the scored compartment, the likelihood mode, the normalised force of infection, "no
+ * seasonal forcing, no discontinuity points, adaptive steps" as compile-time facts, which dyn_solve_batch_loglik dispatches to when
+ * the call is that (the reference's inference example: 62.8 -> 49.1 us per gradient-solve; the 2-age x 3-strain model: 229 -> 151)?
+ * 1: yes.  0: not applicable (no tangent kernel; a model with seasonal forcing, introduced strains or an un-normalised force of
+ * infection; the SEIP family).  -1: the tangent kernel exists without this twin; *spl and *features then hold what a builder
+ * registers: dyn_register_instance(..., n_dir, *spl, *features, launch<..., *spl, *features>) -- and the same with | 0x1000 for
+ * the twin that carries the sampler (dyn_fused_twin).  dynode_amd/jit.py does on first use. */
+int32_t dyn_lean_twin(const dyn_model_desc *m, const dyn_solver_opts *o, int32_t n_dir, int32_t obs_compartment, int32_t obs_mode,
+                      int32_t *spl, int32_t *features);
 
 /*
  * One NUTS sampler iteration for n_chains independent chains (one GPU thread per chain).

@@ -758,6 +758,41 @@ def test_fused_twin_of_a_built_in_tangent_kernel_is_built_on_first_use():
     assert jit.ensure_fused_twin(f.call["model"], torch.float32, "tsit5", 1) and not jit.ensure_fused_twin(f.call["model"], torch.float64, "tsit5", 1)
 
 
+@pytest.mark.on_demand_build
+def test_lean_twin_of_another_likelihood_is_built_on_first_use(hints):
+    """The lean instances compiled in score what the two inference examples score (increments of r / of c).  A model observed
+    otherwise -- here the 2-age x 3-strain model on the daily VALUES of its infectious compartment -- gets its own lean twin
+    (FEAT bit 13 + the compartment code in bits 17-19 + bit 20) the first time a folded potential solves on it
+    (`dyn_lean_twin`, `jit.ensure_lean_twin`): same potential as on the general tangent instance to float32 rounding, the
+    instance named in `dyn_last_kernel_name`."""
+    from dynode_amd import PoissonObservation, _abi
+    from dynode_amd.infer import folded, sample_then_resolve
+    from examples import infer_multi_strain as ex_m
+
+    cfg = ex_m.base.get_config(**ex_m.TRUTH)
+    values = ex_m._solve(cfg, 120).ys[cfg.idx.i].cpu()
+
+    def model(config, tf, obs_data):
+        config = config.model_copy(deep=False)
+        config.parameters = config.parameters.model_copy(deep=False)
+        config.parameters.transmission_params = sample_then_resolve(config.parameters.transmission_params)
+        sol = ex_m._solve(config, tf, observe=PoissonObservation(compartment=config.idx.i, data=obs_data, increments=False, floor=1e-6))
+        handlers.factor("prevalence", sol.log_likelihood)
+
+    pot = Potential(model, dict(config=ex_m.get_config(6), tf=120, obs_data=values), 0, torch.device("cuda"))
+    f = folded.discover(pot)
+    assert f is not None
+    z = pot.initial(32, init_to_median, 3) + 0.2 * torch.randn(32, 6, dtype=torch.float64, generator=torch.Generator().manual_seed(5)).cuda()
+    u1, g1 = f(z)
+    lean_name = _abi.lib().dyn_last_kernel_name().decode()
+    feat = int(lean_name.rsplit(", ", 1)[1].rstrip(">"))
+    assert feat & 0x2000 and (feat >> 17) & 0x7 == 2 and feat & 0x100000, lean_name      # lean, compartment code 2 (i), values
+    hints(general_instance=1)
+    u0, g0 = f(z)
+    assert _abi.lib().dyn_last_kernel_name().decode().endswith(", 0>")
+    assert torch.allclose(u1, u0, rtol=1e-6, atol=1e-3) and torch.allclose(g1, g0, rtol=2e-4, atol=1e-4 * float(g0.abs().max()))
+
+
 def test_a_call_that_cannot_carry_the_sampler_is_refused(data):
     """A nuts_tail the library did not pack is an option error; a packed one whose chains are not this batch's returns
     DYN_ERR_UNSUPPORTED.  Nothing runs either way."""
