@@ -98,6 +98,8 @@ struct KArgs {
     int32_t pull_mode, pull_waves;
 };
 constexpr int kMaxJumps = 64;   // (a year of weekly interventions: 52)
+// both arguments of a fused launch travel by value: 4 KB of kernel-argument segment hold them (3144 bytes in float64)
+static_assert(sizeof(KArgs<double>) + sizeof(dynnuts::Tail) + 64 <= 4096, "KArgs + Tail exceed the kernel-argument segment");
 
 // ---------------------------------------------------------------- math per precision
 template <typename T>
