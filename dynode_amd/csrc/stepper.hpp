@@ -359,6 +359,7 @@ struct Stepper {
                 ++n_rej;
             }
             [[maybe_unused]] const bool fsal_from_k6 = accept;
+            [[maybe_unused]] bool landed_now = false;      // this attempt ended on a discontinuity point (and was accepted)
             // ---- next interval: prev_dt * factor, then diffeqsolve's clip-to-end
             T next_t0 = accept ? tnext : tprev;
             // (the product is rounded on its own in every instance: where `constant` is a compile-time false the compiler would
@@ -412,14 +413,18 @@ struct Stepper {
                     next_t0 = M::next(jt_tab[jidx], M::inf());
                     next_t1 = next_t0 + (constant ? ka.constant_dt : dt_unclipped * factor);
                     ++jidx;
+                    landed_now = true;
                 }
-                if (__any(landed)) { // FSAL is invalid across a jump: k[0] = f(t_jump+, y)
-                    L.rhs(next_t0, y, k[1]);
-                    if (landed) {
+                // FSAL is invalid across a jump: k[0] = f(t_jump+, y).  (PRESCALE: formed below, with the NEXT step's rates)
+                if constexpr (!PRESCALE) {
+                    if (__any(landed)) {
+                        L.rhs(next_t0, y, k[1]);
+                        if (landed) {
 #pragma unroll
-                        for (int c = 0; c < NC; ++c)
+                            for (int c = 0; c < NC; ++c)
 #pragma unroll
-                            for (int pp = 0; pp < NP; ++pp) k[PRESCALE ? 6 : 0][c].p[pp] = k[1][c].p[pp];   // (PRESCALE: k[6] is what becomes k[0] below)
+                                for (int pp = 0; pp < NP; ++pp) k[0][c].p[pp] = k[1][c].p[pp];
+                        }
                     }
                 }
                 if (act) at_jump = false;
@@ -461,6 +466,22 @@ struct Stepper {
                         for (int pp = 0; pp < NP; ++pp) k[0][c].p[pp] = k[0][c].p[pp] * ratio;
                 }
                 L.scale_rates(tb.rate_tab, lane, dt_new);
+                // ... and across a discontinuity point the first stage is evaluated afresh, K0 = dt_new f(t_jump+, y), on the
+                // new step's rates.  (Rescaling a derivative taken on the clipped step's rates, as the FSAL above, divides by
+                // that step's length -- which is ZERO when the step before happened to end on the last representable time
+                // in front of the point: the clipped step then has tnext == tprev, is accepted with error 0, as in the
+                // reference's controller, and 0 * inf made every later attempt non-finite.  Found by the fuzz sweep, seed 21447.)
+                if (__builtin_expect(n_jump > 0, 0)) {
+                    if (__any(landed_now)) {
+                        L.rhs(tprev, y, k[1]);
+                        if (landed_now) {
+#pragma unroll
+                            for (int c = 0; c < NC; ++c)
+#pragma unroll
+                                for (int pp = 0; pp < NP; ++pp) k[0][c].p[pp] = k[1][c].p[pp];
+                        }
+                    }
+                }
             }
 
             // ---- a trajectory that finished in this iteration is written off (stepper_writeoff.inc), and its slot asks for the next one

@@ -662,6 +662,22 @@ def fuzz_compare(case, dtype=F64):
     return err, same
 
 
+def test_zero_length_step_in_front_of_a_discontinuity_point():
+    """Fuzz seed 21447 (found by tests/probes/probe_fuzz.py in round 4): five equal steps end on the last representable time in
+    front of a discontinuity point, so the next step is clipped to length ZERO -- accepted with error 0 by the reference's
+    controller, restarted behind the point.  The step-scaled first stage used to be rescaled by new length / old length there
+    (0 * inf: every later attempt non-finite, status 2); it is evaluated afresh now.  Same step counts as the oracle."""
+    case = fuzz_case(21447)
+    assert case is not None and len(case[6]["jump_ts"]) == 2
+    err, same = fuzz_compare(case)
+    assert same and err < 1e-10, (err, same)
+    # ... and the same situation built by hand: constant-rate decay where the controller's steps are easy to foresee is not
+    # needed -- the jump directly AT a step end the controller would take anyway
+    m, y0, p, C, t1, ts, kw = case
+    base = solve_batch(m, y0, p, C, t1, ts, dtype=F64, **{k: v for k, v in kw.items() if k != "jump_ts"})
+    assert int(base.status.max()) == 0
+
+
 def test_randomized_parity_sweep():
     """80 random draws of `fuzz_case` (tests/probes/probe_fuzz.py runs thousands): float64 values to
     1e-10 of scale, identical status, accepted and rejected step counts, identical +inf pattern."""
