@@ -428,6 +428,9 @@ struct Stepper {
                     }
                 }
                 if (act) at_jump = false;
+                // (points at or behind the next step's start are done with -- also one a step happened to END on exactly:
+                // constant steps on a grid the point lies on; the index would otherwise stay on it and later points be ignored)
+                while (act && jidx < n_jump && jt_tab[jidx] <= next_t0) ++jidx;
                 if (act && jidx < n_jump) {
                     const T tj = jt_tab[jidx];
                     if (tj < next_t1 && tj > next_t0) {

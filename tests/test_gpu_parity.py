@@ -678,6 +678,19 @@ def test_zero_length_step_in_front_of_a_discontinuity_point():
     assert int(base.status.max()) == 0
 
 
+def test_a_discontinuity_point_a_step_ends_on_does_not_hide_the_later_ones():
+    """tests/test_oracle.py, the same case on the HIP path: constant steps that end exactly on a discontinuity point, another
+    point behind it.  Float64 equals the oracle with identical step counts; the later point still clips a step."""
+    m = ModelDesc(n_age=1, has_e=True, has_wane=True)
+    y0, p, C, _, _ = random_workload(m, 5, seed=4, t1=100.0)
+    ts = synthetic.save_grid(100.0)
+    got, st, na, nr = hip(m, y0, p, C, 100.0, ts, dtype=F64, constant_dt=0.25, jump_ts=[30.0, 45.1])
+    want, st_o, na_o, nr_o = O.solve(H.omodel(m), y0, p, C, 100.0, ts, dtype=np.float64, constant_dt=0.25, jump_ts=[30.0, 45.1])
+    assert st.max() == 0 and np.array_equal(na, na_o) and np.array_equal(nr, nr_o) and np.abs(got - want).max() / 1000.0 < 1e-11
+    only, _, na1, _ = hip(m, y0, p, C, 100.0, ts, dtype=F64, constant_dt=0.25, jump_ts=[45.1])
+    assert np.array_equal(na, na1) and (na > 400).all() and np.array_equal(got, only)
+
+
 def test_randomized_parity_sweep():
     """80 random draws of `fuzz_case` (tests/probes/probe_fuzz.py runs thousands): float64 values to
     1e-10 of scale, identical status, accepted and rejected step counts, identical +inf pattern."""

@@ -268,6 +268,21 @@ def test_discontinuity_points_are_hit_and_harmless_for_smooth_rhs():
     assert np.abs(ys - base).max() < 5e-5
 
 
+def test_a_discontinuity_point_a_step_ends_on_does_not_hide_the_later_ones():
+    """Constant steps of 0.25 end exactly on t = 30: that point needs no clipping -- and must not keep the index of the next
+    point to come, or every later point would be ignored (round 4; the stepper only moved the index when a clipped step
+    landed).  With it out of the way the point at 45.1 clips a step: one more step than without points, the same as with that
+    point alone."""
+    args = (SEIRS, [0.99, 0, 0.01, 0], [2 / 7, 1 / 7, 1 / 3, 1 / 60], [[1.0]], 100)
+    plain, _, na0, _ = solve(*args, dtype=np.float64, constant_dt=0.25)
+    both, st, na, nr = solve(*args, dtype=np.float64, constant_dt=0.25, jump_ts=[30.0, 45.1])
+    only, _, na1, _ = solve(*args, dtype=np.float64, constant_dt=0.25, jump_ts=[45.1])
+    assert st[0] == 0 and nr[0] == 0 and na0[0] == 400
+    assert na[0] == na1[0] and na[0] > na0[0]
+    np.testing.assert_array_equal(both, only)
+    assert np.abs(both - plain).max() < 1e-6
+
+
 def test_batch_is_independent_of_threads_and_order():
     wl = synthetic.seirs_multi_strain(48, seed=7)
     a, _, na, _ = O.solve(H.omodel(wl.model), wl.y0, wl.params, wl.contact, 120, synthetic.save_grid(120), n_threads=1)
