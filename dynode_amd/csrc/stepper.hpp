@@ -280,7 +280,10 @@ struct Stepper {
 
             // ---- SaveAt(ts): dense output at every save time in (tprev, tnext]
             bool pending = accept && (save_idx < n_save) && (ts_next <= tnext);
-            const T inv_dt = M::recip(dt);
+            T inv_dt = M::recip(dt);
+            // (a step clipped to length zero in front of a discontinuity point: its rows are the state itself, theta = 0, as
+            // in the oracle -- not 0 * inf)
+            if (__builtin_expect(n_jump > 0, 0)) inv_dt = dt > T(0) ? inv_dt : T(0);
             if constexpr (PC) { // the rows are wave 1's: publish the accepted step (see consume())
                 pending = false;
                 if (__any(accept)) {

@@ -691,6 +691,48 @@ def test_a_discontinuity_point_a_step_ends_on_does_not_hide_the_later_ones():
     assert np.array_equal(na, na1) and (na > 400).all() and np.array_equal(got, only)
 
 
+def edge_sweep(report=None):
+    """Discontinuity points and save times in special position (float64, HIP vs oracle, identical step counts asked): points
+    ON save times, on t0 / t1 / the last time in front of t1, one ulp and 1e-9 apart, on the constant-step grid, sixty-four of
+    them, on the smallest denormal (a first step of length zero); save grids that start at t0, end before t1, sit on step
+    ends.  Returns (cases run, mismatches)."""
+    import itertools
+
+    models = [ModelDesc(n_age=1), ModelDesc(n_age=8), ModelDesc(n_age=2, n_strain=3, has_e=True, has_wane=True, has_c=True),
+              ModelDesc(n_age=1, has_e=True, has_wane=True, seasonal=True)]
+    ran, bad = 0, []
+    for m, t1 in itertools.product(models, (10.0, 60.0)):
+        y0, p, C, _, _ = random_workload(m, 9, seed=int(t1) + m.n_age, t1=t1)
+        grids = {"end": np.array([t1]), "from_t0": np.linspace(0.0, t1, 11), "inside": np.linspace(0.5, t1 - 0.5, 7),
+                 "quarter": np.arange(0.0, t1 + 1e-9, 0.25)}
+        jumpsets = {"none": [], "on_save": [t1 / 2], "t0": [0.0], "t1": [t1], "before_t1": [float(np.nextafter(t1, 0.0))],
+                    "ulp_pair": [5.0, float(np.nextafter(5.0, 9.0))], "close_pair": [5.0, 5.0 + 1e-9], "grid": [2.5, 5.0, 7.25],
+                    "many": list(np.linspace(0.1, t1 - 0.1, 64)), "first_ulp": [float(np.nextafter(0.0, 1.0)), 3.0]}
+        modes = {"adaptive": dict(rtol=1e-6, atol=1e-8), "tight": dict(rtol=1e-10, atol=1e-12), "const_.25": dict(constant_dt=0.25),
+                 "const_.7": dict(constant_dt=0.7)}
+        for (gn, ts), (jn, js), (mn, kw), method in itertools.product(grids.items(), jumpsets.items(), modes.items(), ("tsit5", "dopri5")):
+            kk = dict(kw, method=method, **({"jump_ts": js} if js else {}))
+            r = solve_batch(m, y0, p, C, t1, ts, dtype=F64, **kk)
+            want, st, na, nr = O.solve(H.omodel(m), y0, p, C, t1, ts, dtype=np.float64, **kk)
+            ran += 1
+            got, fin = r.ys.cpu().numpy(), np.isfinite(want)
+            err = np.abs(got[fin] - want[fin]).max() / max(np.abs(want[fin]).max(), 1.0) if fin.any() else 0.0
+            same = (np.array_equal(np.isfinite(got), fin) and np.array_equal(r.status.cpu().numpy(), st)
+                    and np.array_equal(r.n_accept.cpu().numpy(), na) and np.array_equal(r.n_reject.cpu().numpy(), nr))
+            if not same or not err <= 1e-10:
+                bad.append(((m.n_age, m.n_strain, m.seasonal), t1, gn, jn, mn, method, float(err)))
+                if report:
+                    report(bad[-1])
+    return ran, bad
+
+
+def test_points_and_save_times_in_special_position():
+    """`edge_sweep`: 2560 combinations in a few seconds.  Found in round 4: the zero-length first step behind a point on the
+    smallest denormal wrote its t0 row as 0 * inf (the oracle takes theta = 0 for a step of length zero)."""
+    ran, bad = edge_sweep()
+    assert ran == 2560 and not bad, bad[:5]
+
+
 def test_randomized_parity_sweep():
     """80 random draws of `fuzz_case` (tests/probes/probe_fuzz.py runs thousands): float64 values to
     1e-10 of scale, identical status, accepted and rejected step counts, identical +inf pattern."""
