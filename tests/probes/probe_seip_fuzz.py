@@ -34,10 +34,10 @@ for seed in range(seed0, seed0 + N):
     if rng.integers(2):
         mask = rng.integers(0, 2, 4).astype(np.uint8)
         kw["save_mask"] = mask if mask.any() else np.array([0, 0, 0, 1], np.uint8)
+    from dynode_amd import engine
+    engine.clear_dispatch_hints()
     if shape["K1"] > 1 and (wl.model.n_age <= 4) and rng.integers(2):
-        os.environ["DYNODE_HIP_SEIP_TIER_LANES"] = str(int(rng.integers(2)))
-    else:
-        os.environ.pop("DYNODE_HIP_SEIP_TIER_LANES", None)
+        engine.set_dispatch_hints(seip_tier_lanes=1 if rng.integers(2) else -1)    # (tiers dealt over two lanes: on / off)
     try:
         r = solve_batch(wl.model, wl.y0, wl.params, wl.contact, t1, ts, dtype=torch.float64, **kw)
         want, st, na, nr = O.solve(H.omodel(wl.model), wl.y0, wl.params, wl.contact, t1, ts, dtype=np.float64, n_threads=8, **kw)
