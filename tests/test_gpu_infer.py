@@ -470,6 +470,53 @@ def test_fused_latent_sites_match_the_torch_definitions():
     assert fused_sites.build_table([dist.Normal(0.0, 1.0)] * 9) is not None and fused_sites.build_table([dist.Normal(0.0, 1.0)] * 17) is None
 
 
+@pytest.mark.parametrize("rows", [0, 1, 4])
+def test_parameter_map_and_seeds_against_autograd_also_where_a_site_value_is_zero(rows):
+    """dyn_latent_param_map: parameter rows p_j = coef_j prod_i x_i^e_ji and seeds d p_j / d z_i against torch autograd of the
+    same monomials -- general exponents (1, -1, 2, 0.5, 0), three sites of different families, and rows where an identity site
+    sits EXACTLY at 0: the seed of a first power is then the coefficient times the other factors (not 0 * inf), of a square 0,
+    and a parameter that does not depend on the site gets an exact 0.  ``rows``: all directions in the chain's one row, one
+    direction per row, chains padded to four rows."""
+    import ctypes
+
+    from dynode_amd import _abi
+    from dynode_amd.infer import distributions as dist
+    from dynode_amd.infer import fused_sites
+    from dynode_amd.infer.distributions import biject_to
+
+    dists = [dist.Normal(0.0, 1.0), dist.Uniform(0.5, 4.0), dist.Normal(1.0, 2.0)]
+    arr, n = fused_sites.build_table(dists)
+    coef = torch.tensor([3.0, 2.0, 5.0, -1.5, 7.0], dtype=torch.float64)
+    expo = torch.tensor([[1, 0, 0], [1, 1, 0], [0, 0, 2], [1, -1, 1], [0, 0.5, 0]], dtype=torch.float64)
+    P, C = 5, 6
+    z = torch.tensor([[0.0, 0.3, 2.0], [1.5, -1.0, 0.0], [0.0, 2.0, 0.0], [1.0, 0.0, -2.0], [-0.7, 1.1, 0.4], [0.0, -3.0, 1.0]], dtype=torch.float64)
+    dev = torch.device("cuda")
+    R = {0: 1, 1: n, 4: 4}[rows]
+    x, lp, dlp = torch.empty((C, n), dtype=torch.float64, device=dev), torch.empty(C, dtype=torch.float64, device=dev), torch.empty((C, n), dtype=torch.float64, device=dev)
+    params = torch.full((C * R, P), float("nan"), dtype=torch.float64, device=dev)
+    seeds = torch.full((C * R if rows else C * n, P), float("nan"), dtype=torch.float64, device=dev)
+    z_d, coef_d, expo_d = z.to(dev), coef.to(dev), expo.to(dev).contiguous()       # (named: the pointers must outlive the call)
+    rc = _abi.lib().dyn_latent_param_map(arr, n, C, z_d.data_ptr(), x.data_ptr(), lp.data_ptr(), dlp.data_ptr(), P, coef_d.data_ptr(),
+                                         expo_d.data_ptr(), _abi.DYN_F64, rows, params.data_ptr(), seeds.data_ptr(),
+                                         ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    assert rc == 0
+    zr = z.clone().requires_grad_(True)
+    bij = [biject_to(d.support) for d in dists]
+    xt = torch.stack([b(zr[:, i]) for i, b in enumerate(bij)], dim=1)
+    assert torch.allclose(x.cpu(), xt.detach(), rtol=1e-14, atol=0) and float(xt[0, 0].detach()) == 0.0 and float(xt[2, 2].detach()) == 0.0
+    want_p = torch.stack([coef[j] * torch.prod(torch.where(expo[j] == 0, torch.ones_like(xt), xt ** expo[j]), dim=1) for j in range(P)], dim=1)
+    want_s = torch.stack([torch.autograd.grad(want_p[:, j].sum(), zr, retain_graph=True)[0] for j in range(P)], dim=2)     # [C, n, P]
+    got_p = params.cpu().view(C, R, P)
+    assert torch.allclose(got_p[:, 0], want_p.detach(), rtol=1e-13, atol=1e-300) and torch.equal(got_p, got_p[:, :1].expand(-1, R, -1))
+    got_s = seeds.cpu().view(C, R if rows else n, P)
+    assert torch.allclose(got_s[:, :n], want_s, rtol=1e-12, atol=1e-14), (got_s[:, :n] - want_s).abs().max()
+    assert not bool(got_s[:, n:].any())                              # padding rows: zero seeds
+    # the rows this test is for: x_0 == 0 exactly
+    assert float(got_s[0, 0, 0]) == 3.0 and float(got_s[0, 0, 1]) == 2.0 * float(xt[0, 1].detach()) and float(got_s[0, 0, 2]) == 0.0
+    assert float(got_s[2, 2, 2]) == 0.0 and float(got_s[2, 0, 3]) == 0.0      # the square at 0; a first power next to another zero factor
+
+
 def test_potential_with_fused_sites_equals_the_generic_path(data):
     pot = Potential(ex.model, dict(config=ex.get_config(), tf=100, obs_data=data), 0, torch.device("cuda"))
     assert pot.site_table is not None                      # the example's priors are in the fused families
