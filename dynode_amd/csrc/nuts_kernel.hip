@@ -67,30 +67,329 @@ __global__ void __launch_bounds__(64) nuts_advance(const dyn_nuts_state st, cons
         if (map.enabled) map_lanes<NS>(map, go, ze, D, c, sub);     // (wave-uniform)
 }
 
-// ... beyond kRegDim dimensions: the same state machine with the dimension a run-time number (nuts_device.hpp).  The
-// potential arrives as (u_new, g_new) or -- up to DYN_MAX_SITES dimensions -- in the parts of a folded potential (pot_*),
-// with the map of the next position behind it (dyn_nuts_advance_mapped).
-template <int NS>
-__global__ void __launch_bounds__(64) nuts_advance_any_dim(const dyn_nuts_state st, const dynlat::MapArgs map) {
-    const int t = blockIdx.x * 64 + threadIdx.x;
-    const int c = t / NS, sub = t % NS;
-    bool go = false;
-    double ze[DYN_NUTS_MAX_DIM];
-    if constexpr (NS > 1)
-        for (int i = 0; i < NS; ++i) ze[i] = 0.0;
-    if (sub == 0 && c < st.n_chains) {
-        Handed<DYN_NUTS_MAX_DIM> handed;
-        handed.ll = 0.0;
-        if (st.pot_lp != nullptr) {
-            const int D = st.dim;
-            handed.ll = st.pot_ll[(int64_t)c * st.pot_ll_stride];
-            const int64_t first = (int64_t)c * (st.pot_dll_stride > 0 ? st.pot_dll_stride : D);
-            for (int i = 0; i < D; ++i) handed.dll[i] = st.pot_dll[first + i];
-        }
-        go = advance_chain<DYN_NUTS_MAX_DIM, true, NS == 1>(st, map, c, handed, ze);
+// ---- beyond kRegDim dimensions: DYN_NUTS_MAX_DIM (32) lanes per chain.  Lane l of a chain's group holds element l of every
+// per-chain vector in a register (loaded and stored coalesced) and row l of the matrices; every lane of the group runs the
+// chain's scalar state machine redundantly on identical values (sums over the dimension are butterfly reductions, which leave
+// the same bits in every lane), so control flow is uniform within a group and the dozens of short run-time loops of
+// `advance_chain<DMAX, RT = true>` -- each a chain of scratch / L2 round trips in one thread -- become single instructions.
+// A matrix-vector product is D fused multiply-adds per lane, the vector going round by lane shuffles.  The same transitions
+// as the one-thread form up to the order of those sums (per-chain adaptation only; pooled windows are refused above).
+constexpr int kGroup = DYN_NUTS_MAX_DIM;
+static_assert(kGroup == 32, "one half wave per chain");
+
+__device__ __forceinline__ double lane_value(double v, int j) { return __shfl(v, j, kGroup); }   // the group's lane j
+__device__ __forceinline__ double group_sum(double x) {
+#pragma unroll
+    for (int o = kGroup / 2; o > 0; o >>= 1) x += __shfl_xor(x, o, kGroup);
+    return x;
+}
+__device__ __forceinline__ bool group_any(bool b) {
+    const unsigned long long m = __ballot(b);
+    return ((m >> (threadIdx.x & 32)) & 0xffffffffull) != 0;
+}
+// y_l = sum_j M[l][j] v_j (lanes beyond D: 0)
+__device__ __forceinline__ double matvec_lanes(const double *M, double v, int D, int l) {
+    const double *row = M + (l < D ? l : 0) * D;
+    double a = 0.0;
+    for (int j = 0; j < D; ++j) a += row[j] * lane_value(v, j);
+    return l < D ? a : 0.0;
+}
+__device__ __forceinline__ bool is_turning_lanes(const double *imm, double rl, double rr, double rsum, int D, int l) {
+    const double rs = rsum - 0.5 * (rl + rr);
+    const double *row = imm + (l < D ? l : 0) * D;
+    double vl = 0.0, vr = 0.0;
+    for (int j = 0; j < D; ++j) {
+        const double m = row[j];
+        vl += m * lane_value(rl, j);
+        vr += m * lane_value(rr, j);
     }
-    if constexpr (NS > 1)
-        if (map.enabled) map_lanes<NS>(map, go, ze, st.dim, c, sub);
+    if (l >= D) { vl = 0.0; vr = 0.0; }
+    return group_sum(vl * rs) <= 0.0 || group_sum(vr * rs) <= 0.0;
+}
+
+// chol(inv(imm)) by the lanes of a chain: the operations of mass_sqrt_into (nuts_device.hpp), element by element in the same
+// order -- Gauss-Jordan with lane l on column l, Cholesky column by column with lane i on row i.  A (the matrix, filled by the
+// caller) and I: LDS, row stride kLdsStride (both access patterns conflict-free); the factor goes to `out` in global memory.
+constexpr int kLdsStride = kGroup + 1;
+__device__ __forceinline__ void wave_sync() {   // LDS operations of a wave execute in order: only the compiler has to be told
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ void mass_sqrt_lanes(double *out, double *A, double *I, int D, int l) {
+    constexpr int S = kLdsStride;
+    const bool own = l < D;
+    if (own)
+        for (int r = 0; r < D; ++r) I[r * S + l] = r == l ? 1.0 : 0.0;
+    wave_sync();
+    for (int c = 0; c < D; ++c) {
+        const double p = 1.0 / A[c * S + c];
+        wave_sync();
+        double ac = 0.0, ic = 0.0;
+        if (own) {
+            ac = A[c * S + l] * p;
+            ic = I[c * S + l] * p;
+            A[c * S + l] = ac;
+            I[c * S + l] = ic;
+        }
+        const double below = own ? A[l * S + c] : 0.0;   // lane r: a[r][c], read before any row changes (row c's is not used)
+        wave_sync();
+        for (int r = 0; r < D; ++r) {
+            if (r == c) continue;
+            const double f = lane_value(below, r);
+            if (own) {
+                A[r * S + l] -= f * ac;
+                I[r * S + l] -= f * ic;
+            }
+        }
+        wave_sync();
+    }
+    for (int j = 0; j < D; ++j) {     // (in place: the lower triangle of I becomes the factor, the upper one is only read)
+        double s = 0.0;
+        const bool mine = own && l >= j;
+        if (mine) {
+            s = 0.5 * (I[l * S + j] + I[j * S + l]);
+            for (int k = 0; k < j; ++k) s -= I[l * S + k] * I[j * S + k];
+        }
+        const double djj = sqrt(fmax(lane_value(s, j), 1e-300));
+        if (mine) I[l * S + j] = l == j ? djj : s / djj;
+        wave_sync();
+    }
+    if (own)
+        for (int r = 0; r < D; ++r) out[r * D + l] = l <= r ? I[r * S + l] : 0.0;
+}
+
+template <bool MAPPED>
+__global__ void __launch_bounds__(64) nuts_advance_lanes(const dyn_nuts_state st, const dynlat::MapArgs map) {
+    const int t = blockIdx.x * 64 + threadIdx.x;
+    const int c = t / kGroup, l = t % kGroup;
+    const int D = st.dim, Dm = st.max_depth;
+    const int total = st.num_warmup + st.num_samples;
+    __shared__ double window_ws[2][2][kGroup * kLdsStride];   // (a window's end: the matrix and its inverse, mass_sqrt_lanes)
+    if (c >= st.n_chains || st.it[c] >= total) return;   // (a whole group leaves together; finished chains idle)
+    const bool own = l < D;
+    const int64_t cD = (int64_t)c * D;
+    auto ld = [&](const double *p) { return own ? p[cD + l] : 0.0; };
+    auto sv = [&](double *p, double v) { if (own) p[cD + l] = v; };
+
+    double L_u = st.u[c], L_eps = st.eps[c], L_eps_avg = st.eps_avg[c], L_da_mu = st.da_mu[c], L_da_xbar = st.da_xbar[c],
+           L_da_gbar = st.da_gbar[c], L_da_t = st.da_t[c], L_wf_n = st.wf_n[c], L_e0 = st.e0[c], L_up = st.up[c],
+           L_weight = st.weight[c], L_sum_acc = st.sum_acc[c], L_sgn = st.sgn[c], L_s_up = st.s_up[c], L_s_acc = st.s_acc[c];
+    int L_it = st.it[c], L_wi = st.wi[c], L_n_prop = st.n_prop[c], L_s_n = st.s_n[c];
+    const bool right = st.right[c] != 0;
+    int depth = st.depth[c], leaf = st.leaf[c];
+    bool s_turn = st.s_turn[c] != 0;
+    double s_weight = st.s_weight[c];
+    uint64_t ctr = (uint64_t)st.rng_ctr[c];
+    auto uniform = [&]() {
+        Philox r{(uint32_t)st.seed, (uint32_t)(st.seed >> 32), ctr, (uint32_t)c};
+        ++ctr;
+        return r.uniform();
+    };
+    double *const imm = st.imm + cD * D, *const mms = st.mm_sqrt + cD * D, *const m2 = st.wf_m2 + cD * D;
+    // this lane's element of the chain's vectors (z, g: written at a transition's end, never read before)
+    double gl = ld(st.gl), gp = ld(st.gp), gr = ld(st.gr), r_sum = ld(st.r_sum), rl = ld(st.rl), rr = ld(st.rr),
+           s_gp = ld(st.s_gp), s_rsum = ld(st.s_rsum), s_zp = ld(st.s_zp), zl = ld(st.zl), zp = ld(st.zp), zr = ld(st.zr);
+    double z = 0.0, g = 0.0;
+    const double eps_signed = L_eps * L_sgn;
+
+    // ---- finish the leapfrog started by the previous launch (advance_chain has the commentary of every phase)
+    double un, gn;
+    if (st.pot_lp != nullptr) {
+        const int64_t first = (int64_t)c * (st.pot_dll_stride > 0 ? st.pot_dll_stride : D);
+        un = -(st.pot_lp[c] + st.pot_ll[(int64_t)c * st.pot_ll_stride] + st.pot_offset);
+        gn = own ? -(st.pot_dlp[cD + l] + st.pot_dll[first + l]) : 0.0;
+    } else {
+        un = st.u_new[c];
+        gn = ld(st.g_new);
+    }
+    const double zn = ld(st.z_eval);
+    const bool bad = group_any(!isfinite(un) || !isfinite(gn));
+    const double rn = ld(st.r_half) - 0.5 * eps_signed * (bad ? 0.0 : gn);
+    double tmp = matvec_lanes(imm, rn, D, l);
+    double de = (bad ? INFINITY : un) + 0.5 * group_sum(rn * tmp) - L_e0;
+    if (isnan(de)) de = INFINITY;
+    const double lw = -de;
+    const bool div = de > st.max_delta_energy;
+    const double acc = exp(fmin(-de, 0.0));
+
+    // ---- grow the subtree by this leaf
+    const double new_w = logaddexp(s_weight, lw);
+    if (uniform() < exp(lw - new_w)) {
+        s_zp = zn;
+        s_gp = bad ? 0.0 : gn;
+        L_s_up = bad ? INFINITY : un;
+    }
+    s_weight = new_w;
+    s_rsum += rn;
+    bool s_div = st.s_div[c] != 0 || div;
+    const double s_acc = L_s_acc + acc;
+    const int s_n = L_s_n + 1;
+    double zc = zn, rc = rn, gc = bad ? 0.0 : gn;
+
+    // ---- checkpointed U-turn test
+    const int idx_max = __popc((unsigned)(leaf >> 1));
+    int trailing = 0;
+    while ((leaf >> trailing) & 1) ++trailing;
+    const int idx_min = idx_max - trailing + 1;
+    double *const r_ck = st.r_ck + cD * Dm, *const rs_ck = st.rs_ck + cD * Dm;
+    if ((leaf & 1) == 0) {
+        if (own) { r_ck[idx_max * D + l] = rn; rs_ck[idx_max * D + l] = s_rsum; }
+    } else {
+        for (int k = idx_max; k >= idx_min && !s_turn; --k) {
+            const double rk = own ? r_ck[k * D + l] : 0.0, rsk = own ? rs_ck[k * D + l] : 0.0;
+            s_turn = is_turning_lanes(imm, rk, rn, s_rsum - rsk + rk, D, l);
+        }
+    }
+    ++leaf;
+
+    // ---- subtree complete -> merge into the trajectory
+    const bool sub_done = s_turn || s_div || leaf >= (1 << depth);
+    bool stop = false;
+    if (sub_done) {
+        const bool ok = !s_turn && !s_div;
+        if (ok && uniform() < exp(fmin(s_weight - L_weight, 0.0))) { zp = s_zp; gp = s_gp; L_up = L_s_up; }
+        if (right) { zr = zc; rr = rc; gr = gc; } else { zl = zc; rl = rc; gl = gc; }
+        L_weight = logaddexp(L_weight, s_weight);
+        r_sum += s_rsum;
+        L_sum_acc += s_acc;
+        L_n_prop += s_n;
+        ++depth;
+        stop = s_turn || s_div || is_turning_lanes(imm, rl, rr, r_sum, D, l) || depth >= Dm;
+    }
+
+    int it = L_it;
+    double eps = L_eps;
+    if (stop) {
+        // ---- transition complete: adapt, record, next transition
+        const bool warm = it < st.num_warmup;
+        const int n_prop = L_n_prop;
+        const double a_prob = L_sum_acc / (double)(n_prop > 0 ? n_prop : 1);
+        z = zp; g = gp;
+        L_u = L_up;
+        if (warm) {
+            const double t1 = L_da_t + 1.0, w = 1.0 / (t1 + 10.0);
+            const double gbar = (1.0 - w) * L_da_gbar + w * (st.target_accept - a_prob);
+            const double x = L_da_mu - sqrt(t1) / 0.05 * gbar;
+            const double wx = pow(t1, -0.75);
+            const double xbar = (1.0 - wx) * L_da_xbar + wx * x;
+            L_da_t = t1; L_da_gbar = gbar; L_da_xbar = xbar;
+            eps = exp(x);
+            L_eps_avg = exp(xbar);
+            const int wi = L_wi;
+            if (wi < st.n_windows && it >= st.w_start[wi] && it < st.w_end[wi]) {
+                // Welford: this lane the mean's element l and row l of the co-moment matrix
+                const double n1 = L_wf_n + 1.0;
+                double mean = ld(st.wf_mean);
+                const double d0 = z - mean;
+                mean += d0 / n1;
+                const double zm = z - mean;
+                double *const row = m2 + (own ? l : 0) * D;
+                const bool last = it + 1 == st.w_end[wi];
+                const double nn = fmax(n1, 2.0);
+                double *const A = window_ws[(threadIdx.x >> 5) & 1][0], *const I = window_ws[(threadIdx.x >> 5) & 1][1];
+                for (int j = 0; j < D; ++j) {
+                    const double zj = lane_value(zm, j);
+                    if (own) {
+                        const double m = row[j] + d0 * zj;
+                        row[j] = last ? 0.0 : m;
+                        if (last) {   // the window's matrix: regularised as numpyro does, row l
+                            const double v = (nn / (nn + 5.0)) * m / (nn - 1.0) + (l == j ? 1e-3 * (5.0 / (nn + 5.0)) : 0.0);
+                            imm[l * D + j] = v;
+                            A[l * kLdsStride + j] = v;
+                        }
+                    }
+                }
+                L_wf_n = n1;
+                if (last) {
+                    mass_sqrt_lanes(mms, A, I, D, l);
+                    __threadfence();    // (the factor's columns were written by other lanes than the ones that read its rows below)
+                    eps = L_eps_avg;
+                    L_da_mu = log(10.0 * eps);
+                    L_da_t = 0.0; L_da_gbar = 0.0; L_da_xbar = 0.0;
+                    L_wf_n = 0.0;
+                    mean = 0.0;
+                    L_wi = wi + 1;
+                }
+                sv(st.wf_mean, mean);
+            }
+            if (it + 1 == st.num_warmup) eps = L_eps_avg;
+        } else {
+            const int64_t j = (int64_t)c * st.num_samples + (it - st.num_warmup);
+            if (own) st.out_z[j * D + l] = z;
+            if (l == 0) {
+                st.out_acc[j] = a_prob;
+                st.out_n[j] = n_prop;
+                st.out_div[j] = s_div ? 1 : 0;
+            }
+        }
+        L_eps = eps;
+        L_it = ++it;
+        // fresh momentum r0 = chol(M) * normal (normal i from counters ctr + 2 i, ctr + 2 i + 1, as the serial draw order has them)
+        Philox r{(uint32_t)st.seed, (uint32_t)(st.seed >> 32), ctr + 2ull * (uint64_t)(own ? l : 0), (uint32_t)c};
+        const double nrm = own ? r.normal() : 0.0;
+        ctr += 2ull * (uint64_t)D;
+        const double r0 = matvec_lanes(mms, nrm, D, l);
+        tmp = matvec_lanes(imm, r0, D, l);
+        L_e0 = L_u + 0.5 * group_sum(r0 * tmp);
+        zl = zr = zp = z;
+        rl = rr = r_sum = r0;
+        gl = gr = gp = g;
+        L_up = L_u;
+        L_weight = 0.0; L_sum_acc = 0.0; L_n_prop = 0;
+        depth = 0;
+    }
+
+    bool go_right = right;
+    if (sub_done) {
+        // ---- next subtree
+        go_right = uniform() < 0.5;
+        L_sgn = go_right ? 1.0 : -1.0;
+        zc = go_right ? zr : zl; rc = go_right ? rr : rl; gc = go_right ? gr : gl;
+        s_zp = zp; s_gp = gp; s_rsum = 0.0;
+        L_s_up = L_up;
+        s_weight = -INFINITY;
+        L_s_acc = 0.0; L_s_n = 0;
+        s_turn = false; s_div = false;
+        leaf = 0;
+        if (own)
+            for (int k = 0; k < Dm; ++k) { r_ck[k * D + l] = 0.0; rs_ck[k * D + l] = 0.0; }
+    } else {
+        L_s_acc = s_acc; L_s_n = s_n;
+    }
+
+    // ---- first half of the next leapfrog, and the position the potential is needed at
+    const double es = eps * (go_right ? 1.0 : -1.0);
+    const double rh = rc - 0.5 * es * gc;
+    tmp = matvec_lanes(imm, rh, D, l);
+    const double ze = (it >= total) ? z : zc + es * tmp;
+    sv(st.r_half, rh);
+    sv(st.z_eval, ze);
+    sv(st.gc, gc); sv(st.gl, gl); sv(st.gp, gp); sv(st.gr, gr);
+    sv(st.r_sum, r_sum); sv(st.rc, rc); sv(st.rl, rl); sv(st.rr, rr);
+    sv(st.s_gp, s_gp); sv(st.s_rsum, s_rsum); sv(st.s_zp, s_zp);
+    sv(st.zc, zc); sv(st.zl, zl); sv(st.zp, zp); sv(st.zr, zr);
+    if (stop) { sv(st.z, z); sv(st.g, g); }
+    if (l == 0) {
+        st.rng_ctr[c] = (int64_t)ctr;
+        st.u[c] = L_u; st.eps[c] = L_eps; st.eps_avg[c] = L_eps_avg; st.da_mu[c] = L_da_mu; st.da_xbar[c] = L_da_xbar;
+        st.da_gbar[c] = L_da_gbar; st.da_t[c] = L_da_t; st.wf_n[c] = L_wf_n; st.e0[c] = L_e0; st.up[c] = L_up;
+        st.weight[c] = L_weight; st.sum_acc[c] = L_sum_acc; st.sgn[c] = L_sgn; st.s_up[c] = L_s_up; st.s_weight[c] = s_weight;
+        st.s_acc[c] = L_s_acc; st.it[c] = L_it; st.wi[c] = L_wi; st.n_prop[c] = L_n_prop; st.depth[c] = depth;
+        st.right[c] = go_right ? 1 : 0; st.leaf[c] = leaf; st.s_turn[c] = s_turn ? 1 : 0; st.s_div[c] = s_div ? 1 : 0;
+        st.s_n[c] = L_s_n;
+    }
+    // the map of the position handed out: the group's first DYN_MAX_SITES lanes, one site each (dyn_nuts_advance_mapped)
+    if constexpr (MAPPED) {
+        if (l < DYN_MAX_SITES) {
+            const int leader = (int)(threadIdx.x & 63) - l;
+            if (map.f64)
+                dynlat::map_chain_lanes<double, DYN_MAX_SITES>(map.tab, c, l, leader, ze, map.x, map.lp, map.dlp_dz, map.P, map.coef,
+                                                               map.expo, (double *)map.params, (double *)map.seeds, map.split);
+            else
+                dynlat::map_chain_lanes<float, DYN_MAX_SITES>(map.tab, c, l, leader, ze, map.x, map.lp, map.dlp_dz, map.P, map.coef,
+                                                              map.expo, (float *)map.params, (float *)map.seeds, map.split);
+        }
+    }
 }
 
 } // namespace dynnuts
@@ -122,14 +421,13 @@ static int advance(const dyn_nuts_state *st, const dynlat::MapArgs &map, void *s
         dynnuts::nuts_advance<5, 8>, dynnuts::nuts_advance<6, 8>, dynnuts::nuts_advance<7, 8>, dynnuts::nuts_advance<8, 8>};
     static const int lanes_of[dynnuts::kRegDim] = {1, 2, 4, 4, 8, 8, 8, 8};
     if (st->dim > dynnuts::kRegDim) {
-        // the run-time-dimension instance: per-chain adaptation; (u_new, g_new), or a folded potential's parts and map
+        // a half wave per chain: per-chain adaptation; (u_new, g_new), or a folded potential's parts and map
         if (st->pooled) return DYN_ERR_UNSUPPORTED;
-        const int ns = map.enabled ? DYN_MAX_SITES : 1;
-        const unsigned blocks = (unsigned)(((int64_t)st->n_chains * ns + 63) / 64);
+        const unsigned blocks = (unsigned)(((int64_t)st->n_chains * dynnuts::kGroup + 63) / 64);
         if (map.enabled)
-            hipLaunchKernelGGL(dynnuts::nuts_advance_any_dim<DYN_MAX_SITES>, dim3(blocks), dim3(64), 0, (hipStream_t)stream, *st, map);
+            hipLaunchKernelGGL(dynnuts::nuts_advance_lanes<true>, dim3(blocks), dim3(64), 0, (hipStream_t)stream, *st, map);
         else
-            hipLaunchKernelGGL(dynnuts::nuts_advance_any_dim<1>, dim3(blocks), dim3(64), 0, (hipStream_t)stream, *st, map);
+            hipLaunchKernelGGL(dynnuts::nuts_advance_lanes<false>, dim3(blocks), dim3(64), 0, (hipStream_t)stream, *st, map);
         return hipGetLastError() == hipSuccess ? 0 : DYN_ERR_LAUNCH;
     }
     const int ns = map.enabled ? lanes_of[st->dim - 1] : 1;
