@@ -49,11 +49,9 @@ __device__ inline double logaddexp(double a, double b) {
     return m + log1p(exp(-fabs(a - b)));
 }
 
-// The dimension of a chain is a compile-time constant up to kRegDim (DMAX = D: every loop unrolls, every vector lives in
-// registers) and a run-time number beyond (DMAX = DYN_NUTS_MAX_DIM: the same code with loops over st.dim and the per-chain
-// vectors / matrices in scratch and L2 -- one thread per chain still; at 32 dimensions a matrix-vector product is 1024
-// multiply-adds, about the cost of a tenth of a gradient-solve).  The helpers take D as an argument and are always inlined, so
-// a constant D propagates.
+// The dimension of a chain is a compile-time constant here, up to kRegDim: every loop unrolls, every vector lives in
+// registers, one thread runs a chain (the helpers take D as an argument and are always inlined, so the constant propagates).
+// Beyond kRegDim the state machine is a kernel of its own with a half wave per chain (nuts_kernel.hip, nuts_advance_lanes).
 constexpr int kRegDim = 8;
 
 // y = M v for a row-major D x D matrix
@@ -85,9 +83,7 @@ __device__ __forceinline__ bool is_turning(const double *imm, const double *rl, 
 }
 
 // mm_sqrt = chol(inv(imm)) for a symmetric positive definite D x D (Gauss-Jordan + Cholesky).  `a` and `inv`: D x D of
-// workspace each (local arrays below kRegDim; beyond, the chain's idle Welford accumulator and `out` itself -- the Cholesky
-// factor overwrites the lower triangle of the inverse in place, reading the symmetric partner from the upper one, and the
-// upper triangle is cleared at the end: the same operations in the same order either way).
+// workspace each.  (nuts_kernel.hip's mass_sqrt_lanes does the same operations in the same order, spread over lanes.)
 __device__ inline void mass_sqrt_into(const double *imm, double *out, double *a, double *inv, const int D) {
     for (int i = 0; i < D * D; ++i) a[i] = imm[i];
     for (int i = 0; i < D; ++i)
@@ -124,14 +120,13 @@ struct Handed {
     double dll[DMAX];
 };
 
-// One sampler iteration of chain c (everything between two potential evaluations).  RT: the dimension is st.dim (<= DMAX)
-// instead of DMAX itself (see kRegDim above).
+// One sampler iteration of chain c (everything between two potential evaluations), in DMAX dimensions.
 // INLINE_MAP: this thread also does the map of the position it hands out (dyn_nuts_advance_mapped; the fused launch's tail).
 // Without it the caller does -- nuts_kernel.hip spreads that over the lanes of a chain (dynlat::map_chain_lanes) -- and takes
 // the position from `ze_out`.  Returns whether a position was handed out (false: no such chain, or a finished one).
-template <int DMAX, bool RT, bool INLINE_MAP = true, typename ST, typename MAP>
+template <int DMAX, bool INLINE_MAP = true, typename ST, typename MAP>
 __device__ __forceinline__ bool advance_chain(const ST &st, const MAP &map, const int c, const Handed<DMAX> &handed, double *ze_out = nullptr) {
-    const int D = RT ? (int)st.dim : DMAX;
+    constexpr int D = DMAX;
     const int C = st.n_chains, Dm = st.max_depth;
     if (c >= C) return false;
     const int total = st.num_warmup + st.num_samples;
@@ -290,7 +285,7 @@ __device__ __forceinline__ bool advance_chain(const ST &st, const MAP &map, cons
             L_da_t = t1; L_da_gbar = gbar; L_da_xbar = xbar;
             eps = exp(x);
             L_eps_avg = exp(xbar);
-            if constexpr (!RT) if (st.pooled && L_pend > 0) {   // (pooled windows: up to kRegDim dimensions, dyn_nuts_advance checks)
+            if (st.pooled && L_pend > 0) {
                 // pooled window statistics of every chain that has closed this window so far
                 // (pool_ro = the pool as it stood after the previous launch: no concurrent writers)
                 const int64_t *pw = st.pool_ro + (int64_t)(L_pend - 1) * (1 + D + D * D);
@@ -344,8 +339,7 @@ __device__ __forceinline__ bool advance_chain(const ST &st, const MAP &map, cons
                             for (int j = 0; j < D; ++j)
                                 imm[i * D + j] = (nn / (nn + 5.0)) * m2[i * D + j] / (nn - 1.0) +
                                                  (i == j ? 1e-3 * (5.0 / (nn + 5.0)) : 0.0);
-                        if constexpr (RT) mass_sqrt_into(imm, mms, m2, mms, D);   // (m2 is cleared below; the inverse is built in mms itself)
-                        else mass_sqrt<DMAX>(imm, mms, D);
+                        mass_sqrt<DMAX>(imm, mms, D);
                         eps = L_eps_avg; // restart dual averaging around the running average
                         L_da_mu = log(10.0 * eps);
                         L_da_t = 0.0; L_da_gbar = 0.0; L_da_xbar = 0.0;
@@ -437,10 +431,10 @@ __device__ __forceinline__ bool advance_chain(const ST &st, const MAP &map, cons
     // top of this call were consumed above, so their buffers can take the next position's values now)
     if constexpr (INLINE_MAP) if (map.enabled) {
         if (map.f64)
-            dynlat::map_chain<double, (RT ? DYN_MAX_SITES : DMAX)>(map.tab, st.n_chains, c, ze, map.x, map.lp, map.dlp_dz, map.P, map.coef, map.expo,
+            dynlat::map_chain<double, DMAX>(map.tab, st.n_chains, c, ze, map.x, map.lp, map.dlp_dz, map.P, map.coef, map.expo,
                                       (double *)map.params, (double *)map.seeds, map.split);
         else
-            dynlat::map_chain<float, (RT ? DYN_MAX_SITES : DMAX)>(map.tab, st.n_chains, c, ze, map.x, map.lp, map.dlp_dz, map.P, map.coef, map.expo,
+            dynlat::map_chain<float, DMAX>(map.tab, st.n_chains, c, ze, map.x, map.lp, map.dlp_dz, map.P, map.coef, map.expo,
                                      (float *)map.params, (float *)map.seeds, map.split);
     }
     st.rng_ctr[c] = (int64_t)rng.ctr;
@@ -497,7 +491,7 @@ __device__ __forceinline__ void tail_chain(const TL &tl, const int c, const doub
     // directions split: [C rows][1], row r of a chain carries direction r (rows beyond D are padding); else [C][D]
     const int64_t first = (int64_t)c * (tl.map.split ? tl.rows_per_chain : D);
     for (int i = 0; i < D; ++i) handed.dll[i] = load_written(dll_out + first + i);
-    advance_chain<D, false>(tl.st, tl.map, c, handed);
+    advance_chain<D>(tl.st, tl.map, c, handed);
 }
 
 constexpr int kFusedMaxDim = kRegDim;   // every compile-time-dimension instance of the state machine ...

@@ -61,7 +61,7 @@ __global__ void __launch_bounds__(64) nuts_advance(const dyn_nuts_state st, cons
             const int64_t first = (int64_t)c * (st.pot_dll_stride > 0 ? st.pot_dll_stride : D);
             for (int i = 0; i < D; ++i) handed.dll[i] = st.pot_dll[first + i];
         }
-        go = advance_chain<D, false, NS == 1>(st, map, c, handed, ze);
+        go = advance_chain<D, NS == 1>(st, map, c, handed, ze);
     }
     if constexpr (NS > 1)
         if (map.enabled) map_lanes<NS>(map, go, ze, D, c, sub);     // (wave-uniform)
@@ -71,9 +71,9 @@ __global__ void __launch_bounds__(64) nuts_advance(const dyn_nuts_state st, cons
 // per-chain vector in a register (loaded and stored coalesced) and row l of the matrices; every lane of the group runs the
 // chain's scalar state machine redundantly on identical values (sums over the dimension are butterfly reductions, which leave
 // the same bits in every lane), so control flow is uniform within a group and the dozens of short run-time loops of
-// `advance_chain<DMAX, RT = true>` -- each a chain of scratch / L2 round trips in one thread -- become single instructions.
+// a one-thread form with a run-time dimension -- each a chain of scratch / L2 round trips -- become single instructions.
 // A matrix-vector product is D fused multiply-adds per lane, the vector going round by lane shuffles.  The same transitions
-// as the one-thread form up to the order of those sums (per-chain adaptation only; pooled windows are refused above).
+// as `advance_chain` makes up to the order of those sums (per-chain adaptation only; pooled windows are refused below).
 constexpr int kGroup = DYN_NUTS_MAX_DIM;
 static_assert(kGroup == 32, "one half wave per chain");
 

@@ -794,8 +794,8 @@ class KernelNUTS(LockstepNUTS):
     thread per chain: leapfrog halves, tree, adaptation incl. the mass-matrix Cholesky, recording,
     counter-based Philox randomness), captured together in one HIP graph.  The host replays the
     graph and looks at the per-chain transition counters every `block` iterations.  Needs the HIP
-    library and device tensors (no CPU form); dimension <= 32 (one compiled instance per dimension up to 8, a run-time-dimension
-    instance beyond), tree depth <= 10.
+    library and device tensors (no CPU form); dimension <= 32 (one compiled instance per dimension up to 8, one thread per chain; a half wave
+    per chain beyond), tree depth <= 10.
 
     ``adaptation="per_chain"`` is numpyro's behaviour: every chain estimates its own dense mass
     matrix from its own window.  ``"pooled"`` merges the window statistics of all chains of this

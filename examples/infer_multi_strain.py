@@ -8,7 +8,7 @@ daily incidence by age and strain (increments of the cumulative-infection compar
 ``get_config(sites=6)``: r0 and infectious period of the three strains (6 sampled dimensions: the sampler kernel's
 per-dimension instances, folded potential: the gradient-solve, eight lane groups per trajectory, and the sampler kernel -- two
 launches per iteration; `dyn_solver_opts::nuts_tail` would make it one at four lane groups, which measured slower).  ``sites=9`` adds the three latent periods: beyond
-eight dimensions the sampler kernel's run-time-dimension instance (``dyn_nuts_advance_mapped``, include/dynode_hip.h) behind the
+eight dimensions the sampler kernel's half-wave-per-chain form (``dyn_nuts_advance_mapped``, include/dynode_hip.h) behind the
 same folded potential (up to sixteen sites).  The initial infections are split evenly over the strains here (the reference splits them in proportion
 to r0, :153-167, which would make the initial state a function of the sampled values).
 """

@@ -359,9 +359,10 @@ int32_t dyn_lean_twin(const dyn_model_desc *m, const dyn_solver_opts *o, int32_t
  * every call costs every unfinished chain exactly one gradient.  All arrays are device arrays,
  * row-major with the chain index first; real = float64.
  */
-#define DYN_NUTS_MAX_DIM 32 /* up to 8: one compiled instance per dimension, a chain's vectors in registers; 9..32: one instance with
-                               the dimension a run-time number (plain u_new / g_new potential, per-chain adaptation: pooled windows
-                               and the mapped / fused forms stop at 8 -- DYN_ERR_UNSUPPORTED beyond) */
+#define DYN_NUTS_MAX_DIM 32 /* up to 8: one compiled instance per dimension, one thread per chain, its vectors in registers; 9..32: a half
+                               wave per chain, element l of every vector in lane l (plain u_new / g_new potential or, up to
+                               DYN_MAX_SITES, a folded potential's parts; per-chain adaptation: pooled windows and the fused form
+                               stop at 8 -- DYN_ERR_UNSUPPORTED beyond) */
 #define DYN_NUTS_MAX_DEPTH 10
 #define DYN_NUTS_MAX_WINDOWS 16
 typedef struct dyn_nuts_state {
@@ -463,7 +464,7 @@ int dyn_potential_combine(int64_t C, int32_t n, const double *lp, const double *
 /* dyn_nuts_advance that also does, for the position it hands out (z_eval), what dyn_latent_param_map (below) would do in a
  * launch of its own: constrained values, log prior and its derivative, the parameter rows and tangent seeds of the solve that
  * follows.  With st->pot_* set, a sampler iteration of the folded potential is TWO launches: dyn_solve_batch_loglik and this.
- * n_sites must equal st->dim (up to DYN_MAX_SITES: beyond 8 the run-time-dimension instance of the state machine, per-chain
+ * n_sites must equal st->dim (up to DYN_MAX_SITES: beyond 8 the half-wave-per-chain form of the state machine, per-chain
  * adaptation only); the buffers are those of dyn_latent_param_map (lp = st->pot_lp, dlp_dz = st->pot_dlp of the next call). */
 int dyn_nuts_advance_mapped(const dyn_nuts_state *st, const dyn_site_desc *sites, int32_t n_sites, int32_t P, const double *coef,
                             const double *expo, int32_t dtype, int32_t split_directions, double *x, double *lp, double *dlp_dz,

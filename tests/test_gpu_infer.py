@@ -1211,7 +1211,7 @@ def _ks_at_effective_sizes(a_groups, b_groups):
 def test_kernel_sampler_on_the_multi_strain_model_agrees_with_the_gradient_free_sampler(sites):
     """the reference's 2-age x 3-strain model (examples/seirs_multi_strain_age_stratified.py:46-49,187-209)
     with priors on every strain's r0 and infectious period (6 sampled dimensions) and, second case, latent period (9: beyond the
-    eight per-dimension instances, the run-time-dimension instance of the state machine behind `dyn_nuts_advance_mapped`).  The sampler kernel must be what runs --
+    eight per-dimension instances, the half-wave-per-chain kernel behind `dyn_nuts_advance_mapped`).  The sampler kernel must be what runs --
     no torch-op downgrade -- and its posterior must agree, site by site, with the gradient-free ensemble sampler's
     (infer/ensemble.py: stretch moves, no tangents, no mass matrix): two-sample KS at the draws' effective sizes, family-wise level 1 %."""
     from dynode_amd import _abi
@@ -1227,7 +1227,7 @@ def test_kernel_sampler_on_the_multi_strain_model_agrees_with_the_gradient_free_
     # folded potential (up to DYN_MAX_SITES = 16 sites), one tangent direction per trajectory row, chains padded to eight /
     # sixteen rows, eight lane groups per trajectory (the library's choice for a scored gradient-solve this small): a chain's
     # rows span several waves, so the gradient-solve and dyn_nuts_advance_mapped stay two launches (six sites: measured
-    # faster than fusing at four groups; nine: the run-time-dimension instance of the state machine, which the fused launch
+    # faster than fusing at four groups; nine: the half-wave-per-chain form of the state machine, which the fused launch
     # does not carry)
     assert mcmc.launches_per_iteration == 2 and mcmc.potential.site_table is not None
     assert _abi.lib().dyn_last_kernel_name().decode().startswith("dyn::solve_kernel<float, 0, 2, 3, true, true, true, 1, 1, 3")
@@ -1300,7 +1300,7 @@ def test_vector_valued_sites_sample_the_same_posterior_as_scalar_ones():
 
 
 def test_sampler_kernel_beyond_eight_dimensions_on_a_correlated_gaussian():
-    """The run-time-dimension instance of dyn_nuts_advance (9 .. 32 dimensions; csrc/nuts_device.hpp `advance_chain<DMAX, RT>`)
+    """The half-wave-per-chain form of dyn_nuts_advance (9 .. 32 dimensions; csrc/nuts_kernel.hip `nuts_advance_lanes`)
     on an analytic 12-dimensional target, and the 8-dimensional compiled instance beside it on the leading 8 x 8 block: moments,
     per-coordinate KS tests, adapted mass matrices, reproducibility; pooled windows are refused beyond eight dimensions."""
     from dynode_amd.infer.nuts import KernelNUTS
@@ -1335,7 +1335,7 @@ def test_sampler_kernel_beyond_eight_dimensions_on_a_correlated_gaussian():
 
 
 def test_dimensions_beyond_the_sampler_kernel_fall_back_loudly_and_twenty_run_on_it():
-    """A model without an ODE and many latent sites (plain torch code): 20 sites run the sampler kernel's run-time-dimension
+    """A model without an ODE and many latent sites (plain torch code): 20 sites run the sampler kernel's half-wave-per-chain
     instance; 34 are beyond its 32 and `MCMCProcess` says so (RuntimeWarning) before running the torch-op sampler -- never a
     silent change of performance class.  Both posteriors are the conjugate normal ones."""
     import warnings
