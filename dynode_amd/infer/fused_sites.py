@@ -2,7 +2,7 @@
 
 `Potential.log_joint` evaluates, for every chain, the bijection of each scalar latent site, its
 log prior and the log-Jacobian -- op by op that is ~50 tiny launches per site and gradient.  When
-every latent site is a scalar with constant parameters from the supported families (the
+every latent site has constant parameters from the supported families (the
 reference's priors, examples/sir_infer_parameters.py:47-58: affine-transformed Beta, truncated
 normal; plus Normal and Uniform), the whole block is one launch with analytic derivatives.  Sites
 outside that set keep the generic torch path (`distributions.py`), which stays the definition
@@ -21,16 +21,28 @@ from .. import _abi
 from . import distributions as D
 
 
-def _scalar(t) -> Optional[float]:
+def _scalar(t, shape=(), elem=None) -> Optional[float]:
+    """A distribution parameter as a python float: the parameter itself for a scalar site, element `elem` (row-major) of it
+    broadcast to the site's batch shape for a tensor-valued one.  None if it is not a constant."""
     if isinstance(t, torch.Tensor):
-        if t.numel() != 1 or t.requires_grad:
+        if t.requires_grad:
             return None
-        return float(t)
+        if elem is not None:
+            try:
+                return float(torch.broadcast_to(t, shape).reshape(-1)[elem])
+            except RuntimeError:
+                return None
+        return float(t) if t.numel() == 1 else None
     return float(t)
 
 
-def describe(dist) -> Optional[_abi.SiteDescC]:
-    """``dyn_site_desc`` of a distribution object, or None if it is outside the fused families."""
+def describe(dist, elem=None) -> Optional[_abi.SiteDescC]:
+    """``dyn_site_desc`` of a distribution object -- of element `elem` of a distribution with a batch shape (element-wise
+    independent: each element is a scalar site of its own) --, or None if it is outside the fused families."""
+    shape = tuple(dist.batch_shape)
+    if (elem is None) != (shape == ()):
+        return None
+    sc = lambda t: _scalar(t, shape, elem)  # noqa: E731
     aff_loc, aff_scale = 0.0, 1.0
     base = dist
     if isinstance(dist, D.TransformedDistribution):
@@ -38,24 +50,32 @@ def describe(dist) -> Optional[_abi.SiteDescC]:
         for t in dist.transforms:
             if not isinstance(t, D.AffineTransform):
                 return None
-            aff_loc, aff_scale = t.loc + t.scale * aff_loc, t.scale * aff_scale
+            loc, scale = sc(t.loc), sc(t.scale)
+            if loc is None or scale is None:
+                return None
+            aff_loc, aff_scale = loc + scale * aff_loc, scale * aff_scale
     d = _abi.SiteDescC()
     d.aff_loc, d.aff_scale = aff_loc, aff_scale
-    d.lo, d.hi = (float(v) for v in dist.support)
+    d.lo, d.hi = (float(v) for v in dist.support)        # (the bijection's interval: one per site, as distributions.biject_to has it)
     d.base_lo, d.base_hi = -math.inf, math.inf
     if type(base) is D.Normal:
-        vals = (_scalar(base.loc), _scalar(base.scale))
+        vals = (sc(base.loc), sc(base.scale))
         d.dist = _abi.DIST_NORMAL
     elif type(base) is D.Uniform:
-        vals = (_scalar(base.low), _scalar(base.high))
+        vals = (sc(base.low), sc(base.high))
+        if elem is not None and (float(base.low.min()) != float(base.low.max()) or float(base.high.min()) != float(base.high.max())):
+            return None     # (element-wise different bounds under the site's one bijection interval: the generic path's business)
         d.dist = _abi.DIST_UNIFORM
     elif type(base) is D.Beta:
-        a, b = _scalar(base.a), _scalar(base.b)
+        a, b = sc(base.a), sc(base.b)
         vals = (a, b, None if a is None or b is None else math.lgamma(a) + math.lgamma(b) - math.lgamma(a + b))
         d.dist = _abi.DIST_BETA
     elif type(base) is D.TruncatedNormal:
-        vals = (_scalar(base.loc), _scalar(base.scale), _scalar(base._logz))
-        d.base_lo, d.base_hi = float(base.low), float(base.high)
+        vals = (sc(base.loc), sc(base.scale), sc(base._logz))
+        lo, hi = sc(base.low), sc(base.high)
+        if lo is None or hi is None:
+            return None
+        d.base_lo, d.base_hi = lo, hi
         d.dist = _abi.DIST_TRUNCNORMAL
     else:
         return None
@@ -67,8 +87,20 @@ def describe(dist) -> Optional[_abi.SiteDescC]:
 
 
 def build_table(dists) -> Optional[tuple]:
-    """(ctypes array of descriptors, n) for the latent sites, or None if any site is not fusable."""
-    descs = [describe(d) for d in dists]
+    """(ctypes array of descriptors, n) for the latent sites -- one descriptor per unconstrained coordinate, a tensor-valued
+    site contributing one per element in row-major order --, or None if any site is not fusable."""
+    descs = []
+    for dist in dists:
+        shape = tuple(dist.batch_shape)
+        if shape == ():
+            descs.append(describe(dist))
+        else:
+            k = 1
+            for v in shape:
+                k *= int(v)
+            if k > _abi.MAX_SITES:
+                return None
+            descs.extend(describe(dist, i) for i in range(k))
     if not descs or len(descs) > _abi.MAX_SITES or any(d is None for d in descs):
         return None
     return (_abi.SiteDescC * len(descs))(*descs), len(descs)

@@ -68,11 +68,12 @@ class Potential:
         self.bij = OrderedDict((n, biject_to(d.support)) for n, d in self.latent.items())
         self.dim = offset
         self.scalar_sites = all(shape == () for shape in self.shapes.values())
-        # bijections + log priors + log-Jacobians of all latent sites as one kernel launch, when every
-        # site is a scalar in the fused families (fused_sites.py); otherwise the generic torch path below
+        # bijections + log priors + log-Jacobians of all latent sites as one kernel launch, when every site is in the fused
+        # families (fused_sites.py: one descriptor per unconstrained coordinate, a tensor-valued site one per element);
+        # otherwise the generic torch path below
         self.site_table = None
         self._ones: dict = {}
-        if torch.device(device).type == "cuda" and self.scalar_sites:
+        if torch.device(device).type == "cuda":
             from . import fused_sites
 
             self.site_table = fused_sites.build_table(self.latent.values())
@@ -103,7 +104,7 @@ class Potential:
             from .fused_sites import LatentSites
 
             x_all, total = LatentSites.apply(z, self.site_table)
-            x = OrderedDict(zip(self.bij, x_all.unbind(-1)))
+            x = OrderedDict((n, self._coords(x_all, n)) for n in self.bij)
             with handlers.substitute(x), handlers.trace() as tr:
                 self.model(**self.kwargs)
         else:

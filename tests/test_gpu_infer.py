@@ -464,7 +464,29 @@ def test_fused_latent_sites_match_the_torch_definitions():
         assert torch.allclose(x_f, x_t, rtol=1e-13, atol=1e-13)
         assert torch.allclose(lp_f, lp_t, rtol=1e-12, atol=1e-11)
         assert torch.allclose(g_f, g_t, rtol=1e-10, atol=1e-10)
-    # outside the fused families: tensor-valued parameters, other distributions, too many sites
+    # a tensor-valued site (a distribution with a batch shape): one descriptor per element, in row-major order, the parameters
+    # of that element; against the torch definitions through a Potential with and without the table
+    vec = [dist.Normal(torch.tensor([0.25, -1.0, 2.0]), 1.7), T(dist.Beta(torch.full((2, 2), 2.0), torch.tensor([2.0, 3.5])), A(1.2, 2.0)),
+           dist.TruncatedNormal(loc=torch.tensor([7.0, 5.0]), scale=2.0, low=3.0, high=12.0), dist.Uniform(-2.0, 5.0)]
+    table = fused_sites.build_table(vec)
+    assert table is not None and table[1] == 3 + 4 + 2 + 1
+    assert [table[0][i].p[0] for i in range(3)] == [0.25, -1.0, 2.0] and [table[0][3 + i].p[1] for i in range(4)] == [2.0, 3.5, 2.0, 3.5]
+
+    def model():
+        for i, d in enumerate(vec):
+            handlers.sample(f"s{i}", d)
+
+    pot = Potential(model, {}, seed=0, device=dev)
+    assert pot.dim == 10 and pot.site_table is not None and pot.shapes == {"s0": (3,), "s1": (2, 2), "s2": (2,), "s3": ()}
+    z = ((torch.rand((65, 10), generator=gen, dtype=torch.float64) - 0.5) * 10.0).to(dev)
+    u_f, g_f = pot.potential_and_grad(z)
+    x_f = pot.log_joint(z)[1].sites["s1"]["value"]
+    pot.site_table = None
+    u_t, g_t = pot.potential_and_grad(z)
+    assert tuple(x_f.shape) == (65, 2, 2) and torch.allclose(x_f, pot.log_joint(z)[1].sites["s1"]["value"], rtol=1e-13, atol=1e-13)
+    assert torch.allclose(u_f, u_t, rtol=1e-12, atol=1e-11) and torch.allclose(g_f, g_t, rtol=1e-10, atol=1e-10)
+    assert fused_sites.build_table([dist.Uniform(torch.tensor([0.0, 1.0]), 5.0)]) is None      # (element-wise bounds: one bijection interval per site)
+    # outside the fused families: a batch shape asked for as ONE descriptor, other distributions, too many sites
     assert fused_sites.describe(dist.Normal(torch.zeros(2), 1.0)) is None
     assert fused_sites.describe(dist.Poisson(torch.ones(3))) is None
     assert fused_sites.build_table([dist.Normal(0.0, 1.0)] * 9) is not None and fused_sites.build_table([dist.Normal(0.0, 1.0)] * 17) is None
@@ -1255,8 +1277,8 @@ def test_kernel_sampler_on_the_multi_strain_model_agrees_with_the_gradient_free_
 def test_vector_valued_sites_sample_the_same_posterior_as_scalar_ones():
     """The 2-age x 3-strain model with ONE site per parameter kind -- ``r0 ~ shape (3,)``, ``infectious_period ~ shape (3,)``,
     the way a numpyro model would declare per-strain priors as a distribution with a batch shape -- against the six scalar
-    sites of examples/infer_multi_strain.py (same priors, same data): six unconstrained coordinates either way, the sampler
-    kernel on the general autograd potential, per-element two-sample KS (family-wise level 1 %) and means within three standard errors."""
+    sites of examples/infer_multi_strain.py (same priors, same data): six unconstrained coordinates either way, the same folded
+    potential behind the sampler kernel, per-element two-sample KS (family-wise level 1 %) and means within three standard errors."""
     from dynode_amd import PoissonObservation, simulate
     from dynode_amd.infer import distributions as dist
     from dynode_amd.rhs import SEIRS_MultiStrain_ODEParams, seirs_multi_strain_ode
@@ -1283,6 +1305,8 @@ def test_vector_valued_sites_sample_the_same_posterior_as_scalar_ones():
     vec = MCMCProcess(numpyro_model=model, num_warmup=draws, num_samples=draws, num_chains=chains, nuts_max_tree_depth=8, progress_bar=False)
     mcmc = vec.infer(tf=120, obs_data=obs, t_lat=t_lat)
     assert mcmc.sampler == "KernelNUTS" and mcmc.potential.dim == 6 and mcmc.potential.shapes == {"r0": (3,), "infectious_period": (3,)}
+    # one descriptor per element (infer/fused_sites.py), so the potential folds as the scalar-site model's does
+    assert vec._folded_potential and mcmc.launches_per_iteration == 2 and mcmc.potential.site_table[1] == 6
     post = vec.get_samples(group_by_chain=True)
     assert tuple(post["r0"].shape) == (chains, draws, 3) and tuple(vec.get_samples()["r0"].shape) == (chains * draws, 3)
     assert set(mcmc.summary()) == {f"{n}[{k}]" for n in ("r0", "infectious_period") for k in range(3)}
