@@ -1,7 +1,9 @@
 """dev probe: every launch of the sampler kernel of a run repeated, from the same state, by ANOTHER build of the library
 (`--lib`): the two results must agree to rounding in every field, launch by launch, through warm-up windows and their
 Cholesky factors, transition ends and recorded draws (a run-against-run comparison drifts apart chaotically after a few
-hundred launches; this one does not).    python tools/probes/probe_sampler_step_ab.py --lib tools/probes/_lib_OLD.so [dim]"""
+hundred launches; this one does not).  `--wall`: the potential is +inf (and its gradient NaN) beyond |z_i| = 2.5, the
+non-finite branch of the state machine; `--chains N`, `--depth N`.
+    python tools/probes/probe_sampler_step_ab.py --lib tools/probes/_lib_OLD.so [--wall] [--chains 7] [--depth 10] [dim]"""
 import ctypes, os, sys
 import numpy as np, torch
 
@@ -30,9 +32,19 @@ cov = (A @ A.T / D + torch.diag(torch.linspace(0.2, 2.0, D, dtype=torch.float64)
 prec = torch.linalg.inv(cov)
 
 
+WALL = "--wall" in sys.argv
+CHAINS = int(sys.argv[sys.argv.index("--chains") + 1]) if "--chains" in sys.argv else 8
+DEPTH = int(sys.argv[sys.argv.index("--depth") + 1]) if "--depth" in sys.argv else 6
+
+
 def pg(z):
     gr = z @ prec
-    return 0.5 * (z * gr).sum(-1), gr
+    u = 0.5 * (z * gr).sum(-1)
+    if WALL:
+        out = (z.abs() > 2.5).any(-1)
+        u = torch.where(out, torch.full_like(u, float("inf")), u)
+        gr = torch.where(out[:, None], torch.full_like(gr, float("nan")), gr)
+    return u, gr
 
 
 state = {"prev": None, "k": 0, "worst": 0.0, "bad": 0, "events": {"window_end": 0, "transition_end": 0, "draw": 0}}
@@ -81,6 +93,6 @@ def init(self, *a, **kw):
 
 
 N.KernelNUTS.__init__ = init
-z0 = torch.randn(8, D, generator=g, dtype=torch.float64).to(dev)
-res = N.KernelNUTS(pg, max_tree_depth=6, seed=2).run(z0, num_warmup=220, num_samples=12)
-print(f"dim {D}: {state['k']} launches, worst relative difference {state['worst']:.3e}, fields beyond 1e-9: {state['bad']}, events {state['events']}")
+z0 = (0.3 * torch.randn(CHAINS, D, generator=g, dtype=torch.float64)).to(dev)
+res = N.KernelNUTS(pg, max_tree_depth=DEPTH, seed=2).run(z0, num_warmup=220, num_samples=12)
+print(f"dim {D}, {CHAINS} chains, depth {DEPTH}, wall {WALL}, divergent draws {int(res.diverging.sum())}: {state['k']} launches, worst relative difference {state['worst']:.3e}, fields beyond 1e-9: {state['bad']}, events {state['events']}")
