@@ -1356,6 +1356,24 @@ def test_sampler_kernel_beyond_eight_dimensions_on_a_correlated_gaussian():
         assert torch.equal(again.samples, res.samples)
     with pytest.raises(ValueError, match="pooled"):
         KernelNUTS(pg, max_tree_depth=8, seed=2, adaptation="pooled").run(torch.zeros(4, 12, dtype=torch.float64, device=dev), 50, 50)
+    # the kernel's largest dimension, an odd number of chains (the last half wave of the launch has no chain), the deepest tree,
+    # and a potential that is +inf with a NaN gradient beyond a wall: every lane of a chain's group owns an element, the
+    # non-finite branch is taken, divergences are recorded, nothing non-finite is ever stored as a draw
+    prec32 = torch.diag(torch.linspace(0.5, 4.0, 32, dtype=torch.float64)).to(dev)
+
+    def walled(z):
+        gr = z @ prec32
+        out = (z.abs() > 3.0).any(-1)
+        return (torch.where(out, torch.full_like(gr[:, 0], float("inf")), 0.5 * (z * gr).sum(-1)),
+                torch.where(out[:, None], torch.full_like(gr, float("nan")), gr))
+
+    z0 = (0.2 * torch.randn(7, 32, generator=g, dtype=torch.float64)).to(dev)
+    res = KernelNUTS(walled, max_tree_depth=10, seed=3).run(z0, num_warmup=150, num_samples=100)
+    assert res.samples.shape == (7, 100, 32) and bool(torch.isfinite(res.samples).all()) and float(res.samples.abs().max()) <= 3.0
+    assert 0.5 < float(res.accept_prob.mean()) < 0.99 and bool(torch.isfinite(res.inverse_mass).all())
+    sd = res.samples.reshape(-1, 32).std(0) * torch.sqrt(torch.diagonal(prec32))
+    assert float((sd - 1.0).abs().max()) < 0.3, sd            # (unit variance in every coordinate, 700 correlated draws)
+    assert torch.equal(KernelNUTS(walled, max_tree_depth=10, seed=3).run(z0, num_warmup=150, num_samples=100).samples, res.samples)
 
 
 def test_dimensions_beyond_the_sampler_kernel_fall_back_loudly_and_twenty_run_on_it():
