@@ -14,6 +14,8 @@ variance -- both are anti-conservative.  What this module provides instead:
                       chains do not dominate it: hence the CORE second moment (within 3 sd of the mean) next to the variance.
 `pool_runs`           several runs (sampler seeds) pooled: sd ratio with its across-chain standard error, Fisher's
                       combination and a uniformity test of the runs' KS p-values.
+`ks_two_sample_effective`  two samplers' draws of one site against each other (no quadrature: any dimension): the KS statistic
+                      of all draws, its p-value at the samples' effective sizes, taken from replicate groups.
 `stationarity`        the exactly calibrated test of a transition kernel: C chains start at independent exact posterior
                       draws, nothing adapts, T transitions; if the kernel leaves the posterior invariant the C states
                       after any number of transitions are i.i.d. posterior draws, so KS p-values are uniform without any
@@ -282,3 +284,24 @@ def stationarity(post: GridPosterior, sampler, step_size, inverse_mass, chains: 
         out["after"][str(t)] = compare(z[:, t - 1])
     out["last"] = out["after"][str(at[-1])]
     return out
+
+
+def ks_two_sample_effective(a_groups: Sequence[np.ndarray], b_groups: Sequence[np.ndarray]) -> tuple:
+    """Two-sample Kolmogorov-Smirnov on correlated draws: the statistic from all draws, its p-value at the samples' EFFECTIVE
+    sizes.  `*_groups`: arrays whose means are replicate estimates of the same mean -- a sampler's independent chains; the
+    time blocks of an ensemble of coupled walkers --: n_eff = groups x pooled variance / variance of the group means, at most
+    the number of draws.  Thinned draws counted as independent make the p-value anti-conservative by the factor they are
+    not (the stretch-move ensemble in nine dimensions: about 5), and then a correct sampler fails by realization.  Returns
+    (statistic, p, n_eff_a, n_eff_b); the asymptotic Kolmogorov distribution, so a few hundred effective draws at least."""
+    from scipy import stats
+    from scipy.special import kolmogorov
+
+    def n_eff(groups):
+        pooled = np.concatenate([np.asarray(g, dtype=np.float64).ravel() for g in groups])
+        means = np.array([np.mean(g) for g in groups])
+        return float(min(pooled.size, len(groups) * pooled.var() / max(means.var(ddof=1), 1e-300))), pooled
+
+    na, a = n_eff(a_groups)
+    nb, b = n_eff(b_groups)
+    d = float(stats.ks_2samp(a, b).statistic)
+    return d, float(kolmogorov(np.sqrt(na * nb / (na + nb)) * d)), na, nb

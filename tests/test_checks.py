@@ -83,3 +83,36 @@ def test_stationarity_check_passes_an_exact_kernel_and_catches_a_wrong_one():
     wide = checks.GridPosterior([z0g, z1g], g.p ** (1 / 1.44), g._constrain, g.names)        # the same shape, sd x 1.2
     bad = checks.stationarity(wide, BatchedNUTS(pg, max_tree_depth=6, seed=5), eps, imm, 4000, 20, rng, at=(20,), device="cpu")
     assert bad["last"]["b"]["ks_p"] < 1e-4 and bad["last"]["b"]["var_z"] < -6
+
+
+def test_two_sample_ks_at_effective_sizes_is_calibrated_on_correlated_chains():
+    """AR(1) chains with a N(0, 1) marginal against other such chains (the same distribution): counted as independent their
+    draws reject far too often; read at the effective sizes the rejection rate is the nominal one.  Independent draws: the
+    effective sizes are the sample sizes and the p-values those of the plain test."""
+    rng = np.random.default_rng(11)
+
+    def ar1(chains, n, rho):
+        x = np.empty((chains, n))
+        x[:, 0] = rng.standard_normal(chains)
+        e = rng.standard_normal((chains, n)) * np.sqrt(1.0 - rho * rho)
+        for t in range(1, n):
+            x[:, t] = rho * x[:, t - 1] + e[:, t]
+        return x
+
+    naive, eff, n_effs = [], [], []
+    for _ in range(150):
+        a, b = ar1(32, 200, 0.9), ar1(24, 300, 0.8)
+        naive.append(stats.ks_2samp(a.ravel(), b.ravel()).pvalue)
+        d, p, na, nb = checks.ks_two_sample_effective(list(a), list(b))
+        eff.append(p)
+        n_effs.append((na, nb))
+    naive, eff, n_effs = np.array(naive), np.array(eff), np.array(n_effs)
+    assert (naive < 0.01).mean() > 0.25                                   # (the plain test: a quarter of correct pairs and more fail at 1 %)
+    assert (eff < 0.01).mean() <= 0.04 and (eff < 0.1).mean() <= 0.2      # (nominal 1 % / 10 %; 150 repetitions)
+    # effective sizes: N (1 - rho) / (1 + rho) = 337 / 800, estimated from 32 / 24 replicates
+    assert 250 < np.median(n_effs[:, 0]) < 450 and 600 < np.median(n_effs[:, 1]) < 1050
+    a, b = rng.standard_normal((40, 50)), rng.standard_normal((40, 50))
+    d, p, na, nb = checks.ks_two_sample_effective(list(a), list(b))
+    assert na > 1000 and nb > 1000 and abs(p - stats.ks_2samp(a.ravel(), b.ravel(), method="asymp").pvalue) < 0.1
+    d, p, _, _ = checks.ks_two_sample_effective(list(a), list(b + 0.25))   # a quarter of a standard deviation apart: rejected
+    assert p < 1e-3

@@ -1210,25 +1210,6 @@ def test_default_nuts_fits_the_seip_model_with_adaptive_steps():
     assert chi.std() < 0.05 and r0.std() < 0.02 and float(mcmc.nuts.accept_prob.mean()) > 0.6
 
 
-def _ks_at_effective_sizes(a_groups, b_groups):
-    """Two-sample Kolmogorov-Smirnov on correlated draws: the statistic from all draws, its p-value at the samples' EFFECTIVE
-    sizes.  `*_groups`: arrays whose means are replicate estimates of the same mean (a sampler's independent chains; the time
-    blocks of an ensemble of coupled walkers): n_eff = groups x pooled variance / variance of the group means, at most the
-    number of draws.  Thinned draws counted as independent make the p-value anti-conservative by the factor they are not
-    (the stretch-move ensemble in nine dimensions: ~5), and then a correct sampler fails by realization."""
-    from scipy.special import kolmogorov
-
-    def n_eff(groups):
-        pooled = np.concatenate([g.ravel() for g in groups])
-        means = np.array([g.mean() for g in groups])
-        return float(min(pooled.size, len(groups) * pooled.var() / max(means.var(ddof=1), 1e-300))), pooled
-
-    na, a = n_eff(a_groups)
-    nb, b = n_eff(b_groups)
-    d = stats.ks_2samp(a, b).statistic
-    return d, float(kolmogorov(np.sqrt(na * nb / (na + nb)) * d)), na, nb
-
-
 @pytest.mark.parametrize("sites", [6, 9])
 def test_kernel_sampler_on_the_multi_strain_model_agrees_with_the_gradient_free_sampler(sites):
     """the reference's 2-age x 3-strain model (examples/seirs_multi_strain_age_stratified.py:46-49,187-209)
@@ -1237,6 +1218,7 @@ def test_kernel_sampler_on_the_multi_strain_model_agrees_with_the_gradient_free_
     no torch-op downgrade -- and its posterior must agree, site by site, with the gradient-free ensemble sampler's
     (infer/ensemble.py: stretch moves, no tangents, no mass matrix): two-sample KS at the draws' effective sizes, family-wise level 1 %."""
     from dynode_amd import _abi
+    from dynode_amd.infer import checks
     from examples import infer_multi_strain as ex_m
 
     obs = ex_m.synthetic_incidence(120)
@@ -1264,7 +1246,7 @@ def test_kernel_sampler_on_the_multi_strain_model_agrees_with_the_gradient_free_
     for name in post:
         a = post[name].cpu().numpy()                                 # independent chains
         b = post_e[name].cpu().numpy()                               # coupled walkers: replicate estimates = blocks of time
-        d, p, na, nb = _ks_at_effective_sizes(list(a), np.split(b, 10, axis=1))
+        d, p, na, nb = checks.ks_two_sample_effective(list(a), np.split(b, 10, axis=1))
         print(f"[{sites} sites] {name}: NUTS {a.mean():.4f} +- {a.std():.4f} (n_eff {na:.0f}), ensemble {b.mean():.4f} +- {b.std():.4f} "
               f"(n_eff {nb:.0f}), KS {d:.4f}, p {p:.3f}")
         # one test per site: the 1 % level is for the FAMILY (Bonferroni)
