@@ -1,3 +1,5 @@
+"""dev probe: mean per launch of every counter in a `rocprofv3 --pmc ... --output-format csv -d DIR` output directory, solve
+kernels only, over the later half of the launches (the timed ones of a bench.py run).    python tools/probes/pmc_mean.py DIR"""
 import csv, glob, sys, collections
 acc = collections.defaultdict(list)
 for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
