@@ -1358,6 +1358,68 @@ def test_sampler_kernel_beyond_eight_dimensions_on_a_correlated_gaussian():
     assert torch.equal(KernelNUTS(walled, max_tree_depth=10, seed=3).run(z0, num_warmup=150, num_samples=100).samples, res.samples)
 
 
+@pytest.mark.parametrize("D", [3, 8, 12, 32])
+def test_sampler_kernel_launch_by_launch_against_the_numpy_twin(D):
+    """Every launch of `dyn_nuts_advance` of a short run -- warm-up with two mass-matrix windows, their Cholesky factors,
+    transition ends, recorded draws, a potential that is +inf with a NaN gradient beyond a wall -- repeated from the kernel's
+    own state by the NumPy restatement of the state machine (tests/nuts_twin.py: Philox stream included), every field of the
+    state compared: the one-thread-per-chain instances (3, 8 dimensions) and the half-wave-per-chain kernel (12, 32) do
+    what the restatement does, to rounding, launch after launch."""
+    import nuts_twin
+    from dynode_amd.infer import nuts as N
+
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(17 + D)
+    A = torch.randn(D, D, generator=g, dtype=torch.float64)
+    prec = torch.linalg.inv(A @ A.T / D + torch.diag(torch.linspace(0.3, 2.0, D, dtype=torch.float64))).to(dev)
+
+    def pg(z):
+        gr = z @ prec
+        out = (z.abs() > 2.5).any(-1)
+        return (torch.where(out, torch.full_like(gr[:, 0], float("inf")), 0.5 * (z * gr).sum(-1)),
+                torch.where(out[:, None], torch.full_like(gr, float("nan")), gr))
+
+    chains, num_warmup, num_samples, depth = 5, 200, 6, 5
+    sampler = N.KernelNUTS(pg, max_tree_depth=depth, seed=4, use_graph=False, block=1)
+    sampler.unroll = 1
+    K = dict(seed=(4 * 0x9E3779B97F4A7C15 + 0x1234567) & (2 ** 64 - 1), num_warmup=num_warmup, num_samples=num_samples, max_depth=depth,
+             target_accept=sampler.target, max_delta_energy=sampler.max_de, windows=N._adaptation_windows(num_warmup, 75))
+    seen = dict(prev=None, launches=0, worst=0.0, window_ends=0, transitions=0, bad=0)
+
+    def monitor(S):
+        now = {k: v.detach().cpu().numpy().copy() for k, v in S.items()}
+        prev = seen["prev"]
+        if prev is not None:
+            u, gr = pg(torch.as_tensor(prev["z_eval"], device=dev))
+            seen["bad"] += int((~torch.isfinite(u)).sum())
+            nuts_twin.advance(prev, K, u.cpu().numpy(), gr.cpu().numpy())
+            seen["window_ends"] += int((now["wi"] > seen["wi"]).sum())
+            seen["transitions"] += int((now["it"] > seen["it"]).sum())
+            for k in now:
+                if k in ("pool", "pool_ro", "pend", "u_new", "g_new"):
+                    continue
+                x, y = prev[k].astype(np.float64), now[k].astype(np.float64)
+                same = (x == y) | (np.isnan(x) & np.isnan(y))
+                with np.errstate(invalid="ignore"):
+                    d = np.where(same, 0.0, np.abs(x - y) / (1.0 + np.abs(x)))
+                d = np.nan_to_num(d, nan=np.inf)
+                assert d.max() < 1e-9, (D, seen["launches"], k, float(d.max()), np.argwhere(d >= 1e-9)[:4].tolist())
+                seen["worst"] = max(seen["worst"], float(d.max()))
+        seen["prev"], seen["wi"], seen["it"] = now, now["wi"].copy(), now["it"].copy()
+        seen["launches"] += 1
+
+    sampler.monitor = monitor
+    z0 = (0.3 * torch.randn(chains, D, generator=g, dtype=torch.float64)).to(dev)
+    res = sampler.run(z0, num_warmup=num_warmup, num_samples=num_samples)
+    st = sampler._keep[1]
+    assert (st.seed, st.num_warmup, st.num_samples, st.max_depth, st.n_windows) == (K["seed"], num_warmup, num_samples, depth, len(K["windows"]))
+    assert [(st.w_start[i], st.w_end[i]) for i in range(st.n_windows)] == K["windows"] and st.pooled == 0
+    print(f"dim {D}: {seen['launches']} launches, {seen['transitions']} transition ends, {seen['window_ends']} window ends, "
+          f"{seen['bad']} non-finite potentials, worst relative difference {seen['worst']:.2e}")
+    assert seen["launches"] > 800 and seen["window_ends"] == 2 * chains and seen["transitions"] >= chains * (num_warmup + num_samples) - chains
+    assert seen["bad"] > 0 and bool(torch.isfinite(res.samples).all())
+
+
 def test_dimensions_beyond_the_sampler_kernel_fall_back_loudly_and_twenty_run_on_it():
     """A model without an ODE and many latent sites (plain torch code): 20 sites run the sampler kernel's half-wave-per-chain
     instance; 34 are beyond its 32 and `MCMCProcess` says so (RuntimeWarning) before running the torch-op sampler -- never a

@@ -75,3 +75,35 @@ def test_async_needs_far_fewer_gradient_solves_than_lockstep():
     per_chain = float(a.num_steps.double().mean())
     assert a.potential_evals < 0.6 * b.potential_evals
     assert a.potential_evals < 250 * (per_chain + 1) * 2.0          # ~ leapfrogs of the slowest chain, not the sum of maxima
+
+
+def test_the_numpy_twin_of_the_sampler_kernel_has_the_published_philox_stream():
+    """tests/nuts_twin.py (the restatement the GPU suite holds `dyn_nuts_advance` against, launch by launch): its
+    Philox4x32-10 on the known-answer vectors of the Random123 distribution, its uniforms in (0, 1) with 52 random bits,
+    and one fabricated chain through a full short run (a window end and recorded draws included) without leaving the reals."""
+    import math
+
+    import nuts_twin
+
+    assert nuts_twin.philox4x32_10((0, 0, 0, 0), (0, 0)) == (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)
+    assert nuts_twin.philox4x32_10((0xffffffff,) * 4, (0xffffffff,) * 2) == (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)
+    assert nuts_twin.philox4x32_10((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0)) == (
+        0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1)
+    s = nuts_twin.Stream(0x0123456789abcdef, 5, 3)
+    u = [s.uniform() for _ in range(2000)]
+    assert s.ctr == 2005 and 0.0 < min(u) and max(u) < 1.0 and abs(np.mean(u) - 0.5) < 0.02
+    C, D, Dm = 2, 3, 4
+    f = lambda *sh: np.zeros(sh)  # noqa: E731
+    S = dict(z=f(C, D), u=f(C), g=f(C, D), eps=np.full(C, 0.1), eps_avg=np.full(C, 0.1), da_mu=f(C), da_xbar=f(C), da_gbar=f(C), da_t=f(C),
+             imm=np.tile(np.eye(D), (C, 1, 1)), mm_sqrt=np.tile(np.eye(D), (C, 1, 1)), wf_n=f(C), wf_mean=f(C, D), wf_m2=f(C, D, D), e0=f(C),
+             zl=f(C, D), rl=f(C, D), gl=f(C, D), zr=f(C, D), rr=f(C, D), gr=f(C, D), zp=f(C, D), up=f(C), gp=f(C, D), weight=f(C),
+             r_sum=f(C, D), sum_acc=f(C), sgn=np.ones(C), zc=f(C, D), rc=f(C, D), gc=f(C, D), r_half=np.ones((C, D)), s_zp=f(C, D),
+             s_up=f(C), s_gp=f(C, D), s_weight=np.full(C, -math.inf), s_rsum=f(C, D), s_acc=f(C), r_ck=f(C, Dm, D), rs_ck=f(C, Dm, D),
+             z_eval=f(C, D), it=np.zeros(C, int), wi=np.zeros(C, int), n_prop=np.zeros(C, int), depth=np.zeros(C, int),
+             right=np.ones(C, int), leaf=np.zeros(C, int), s_turn=np.zeros(C, int), s_div=np.zeros(C, int), s_n=np.zeros(C, int),
+             rng_ctr=np.zeros(C, np.int64), out_z=f(C, 2, D), out_acc=f(C, 2), out_n=np.zeros((C, 2), int), out_div=np.zeros((C, 2), int))
+    K = dict(seed=123456789012345, num_warmup=3, num_samples=2, max_depth=Dm, target_accept=0.8, max_delta_energy=1000.0, windows=[(1, 3)])
+    for _ in range(400):
+        nuts_twin.advance(S, K, 0.5 * (S["z_eval"] ** 2).sum(-1), S["z_eval"].copy())
+    assert S["it"].tolist() == [5, 5] and S["wi"].tolist() == [1, 1] and all(np.isfinite(v).all() for k, v in S.items() if k != "s_weight")
+    assert np.abs(S["out_z"]).max() > 0 and (S["out_n"] > 0).all() and not np.array_equal(S["imm"][0], np.eye(D))
