@@ -1420,6 +1420,59 @@ def test_sampler_kernel_launch_by_launch_against_the_numpy_twin(D):
     assert seen["bad"] > 0 and bool(torch.isfinite(res.samples).all())
 
 
+@pytest.mark.parametrize("sites", [6, 9])
+def test_mapped_sampler_kernel_launch_by_launch_against_the_numpy_twin(sites, monkeypatch):
+    """`dyn_nuts_advance_mapped` behind the folded potential of the 2-age x 3-strain model (six sites: the compiled
+    six-dimension instance with the lanes map; nine: the half-wave-per-chain kernel): the potential arrives as its parts
+    (`dyn_nuts_state.pot_*`: u = -(lp + ll + offset), g = -(dlp + dll)), the kernel maps the position it hands out.  Every
+    launch of a short `MCMCProcess` run is repeated from the kernel's own state by tests/nuts_twin.py on the folded
+    potential's value and gradient at the position the kernel asked for; every field of the sampler state must agree."""
+    import nuts_twin
+    from dynode_amd.infer import nuts as N
+    from examples import infer_multi_strain as ex_m
+
+    chains, num_warmup, num_samples, depth = 6, 100, 5, 5
+    seen = dict(prev=None, launches=0, worst=0.0, sampler=None)
+    orig = N.KernelNUTS.__init__
+
+    def init(self, *a, **kw):
+        kw.update(use_graph=False, block=1)
+        orig(self, *a, **kw)
+        self.unroll, self.recheck_blocks, self.monitor = 1, (), lambda S: monitor(self, S)
+        seen["sampler"] = self
+
+    def monitor(sampler, S):
+        folded = sampler.pg
+        assert hasattr(folded, "solve_current"), "the model did not fold"
+        now = {k: v.detach().cpu().numpy().copy() for k, v in S.items()}
+        prev = seen["prev"]
+        if prev is not None:
+            u, gr = folded(torch.as_tensor(prev["z_eval"], device=S["z"].device))
+            folded.map_now(S["z_eval"])               # (the kernel had these buffers filled for its next gradient-solve: put them back)
+            K = dict(seed=(sampler.seed * 0x9E3779B97F4A7C15 + 0x1234567) & (2 ** 64 - 1), num_warmup=num_warmup, num_samples=num_samples,
+                     max_depth=depth, target_accept=sampler.target, max_delta_energy=sampler.max_de, windows=N._adaptation_windows(num_warmup, 75))
+            nuts_twin.advance(prev, K, u.cpu().numpy(), gr.cpu().numpy())
+            for k in now:
+                if k in ("pool", "pool_ro", "pend", "u_new", "g_new"):
+                    continue
+                x, y = prev[k].astype(np.float64), now[k].astype(np.float64)
+                same = (x == y) | (np.isnan(x) & np.isnan(y))
+                with np.errstate(invalid="ignore"):
+                    d = np.where(same, 0.0, np.abs(x - y) / (1.0 + np.abs(x)))
+                d = np.nan_to_num(d, nan=np.inf)
+                assert d.max() < 1e-8, (sites, seen["launches"], k, float(d.max()), np.argwhere(d >= 1e-8)[:4].tolist())
+                seen["worst"] = max(seen["worst"], float(d.max()))
+        seen["prev"] = now
+        seen["launches"] += 1
+
+    monkeypatch.setattr(N.KernelNUTS, "__init__", init)
+    proc = MCMCProcess(numpyro_model=ex_m.model, num_warmup=num_warmup, num_samples=num_samples, num_chains=chains, nuts_max_tree_depth=depth, progress_bar=False)
+    mcmc = proc.infer(config=ex_m.get_config(sites), tf=120, obs_data=ex_m.synthetic_incidence(120))
+    print(f"{sites} sites: {seen['launches']} launches, worst relative difference {seen['worst']:.2e}")
+    assert mcmc.sampler == "KernelNUTS" and mcmc.launches_per_iteration == 2 and seen["launches"] > 400
+    assert int(seen["prev"]["wi"].min()) == 1 and int(seen["prev"]["it"].min()) == num_warmup + num_samples
+
+
 def test_dimensions_beyond_the_sampler_kernel_fall_back_loudly_and_twenty_run_on_it():
     """A model without an ODE and many latent sites (plain torch code): 20 sites run the sampler kernel's half-wave-per-chain
     instance; 34 are beyond its 32 and `MCMCProcess` says so (RuntimeWarning) before running the torch-op sampler -- never a
