@@ -1,4 +1,4 @@
-"""Test infrastructure: a NumPy restatement of ONE launch of the sampler kernel (`dyn_nuts_advance`, per-chain adaptation) --
+"""Test infrastructure: a NumPy restatement of ONE launch of the sampler kernel (`dyn_nuts_advance`; per-chain adaptation, or pooled windows with K['pooled']) --
 everything a chain does between two potential evaluations, as csrc/nuts_device.hpp `advance_chain` and csrc/nuts_kernel.hip
 `nuts_advance_lanes` do it: second momentum half step and energy error, multinomial choice inside the subtree, checkpointed
 U-turn test, biased progressive merge, dual averaging (t0 = 10, kappa = 0.75, gamma = 0.05), Welford window with the
@@ -12,6 +12,7 @@ import math
 import numpy as np
 
 M32 = 0xFFFFFFFF
+POOL_SCALE = 1073741824.0     # 2^30 fixed point of the pooled window sums (csrc/nuts_device.hpp)
 
 
 def philox4x32_10(c, k):
@@ -66,6 +67,8 @@ def advance(S, K, u_new, g_new):
         for c in range(C):
             if S["it"][c] < total:
                 _advance_chain(S, K, c, D, Dm, total, u_new, g_new)
+    if K.get("pooled"):
+        S["pool_ro"][...] = S["pool"]      # (readers of the next launch see the pool as it stands after this one)
 
 
 def _advance_chain(S, K, c, D, Dm, total, u_new, g_new):
@@ -139,6 +142,26 @@ def _advance_chain(S, K, c, D, Dm, total, u_new, g_new):
             S["da_t"][c], S["da_gbar"][c], S["da_xbar"][c] = t1, gbar, xbar
             eps = math.exp(x)
             S["eps_avg"][c] = math.exp(xbar)
+            if K.get("pooled") and S["pend"][c] > 0:
+                # the pooled statistics of every chain that had closed this window when the previous launch ended
+                pw = S["pool_ro"][int(S["pend"][c]) - 1].astype(np.float64)
+                N = pw[0]
+                nn = max(N, 2.0)
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    mu = pw[1:1 + D] / POOL_SCALE / N
+                    cov = (pw[1 + D:].reshape(D, D) / POOL_SCALE - N * np.outer(mu, mu)) / (nn - 1.0)
+                cand = (nn / (nn + 5.0)) * cov + 1e-3 * (5.0 / (nn + 5.0)) * np.eye(D)
+                try:
+                    chol = mass_sqrt(cand)
+                except np.linalg.LinAlgError:
+                    chol = np.full((D, D), np.nan)
+                if N >= 2.0 and np.isfinite(cand).all() and np.isfinite(chol).all() and (np.diag(chol) > 0).all() and (np.diag(cand) > 0).all():
+                    S["imm"][c], S["mm_sqrt"][c] = cand, chol
+                    imm = S["imm"][c]
+                    eps = float(S["eps_avg"][c])
+                    S["da_mu"][c] = math.log(10.0 * eps)
+                    S["da_t"][c] = S["da_gbar"][c] = S["da_xbar"][c] = 0.0
+                S["pend"][c] = 0
             wi = int(S["wi"][c])
             if wi < len(K["windows"]) and K["windows"][wi][0] <= it < K["windows"][wi][1]:
                 n1 = S["wf_n"][c] + 1.0
@@ -146,7 +169,14 @@ def _advance_chain(S, K, c, D, Dm, total, u_new, g_new):
                 S["wf_mean"][c] += d0 / n1
                 S["wf_m2"][c] += np.outer(d0, z - S["wf_mean"][c])
                 S["wf_n"][c] = n1
-                if it + 1 == K["windows"][wi][1]:
+                if it + 1 == K["windows"][wi][1] and K.get("pooled"):
+                    # this chain's window into the pool (fixed point: the sums do not depend on the order); applied at its NEXT transition end
+                    mean, fix = S["wf_mean"][c], lambda v: np.rint(np.asarray(v) * POOL_SCALE).astype(np.int64)
+                    S["pool"][wi, 0] += int(n1)
+                    S["pool"][wi, 1:1 + D] += fix(n1 * mean)
+                    S["pool"][wi, 1 + D:] += fix(S["wf_m2"][c] + n1 * np.outer(mean, mean)).ravel()
+                    S["pend"][c] = wi + 1
+                elif it + 1 == K["windows"][wi][1]:
                     nn = max(n1, 2.0)
                     S["imm"][c] = (nn / (nn + 5.0)) * S["wf_m2"][c] / (nn - 1.0) + 1e-3 * (5.0 / (nn + 5.0)) * np.eye(D)
                     S["mm_sqrt"][c] = mass_sqrt(S["imm"][c])
@@ -154,10 +184,18 @@ def _advance_chain(S, K, c, D, Dm, total, u_new, g_new):
                     eps = float(S["eps_avg"][c])
                     S["da_mu"][c] = math.log(10.0 * eps)
                     S["da_t"][c] = S["da_gbar"][c] = S["da_xbar"][c] = 0.0
+                if it + 1 == K["windows"][wi][1]:
                     S["wf_n"][c], S["wf_mean"][c], S["wf_m2"][c] = 0.0, 0.0, 0.0
                     S["wi"][c] = wi + 1
             if it + 1 == K["num_warmup"]:
                 eps = float(S["eps_avg"][c])
+                if K.get("pooled"):
+                    # final step size: geometric mean over the chains that had finished warm-up when the previous launch ended, and this one
+                    nw, le = len(K["windows"]), math.log(S["eps_avg"][c])
+                    pr = S["pool_ro"][nw]
+                    S["pool"][nw, 0] += 1
+                    S["pool"][nw, 1] += int(np.rint(le * POOL_SCALE))
+                    eps = math.exp((float(pr[1]) / POOL_SCALE + le) / (float(pr[0]) + 1.0))
         else:
             j = it - K["num_warmup"]
             S["out_z"][c, j], S["out_acc"][c, j], S["out_n"][c, j], S["out_div"][c, j] = z, a_prob, n_prop, int(s_div)

@@ -1358,13 +1358,14 @@ def test_sampler_kernel_beyond_eight_dimensions_on_a_correlated_gaussian():
     assert torch.equal(KernelNUTS(walled, max_tree_depth=10, seed=3).run(z0, num_warmup=150, num_samples=100).samples, res.samples)
 
 
-@pytest.mark.parametrize("D", [3, 8, 12, 32])
-def test_sampler_kernel_launch_by_launch_against_the_numpy_twin(D):
+@pytest.mark.parametrize("D, adaptation", [(3, "per_chain"), (8, "per_chain"), (12, "per_chain"), (32, "per_chain"), (3, "pooled"), (8, "pooled")])
+def test_sampler_kernel_launch_by_launch_against_the_numpy_twin(D, adaptation):
     """Every launch of `dyn_nuts_advance` of a short run -- warm-up with two mass-matrix windows, their Cholesky factors,
     transition ends, recorded draws, a potential that is +inf with a NaN gradient beyond a wall -- repeated from the kernel's
     own state by the NumPy restatement of the state machine (tests/nuts_twin.py: Philox stream included), every field of the
     state compared: the one-thread-per-chain instances (3, 8 dimensions) and the half-wave-per-chain kernel (12, 32) do
-    what the restatement does, to rounding, launch after launch."""
+    what the restatement does, to rounding, launch after launch.  With pooled windows (opt-in, up to 8 dimensions): the
+    fixed-point pool, the matrices applied from it a transition later and the pooled final step size included."""
     import nuts_twin
     from dynode_amd.infer import nuts as N
 
@@ -1380,10 +1381,11 @@ def test_sampler_kernel_launch_by_launch_against_the_numpy_twin(D):
                 torch.where(out[:, None], torch.full_like(gr, float("nan")), gr))
 
     chains, num_warmup, num_samples, depth = 5, 200, 6, 5
-    sampler = N.KernelNUTS(pg, max_tree_depth=depth, seed=4, use_graph=False, block=1)
+    sampler = N.KernelNUTS(pg, max_tree_depth=depth, seed=4, use_graph=False, block=1, adaptation=adaptation)
     sampler.unroll = 1
     K = dict(seed=(4 * 0x9E3779B97F4A7C15 + 0x1234567) & (2 ** 64 - 1), num_warmup=num_warmup, num_samples=num_samples, max_depth=depth,
-             target_accept=sampler.target, max_delta_energy=sampler.max_de, windows=N._adaptation_windows(num_warmup, 75))
+             target_accept=sampler.target, max_delta_energy=sampler.max_de, windows=N._adaptation_windows(num_warmup, 75),
+             pooled=adaptation == "pooled")
     seen = dict(prev=None, launches=0, worst=0.0, window_ends=0, transitions=0, bad=0)
 
     def monitor(S):
@@ -1396,7 +1398,7 @@ def test_sampler_kernel_launch_by_launch_against_the_numpy_twin(D):
             seen["window_ends"] += int((now["wi"] > seen["wi"]).sum())
             seen["transitions"] += int((now["it"] > seen["it"]).sum())
             for k in now:
-                if k in ("pool", "pool_ro", "pend", "u_new", "g_new"):
+                if k in ("u_new", "g_new") or (k in ("pool", "pool_ro", "pend") and not K["pooled"]):
                     continue
                 x, y = prev[k].astype(np.float64), now[k].astype(np.float64)
                 same = (x == y) | (np.isnan(x) & np.isnan(y))
@@ -1413,7 +1415,7 @@ def test_sampler_kernel_launch_by_launch_against_the_numpy_twin(D):
     res = sampler.run(z0, num_warmup=num_warmup, num_samples=num_samples)
     st = sampler._keep[1]
     assert (st.seed, st.num_warmup, st.num_samples, st.max_depth, st.n_windows) == (K["seed"], num_warmup, num_samples, depth, len(K["windows"]))
-    assert [(st.w_start[i], st.w_end[i]) for i in range(st.n_windows)] == K["windows"] and st.pooled == 0
+    assert [(st.w_start[i], st.w_end[i]) for i in range(st.n_windows)] == K["windows"] and st.pooled == int(K["pooled"])
     print(f"dim {D}: {seen['launches']} launches, {seen['transitions']} transition ends, {seen['window_ends']} window ends, "
           f"{seen['bad']} non-finite potentials, worst relative difference {seen['worst']:.2e}")
     assert seen["launches"] > 800 and seen["window_ends"] == 2 * chains and seen["transitions"] >= chains * (num_warmup + num_samples) - chains
