@@ -1475,6 +1475,55 @@ def test_mapped_sampler_kernel_launch_by_launch_against_the_numpy_twin(sites, mo
     assert int(seen["prev"]["wi"].min()) == 1 and int(seen["prev"]["it"].min()) == num_warmup + num_samples
 
 
+@pytest.mark.parametrize("adaptation", ["per_chain", "pooled"])
+@pytest.mark.parametrize("fuse", [True, False])
+def test_inference_example_iteration_launch_by_launch_against_the_numpy_twin(data, adaptation, fuse):
+    """BASELINE cfg 4's model (examples/sir_infer_parameters.py, folded potential): the ONE-launch iteration -- the
+    gradient-solve's waves running the sampler's state machine for the chains they scored (`dyn_solver_opts::nuts_tail`) --
+    and the two-launch one, each launch repeated from the kernel's own state by tests/nuts_twin.py on the folded potential's
+    value and gradient at the position the kernel asked for.  Pooled windows (16 chains: the early window schedule) included."""
+    import nuts_twin
+    from dynode_amd.infer import folded
+    from dynode_amd.infer import nuts as N
+
+    chains, num_warmup, num_samples, depth = 16, 160, 6, 6
+    pot = Potential(ex.model_fused, dict(config=ex.get_config(), tf=100, obs_data=data), 0, torch.device("cuda"))
+    f = folded.discover(pot)
+    assert f is not None
+    sampler = N.KernelNUTS(f, max_tree_depth=depth, target_accept=0.8, seed=11, adaptation=adaptation, fuse=fuse, block=1, use_graph=False)
+    sampler.unroll, sampler.recheck_blocks = 1, ()
+    K = dict(seed=(11 * 0x9E3779B97F4A7C15 + 0x1234567) & (2 ** 64 - 1), num_warmup=num_warmup, num_samples=num_samples, max_depth=depth,
+             target_accept=sampler.target, max_delta_energy=sampler.max_de, pooled=adaptation == "pooled",
+             windows=N._adaptation_windows(num_warmup, 25 if adaptation == "pooled" else 75))
+    seen = dict(prev=None, launches=0, worst=0.0)
+
+    def monitor(S):
+        now = {k: v.detach().cpu().numpy().copy() for k, v in S.items()}
+        prev = seen["prev"]
+        if prev is not None:
+            u, gr = f(torch.as_tensor(prev["z_eval"], device=S["z"].device))
+            f.map_now(S["z_eval"])                    # (the kernel had these buffers filled for its next gradient-solve: put them back)
+            nuts_twin.advance(prev, K, u.cpu().numpy(), gr.cpu().numpy())
+            for k in now:
+                if k in ("u_new", "g_new") or (k in ("pool", "pool_ro", "pend") and not K["pooled"]):
+                    continue
+                x, y = prev[k].astype(np.float64), now[k].astype(np.float64)
+                same = (x == y) | (np.isnan(x) & np.isnan(y))
+                with np.errstate(invalid="ignore"):
+                    d = np.where(same, 0.0, np.abs(x - y) / (1.0 + np.abs(x)))
+                d = np.nan_to_num(d, nan=np.inf)
+                assert d.max() < 1e-8, (adaptation, fuse, seen["launches"], k, float(d.max()), np.argwhere(d >= 1e-8)[:4].tolist())
+                seen["worst"] = max(seen["worst"], float(d.max()))
+        seen["prev"] = now
+        seen["launches"] += 1
+
+    sampler.monitor = monitor
+    res = sampler.run(pot.initial(chains, init_to_median, 3), num_warmup, num_samples)
+    print(f"{adaptation}, {'one launch' if fuse else 'two launches'}: {seen['launches']} launches, worst relative difference {seen['worst']:.2e}")
+    assert sampler.launches_per_iteration == (1 if fuse else 2) and seen["launches"] > 300 and bool(torch.isfinite(res.samples).all())
+    assert int(seen["prev"]["wi"].min()) == len(K["windows"]) and int(seen["prev"]["it"].min()) == num_warmup + num_samples
+
+
 def test_dimensions_beyond_the_sampler_kernel_fall_back_loudly_and_twenty_run_on_it():
     """A model without an ODE and many latent sites (plain torch code): 20 sites run the sampler kernel's half-wave-per-chain
     instance; 34 are beyond its 32 and `MCMCProcess` says so (RuntimeWarning) before running the torch-op sampler -- never a
