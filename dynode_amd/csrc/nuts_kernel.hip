@@ -1,5 +1,7 @@
 // nuts_kernel.hip -- one HIP kernel per sampler iteration: the asynchronous batched NUTS state
-// machine of dynode_amd/infer/nuts.py (`GraphNUTS._step`), one thread per chain.
+// machine of dynode_amd/infer/nuts.py (`GraphNUTS._step`): one thread per chain up to eight dimensions (`nuts_advance`,
+// state machine in nuts_device.hpp), a half wave per chain beyond (`nuts_advance_lanes` below).  tests/nuts_twin.py restates a
+// launch in NumPy; the GPU suite holds every form to it launch by launch.
 //
 // Under numpyro (reference src/dynode/infer/inference.py:149-163) the NUTS transition is traced
 // into the same XLA program as the model.  Here the model's potential/gradient stays a torch
