@@ -1358,6 +1358,23 @@ def test_sampler_kernel_beyond_eight_dimensions_on_a_correlated_gaussian():
     assert torch.equal(KernelNUTS(walled, max_tree_depth=10, seed=3).run(z0, num_warmup=150, num_samples=100).samples, res.samples)
 
 
+def _worst_state_difference(twin: dict, kernel: dict, pooled: bool, bar: float, where) -> float:
+    """Largest relative difference between the twin's state and the kernel's over every field of `dyn_nuts_state` both hold
+    (NaN = NaN, inf = inf); asserts it is below `bar`, naming the field and the chains."""
+    worst = 0.0
+    for k in kernel:
+        if k in ("u_new", "g_new") or (k in ("pool", "pool_ro", "pend") and not pooled):
+            continue
+        x, y = twin[k].astype(np.float64), kernel[k].astype(np.float64)
+        same = (x == y) | (np.isnan(x) & np.isnan(y))
+        with np.errstate(invalid="ignore"):
+            d = np.where(same, 0.0, np.abs(x - y) / (1.0 + np.abs(x)))
+        d = np.nan_to_num(d, nan=np.inf)
+        assert d.max() < bar, (where, k, float(d.max()), np.argwhere(d >= bar)[:4].tolist())
+        worst = max(worst, float(d.max()))
+    return worst
+
+
 @pytest.mark.parametrize("D, adaptation", [(3, "per_chain"), (8, "per_chain"), (12, "per_chain"), (32, "per_chain"), (3, "pooled"), (8, "pooled")])
 def test_sampler_kernel_launch_by_launch_against_the_numpy_twin(D, adaptation):
     """Every launch of `dyn_nuts_advance` of a short run -- warm-up with two mass-matrix windows, their Cholesky factors,
@@ -1397,16 +1414,7 @@ def test_sampler_kernel_launch_by_launch_against_the_numpy_twin(D, adaptation):
             nuts_twin.advance(prev, K, u.cpu().numpy(), gr.cpu().numpy())
             seen["window_ends"] += int((now["wi"] > seen["wi"]).sum())
             seen["transitions"] += int((now["it"] > seen["it"]).sum())
-            for k in now:
-                if k in ("u_new", "g_new") or (k in ("pool", "pool_ro", "pend") and not K["pooled"]):
-                    continue
-                x, y = prev[k].astype(np.float64), now[k].astype(np.float64)
-                same = (x == y) | (np.isnan(x) & np.isnan(y))
-                with np.errstate(invalid="ignore"):
-                    d = np.where(same, 0.0, np.abs(x - y) / (1.0 + np.abs(x)))
-                d = np.nan_to_num(d, nan=np.inf)
-                assert d.max() < 1e-9, (D, seen["launches"], k, float(d.max()), np.argwhere(d >= 1e-9)[:4].tolist())
-                seen["worst"] = max(seen["worst"], float(d.max()))
+            seen["worst"] = max(seen["worst"], _worst_state_difference(prev, now, K["pooled"], 1e-9, (D, adaptation, seen["launches"])))
         seen["prev"], seen["wi"], seen["it"] = now, now["wi"].copy(), now["it"].copy()
         seen["launches"] += 1
 
@@ -1454,16 +1462,7 @@ def test_mapped_sampler_kernel_launch_by_launch_against_the_numpy_twin(sites, mo
             K = dict(seed=(sampler.seed * 0x9E3779B97F4A7C15 + 0x1234567) & (2 ** 64 - 1), num_warmup=num_warmup, num_samples=num_samples,
                      max_depth=depth, target_accept=sampler.target, max_delta_energy=sampler.max_de, windows=N._adaptation_windows(num_warmup, 75))
             nuts_twin.advance(prev, K, u.cpu().numpy(), gr.cpu().numpy())
-            for k in now:
-                if k in ("pool", "pool_ro", "pend", "u_new", "g_new"):
-                    continue
-                x, y = prev[k].astype(np.float64), now[k].astype(np.float64)
-                same = (x == y) | (np.isnan(x) & np.isnan(y))
-                with np.errstate(invalid="ignore"):
-                    d = np.where(same, 0.0, np.abs(x - y) / (1.0 + np.abs(x)))
-                d = np.nan_to_num(d, nan=np.inf)
-                assert d.max() < 1e-8, (sites, seen["launches"], k, float(d.max()), np.argwhere(d >= 1e-8)[:4].tolist())
-                seen["worst"] = max(seen["worst"], float(d.max()))
+            seen["worst"] = max(seen["worst"], _worst_state_difference(prev, now, False, 1e-8, (sites, seen["launches"])))
         seen["prev"] = now
         seen["launches"] += 1
 
@@ -1504,16 +1503,7 @@ def test_inference_example_iteration_launch_by_launch_against_the_numpy_twin(dat
             u, gr = f(torch.as_tensor(prev["z_eval"], device=S["z"].device))
             f.map_now(S["z_eval"])                    # (the kernel had these buffers filled for its next gradient-solve: put them back)
             nuts_twin.advance(prev, K, u.cpu().numpy(), gr.cpu().numpy())
-            for k in now:
-                if k in ("u_new", "g_new") or (k in ("pool", "pool_ro", "pend") and not K["pooled"]):
-                    continue
-                x, y = prev[k].astype(np.float64), now[k].astype(np.float64)
-                same = (x == y) | (np.isnan(x) & np.isnan(y))
-                with np.errstate(invalid="ignore"):
-                    d = np.where(same, 0.0, np.abs(x - y) / (1.0 + np.abs(x)))
-                d = np.nan_to_num(d, nan=np.inf)
-                assert d.max() < 1e-8, (adaptation, fuse, seen["launches"], k, float(d.max()), np.argwhere(d >= 1e-8)[:4].tolist())
-                seen["worst"] = max(seen["worst"], float(d.max()))
+            seen["worst"] = max(seen["worst"], _worst_state_difference(prev, now, K["pooled"], 1e-8, (adaptation, fuse, seen["launches"])))
         seen["prev"] = now
         seen["launches"] += 1
 
