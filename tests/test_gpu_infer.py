@@ -1375,13 +1375,13 @@ def _worst_state_difference(twin: dict, kernel: dict, pooled: bool, bar: float, 
     return worst
 
 
-@pytest.mark.parametrize("D, adaptation", [(3, "per_chain"), (8, "per_chain"), (12, "per_chain"), (32, "per_chain"), (3, "pooled"), (8, "pooled")])
+@pytest.mark.parametrize("D, adaptation", [(3, "per_chain"), (12, "per_chain"), (32, "per_chain"), (8, "pooled")])
 def test_sampler_kernel_launch_by_launch_against_the_numpy_twin(D, adaptation):
     """Every launch of `dyn_nuts_advance` of a short run -- warm-up with two mass-matrix windows, their Cholesky factors,
     transition ends, recorded draws, a potential that is +inf with a NaN gradient beyond a wall -- repeated from the kernel's
     own state by the NumPy restatement of the state machine (tests/nuts_twin.py: Philox stream included), every field of the
-    state compared: the one-thread-per-chain instances (3, 8 dimensions) and the half-wave-per-chain kernel (12, 32) do
-    what the restatement does, to rounding, launch after launch.  With pooled windows (opt-in, up to 8 dimensions): the
+    state compared: the one-thread-per-chain instances (3 dimensions; 8 with pooled windows) and the half-wave-per-chain kernel (12, 32) do
+    what the restatement does, to rounding, launch after launch.  With pooled windows (opt-in, up to 8 dimensions) the
     fixed-point pool, the matrices applied from it a transition later and the pooled final step size included."""
     import nuts_twin
     from dynode_amd.infer import nuts as N
@@ -1474,8 +1474,7 @@ def test_mapped_sampler_kernel_launch_by_launch_against_the_numpy_twin(sites, mo
     assert int(seen["prev"]["wi"].min()) == 1 and int(seen["prev"]["it"].min()) == num_warmup + num_samples
 
 
-@pytest.mark.parametrize("adaptation", ["per_chain", "pooled"])
-@pytest.mark.parametrize("fuse", [True, False])
+@pytest.mark.parametrize("adaptation, fuse", [("per_chain", True), ("pooled", True), ("per_chain", False)])
 def test_inference_example_iteration_launch_by_launch_against_the_numpy_twin(data, adaptation, fuse):
     """BASELINE cfg 4's model (examples/sir_infer_parameters.py, folded potential): the ONE-launch iteration -- the
     gradient-solve's waves running the sampler's state machine for the chains they scored (`dyn_solver_opts::nuts_tail`) --
