@@ -5,7 +5,7 @@
 #include <cstdlib>
 #include <map>
 #include <vector>
-__global__ void __launch_bounds__(512) where(unsigned *out, long long spin) {
+__global__ void __launch_bounds__(1024) where(unsigned *out, long long spin) {
     extern __shared__ float pad[];
     const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);     // HW_REG_HW_ID
     const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // HW_REG_XCC_ID
